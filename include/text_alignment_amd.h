@@ -1,0 +1,106 @@
+/*
+ * text_alignment_amd.h -- C ABI of libta_hip.so, the MI355X (gfx950) hot path of
+ * DDMAL/text_alignment.
+ *
+ * The reference has no FFI on this path: its boundary is two Python calls and one shell
+ * command.  Each entry point below names the reference interface
+ * whose arithmetic it replaces; the Python mirror of that interface lives in
+ * text_alignment_amd/ and binds these symbols with ctypes.
+ *
+ * Conventions: plain pointers and sizes only; every pointer marked [dev] is a device
+ * (HBM) address owned by the caller; [host] is host memory.  `stream` is a hipStream_t
+ * passed as void* (NULL = default stream).  Calls enqueue work and return without
+ * synchronising.  Return value: 0 = ok, negative = TA_E*; ta_last_error() describes the
+ * most recent failure on the calling thread.  The library keeps no global state.
+ */
+#ifndef TEXT_ALIGNMENT_AMD_H
+#define TEXT_ALIGNMENT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TA_OK 0
+#define TA_EINVAL (-1)    /* bad argument (null pointer, negative size, unsupported shape) */
+#define TA_ERANGE (-2)    /* scores would overflow the integer fast path */
+#define TA_EHIP (-3)      /* a HIP runtime call failed */
+#define TA_ELIMIT (-4)    /* problem exceeds a kernel limit (LDS capacity) */
+
+/* bit flags for ta_nw_batch */
+#define TA_NW_FILL 1u
+#define TA_NW_TRACEBACK 2u
+
+int ta_version(void);
+const char* ta_last_error(void);
+
+/*
+ * Affine-gap Needleman-Wunsch, replaces textSeqCompare.perform_alignment
+ * (reference textSeqCompare.py:13-177; called from alignToOCR.py:273).
+ *
+ * ta_nw_workspace_bytes: bytes of pointer-matrix workspace one n x m problem needs
+ * (1 byte per DP cell plus the skew padding of the strip layout, multiple of 1024).
+ */
+int64_t ta_nw_workspace_bytes(int32_t n, int32_t m);
+
+/* largest m (OCR-side length) the LDS-resident hand-off row supports */
+int32_t ta_nw_max_m(void);
+
+/*
+ * ta_nw_batch: fill (textSeqCompare.py:53-88) and/or traceback (textSeqCompare.py:96-170)
+ * of `nprob` independent problems.
+ *
+ *   t_codes, o_codes [dev]  concatenated int32 token ids of all transcripts / OCR strings;
+ *                           equal ids <=> equal tokens (textSeqCompare.py:32); ids < 65536
+ *   t_off, o_off     [dev]  int64[nprob+1] prefix offsets into the code arrays
+ *   params           [dev]  int32 scoring systems, 6 per system: match, mismatch,
+ *                           gap_open_x, gap_open_y, gap_extend_x, gap_extend_y
+ *                           (textSeqCompare.py:30-34); params_stride = 0 -> one shared
+ *                           system, 6 -> one per problem (the parameter grid of
+ *                           evaluate_text_alignment.py:181-198)
+ *   ws               [dev]  pointer-matrix workspace; ws_off [dev] int64[nprob] byte offset of
+ *                           each problem's region (16-byte aligned, ta_nw_workspace_bytes long)
+ *   ops_out          [dev]  alignment columns; problem p owns ops_off[p] .. ops_off[p] + n_p + m_p
+ *                           and its alignment is RIGHT-aligned in that region: the last
+ *                           ops_len[p] bytes, forward order, 0 = (t,o) pair, 1 = (t,'_'),
+ *                           2 = ('_',o)  (textSeqCompare.py:115-164 after the reversal at :167)
+ *   ops_off          [dev]  int64[nprob]
+ *   ops_len          [dev]  int32[nprob] alignment lengths (written by the traceback)
+ *   max_n, max_m            host-side maxima of the problem sizes (sizes LDS and the grid)
+ *   score_bound             host-side bound on (max_n + max_m + 2) * max|param| used for the
+ *                           overflow check (TA_ERANGE if it does not fit 2^23)
+ *   flags                   TA_NW_FILL | TA_NW_TRACEBACK
+ */
+int ta_nw_batch(const int32_t* t_codes, const int64_t* t_off,
+                const int32_t* o_codes, const int64_t* o_off, int32_t nprob,
+                const int32_t* params, int32_t params_stride,
+                uint8_t* ws, const int64_t* ws_off,
+                uint8_t* ops_out, const int64_t* ops_off, int32_t* ops_len,
+                int32_t max_n, int32_t max_m, int64_t score_bound,
+                uint32_t flags, void* stream);
+
+/*
+ * ta_nw_general: the same aligner for scoring systems the integer kernel does not take --
+ * a caller-supplied scoring function (textSeqCompare.py:27-29; the host tabulates it over
+ * the distinct tokens into `table`, row-major [t id][o id], row length tm) or non-integral
+ * numbers.  IEEE float64 throughout, bit-identical to the reference.  One problem per call.
+ *
+ *   t, o      [dev]  int32 token ids, n and m of them
+ *   params    [dev]  6 doubles: match, mismatch, gap_open_x, gap_open_y, gap_extend_x, gap_extend_y
+ *   table     [dev]  optional (NULL = use match/mismatch)
+ *   score_ws  [dev]  ta_nw_general_score_bytes(n) bytes
+ *   ptr_ws    [dev]  ta_nw_general_ptr_bytes(n, m) bytes
+ *   ops_out   [dev]  n + m bytes, alignment right-aligned as in ta_nw_batch; ops_len [dev] int32
+ */
+int64_t ta_nw_general_score_bytes(int32_t n);
+int64_t ta_nw_general_ptr_bytes(int32_t n, int32_t m);
+int ta_nw_general(const int32_t* t, int32_t n, const int32_t* o, int32_t m,
+                  const double* params, const double* table, int32_t tm,
+                  double* score_ws, uint8_t* ptr_ws,
+                  uint8_t* ops_out, int32_t* ops_len, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEXT_ALIGNMENT_AMD_H */

@@ -1,0 +1,86 @@
+"""CPU-side checks of the C-ABI shared library: it loads and exports every symbol that
+include/text_alignment_amd.h declares (no compute calls without a GPU)."""
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+
+
+@pytest.fixture(scope="module")
+def native():
+    if not os.path.exists(os.path.join(REPO, "text_alignment_amd", "libta_hip.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+    from text_alignment_amd import _native
+    return _native
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(REPO, "include", "text_alignment_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(ta_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_exported(native):
+    syms = _declared_symbols()
+    assert "ta_nw_batch" in syms and "ta_version" in syms
+    for s in syms:
+        assert hasattr(native.lib, s), s
+    assert sorted(native.EXPORTS) == syms
+
+
+def test_version_and_sizes(native):
+    lib = native.lib
+    assert lib.ta_version() >= 100
+    assert lib.ta_nw_workspace_bytes(0, 10) == 0
+    b = lib.ta_nw_workspace_bytes(4096, 4096)
+    assert b % 1024 == 0 and 4096 * 4096 <= b <= int(4096 * 4096 * 1.03)
+    assert lib.ta_nw_max_m() >= 8192
+    assert lib.ta_nw_general_ptr_bytes(3, 4) == 20
+
+
+def test_argument_errors_without_gpu(native):
+    lib = native.lib
+    # validation happens before any HIP call, so this is safe on a CPU-only box
+    rc = lib.ta_nw_batch(None, None, None, None, 1, None, 0, None, None, None, None, None,
+                         10, 10, 100, 3, None)
+    assert rc == native.TA_EINVAL
+    assert b"null" in lib.ta_last_error()
+    with pytest.raises(ValueError):
+        native.check(rc, "ta_nw_batch")
+    assert lib.ta_nw_batch(None, None, None, None, -1, None, 0, None, None, None, None, None,
+                           0, 0, 0, 3, None) == native.TA_EINVAL
+
+
+def test_scoring_parse_and_errors():
+    from text_alignment_amd import textSeqCompare as tsc
+    assert tsc.default_sys == [8, -4, -7, -7, -3, 0] and tsc.gap_extend == -1
+    assert tsc.parse_scoring_system(None)[0] == [8, -4, -7, -7, -3, 0]
+    assert tsc.parse_scoring_system([10, -5, -7, -2])[0] == [10, -5, -7, -7, -2, -2]
+    f = lambda a, b: 1
+    p, fn = tsc.parse_scoring_system([f, -1, -2, -3, -4])
+    assert fn is f and p[2:] == [-1, -2, -3, -4]
+    for bad in ([1, 2, 3], [1, 2, 3, 4, 5], [1, 2, 3, 4, 5, 6, 7], []):
+        with pytest.raises(ValueError) as ei:
+            tsc.perform_alignment(list("ab"), list("ab"), bad)
+        assert str(ei.value) == 'scoring_system {} invalid'.format(bad)
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from text_alignment_amd import textSeqCompare as tsc
+    with pytest.raises(RuntimeError):
+        tsc.perform_alignment(list("abc"), list("abd"))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(REPO, "text_alignment_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(root, f), encoding="utf-8").read()
+                assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", ""), f

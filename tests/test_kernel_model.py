@@ -1,0 +1,71 @@
+"""CPU check of the kernel's arithmetic and layout: the host lane simulator
+(tests/native/sim_nw.cpp) compiles the same nw_cell.h as the HIP kernel and must reproduce
+the oracle's alignment bit for bit (reference behaviour: textSeqCompare.py:53-170)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from oracle import nw_oracle
+from oracle.synth import synth_pair_ids
+
+_SRC = os.path.join(REPO, "tests", "native", "sim_nw.cpp")
+_SO = os.path.join(REPO, "tests", "native", "libsim_nw.so")
+
+
+@pytest.fixture(scope="module")
+def sim():
+    hdr = os.path.join(REPO, "text_alignment_amd", "csrc", "nw_cell.h")
+    if (not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(_SRC), os.path.getmtime(hdr))):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", _SO, _SRC])
+    lib = ctypes.CDLL(_SO)
+    lib.sim_nw.restype = ctypes.c_int
+    lib.sim_nw.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                           ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    return lib
+
+
+def _sim_ops(lib, t, o, params, R):
+    t = np.ascontiguousarray(t, dtype=np.int32)
+    o = np.ascontiguousarray(o, dtype=np.int32)
+    p = np.asarray(params, dtype=np.int32)
+    ops = np.zeros(len(t) + len(o) + 1, dtype=np.uint8)
+    ln = ctypes.c_int(0)
+    rc = lib.sim_nw(t.ctypes.data, len(t), o.ctypes.data, len(o), p.ctypes.data, R,
+                    ops.ctypes.data, ctypes.byref(ln))
+    assert rc == 0, rc
+    return ops[:ln.value]
+
+
+SYSTEMS = [[8, -4, -7, -7, -3, 0], [10, -5, -7, -7, -7, -7], [5, -10, -2, -7, 0, -5],
+           [11, -4, -2, -2, 0, 0], [1, -1, -1, -1, -1, -1], [3, -3, 0, 0, 0, 0],
+           [2, -1, 1, -3, -1, 1], [0, 0, 0, 0, 0, 0], [4, -6, -9, -1, -2, -4], [7, 7, 3, 2, 1, 1]]
+
+
+@pytest.mark.parametrize("R", [4, 8, 16])
+def test_sim_matches_oracle_random(sim, R):
+    rng = np.random.default_rng(100 + R)
+    for k in range(120):
+        asz = [2, 4, 27][k % 3]
+        n = int(rng.integers(0, 90)) if k % 4 else int(rng.integers(200, 700))
+        m = int(rng.integers(0, 90)) if k % 5 else int(rng.integers(100, 400))
+        t = rng.integers(0, asz, size=n)
+        o = rng.integers(0, asz, size=m)
+        if k % 2 == 0 and n and m:
+            o[:min(n, m)] = np.where(rng.random(min(n, m)) < 0.8, t[:min(n, m)], o[:min(n, m)])
+        sc = SYSTEMS[k % len(SYSTEMS)]
+        want = nw_oracle.align_ids(t, o, sc)
+        got = _sim_ops(sim, t, o, sc, R)
+        assert got.tolist() == want.tolist(), (R, n, m, sc)
+
+
+@pytest.mark.parametrize("R", [4, 8])
+def test_sim_matches_oracle_synth(sim, R):
+    for n, m, seed in [(500, 500, 1234), (300, 700, 1236), (1030, 515, 7), (257, 255, 1238)]:
+        t, o = synth_pair_ids(n, m, seed)
+        want = nw_oracle.align_ids(t, o, [8, -4, -7, -7, -3, 0])
+        got = _sim_ops(sim, t, o, [8, -4, -7, -7, -3, 0], R)
+        assert got.tolist() == want.tolist(), (R, n, m, seed)

@@ -1,0 +1,180 @@
+"""GPU parity tests of the NW hot path: HIP kernels (through the C ABI) vs the CPU oracle and
+vs golden vectors captured from the reference (textSeqCompare.py:13-177).  Bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import kat_scoring, load_golden, unrle
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def tsc():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from text_alignment_amd import textSeqCompare
+    return textSeqCompare
+
+
+def _sha16(tra, ocr):
+    return hashlib.sha256(("".join(tra) + "|" + "".join(ocr)).encode()).hexdigest()[:16]
+
+
+def _decode_ptr(ws, n, m, R=4):
+    """Pointer bytes of one problem from the kernel's strip layout (nw_cell.h PtrLayout)."""
+    SR, SPG = 64 * R, 16 // R
+    ngroups = (m + 63 + SPG - 1) // SPG
+    strip_bytes = ngroups * 1024
+    i = np.arange(1, n + 1)[:, None]
+    j = np.arange(1, m + 1)[None, :]
+    i0 = i - 1
+    strip, l, r = i0 // SR, (i0 % SR) // R, i0 % R
+    k = (j - 1) + l
+    addr = strip * strip_bytes + ((k // SPG) * 64 + l) * 16 + (k % SPG) * R + r
+    b = ws[addr]
+    return (2 - (b & 3)) | ((2 - ((b >> 2) & 3)) << 2) | ((2 - ((b >> 4) & 3)) << 4)
+
+
+def test_golden_kat(tsc):
+    g = load_golden("nw_kat.json")
+    for c in g["cases"]:
+        tra, ocr = tsc.perform_alignment(c["transcript"], c["ocr"], kat_scoring(c))
+        assert tra == c["tra_align"], c["name"]
+        assert ocr == c["ocr_align"], c["name"]
+
+
+def test_golden_random_small_one_launch(tsc):
+    g = load_golden("nw_random_small.json")
+    pairs = [(list(c["t"]), list(c["o"])) for c in g["cases"]]
+    systems = [c["scoring"] for c in g["cases"]]
+    res = tsc.perform_alignment_batch(pairs, systems)
+    for c, (tra, ocr) in zip(g["cases"], res):
+        assert "".join(tra) == c["tra"] and "".join(ocr) == c["ocr"], c
+
+
+def test_golden_synth(tsc):
+    from oracle.synth import synth_pair
+    g = load_golden("nw_synth.json")
+    for c in g["cases"]:
+        t, o = synth_pair(c["n"], c["m"], c["seed"])
+        sc = np.array(c["scoring"]) if (c["scoring"] is not None and c["seed"] == 99) else c["scoring"]
+        tra, ocr = tsc.perform_alignment(t, o, sc)
+        assert len(tra) == c["align_len"], (c["n"], c["m"])
+        assert _sha16(tra, ocr) == c["sha16"], (c["n"], c["m"], c["seed"])
+
+
+def test_inputs_not_mutated_and_types(tsc):
+    t, o = list("abcd"), list("xbcy")
+    tra, ocr = tsc.perform_alignment(t, o)
+    assert t == list("abcd") and o == list("xbcy")
+    assert isinstance(tra, list) and isinstance(ocr, list)
+    assert ("".join(tra), "".join(ocr)) == ("a_bcd", "_xbcy")
+    assert tsc.perform_alignment([], []) == ([], [])
+    assert tsc.perform_alignment([], list("ab")) == (['_', '_'], ['a', 'b'])
+    assert tsc.perform_alignment(list("ab"), []) == (['a', 'b'], ['_', '_'])
+
+
+SYSTEMS = [[8, -4, -7, -7, -3, 0], [10, -5, -7, -7, -7, -7], [5, -10, -2, -7, 0, -5],
+           [11, -4, -2, -2, 0, 0], [1, -1, -1, -1, -1, -1], [3, -3, 0, 0, 0, 0],
+           [2, -1, 1, -3, -1, 1], [0, 0, 0, 0, 0, 0], [4, -6, -9, -1, -2, -4], [7, 7, 3, 2, 1, 1]]
+
+
+def _random_problem(rng, n, m, asz, related):
+    t = rng.integers(0, asz, size=n).astype(np.int32)
+    o = rng.integers(0, asz, size=m).astype(np.int32)
+    if related and n and m:
+        k = min(n, m)
+        o[:k] = np.where(rng.random(k) < 0.8, t[:k], o[:k])
+    return t, o
+
+
+def test_ragged_batch_vs_oracle_full_pointer_matrix(tsc):
+    """Ragged sizes around every strip / group boundary, per-problem scoring systems; compares
+    the whole pointer matrix (not only the traceback path) with the oracle."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(7)
+    sizes = [(0, 0), (0, 5), (5, 0), (1, 1), (1, 70), (70, 1), (3, 64), (64, 3), (63, 63), (64, 64),
+             (65, 65), (255, 300), (256, 61), (257, 130), (511, 17), (512, 512), (513, 200),
+             (300, 1000), (1000, 300), (1024, 64), (1025, 1023), (700, 2049), (2049, 130),
+             (100, 4500), (2100, 600)]
+    t_list, o_list, prm = [], [], []
+    for k, (n, m) in enumerate(sizes):
+        t, o = _random_problem(rng, n, m, [2, 4, 27][k % 3], k % 2 == 0)
+        t_list.append(t); o_list.append(o); prm.append(SYSTEMS[k % len(SYSTEMS)])
+    batch = tsc.NWBatch(t_list, o_list, prm)
+    batch.run()
+    torch.cuda.synchronize()
+    res = batch.results()
+    ws = batch.ws.cpu().numpy()
+    ws_off = batch.ws_off.cpu().numpy()
+    for k, (n, m) in enumerate(sizes):
+        want_ops, want_ptr, _ = nw_oracle.align_ids(t_list[k], o_list[k], prm[k], want_ptr=True)
+        assert res[k].tolist() == want_ops.tolist(), (k, n, m, prm[k])
+        if n and m:
+            got_ptr = _decode_ptr(ws[ws_off[k]:], n, m)
+            assert np.array_equal(got_ptr, want_ptr[1:, 1:]), (k, n, m, prm[k])
+
+
+def test_waves_per_problem_variants(tsc):
+    """Same problems through batches whose largest problem selects W = 1, 2, 4, 8 waves."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(11)
+    base = [_random_problem(rng, n, m, 27, True) for n, m in [(200, 333), (90, 1200), (256, 256)]]
+    want = [nw_oracle.align_ids(t, o, SYSTEMS[0]).tolist() for t, o in base]
+    for big_n in (250, 400, 1100, 2300, 4200):
+        big = _random_problem(rng, big_n, 700, 27, True)
+        probs = base + [big]
+        batch = tsc.NWBatch([p[0] for p in probs], [p[1] for p in probs], SYSTEMS[0])
+        batch.run()
+        res = batch.results()
+        for k in range(len(base)):
+            assert res[k].tolist() == want[k], (big_n, k)
+        assert res[-1].tolist() == nw_oracle.align_ids(big[0], big[1], SYSTEMS[0]).tolist(), big_n
+
+
+def test_long_rows_and_long_columns(tsc):
+    from oracle import nw_oracle
+    from oracle.synth import synth_pair_ids
+    for n, m, seed in [(8192, 8192, 5), (3000, 12000, 6), (12000, 900, 7)]:
+        t, o = synth_pair_ids(n, m, seed)
+        batch = tsc.NWBatch([t], [o], SYSTEMS[0])
+        batch.run()
+        got = batch.results()[0]
+        want = nw_oracle.align_ids(t, o, SYSTEMS[0])
+        assert got.tolist() == want.tolist(), (n, m)
+
+
+def test_config2_batch_properties(tsc):
+    """BASELINE.json configs[1] shape (2048 x 2048, default scoring) at reduced batch for the
+    oracle comparison, plus size-independent properties on every problem of the batch."""
+    from oracle import nw_oracle
+    from oracle.synth import synth_pair_ids
+    nprob = 256
+    probs = [synth_pair_ids(2048, 2048, 1234 + k) for k in range(nprob)]
+    batch = tsc.NWBatch([p[0] for p in probs], [p[1] for p in probs], SYSTEMS[0])
+    batch.run()
+    res = batch.results()
+    for k, ops in enumerate(res):
+        c = np.bincount(ops, minlength=3)
+        assert c[0] + c[1] == 2048 and c[0] + c[2] == 2048, k      # every token exactly once
+        assert len(c) == 3
+    for k in (0, 1, 17, 100, 255):
+        want = nw_oracle.align_ids(probs[k][0], probs[k][1], SYSTEMS[0])
+        assert res[k].tolist() == want.tolist(), k
+    g = load_golden("nw_synth.json")
+    c2048 = [c for c in g["cases"] if c["n"] == 2048][0]
+    assert res[0].tolist() == unrle(c2048["ops_rle"])
+    # idempotence: a second run over the same buffers gives the same bytes
+    batch.run()
+    res2 = batch.results()
+    assert all(np.array_equal(a, b) for a, b in zip(res, res2))
+
+
+def test_overflow_guard_routes_to_general_kernel(tsc):
+    from oracle import nw_oracle
+    t, o = list("abcabcabc"), list("abcbcaabc")
+    big = [2 ** 21, -2 ** 20, -7, -7, -3, 0]
+    assert tsc.perform_alignment(t, o, big) == nw_oracle.perform_alignment(t, o, big)

@@ -1,0 +1,64 @@
+"""ctypes binding of libta_hip.so (C ABI: include/text_alignment_amd.h).
+
+The HIP library is the product: if it is missing or does not load, importing this module
+raises -- there is no CPU fallback anywhere in the package.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libta_hip.so")
+
+TA_OK = 0
+TA_EINVAL, TA_ERANGE, TA_EHIP, TA_ELIMIT = -1, -2, -3, -4
+TA_NW_FILL, TA_NW_TRACEBACK = 1, 2
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "libta_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C text_alignment_amd/csrc`). There is no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NativeLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+    vp, i32, i64, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32
+    lib.ta_version.restype = ctypes.c_int
+    lib.ta_version.argtypes = []
+    lib.ta_last_error.restype = ctypes.c_char_p
+    lib.ta_last_error.argtypes = []
+    lib.ta_nw_workspace_bytes.restype = i64
+    lib.ta_nw_workspace_bytes.argtypes = [i32, i32]
+    lib.ta_nw_max_m.restype = i32
+    lib.ta_nw_max_m.argtypes = []
+    lib.ta_nw_batch.restype = ctypes.c_int
+    lib.ta_nw_batch.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp,
+                                i32, i32, i64, u32, vp]
+    lib.ta_nw_general_score_bytes.restype = i64
+    lib.ta_nw_general_score_bytes.argtypes = [i32]
+    lib.ta_nw_general_ptr_bytes.restype = i64
+    lib.ta_nw_general_ptr_bytes.argtypes = [i32, i32]
+    lib.ta_nw_general.restype = ctypes.c_int
+    lib.ta_nw_general.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    return lib
+
+
+lib = _load()
+
+EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch",
+           "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general"]
+
+
+def check(rc, what):
+    if rc != TA_OK:
+        msg = lib.ta_last_error().decode("utf-8", "replace")
+        if rc == TA_EINVAL:
+            raise ValueError("%s: %s" % (what, msg))
+        if rc == TA_ERANGE:
+            raise OverflowError("%s: %s" % (what, msg))
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, msg))

@@ -1,0 +1,405 @@
+// ta_nw.hip -- affine-gap Needleman-Wunsch on MI355X (gfx950): wavefront fill + traceback.
+//
+// Replaces the arithmetic of textSeqCompare.perform_alignment (reference
+// textSeqCompare.py:13-177): boundary rows :53-60, DP fill :62-88, traceback :96-170.
+//
+// Fill kernel (K1).  One workgroup per problem, W waves.  The DP table is cut into strips
+// of 64*R rows; wave w takes strips w, w+W, ...  Inside a strip lane l owns R consecutive
+// rows and sweeps the columns skewed by its lane id, so one step of the wave is one
+// anti-diagonal band: the value a lane needs from the row above is what lane l-1 produced
+// one step earlier and arrives with a single DPP wave_shr:1 (no LDS, no bpermute).  The
+// three affine-gap score bands never leave registers; only the strip's bottom row (two
+// ints per column) goes through an LDS hand-off row to the wave working on the next strip,
+// which runs a few hundred columns behind it (progress words in LDS, polled).  HBM sees
+// exactly one byte per cell: the packed pointers, collected 16 bytes per lane and stored as
+// fully coalesced 1 KiB wave stores in a strip-major skewed layout (nw_cell.h).
+//
+// Traceback kernel (K2).  One wave per problem walks the pointer bytes from (n, m)
+// (textSeqCompare.py:100-164) and writes the alignment columns right-aligned into the
+// caller's buffer.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nw_cell.h"
+#include "ta_common.h"
+
+namespace ta {
+
+struct NwArgs {
+    const int32_t* t_codes; const int64_t* t_off;
+    const int32_t* o_codes; const int64_t* o_off;
+    const int32_t* params; int32_t params_stride;
+    uint8_t* ws; const int64_t* ws_off;
+    uint8_t* ops_out; const int64_t* ops_off; int32_t* ops_len;
+    int32_t nprob;
+};
+
+// ---- single-instruction helpers.  Inline asm pins the instruction selection: left to
+// itself hipcc un-folds the pre-shifted constants and splits max3 / bfi (25 VALU per cell
+// instead of 16, see DESIGN.md "K1 instruction budget").  Non-volatile: each is a pure
+// register op the compiler may schedule freely.
+__device__ __forceinline__ int v_max3(int a, int b, int c) {
+    int d;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ int v_and_or_x(int a, int mask) {            // (a & mask) | kTagX
+    int d;
+    asm("v_and_or_b32 %0, %1, %2, 21" : "=v"(d) : "v"(a), "s"(mask));
+    return d;
+}
+__device__ __forceinline__ unsigned v_bfi3(unsigned a, unsigned b) {    // (a & 3) | (b & ~3)
+    unsigned d;
+    asm("v_bfi_b32 %0, 3, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ unsigned v_bfi12(unsigned a, unsigned b) {   // (a & 12) | (b & ~12)
+    unsigned d;
+    asm("v_bfi_b32 %0, 12, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// t == o ? hit : miss   (textSeqCompare.py:32)
+__device__ __forceinline__ int v_score(int t, int o, int miss, int hit) {
+    int d;
+    asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %4, vcc"
+        : "=v"(d) : "v"(t), "v"(o), "v"(miss), "v"(hit) : "vcc");
+    return d;
+}
+// lane l receives lane l-1's value; lane 0 keeps what the destination held (DPP wave_shr:1,
+// bound_ctrl off).  The leading s_nop covers the VALU-write -> DPP-read wait states (2) that
+// hipcc cannot see across asm statements; NOPS = 4 also covers an EXEC write before a DPP.
+template <int NOPS>
+__device__ __forceinline__ void wave_shr1_pair(int& a_io, int a_src, int& b_io, int b_src) {
+    asm volatile("s_nop %4\n\t"
+                 "v_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                 : "+v"(a_io), "+v"(b_io) : "v"(a_src), "v"(b_src), "n"(NOPS));
+}
+
+constexpr int kOPad = 64;     // o-code padding in front (lanes that have not started yet)
+constexpr int kOTail = 80;    // steps run to m + 62 (+ group round-up) past the last code
+constexpr int kCheck = 16;    // hand-off progress is checked / published every kCheck groups
+
+// LDS carve (dynamic): int2 hvd[m+2] | int2 dummy[64*4] | uint16 ocode[kOPad+m+kOTail] | int prog[16]
+struct NwLds {
+    size_t hvd_bytes, dummy_bytes, oc_bytes, total;
+    __host__ __device__ explicit NwLds(int m) {
+        hvd_bytes = ((size_t)(m + 2) * 8 + 15) & ~(size_t)15;
+        dummy_bytes = 64 * 4 * 8;
+        oc_bytes = ((size_t)(kOPad + m + kOTail) * 2 + 15) & ~(size_t)15;
+        total = hvd_bytes + dummy_bytes + oc_bytes + 64;
+    }
+};
+
+// One interior cell on the encoded values: the arithmetic of ta::cell_update (nw_cell.h,
+// checked on the CPU by the lane simulator), one VALU instruction per line.
+struct CellRegs {
+    int cmis, cmat, gox6, goy6, clean;    // clean = ~kTagMask, wave-uniform
+};
+__device__ __forceinline__ unsigned cell_hw(const CellRegs& k, int d_ul, int v_u, int h_l,
+                                            int t, int o, int& d, int& v, int& h) {
+    const int cs = v_score(t, o, k.cmis, k.cmat);        // v_cmp_eq + v_cndmask
+    const int mr = (d_ul & k.clean) + cs;                 // v_and, v_add
+    const int xr = v_and_or_x(v_u, k.clean);              // v_and_or
+    const int yr = h_l & k.clean;                         // v_and
+    d = v_max3(mr, xr, yr);
+    v = v_max3(mr + k.gox6, xr, yr + k.gox6);             // 2 v_add + v_max3
+    h = v_max3(mr + k.goy6, xr + k.goy6, yr);             // 2 v_add + v_max3
+    return v_bfi3((unsigned)d_ul, v_bfi12((unsigned)v_u, (unsigned)h_l));
+}
+
+// pack the low bytes of four values into one dword (3 v_perm_b32)
+__device__ __forceinline__ unsigned pack4(unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
+    const unsigned lo = __builtin_amdgcn_perm(b1, b0, 0x0C0C0400u);
+    const unsigned hi = __builtin_amdgcn_perm(b3, b2, 0x0C0C0400u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+template <int R, int W>
+__global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
+    using L = PtrLayout<R>;
+    constexpr int SPG = L::SPG;
+    constexpr int DW = R / 4;                     // dwords of pointer bytes per step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int p = blockIdx.x;
+    const int64_t t0 = a.t_off[p], o0 = a.o_off[p];
+    const int n = (int)(a.t_off[p + 1] - t0);
+    const int m = (int)(a.o_off[p + 1] - o0);
+    if (n <= 0 || m <= 0) return;                 // nothing to fill; traceback emits pure gaps
+
+    const int32_t* prm = a.params + (size_t)p * a.params_stride;
+    const CellConsts c = make_consts(prm[0], prm[1], prm[2], prm[3], prm[4], prm[5]);
+    CellRegs kr;
+    kr.cmis = c.cmismatch; kr.cmat = c.cmatch; kr.gox6 = c.gox6; kr.goy6 = c.goy6;
+    kr.clean = ~kTagMask;
+
+    const NwLds lds(m);
+    int2* hvd = reinterpret_cast<int2*>(smem);
+    int2* dummy = reinterpret_cast<int2*>(smem + lds.hvd_bytes);
+    uint16_t* ocode = reinterpret_cast<uint16_t*>(smem + lds.hvd_bytes + lds.dummy_bytes);
+    int* prog = reinterpret_cast<int*>(smem + lds.hvd_bytes + lds.dummy_bytes + lds.oc_bytes);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // stage the OCR codes and the row-0 boundary (textSeqCompare.py:57-60) into LDS
+    for (int j = tid; j < kOPad + m + kOTail; j += W * 64) {
+        const int src = j - kOPad;
+        ocode[j] = (src >= 0 && src < m) ? (uint16_t)a.o_codes[o0 + src] : (uint16_t)0xFFFF;
+    }
+    for (int j = tid; j <= m; j += W * 64) hvd[j] = make_int2(bnd_V_row0(c, j), bnd_D_row0(c, j));
+    if (tid < 16) prog[tid] = 0;
+    __syncthreads();
+
+    const int nstrips = L::nstrips(n);
+    const int ngroups = L::ngroups(m);
+    const int64_t strip_bytes = L::strip_bytes(m);
+    uint8_t* const ws_p = a.ws + a.ws_off[p];
+    const int prev_wave = (wave + W - 1) % W;
+    // groups [g_lo, g_hi) are "steady": every lane is inside 1 <= j <= m on every step
+    const int g_lo = (63 + SPG - 1) / SPG;
+    const int g_hi = m / SPG;
+    int pass = 0;
+
+    for (int s = wave; s < nstrips; s += W, ++pass) {
+        // ---- per-strip lane state: column-0 boundary (textSeqCompare.py:53-56) ----
+        int D[R], V[R], H[R], tc[R];
+        const int row0 = s * L::SR + lane * R;            // 0-based index of this lane's first row
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = row0 + r + 1;
+            D[r] = bnd_D_col0(c, i);
+            H[r] = bnd_H_col0(c, i);
+            V[r] = 0;
+            tc[r] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
+        }
+        int dsave = bnd_D_col0(c, row0);
+        const bool lane_has_rows = row0 < n;
+        uint8_t* out = ws_p + (int64_t)s * strip_bytes + (int64_t)lane * 16;
+        const int prod_pass = (wave == 0) ? pass - 1 : pass;   // pass in which prev_wave did strip s-1
+
+        // the strip above must be kCheck+1 groups ahead before this wave touches a span:
+        // the hand-off entries of group g+1 are prefetched while group g is computed
+        auto wait_span = [&](int g_first) {
+            if (W == 1 || s == 0) return;
+            // the last step of groups [g_first, g_first + kCheck] reads hand-off column
+            // min(k_last + 1, m), written by the producer's lane 63 at its step col + 62
+            const int k_last = min((g_first + kCheck + 1) * SPG - 1, L::nsteps(m) - 1);
+            const int col = min(k_last + 1, m);
+            const int need_groups = min(ngroups, (col + 62) / SPG + 1);
+            const int need = prod_pass * ngroups + need_groups;
+            while (true) {
+                const int have = __hip_atomic_load(&prog[prev_wave], __ATOMIC_ACQUIRE,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__builtin_amdgcn_readfirstlane(have) >= need) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        };
+        auto publish = [&](int g) {
+            if (W == 1) return;
+            if ((g % kCheck) == kCheck - 1 || g == ngroups - 1) {
+                if (lane == 63)
+                    __hip_atomic_store(&prog[wave], pass * ngroups + g + 1, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        // per-group inputs: this lane's OCR codes and (lane 0) the row above, from LDS
+        int oc_next[SPG];
+        int2 hd_next[SPG];
+        auto load_group = [&](int g) {
+            const int idx = kOPad + g * SPG - lane;        // o index of step k is k - lane
+#pragma unroll
+            for (int q = 0; q < SPG; ++q) {
+                oc_next[q] = ocode[idx + q];
+                hd_next[q] = hvd[min(g * SPG + q + 1, m)]; // lane 0's column at step k is k + 1
+            }
+        };
+        auto prefetch = [&](int g) {
+            if (g + 1 < ngroups) {
+                if (((g + 1) % kCheck) == 0) wait_span(g + 1);
+                load_group(g + 1);
+            }
+        };
+        // one group with per-lane activity tests (ramp-up, ramp-down, short rows)
+        auto group_edge = [&](int g) {
+            int oc[SPG];
+            int2 hd[SPG];
+#pragma unroll
+            for (int q = 0; q < SPG; ++q) { oc[q] = oc_next[q]; hd[q] = hd_next[q]; }
+            prefetch(g);
+            unsigned acc[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int q = 0; q < SPG; ++q) {
+                const int k = g * SPG + q;
+                const int j = k - lane + 1;               // this lane's column at step k (1-based)
+                const bool active = (j >= 1) && (j <= m) && lane_has_rows;
+                // lane 0 takes the row above from the hand-off row, lanes 1..63 from lane-1
+                int v_up = hd[q].x, d_next = hd[q].y;
+                wave_shr1_pair<4>(v_up, V[R - 1], d_next, D[R - 1]);
+                if (active) {
+                    int d_ul = dsave, v_u = v_up;
+                    unsigned b[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int d_old = D[r];
+                        b[r] = cell_hw(kr, d_ul, v_u, H[r], tc[r], oc[q], D[r], V[r], H[r]);
+                        d_ul = d_old;
+                        v_u = V[r];
+                    }
+#pragma unroll
+                    for (int x = 0; x < DW; ++x)
+                        acc[q * DW + x] = pack4(b[4 * x], b[4 * x + 1], b[4 * x + 2], b[4 * x + 3]);
+                    dsave = d_next;
+                    if (lane == 63) hvd[j] = make_int2(V[R - 1], D[R - 1]);
+                }
+            }
+            *reinterpret_cast<uint4*>(out + (int64_t)g * 1024) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+            publish(g);
+        };
+
+        wait_span(0);
+        load_group(0);
+        int g = 0;
+        const int e1 = min(g_lo, ngroups);
+        for (; g < e1; ++g) group_edge(g);
+
+        if (g < g_hi) {
+            // ---- steady state: straight-line code, no EXEC changes.  Lanes whose rows lie
+            // below row n compute don't-care values that never reach a valid row. ----
+            // lane 63 publishes its bottom row to hvd[j], j = k - 62; the other lanes write a
+            // private dummy slot so the store needs no EXEC mask
+            int2* wptr = (lane == 63) ? (hvd + (g * SPG - 62)) : (dummy + lane * SPG);
+            const int winc = (lane == 63) ? SPG : 0;
+            for (; g < g_hi; ++g) {
+                int oc[SPG];
+                int2 hd[SPG];
+#pragma unroll
+                for (int q = 0; q < SPG; ++q) { oc[q] = oc_next[q]; hd[q] = hd_next[q]; }
+                prefetch(g);
+                unsigned acc[4];
+#pragma unroll
+                for (int q = 0; q < SPG; ++q) {
+                    int v_up = hd[q].x, d_next = hd[q].y;
+                    wave_shr1_pair<1>(v_up, V[R - 1], d_next, D[R - 1]);
+                    int d_ul = dsave, v_u = v_up;
+                    unsigned b[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int d_old = D[r];
+                        b[r] = cell_hw(kr, d_ul, v_u, H[r], tc[r], oc[q], D[r], V[r], H[r]);
+                        d_ul = d_old;
+                        v_u = V[r];
+                    }
+#pragma unroll
+                    for (int x = 0; x < DW; ++x)
+                        acc[q * DW + x] = pack4(b[4 * x], b[4 * x + 1], b[4 * x + 2], b[4 * x + 3]);
+                    dsave = d_next;
+                    wptr[q] = make_int2(V[R - 1], D[R - 1]);
+                }
+                wptr += winc;
+                *reinterpret_cast<uint4*>(out + (int64_t)g * 1024) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+                publish(g);
+            }
+        }
+        for (; g < ngroups; ++g) group_edge(g);
+    }
+}
+
+// K2: pointer walk, textSeqCompare.py:96-170.  One wave per problem; lane 0 walks.
+template <int R>
+__global__ __launch_bounds__(64) void nw_traceback_kernel(NwArgs a) {
+    using L = PtrLayout<R>;
+    const int p = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const int n = (int)(a.t_off[p + 1] - a.t_off[p]);
+    const int m = (int)(a.o_off[p + 1] - a.o_off[p]);
+    const uint8_t* ws_p = a.ws + a.ws_off[p];
+    uint8_t* ops = a.ops_out + a.ops_off[p];
+    const int cap = n + m;
+    int x = n, y = m, len = 0;
+    int st = 0;
+    if (n > 0 && m > 0) st = ptr_pm(ws_p[L::addr(n, m, m)]);     // start state, textSeqCompare.py:102
+    while (x > 0 && y > 0) {
+        const unsigned b = ws_p[L::addr(x, y, m)];
+        int op;
+        if (st == 0) { op = 0; st = ptr_pm(b); --x; --y; }
+        else if (st == 1) { op = 1; st = ptr_px(b); --x; }
+        else { op = 2; st = ptr_py(b); --y; }
+        ops[cap - 1 - len] = (uint8_t)op;
+        ++len;
+    }
+    while (y > 0) { ops[cap - 1 - len] = 2; ++len; --y; }          // textSeqCompare.py:154-158
+    while (x > 0) { ops[cap - 1 - len] = 1; ++len; --x; }          // textSeqCompare.py:160-164
+    a.ops_len[p] = len;
+}
+
+}  // namespace ta
+
+using namespace ta;
+
+constexpr int kR = 4;          // rows per lane of the production kernel
+
+extern "C" int64_t ta_nw_workspace_bytes(int32_t n, int32_t m) {
+    if (n <= 0 || m <= 0) return 0;
+    return PtrLayout<kR>::total_bytes(n, m);
+}
+
+extern "C" int32_t ta_nw_max_m(void) {
+    // LDS per workgroup = 10 bytes per OCR token + ~2.5 KiB; 160 KiB per CU
+    return 16000;
+}
+
+template <int W>
+static hipError_t launch_fill(const NwArgs& a, int max_m, hipStream_t st) {
+    const size_t lds = NwLds(max_m).total;
+    static bool raised = false;         // allow > 64 KiB of dynamic LDS, once per process
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nw_fill_kernel<kR, W>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL((nw_fill_kernel<kR, W>), dim3(a.nprob), dim3(W * 64), lds, st, a);
+    return hipGetLastError();
+}
+
+extern "C" int ta_nw_batch(const int32_t* t_codes, const int64_t* t_off,
+                           const int32_t* o_codes, const int64_t* o_off, int32_t nprob,
+                           const int32_t* params, int32_t params_stride,
+                           uint8_t* ws, const int64_t* ws_off,
+                           uint8_t* ops_out, const int64_t* ops_off, int32_t* ops_len,
+                           int32_t max_n, int32_t max_m, int64_t score_bound,
+                           uint32_t flags, void* stream) {
+    if (nprob < 0 || max_n < 0 || max_m < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (nprob == 0) return TA_OK;
+    if (!t_off || !o_off || !params || !ws_off || !ops_off || !ops_len)
+        return ta_fail(TA_EINVAL, "null pointer argument");
+    if (params_stride != 0 && params_stride != 6) return ta_fail(TA_EINVAL, "params_stride must be 0 or 6");
+    if (score_bound < 0 || score_bound >= (1ll << 23))
+        return ta_fail(TA_ERANGE, "(n+m+2)*max|param| does not fit the 32-bit encoded scores");
+    if (max_m > ta_nw_max_m()) return ta_fail(TA_ELIMIT, "m exceeds the LDS hand-off row capacity");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    NwArgs a{t_codes, t_off, o_codes, o_off, params, params_stride, ws, ws_off,
+             ops_out, ops_off, ops_len, nprob};
+    if (flags & TA_NW_FILL) {
+        if (max_n > 0 && max_m > 0) {
+            if (!t_codes || !o_codes || !ws) return ta_fail(TA_EINVAL, "null code/workspace pointer");
+            const int nstrips = PtrLayout<kR>::nstrips(max_n);
+            hipError_t e;
+            if (nstrips >= 8) e = launch_fill<8>(a, max_m, st);
+            else if (nstrips >= 4) e = launch_fill<4>(a, max_m, st);
+            else if (nstrips >= 2) e = launch_fill<2>(a, max_m, st);
+            else e = launch_fill<1>(a, max_m, st);
+            if (e != hipSuccess) return ta_fail_hip(e, "nw_fill_kernel launch");
+        }
+    }
+    if (flags & TA_NW_TRACEBACK) {
+        if (!ops_out && (max_n + max_m) > 0) return ta_fail(TA_EINVAL, "null ops_out");
+        hipLaunchKernelGGL((nw_traceback_kernel<kR>), dim3(nprob), dim3(64), 0, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return ta_fail_hip(e, "nw_traceback_kernel launch");
+    }
+    return TA_OK;
+}

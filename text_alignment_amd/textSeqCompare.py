@@ -1,0 +1,237 @@
+"""Affine-gap Needleman-Wunsch aligner on MI355X -- drop-in for the reference module of the
+same name (reference textSeqCompare.py:1-177).
+
+    from text_alignment_amd import textSeqCompare as tsc
+    tra_align, ocr_align = tsc.perform_alignment(list(transcript), list(ocr), scoring_system)
+
+`perform_alignment` keeps the reference's signature, return value and ValueError; the DP fill
+and the traceback run in the HIP kernels of csrc/ta_nw.hip through the C ABI
+(`ta_nw_batch`, include/text_alignment_amd.h).  `NWBatch` is the batched form behind it: many
+independent problems (pages, or one page under many scoring systems as in the reference's
+parameter grid search, evaluate_text_alignment.py:178-198) in one launch.
+"""
+import numpy as np
+import torch
+
+from . import _native
+
+# module attributes of the reference (textSeqCompare.py:5-10)
+default_match = 10
+default_mismatch = -5
+gap_open = -10
+gap_extend = -1          # the boundary rows always use this one (textSeqCompare.py:54-59)
+default_sys = [8, -4, -7, -7, -3, 0]
+
+GAP = '_'
+
+
+def parse_scoring_system(scoring_system):
+    """The three accepted forms of textSeqCompare.py:24-42.
+
+    Returns (params, fn): params = [match, mismatch, gap_open_x, gap_open_y, gap_extend_x,
+    gap_extend_y]; fn is the caller's scoring callable for the 5-element form, else None.
+    """
+    if scoring_system is None:
+        scoring_system = default_sys
+    size = len(scoring_system)
+    if size == 5 and callable(scoring_system[0]):
+        return [0, 0] + [scoring_system[k] for k in range(1, 5)], scoring_system[0]
+    if size == 6:
+        return [scoring_system[k] for k in range(6)], None
+    if size == 4:
+        hit, miss, opn, ext = (scoring_system[k] for k in range(4))
+        return [hit, miss, opn, opn, ext, ext], None
+    raise ValueError('scoring_system {} invalid'.format(scoring_system))
+
+
+def _is_integral(params):
+    try:
+        return all(float(v) == int(v) for v in params)
+    except (TypeError, ValueError, OverflowError):
+        return False
+
+
+def encode_tokens(*seqs):
+    """Dense int32 ids for arbitrary hashable tokens; equal tokens <=> equal ids
+    (the aligner only ever compares tokens with ==, textSeqCompare.py:32)."""
+    ids = {}
+    out = []
+    for seq in seqs:
+        arr = np.empty(len(seq), dtype=np.int32)
+        for k, tok in enumerate(seq):
+            arr[k] = ids.setdefault(tok, len(ids))
+        out.append(arr)
+    return out, ids
+
+
+def ops_to_alignment(ops, transcript, ocr):
+    """Alignment columns (0 pair, 1 transcript token over a gap, 2 gap over an OCR token) ->
+    the reference's two token lists with '_' gap markers (textSeqCompare.py:116-162)."""
+    tra, oc = [], []
+    i = j = 0
+    for op in ops:
+        if op == 0:
+            tra.append(transcript[i]); oc.append(ocr[j]); i += 1; j += 1
+        elif op == 1:
+            tra.append(transcript[i]); oc.append(GAP); i += 1
+        else:
+            tra.append(GAP); oc.append(ocr[j]); j += 1
+    return tra, oc
+
+
+class NWBatch(object):
+    """A batch of independent NW problems resident in HBM.
+
+    t_list / o_list: per-problem int32 id arrays (host).  params: one scoring system
+    (6 integers) or one per problem.  All device buffers are torch tensors on `device`;
+    `run()` only enqueues kernels on torch's current stream.
+    """
+
+    def __init__(self, t_list, o_list, params, device="cuda"):
+        assert len(t_list) == len(o_list)
+        self.device = torch.device(device)
+        self.nprob = len(t_list)
+        self.n = np.array([len(t) for t in t_list], dtype=np.int64)
+        self.m = np.array([len(o) for o in o_list], dtype=np.int64)
+        self.max_n = int(self.n.max()) if self.nprob else 0
+        self.max_m = int(self.m.max()) if self.nprob else 0
+        self.cells = int((self.n * self.m).sum())
+        p = np.asarray(params, dtype=np.int64)
+        if p.ndim == 1:
+            p = p.reshape(1, 6)
+        if p.shape[1] != 6 or p.shape[0] not in (1, self.nprob):
+            raise ValueError("params must be 6 integers, or one row of 6 per problem")
+        self.params_stride = 0 if p.shape[0] == 1 else 6
+        pmax = int(np.abs(p).max()) if p.size else 0
+        self.score_bound = (self.max_n + self.max_m + 2) * (3 * pmax + 2)
+        if np.abs(p).max(initial=0) > 2 ** 20:
+            raise OverflowError("scoring parameters too large for the integer kernels")
+
+        lib = _native.lib
+        t_off = np.zeros(self.nprob + 1, dtype=np.int64); np.cumsum(self.n, out=t_off[1:])
+        o_off = np.zeros(self.nprob + 1, dtype=np.int64); np.cumsum(self.m, out=o_off[1:])
+        ws_sizes = np.array([lib.ta_nw_workspace_bytes(int(a), int(b))
+                             for a, b in zip(self.n, self.m)], dtype=np.int64)
+        ws_off = np.zeros(self.nprob + 1, dtype=np.int64); np.cumsum(ws_sizes, out=ws_off[1:])
+        self.ws_bytes = int(ws_off[-1])
+        cap = self.n + self.m
+        ops_off = np.zeros(self.nprob + 1, dtype=np.int64); np.cumsum(cap, out=ops_off[1:])
+        self.ops_off_host = ops_off
+        self.cap_host = cap
+
+        def dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        cat_t = np.concatenate(t_list) if self.nprob and t_off[-1] else np.zeros(1, np.int32)
+        cat_o = np.concatenate(o_list) if self.nprob and o_off[-1] else np.zeros(1, np.int32)
+        if (cat_t.max(initial=0) >= 65535) or (cat_o.max(initial=0) >= 65535):
+            raise OverflowError("more than 65534 distinct tokens in one batch")
+        self.t_codes = dev(cat_t.astype(np.int32))
+        self.o_codes = dev(cat_o.astype(np.int32))
+        self.t_off = dev(t_off)
+        self.o_off = dev(o_off)
+        self.params = dev(p.astype(np.int32))
+        self.ws_off = dev(ws_off[:-1].copy() if self.nprob else ws_off)
+        self.ops_off = dev(ops_off[:-1].copy() if self.nprob else ops_off)
+        self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=self.device)
+        self.ops = torch.empty(max(int(ops_off[-1]), 16), dtype=torch.uint8, device=self.device)
+        self.ops_len = torch.zeros(max(self.nprob, 1), dtype=torch.int32, device=self.device)
+
+    def run(self, fill=True, traceback=True):
+        if self.nprob == 0:
+            return
+        flags = (_native.TA_NW_FILL if fill else 0) | (_native.TA_NW_TRACEBACK if traceback else 0)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = _native.lib.ta_nw_batch(
+            self.t_codes.data_ptr(), self.t_off.data_ptr(),
+            self.o_codes.data_ptr(), self.o_off.data_ptr(), self.nprob,
+            self.params.data_ptr(), self.params_stride,
+            self.ws.data_ptr(), self.ws_off.data_ptr(),
+            self.ops.data_ptr(), self.ops_off.data_ptr(), self.ops_len.data_ptr(),
+            self.max_n, self.max_m, self.score_bound, flags, stream)
+        _native.check(rc, "ta_nw_batch")
+
+    def results(self):
+        """Host copies of the alignment columns, one uint8 array per problem."""
+        if self.nprob == 0:
+            return []
+        ops = self.ops.cpu().numpy()
+        lens = self.ops_len.cpu().numpy()
+        out = []
+        for k in range(self.nprob):
+            end = int(self.ops_off_host[k] + self.cap_host[k])
+            out.append(ops[end - int(lens[k]):end].copy())
+        return out
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("text_alignment_amd needs an AMD GPU (MI355X): torch.cuda.is_available() "
+                           "is False and there is no CPU fallback")
+
+
+def perform_alignment_batch(pairs, scoring_systems=None):
+    """Align many (transcript, ocr) token-list pairs in one launch.
+
+    scoring_systems: None, one scoring system for all, or a list with one per pair (integer
+    match/mismatch forms only).  Returns a list of (tra_align, ocr_align).
+    """
+    _require_gpu()
+    pairs = [(list(t), list(o)) for t, o in pairs]
+    if scoring_systems is None or not isinstance(scoring_systems, (list, tuple)) or \
+            (len(scoring_systems) in (4, 6) and not isinstance(scoring_systems[0], (list, tuple, np.ndarray))):
+        systems = [scoring_systems] * len(pairs)
+    else:
+        systems = list(scoring_systems)
+        if len(systems) != len(pairs):
+            raise ValueError("need one scoring system per pair")
+    parsed = [parse_scoring_system(s) for s in systems]
+    if any(fn is not None for _, fn in parsed) or not all(_is_integral(p) for p, _ in parsed):
+        return [perform_alignment(t, o, s) for (t, o), s in zip(pairs, systems)]
+    t_list, o_list = [], []
+    for t, o in pairs:
+        (ti, oi), _ = encode_tokens(t, o)
+        t_list.append(ti); o_list.append(oi)
+    params = np.array([[int(v) for v in p] for p, _ in parsed], dtype=np.int64)
+    if len(pairs) and (params == params[0]).all():
+        params = params[:1]
+    batch = NWBatch(t_list, o_list, params)
+    batch.run()
+    return [ops_to_alignment(ops, t, o) for ops, (t, o) in zip(batch.results(), pairs)]
+
+
+def perform_alignment(transcript, ocr, scoring_system=None, verbose=False):
+    '''
+    @scoring_system must be array-like, of one of the following forms:
+    [match_func(a,b), gap_open_x, gap_open_y, gap_extend_x, gap_extend_y]
+    [match, mismatch, gap_open_x, gap_open_y, gap_extend_x, gap_extend_y]
+    [match, mismatch, gap_open, gap_extend]
+
+    Returns (tra_align, ocr_align): two equal-length token lists with '_' where the other
+    sequence has no partner (reference textSeqCompare.py:13, :177).  Inputs are not mutated.
+    '''
+    params, fn = parse_scoring_system(scoring_system)      # raises ValueError like the reference
+    _require_gpu()
+    transcript = list(transcript)
+    ocr = list(ocr)
+    (t_ids, o_ids), ids = encode_tokens(transcript, ocr)
+    if fn is None and _is_integral(params):
+        batch = NWBatch([t_ids], [o_ids], [int(v) for v in params])
+        try:
+            batch.run()
+            ops = batch.results()[0]
+        except OverflowError:
+            ops = _general_alignment(t_ids, o_ids, ids, params, fn)
+    else:
+        ops = _general_alignment(t_ids, o_ids, ids, params, fn)
+    tra_align, ocr_align = ops_to_alignment(ops, transcript, ocr)
+    if verbose:
+        for a, b in zip(tra_align, ocr_align):
+            mark = ' ' if (a == GAP or b == GAP) else ('O' if a == b else '~')
+            print('{} {} {}'.format(a, b, mark))
+    return (tra_align, ocr_align)
+
+
+def _general_alignment(t_ids, o_ids, ids, params, fn):
+    """float64 / substitution-table kernel for callable or non-integral scoring systems."""
+    from . import nw_general
+    return nw_general.align(t_ids, o_ids, ids, params, fn)
