@@ -215,11 +215,11 @@ def perform_alignment(transcript, ocr, scoring_system=None, verbose=False):
     ocr = list(ocr)
     (t_ids, o_ids), ids = encode_tokens(transcript, ocr)
     if fn is None and _is_integral(params):
-        batch = NWBatch([t_ids], [o_ids], [int(v) for v in params])
         try:
+            batch = NWBatch([t_ids], [o_ids], [int(v) for v in params])
             batch.run()
             ops = batch.results()[0]
-        except OverflowError:
+        except OverflowError:       # scores would not fit the 32-bit encoding: float64 kernel
             ops = _general_alignment(t_ids, o_ids, ids, params, fn)
     else:
         ops = _general_alignment(t_ids, o_ids, ids, params, fn)
