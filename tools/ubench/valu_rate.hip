@@ -1,0 +1,69 @@
+// valu_rate.hip -- issue-rate microbenchmark for the VALU instructions the NW kernel uses.
+// Build: hipcc -O3 --offload-arch=gfx950 valu_rate.hip -o valu_rate ; run on the GPU box.
+// Each kernel runs ITER x 32 independent copies of one instruction per wave; with 8 waves
+// per SIMD the reported cycles/instruction/SIMD is the pipe's issue interval.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+#define REP8(X) X X X X X X X X
+#define REP32(X) REP8(X) REP8(X) REP8(X) REP8(X)
+
+template <int OP>
+__global__ __launch_bounds__(512) void k(int* out, int iters, int seed) {
+    int a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7;
+    int b0 = a0 ^ 0x55, b1 = a1 ^ 0x33, b2 = a2 ^ 0x77, b3 = a3 ^ 0x11;
+    int c = seed;
+    for (int it = 0; it < iters; ++it) {
+        if (OP == 0) { REP8(asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %1, %1, %4\n v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c));) }
+        if (OP == 1) { REP8(asm volatile("v_max3_i32 %0, %0, %4, %5\n v_max3_i32 %1, %1, %4, %5\n v_max3_i32 %2, %2, %4, %5\n v_max3_i32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));) }
+        if (OP == 2) { REP8(asm volatile("v_and_b32 %0, %0, %4\n v_and_b32 %1, %1, %4\n v_and_b32 %2, %2, %4\n v_and_b32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c));) }
+        if (OP == 3) { REP8(asm volatile("v_bfi_b32 %0, 12, %0, %4\n v_bfi_b32 %1, 12, %1, %4\n v_bfi_b32 %2, 12, %2, %4\n v_bfi_b32 %3, 12, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
+        if (OP == 4) { REP8(asm volatile("v_cmp_eq_u32 vcc, %0, %4\n v_cndmask_b32 %0, %0, %5, vcc\n v_cmp_eq_u32 vcc, %1, %4\n v_cndmask_b32 %1, %1, %5, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1) : "vcc");) }
+        if (OP == 5) { REP8(asm volatile("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c));) }
+        if (OP == 6) { REP8(asm volatile("v_max3_f32 %0, %0, %4, %5\n v_max3_f32 %1, %1, %4, %5\n v_max3_f32 %2, %2, %4, %5\n v_max3_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));) }
+        if (OP == 7) { REP8(asm volatile("v_pk_add_u16 %0, %0, %4\n v_pk_add_u16 %1, %1, %4\n v_pk_add_u16 %2, %2, %4\n v_pk_add_u16 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c));) }
+        if (OP == 8) { REP8(asm volatile("v_pk_max_i16 %0, %0, %4\n v_pk_max_i16 %1, %1, %4\n v_pk_max_i16 %2, %2, %4\n v_pk_max_i16 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
+        if (OP == 9) { REP8(asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+        if (OP == 10) { REP8(asm volatile("v_perm_b32 %0, %0, %4, %5\n v_perm_b32 %1, %1, %4, %5\n v_perm_b32 %2, %2, %4, %5\n v_perm_b32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));) }
+        if (OP == 11) { REP8(asm volatile("v_and_or_b32 %0, %0, %4, 21\n v_and_or_b32 %1, %1, %4, 21\n v_and_or_b32 %2, %2, %4, 21\n v_and_or_b32 %3, %3, %4, 21" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
+        if (OP == 12) { REP8(asm volatile("v_pk_add_f32 %0, %0, %2\n v_pk_add_f32 %1, %1, %2" : "+v"(*(double*)&a0), "+v"(*(double*)&a2) : "v"(*(double*)&b0));) }
+        if (OP == 13) { REP8(asm volatile("v_max_i32 %0, %0, %4\n v_max_i32 %1, %1, %4\n v_max_i32 %2, %2, %4\n v_max_i32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
+        if (OP == 14) { REP8(asm volatile("v_fma_f32 %0, %0, %4, %5\n v_fma_f32 %1, %1, %4, %5\n v_fma_f32 %2, %2, %4, %5\n v_fma_f32 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));) }
+        if (OP == 15) { REP8(asm volatile("v_pk_mad_i16 %0, %0, %4, %5\n v_pk_mad_i16 %1, %1, %4, %5\n v_pk_mad_i16 %2, %2, %4, %5\n v_pk_mad_i16 %3, %3, %4, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0), "v"(b1));) }
+        if (OP == 16) { REP8(asm volatile("v_max_f32 %0, %0, %4\n v_max_f32 %1, %1, %4\n v_max_f32 %2, %2, %4\n v_max_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
+        if (OP == 17) { REP8(asm volatile("v_pk_max_f16 %0, %0, %4\n v_pk_max_f16 %1, %1, %4\n v_pk_max_f16 %2, %2, %4\n v_pk_max_f16 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
+        if (OP == 18) { REP8(asm volatile("v_pk_sub_i16 %0, %0, %4 clamp\n v_pk_sub_i16 %1, %1, %4 clamp\n v_pk_sub_i16 %2, %2, %4 clamp\n v_pk_sub_i16 %3, %3, %4 clamp" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + b2 + b3;
+}
+
+template <int OP>
+static void run(const char* name, int instr_per_iter) {
+    int* out; hipMalloc(&out, 256 * 8 * 512 * sizeof(int));
+    const int iters = 2000, blocks = 256 * 4;         // 4 blocks of 512 = 32 waves per CU = 8 per SIMD
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(512), 0, 0, out, 10, 1);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(512), 0, 0, out, iters, 1);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    // wave-instructions per SIMD = iters * instr_per_iter * 8 waves
+    double wi = (double)iters * instr_per_iter * 8.0;
+    double ns_per = ms * 1e6 / wi;
+    printf("%-28s %8.3f ms  %6.3f ns per wave-instr per SIMD  (= %.2f cycles @2.4GHz, %.2f @2.0GHz)\n",
+           name, ms, ns_per, ns_per * 2.4, ns_per * 2.0);
+    hipFree(out);
+}
+
+int main() {
+    run<0>("v_add_u32", 32); run<13>("v_max_i32", 32); run<1>("v_max3_i32", 32); run<2>("v_and_b32", 32);
+    run<3>("v_bfi_b32", 32); run<11>("v_and_or_b32", 32); run<4>("v_cmp_eq+v_cndmask (pair=2)", 32);
+    run<10>("v_perm_b32", 32); run<9>("v_mov_b32_dpp wave_shr", 32);
+    run<5>("v_add_f32", 32); run<16>("v_max_f32", 32); run<6>("v_max3_f32", 32); run<14>("v_fma_f32", 32);
+    run<12>("v_pk_add_f32", 16);
+    run<7>("v_pk_add_u16", 32); run<8>("v_pk_max_i16", 32); run<15>("v_pk_mad_i16", 32);
+    run<18>("v_pk_sub_i16 clamp", 32); run<17>("v_pk_max_f16", 32);
+    return 0;
+}
