@@ -17,7 +17,10 @@
 // (PM, PX, PY).  Scores are kept relative to gex*i + gey*j ("hatted"), which removes the
 // extension adds:  M^ = M - gex*i - gey*j etc.;  M^(i,j) = D^(i-1,j-1) + (s - gex - gey),
 // X^(i,j) = V^(i-1,j), Y^(i,j) = H^(i,j-1), V^ = max3(M^+gox, X^, Y^+gox),
-// H^ = max3(M^+goy, X^+goy, Y^).  The common offset never changes a winner.
+// H^ = max3(M^+goy, X^+goy, Y^).  The kernel further carries V~ = V^ - gox and
+// H~ = H^ - goy (so X~ = X^ - gox, Y~ = Y^ - goy arrive ready-made), which leaves two adds
+// per cell:  D = max3(M^, X~+gox, Y~+goy), V~ = max3(M^, X~, Y~+goy), H~ = max3(M^, X~+gox, Y~).
+// A common offset inside one max3 never changes its winner.
 //
 // Encoding.  A value is stored as  (score << 6) | tag  with a static 6-bit tag per source
 // matrix: M -> 0b101010, X -> 0b010101, Y -> 0.  A signed max over encoded candidates
@@ -77,29 +80,31 @@ TA_HD int max3i(int a, int b, int c) {
 TA_HD int bnd_D_row0(const CellConsts& c, int j) {            // D(0, j): M beats X on the tie
     return ((-(1 + c.gey) * j) * 64) | kTagM;
 }
-TA_HD int bnd_V_row0(const CellConsts& c, int j) {            // V(0, j) = max(M^+gox, X^)
+TA_HD int bnd_V_row0(const CellConsts& c, int j) {            // V~(0, j) = max(M^, X^ - gox)
     const int base = -(1 + c.gey) * j;
-    return c.gox >= 0 ? (((base + c.gox) * 64) | kTagM) : ((base * 64) | kTagX);
+    return c.gox >= 0 ? ((base * 64) | kTagM) : (((base - c.gox) * 64) | kTagX);
 }
 TA_HD int bnd_D_col0(const CellConsts& c, int i) {            // D(i, 0): M beats Y on the tie
     return ((-(1 + c.gex) * i) * 64) | kTagM;
 }
-TA_HD int bnd_H_col0(const CellConsts& c, int i) {            // H(i, 0) = max(M^+goy, Y^)
+TA_HD int bnd_H_col0(const CellConsts& c, int i) {            // H~(i, 0) = max(M^, Y^ - goy)
     const int base = -(1 + c.gex) * i;
-    return c.goy >= 0 ? (((base + c.goy) * 64) | kTagM) : ((base * 64) | kTagY);
+    return c.goy >= 0 ? ((base * 64) | kTagM) : (((base - c.goy) * 64) | kTagY);
 }
 
 // ---- one interior cell ----
-// in : d_ul = D(i-1,j-1), v_u = V(i-1,j), h_l = H(i,j-1), cs = cmatch / cmismatch
-// out: d, v, h of (i,j); returns the pointer byte of (i,j) (bits 6-7 don't-care)
+// in : d_ul = D(i-1,j-1), v_u = V~(i-1,j), h_l = H~(i,j-1), cs = cmatch / cmismatch
+// out: d, v, h = D, V~, H~ of (i,j); returns the pointer byte of (i,j) (bits 6-7 don't-care)
 TA_HD unsigned cell_update(int d_ul, int v_u, int h_l, int cs, int gox6, int goy6,
                            int& d, int& v, int& h) {
     const int mr = (d_ul & ~kTagMask) + cs;            // M^ tagged M
-    const int xr = (v_u & ~kTagMask) | kTagX;          // X^ tagged X
-    const int yr = (h_l & ~kTagMask);                  // Y^ tagged Y (= 0)
-    d = max3i(mr, xr, yr);
-    v = max3i(mr + gox6, xr, yr + gox6);
-    h = max3i(mr + goy6, xr + goy6, yr);
+    const int xr = (v_u & ~kTagMask) | kTagX;          // X~ tagged X
+    const int yr = (h_l & ~kTagMask);                  // Y~ tagged Y (= 0)
+    const int xg = xr + gox6;                          // X^
+    const int yg = yr + goy6;                          // Y^
+    d = max3i(mr, xg, yg);
+    v = max3i(mr, xr, yg);
+    h = max3i(mr, xg, yr);
     const unsigned inner = ((unsigned)v_u & 0x0Cu) | ((unsigned)h_l & ~0x0Cu);   // v_bfi_b32
     return ((unsigned)d_ul & 0x03u) | (inner & ~0x03u);                           // v_bfi_b32
 }

@@ -102,9 +102,11 @@ __device__ __forceinline__ unsigned cell_hw(const CellRegs& k, int d_ul, int v_u
     const int mr = (d_ul & k.clean) + cs;                 // v_and, v_add
     const int xr = v_and_or_x(v_u, k.clean);              // v_and_or
     const int yr = h_l & k.clean;                         // v_and
-    d = v_max3(mr, xr, yr);
-    v = v_max3(mr + k.gox6, xr, yr + k.gox6);             // 2 v_add + v_max3
-    h = v_max3(mr + k.goy6, xr + k.goy6, yr);             // 2 v_add + v_max3
+    const int xg = xr + k.gox6;                           // v_add
+    const int yg = yr + k.goy6;                           // v_add
+    d = v_max3(mr, xg, yg);
+    v = v_max3(mr, xr, yg);
+    h = v_max3(mr, xg, yr);
     return v_bfi3((unsigned)d_ul, v_bfi12((unsigned)v_u, (unsigned)h_l));
 }
 
