@@ -100,6 +100,39 @@ int ta_nw_general(const int32_t* t, int32_t n, const int32_t* o, int32_t m,
                   double* score_ws, uint8_t* ptr_ws,
                   uint8_t* ops_out, int32_t* ops_len, void* stream);
 
+/*
+ * Line recogniser: replaces the `ocropus-rpred` subprocess of
+ * alignToOCR.perform_ocr_with_ocropus (reference alignToOCR.py:142-147; arithmetic of the
+ * third-party ocropy 1.3.3).  All pointers [dev].
+ *
+ * Lines are concatenated row-wise: line b owns rows row_off[b] .. row_off[b] + T[b] of
+ *   x     [rows][48]   prepared line (ink = 1, 16 zero columns of padding each side)
+ *   hout  [rows][200]  BiLSTM outputs [forward 100 | reversed LSTM flipped back 100]
+ *   probs [rows][no]   softmax outputs;  logits [rows][no] optional (NULL to skip)
+ *
+ * ta_lstm_forward: group_lines = int32[ngroups][16] line ids (-1 = empty slot); one workgroup
+ *   runs the 16 lines of a group in lockstep, so groups should hold lines of similar length.
+ *   wp   = ta_lstm_packed_weight_floats() floats: MFMA B fragments
+ *          [dir 2][wave 7][gate GI,GF,GO,CI][k-step 38][lane 64] =
+ *          W_gate[unit 16*wave + lane%16][kp 4*kstep + lane/16], kp: 0 bias, 1..48 x,
+ *          49..51 zero, 52..151 h; units >= 100 zero.
+ *   peep = float[2][3][112]: WIP, WFP, WOP per direction, units >= 100 zero.
+ * ta_lstm_output: w2p = float[204][16*ceil(no/16)], row kp = W2[:, kp] for kp <= 200
+ *   (kp 0 = bias column), zero elsewhere.  no <= 128.
+ * ta_decode: translate_back(outputs, threshold) per line; line b writes dec_n[b] (t, class)
+ *   pairs at dec_t/dec_c + dec_off[b] (capacity (T[b] + 1) / 2 entries).
+ */
+int32_t ta_lstm_packed_weight_floats(void);
+int ta_lstm_forward(const float* x, const int64_t* row_off, const int32_t* T,
+                    const int32_t* group_lines, int32_t ngroups,
+                    const float* wp, const float* peep, float* hout, void* stream);
+int ta_lstm_output(const float* y, int64_t rows, const float* w2p, int32_t no,
+                   float* probs, float* logits, void* stream);
+int ta_decode(const float* probs, const int64_t* row_off, const int32_t* T,
+              int32_t nlines, int32_t no, float threshold,
+              int32_t* dec_t, int32_t* dec_c, int32_t* dec_n, const int64_t* dec_off,
+              void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,50 @@
+"""CPU checks of oracle/ocr_ref_f64.py (PARITY UNPINNED: no reference fixture exists for the
+third-party ocropus-rpred arithmetic; these tests pin the restatement's own invariants)."""
+import numpy as np
+
+from oracle import ocr_ref_f64 as R
+
+
+def test_translate_back_runs_and_ties():
+    p = np.full((10, 5), 0.01)
+    p[:, 0] = 0.9
+    p[2:5, 0] = 0.1
+    p[3, 2] = 0.6
+    p[4, 2] = 0.6            # tie with (3, 2): earlier t wins
+    p[8:, 0] = 0.3
+    p[9, 4] = 0.5            # run open at the end of the line
+    assert R.translate_back(p) == [(3, 2), (9, 4)]
+    p[:, 0] = 0.9
+    assert R.translate_back(p) == []
+    p[:, 0] = 0.1            # one long run; blank itself may be the maximum -> class 0
+    p[:, 1:] = 0.05
+    assert R.translate_back(p) == [(0, 0)]
+
+
+def test_shapes_softmax_and_reversal():
+    m = R.synthetic_model(1, no=20)
+    xs = R.synthetic_line(2, width=30)
+    assert xs.shape == (62, 48) and (xs[:16] == 0).all() and (xs[-16:] == 0).all()
+    ys = R.bilstm_states(m, xs)
+    assert ys.shape == (62, 200)
+    z, p = R.softmax_layer(m, ys)
+    assert np.allclose(p.sum(axis=1), 1.0)
+    # Reversed(LSTM): running the reverse net on the flipped line gives the flipped outputs
+    b = R.lstm_forward(m.rev, xs[::-1])[::-1]
+    assert np.array_equal(b, ys[:, 100:])
+    # the output peephole is skipped at t = 0
+    w = m.fwd
+    src = np.concatenate(([1.0], xs[0], np.zeros(100)))
+    gi = 1 / (1 + np.exp(-w["WGI"].dot(src))); ci = np.tanh(w["WCI"].dot(src))
+    go = 1 / (1 + np.exp(-w["WGO"].dot(src)))
+    assert np.allclose(ys[0, :100], np.tanh(ci * gi) * go)
+
+
+def test_llocs_wire_format():
+    m = R.synthetic_model(1, no=20)
+    xs = R.synthetic_line(3, width=50)
+    out = R.recognise(m, xs, raw_width=100)
+    txt = R.llocs_text(out["llocs"])
+    for line, (t, c) in zip(txt.splitlines(), out["decoded"]):
+        ch, x = line.split("\t") if "\t" in line else ("", line)
+        assert abs(float(x) - (t - 16) * 2.0) <= 0.05 + 1e-9

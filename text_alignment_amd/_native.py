@@ -45,13 +45,23 @@ def _load():
     lib.ta_nw_general_ptr_bytes.argtypes = [i32, i32]
     lib.ta_nw_general.restype = ctypes.c_int
     lib.ta_nw_general.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    f32 = ctypes.c_float
+    lib.ta_lstm_packed_weight_floats.restype = i32
+    lib.ta_lstm_packed_weight_floats.argtypes = []
+    lib.ta_lstm_forward.restype = ctypes.c_int
+    lib.ta_lstm_forward.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    lib.ta_lstm_output.restype = ctypes.c_int
+    lib.ta_lstm_output.argtypes = [vp, i64, vp, i32, vp, vp, vp]
+    lib.ta_decode.restype = ctypes.c_int
+    lib.ta_decode.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp]
     return lib
 
 
 lib = _load()
 
 EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch",
-           "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general"]
+           "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general",
+           "ta_lstm_packed_weight_floats", "ta_lstm_forward", "ta_lstm_output", "ta_decode"]
 
 
 def check(rc, what):

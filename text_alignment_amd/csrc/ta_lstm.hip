@@ -1,0 +1,381 @@
+// ta_lstm.hip -- the line recogniser `alignToOCR.py` obtains by shelling out to
+// `ocropus-rpred` (reference alignToOCR.py:142-147), on MI355X (gfx950).
+//
+// Arithmetic restated from ocropy 1.3.3 (third-party, not in the reference tree; SURVEY.md
+// Appendix B): 1-layer bidirectional peephole LSTM (ni = 48, ns = 100), softmax output layer,
+// threshold / arg-max decode.  Three kernels:
+//
+//  K3 lstm_seq_kernel   one workgroup (7 waves) per (group of 16 lines, direction).  The whole
+//                       weight matrix of a direction [4 gates x 100 units x 149 inputs] lives in
+//                       registers as f32 MFMA B-fragments (152 VGPRs per lane), the recurrent
+//                       input [1, x_t, h_{t-1}] of the 16 lines is the A operand, staged in a
+//                       double-buffered LDS tile; per timestep 38 k-steps x 4 gates of
+//                       v_mfma_f32_16x16x4_f32 per wave, the gate non-linearities on the
+//                       accumulator registers, one barrier.  f32 in / f32 accumulate (exact
+//                       fmaf chain), so logits stay within 1e-3 of the float64 restatement.
+//  K4 lstm_output_kernel  Y[rows x 200] . W2^T + bias as an MFMA GEMM with W2 resident in LDS,
+//                       fused clip(-100,100) + softmax on the accumulator tile.
+//  K5 decode_kernel     one wave per line: runs of P(blank) < threshold, first maximum of the
+//                       run over (t, class).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ta_common.h"
+
+namespace ta {
+
+constexpr int kNi = 48;            // input rows (normalised line height)
+constexpr int kNs = 100;           // LSTM states per direction
+constexpr int kLines = 16;         // lines per workgroup (MFMA M)
+constexpr int kWaves = 7;          // 7 x 16 = 112 >= 100 units
+constexpr int kXK = 52;            // [1, x(48), 3 zero pads]
+constexpr int kKP = kXK + kNs;     // 152 padded inputs
+constexpr int kKS = kKP / 4;       // 38 k-steps of 4
+constexpr int kKSP = 40;           // k-steps per LDS row, padded for 16-byte reads
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct LstmArgs {
+    const float* x;            // [rows][48]
+    const int64_t* row_off;    // per line: first row
+    const int32_t* T;          // per line: timesteps
+    const int32_t* group_lines;// [ngroups][16] line ids, -1 = empty slot
+    const float* wp;           // packed B fragments [2][7][4][38][64]
+    const float* peep;         // [2][3][112]
+    float* hout;               // [rows][200]
+};
+
+__device__ __forceinline__ float sigmoid_clip(float x) {       // 1/(1+exp(clip(-x,-20,20)))
+    const float z = fminf(fmaxf(-x, -20.0f), 20.0f);
+    return 1.0f / (1.0f + expf(z));
+}
+
+__global__ __launch_bounds__(kWaves * 64) void lstm_seq_kernel(LstmArgs a) {
+    __shared__ __attribute__((aligned(16))) float src[2][4][kLines][kKSP];
+    __shared__ int s_line[kLines];
+    __shared__ int s_T[kLines];
+    __shared__ long long s_row[kLines];
+
+    const int grp = blockIdx.x, dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    if (tid < kLines) {
+        const int id = a.group_lines[grp * kLines + tid];
+        s_line[tid] = id;
+        s_T[tid] = id >= 0 ? a.T[id] : 0;
+        s_row[tid] = id >= 0 ? a.row_off[id] : 0;
+    }
+    for (int e = tid; e < 2 * 4 * kLines * kKSP; e += kWaves * 64) (&src[0][0][0][0])[e] = 0.0f;
+    __syncthreads();
+    int Tmax = 0;
+#pragma unroll
+    for (int s = 0; s < kLines; ++s) Tmax = max(Tmax, s_T[s]);
+
+    // weights of this wave's 16 units: B fragments, constant over time
+    float Bf[4][kKS];
+    {
+        const float* wp = a.wp + ((size_t)(dir * kWaves + wave) * 4) * kKS * 64 + lane;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int kk = 0; kk < kKS; ++kk) Bf[g4][kk] = wp[((size_t)g4 * kKS + kk) * 64];
+    }
+    const int unit = wave * 16 + (lane & 15);
+    const float wip = a.peep[(dir * 3 + 0) * 112 + unit];
+    const float wfp = a.peep[(dir * 3 + 1) * 112 + unit];
+    const float wop = a.peep[(dir * 3 + 2) * 112 + unit];
+
+    // rows of the accumulator tile this lane owns: slot = (lane>>4)*4 + r
+    int myT[4];
+    long long myrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int slot = (lane >> 4) * 4 + r;
+        myT[r] = s_T[slot];
+        myrow[r] = s_row[slot];
+    }
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // loader role: element e -> (slot, kp) of the x part [16][52]
+    constexpr int kXE = kLines * kXK;                      // 832
+    auto x_value = [&](int e, int t) -> float {
+        const int slot = e / kXK, kp = e % kXK;
+        if (kp == 0) return 1.0f;
+        if (kp > kNi) return 0.0f;
+        const int Tl = s_T[slot];
+        if (Tl <= 0) return 0.0f;
+        int tt = t < Tl ? t : Tl - 1;
+        if (dir) tt = Tl - 1 - tt;                          // Reversed(LSTM): run on xs[::-1]
+        return a.x[(s_row[slot] + tt) * kNi + (kp - 1)];
+    };
+    auto x_store = [&](int e, int buf, float v) {
+        const int slot = e / kXK, kp = e % kXK;
+        src[buf][kp & 3][slot][kp >> 2] = v;
+    };
+    {
+        for (int e = tid; e < kXE; e += kWaves * 64) x_store(e, 0, x_value(e, 0));
+    }
+    __syncthreads();
+
+    const int e0 = tid, e1 = tid + kWaves * 64;            // 448 + 448 >= 832
+    for (int t = 0; t < Tmax; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        // prefetch next step's inputs (global loads fly under the MFMAs)
+        float xn0 = 0.f, xn1 = 0.f;
+        if (t + 1 < Tmax) {
+            xn0 = x_value(e0, t + 1);
+            if (e1 < kXE) xn1 = x_value(e1, t + 1);
+        }
+        // A fragments: src[cur][k = lane>>4][line = lane&15][kk]
+        float A[kKSP];
+        {
+            const f32x4* ap = reinterpret_cast<const f32x4*>(&src[cur][lane >> 4][lane & 15][0]);
+#pragma unroll
+            for (int q = 0; q < kKSP / 4; ++q) {
+                const f32x4 v = ap[q];
+                A[4 * q] = v[0]; A[4 * q + 1] = v[1]; A[4 * q + 2] = v[2]; A[4 * q + 3] = v[3];
+            }
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) acc[g4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < kKS; ++kk) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+                acc[g4] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], Bf[g4][kk], acc[g4], 0, 0, 0);
+        }
+        // gates: acc[0..3] = WGI, WGF, WGO, WCI . src
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float gi = acc[0][r], gf = acc[1][r], go = acc[2][r];
+            const float ci = tanhf(acc[3][r]);
+            if (t > 0) { gi += wip * c[r]; gf += wfp * c[r]; }
+            gi = sigmoid_clip(gi);
+            gf = sigmoid_clip(gf);
+            float cn = ci * gi;
+            if (t > 0) { cn += gf * c[r]; go += wop * cn; }      // output peephole skipped at t = 0
+            go = sigmoid_clip(go);
+            const float h = tanhf(cn) * go;
+            c[r] = cn;
+            if (unit < kNs) {
+                const int slot = (lane >> 4) * 4 + r;
+                const int kp = kXK + unit;
+                src[nxt][kp & 3][slot][kp >> 2] = h;
+                if (t < myT[r]) {
+                    const int tt = dir ? myT[r] - 1 - t : t;
+                    a.hout[(myrow[r] + tt) * (2 * kNs) + dir * kNs + unit] = h;
+                }
+            }
+        }
+        if (t + 1 < Tmax) {
+            x_store(e0, nxt, xn0);
+            if (e1 < kXE) x_store(e1, nxt, xn1);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: z = W2 . [1, y_t]  (No x 201), p = softmax(clip(z, -100, 100))   (Appendix B.4)
+constexpr int kOK = 204;           // 1 + 200 + 3 pads
+constexpr int kOKS = kOK / 4;      // 51 k-steps
+constexpr int kOWaves = 4;
+constexpr int kMaxCT = 8;          // up to 128 classes
+
+struct OutArgs {
+    const float* y;        // [rows][200]
+    int64_t rows;
+    const float* w2p;      // [51][4][NoP]  (kp-major, classes padded to NoP = 16*nct, zero filled)
+    int no, nct;
+    float* probs;          // [rows][no]
+    float* logits;         // optional [rows][no]
+};
+
+__global__ __launch_bounds__(kOWaves * 64) void lstm_output_kernel(OutArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float osm[];
+    const int nop = a.nct * 16;
+    float* w2 = osm;                                        // [204][nop]
+    float* ytile = osm + (size_t)kOK * nop;                 // [4 waves][16][204]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < kOK * nop; e += kOWaves * 64) w2[e] = a.w2p[e];
+    float* yt = ytile + (size_t)wave * 16 * kOK;
+    __syncthreads();
+
+    const int64_t ntiles = (a.rows + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * kOWaves + wave; tile < ntiles;
+         tile += (int64_t)gridDim.x * kOWaves) {
+        const int64_t r0 = tile * 16;
+        // stage [16][204] = [1, y(200), 0, 0, 0] per row, coalesced along the row
+        for (int e = lane; e < 16 * kOK; e += 64) {
+            const int rr = e / kOK, kp = e % kOK;
+            float v = 0.f;
+            if (kp == 0) v = 1.f;
+            else if (kp <= 200 && r0 + rr < a.rows) v = a.y[(r0 + rr) * 200 + (kp - 1)];
+            yt[rr * kOK + kp] = v;
+        }
+        // (a wave's LDS instructions execute in order: its reads below see these writes)
+        f32x4 acc[kMaxCT];
+#pragma unroll
+        for (int ct = 0; ct < kMaxCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 3
+        for (int kk = 0; kk < kOKS; ++kk) {
+            const float av = yt[(lane & 15) * kOK + 4 * kk + (lane >> 4)];
+            const float* bp = w2 + (size_t)(4 * kk + (lane >> 4)) * nop + (lane & 15);
+#pragma unroll
+            for (int ct = 0; ct < kMaxCT; ++ct)
+                if (ct < a.nct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[ct * 16], acc[ct], 0, 0, 0);
+        }
+        // rows (lane>>4)*4 + r, classes ct*16 + (lane&15)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = r0 + (lane >> 4) * 4 + r;
+            float zmax = -3.0e38f;
+#pragma unroll
+            for (int ct = 0; ct < kMaxCT; ++ct) {
+                const int cls = ct * 16 + (lane & 15);
+                if (ct < a.nct && cls < a.no) {
+                    if (a.logits && row < a.rows) a.logits[row * a.no + cls] = acc[ct][r];
+                    const float z = fminf(fmaxf(acc[ct][r], -100.f), 100.f);
+                    acc[ct][r] = z;
+                    zmax = fmaxf(zmax, z);
+                }
+            }
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, d, 16));
+            float sum = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < kMaxCT; ++ct) {
+                const int cls = ct * 16 + (lane & 15);
+                if (ct < a.nct && cls < a.no) {
+                    const float e = __expf(acc[ct][r] - zmax);
+                    acc[ct][r] = e;
+                    sum += e;
+                }
+            }
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d, 16);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int ct = 0; ct < kMaxCT; ++ct) {
+                const int cls = ct * 16 + (lane & 15);
+                if (ct < a.nct && cls < a.no && row < a.rows) a.probs[row * a.no + cls] = acc[ct][r] * inv;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: translate_back(outputs, threshold) (Appendix B.5).  One wave per line.
+struct DecArgs {
+    const float* probs; const int64_t* row_off; const int32_t* T; int nlines, no;
+    float threshold;
+    int32_t* dec_t; int32_t* dec_c; int32_t* dec_n; const int64_t* dec_off;
+};
+
+__global__ __launch_bounds__(64) void decode_kernel(DecArgs a) {
+    const int line = blockIdx.x, lane = threadIdx.x;
+    const int T = a.T[line];
+    const float* p = a.probs + a.row_off[line] * a.no;
+    int32_t* out_t = a.dec_t + a.dec_off[line];
+    int32_t* out_c = a.dec_c + a.dec_off[line];
+    int n = 0;
+    bool in_run = false;
+    unsigned long long best = 0ull;
+    int best_t = 0;
+    for (int t = 0; t < T; ++t) {
+        const float* row = p + (size_t)t * a.no;
+        const float p0 = row[0];
+        // per-lane best over classes lane, lane+64: larger p wins, then the smaller class
+        unsigned long long key = 0ull;
+        for (int cls = lane; cls < a.no; cls += 64) {
+            const unsigned long long k =
+                ((unsigned long long)__float_as_uint(row[cls]) << 32) | (unsigned)(0xFFFFFFFFu - cls);
+            key = k > key ? k : key;
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned lo = __shfl_xor((unsigned)key, d, 64);
+            const unsigned hi = __shfl_xor((unsigned)(key >> 32), d, 64);
+            const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+            key = other > key ? other : key;
+        }
+        if (p0 < a.threshold) {
+            if (!in_run) { in_run = true; best = 0ull; best_t = t; }
+            if (key > best) { best = key; best_t = t; }       // strictly greater: earlier t wins ties
+        } else if (in_run) {
+            if (lane == 0) { out_t[n] = best_t; out_c[n] = (int)(0xFFFFFFFFu - (unsigned)best); }
+            ++n;
+            in_run = false;
+        }
+    }
+    if (in_run) {
+        if (lane == 0) { out_t[n] = best_t; out_c[n] = (int)(0xFFFFFFFFu - (unsigned)best); }
+        ++n;
+    }
+    if (lane == 0) a.dec_n[line] = n;
+}
+
+}  // namespace ta
+
+using namespace ta;
+
+extern "C" int32_t ta_lstm_packed_weight_floats(void) { return 2 * kWaves * 4 * kKS * 64; }
+
+extern "C" int ta_lstm_forward(const float* x, const int64_t* row_off, const int32_t* T,
+                               const int32_t* group_lines, int32_t ngroups,
+                               const float* wp, const float* peep, float* hout, void* stream) {
+    if (ngroups < 0) return ta_fail(TA_EINVAL, "negative group count");
+    if (ngroups == 0) return TA_OK;
+    if (!x || !row_off || !T || !group_lines || !wp || !peep || !hout)
+        return ta_fail(TA_EINVAL, "null pointer argument");
+    LstmArgs a{x, row_off, T, group_lines, wp, peep, hout};
+    hipLaunchKernelGGL(lstm_seq_kernel, dim3(ngroups, 2), dim3(kWaves * 64), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ta_fail_hip(e, "lstm_seq_kernel launch");
+    return TA_OK;
+}
+
+extern "C" int ta_lstm_output(const float* y, int64_t rows, const float* w2p, int32_t no,
+                              float* probs, float* logits, void* stream) {
+    if (rows < 0 || no <= 0 || no > 16 * kMaxCT) return ta_fail(TA_EINVAL, "bad rows / class count");
+    if (rows == 0) return TA_OK;
+    if (!y || !w2p || !probs) return ta_fail(TA_EINVAL, "null pointer argument");
+    const int nct = (no + 15) / 16;
+    OutArgs a{y, rows, w2p, no, nct, probs, logits};
+    const size_t lds = ((size_t)kOK * nct * 16 + (size_t)kOWaves * 16 * kOK) * sizeof(float);
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_output_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return ta_fail_hip(e, "hipFuncSetAttribute");
+        raised = true;
+    }
+    const int64_t ntiles = (rows + 15) / 16;
+    const int grid = (int)((ntiles + kOWaves - 1) / kOWaves < 512 ? (ntiles + kOWaves - 1) / kOWaves : 512);
+    hipLaunchKernelGGL(lstm_output_kernel, dim3(grid), dim3(kOWaves * 64), lds,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ta_fail_hip(e, "lstm_output_kernel launch");
+    return TA_OK;
+}
+
+extern "C" int ta_decode(const float* probs, const int64_t* row_off, const int32_t* T,
+                         int32_t nlines, int32_t no, float threshold,
+                         int32_t* dec_t, int32_t* dec_c, int32_t* dec_n, const int64_t* dec_off,
+                         void* stream) {
+    if (nlines < 0 || no <= 0) return ta_fail(TA_EINVAL, "bad line / class count");
+    if (nlines == 0) return TA_OK;
+    if (!probs || !row_off || !T || !dec_t || !dec_c || !dec_n || !dec_off)
+        return ta_fail(TA_EINVAL, "null pointer argument");
+    DecArgs a{probs, row_off, T, nlines, no, threshold, dec_t, dec_c, dec_n, dec_off};
+    hipLaunchKernelGGL(decode_kernel, dim3(nlines), dim3(64), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ta_fail_hip(e, "decode_kernel launch");
+    return TA_OK;
+}

@@ -1,0 +1,190 @@
+"""Line recogniser on MI355X -- the in-process replacement of the `ocropus-rpred` subprocess
+that the reference shells out to (reference alignToOCR.py:142-147).
+
+The network is ocropy 1.3.3's line model (third-party):
+Stacked([Parallel(LSTM(48,100), Reversed(LSTM(48,100))), Softmax(200, No)]) followed by
+translate_back(threshold 0.7).  `LineRecognizer` packs a model's weights into the MFMA fragment
+layout of csrc/ta_lstm.hip once, then recognises any number of prepared text lines per call:
+lines are sorted by length, grouped 16 to a workgroup, and run through K3 (BiLSTM), K4
+(output layer + softmax) and K5 (decode) behind the C ABI (`ta_lstm_forward`,
+`ta_lstm_output`, `ta_decode`).
+"""
+import numpy as np
+import torch
+
+from . import _native
+
+NI = 48
+NS = 100
+MAX_T = 5000            # ocropy preallocates 5000 timesteps ("input too large for LSTM model")
+THRESHOLD = 0.7         # translate_back default
+PAD = 16                # prepare_line pad
+
+
+class RecognitionError(Exception):
+    pass
+
+
+class LineModel(object):
+    """Weights of one line-recognition model.
+
+    fwd / rev: dicts with WGI, WGF, WGO, WCI (ns x (1+ni+ns)) and WIP, WFP, WOP (ns);
+    W2: (no, 1 + 2*ns); codec: list of `no` strings (class 0 = "", 1 = " ", 2 = "~").
+    """
+
+    def __init__(self, fwd, rev, W2, codec, ni=NI, ns=NS):
+        self.ni, self.ns = ni, ns
+        self.fwd, self.rev = fwd, rev
+        self.W2 = np.asarray(W2)
+        self.no = int(self.W2.shape[0])
+        self.codec = list(codec)
+        if ni != NI or ns != NS:
+            raise ValueError("the HIP kernels are built for ni=48, ns=100 line models")
+        if self.W2.shape[1] != 1 + 2 * ns or len(self.codec) != self.no:
+            raise ValueError("inconsistent output layer / codec sizes")
+
+    @classmethod
+    def random(cls, seed, no=96):
+        """Random-init weights of the architecture (for benchmarks: the trained model files of
+        the reference are absent, .MISSING_LARGE_BLOBS:1-2)."""
+        rng = np.random.default_rng(seed)
+        na = 1 + NI + NS
+
+        def lstm():
+            d = {}
+            for k in ("WGI", "WGF", "WGO", "WCI"):
+                d[k] = rng.uniform(-0.5, 0.5, size=(NS, na))
+            for k in ("WIP", "WFP", "WOP"):
+                d[k] = rng.uniform(-0.5, 0.5, size=(NS,))
+            return d
+        fwd, rev = lstm(), lstm()
+        W2 = rng.uniform(-1.0, 1.0, size=(no, 1 + 2 * NS))
+        codec = ["", " ", "~"] + [chr(ord('a') + (k % 26)) for k in range(no - 3)]
+        return cls(fwd, rev, W2, codec)
+
+
+def _pack_lstm(model):
+    nfl = _native.lib.ta_lstm_packed_weight_floats()
+    wp = np.zeros((2, 7, 4, 38, 64), dtype=np.float32)
+    assert wp.size == nfl
+    peep = np.zeros((2, 3, 112), dtype=np.float32)
+    lane = np.arange(64)
+    for d, w in enumerate((model.fwd, model.rev)):
+        for g, name in enumerate(("WGI", "WGF", "WGO", "WCI")):
+            W = np.asarray(w[name], dtype=np.float64)
+            Wp = np.zeros((112, 152), dtype=np.float64)
+            Wp[:NS, 0:1 + NI] = W[:, 0:1 + NI]            # bias + x
+            Wp[:NS, 52:152] = W[:, 1 + NI:]               # h
+            for wv in range(7):
+                for kk in range(38):
+                    wp[d, wv, g, kk, :] = Wp[16 * wv + (lane & 15), 4 * kk + (lane >> 4)]
+        for q, name in enumerate(("WIP", "WFP", "WOP")):
+            peep[d, q, :NS] = np.asarray(w[name], dtype=np.float64)
+    nct = (model.no + 15) // 16
+    w2p = np.zeros((204, nct * 16), dtype=np.float32)
+    w2p[0:201, :model.no] = np.asarray(model.W2, dtype=np.float64).T
+    return wp, peep, w2p
+
+
+class LineRecognizer(object):
+    def __init__(self, model, device="cuda"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("text_alignment_amd needs an AMD GPU (MI355X); there is no CPU fallback")
+        self.model = model
+        self.device = torch.device(device)
+        wp, peep, w2p = _pack_lstm(model)
+        self.wp = torch.from_numpy(wp).to(self.device)
+        self.peep = torch.from_numpy(peep).to(self.device)
+        self.w2p = torch.from_numpy(w2p).to(self.device)
+
+    # ---- batched device pass -------------------------------------------------------------
+    def prepare(self, lines):
+        """Upload prepared lines ((T, 48) arrays, ink = 1) and allocate outputs."""
+        T = np.array([ln.shape[0] for ln in lines], dtype=np.int64)
+        if len(lines) and T.max() > MAX_T:
+            raise RecognitionError("input too large for LSTM model")
+        for ln in lines:
+            if ln.ndim != 2 or ln.shape[1] != NI:
+                raise ValueError("a prepared line must have shape (T, 48)")
+        order = np.argsort(-T, kind="stable")
+        ngroups = (len(lines) + 15) // 16
+        group_lines = np.full((max(ngroups, 1), 16), -1, dtype=np.int32)
+        group_lines.reshape(-1)[:len(lines)] = order
+        row_off = np.zeros(len(lines) + 1, dtype=np.int64)
+        np.cumsum(T, out=row_off[1:])
+        rows = int(row_off[-1])
+        x = np.concatenate(lines, axis=0).astype(np.float32) if rows else np.zeros((1, NI), np.float32)
+        st = {"n": len(lines), "rows": rows, "T_host": T, "row_off_host": row_off, "ngroups": ngroups}
+        dev = self.device
+        st["x"] = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        st["row_off"] = torch.from_numpy(row_off[:-1].copy() if len(lines) else row_off).to(dev)
+        st["T"] = torch.from_numpy(T.astype(np.int32) if len(lines) else np.zeros(1, np.int32)).to(dev)
+        st["group_lines"] = torch.from_numpy(group_lines).to(dev)
+        st["hout"] = torch.empty((max(rows, 1), 2 * NS), dtype=torch.float32, device=dev)
+        st["probs"] = torch.empty((max(rows, 1), self.model.no), dtype=torch.float32, device=dev)
+        st["logits"] = None
+        st["dec_t"] = torch.zeros(max(rows, 1), dtype=torch.int32, device=dev)
+        st["dec_c"] = torch.zeros(max(rows, 1), dtype=torch.int32, device=dev)
+        st["dec_n"] = torch.zeros(max(len(lines), 1), dtype=torch.int32, device=dev)
+        return st
+
+    def run(self, st, want_logits=False, lstm=True, output=True, decode=True):
+        """Enqueue K3, K4, K5 on torch's current stream."""
+        if st["n"] == 0:
+            return
+        lib = _native.lib
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if lstm:
+            _native.check(lib.ta_lstm_forward(
+                st["x"].data_ptr(), st["row_off"].data_ptr(), st["T"].data_ptr(),
+                st["group_lines"].data_ptr(), st["ngroups"], self.wp.data_ptr(),
+                self.peep.data_ptr(), st["hout"].data_ptr(), stream), "ta_lstm_forward")
+        if output:
+            if want_logits and st["logits"] is None:
+                st["logits"] = torch.empty_like(st["probs"])
+            _native.check(lib.ta_lstm_output(
+                st["hout"].data_ptr(), st["rows"], self.w2p.data_ptr(), self.model.no,
+                st["probs"].data_ptr(), st["logits"].data_ptr() if want_logits else None, stream),
+                "ta_lstm_output")
+        if decode:
+            _native.check(lib.ta_decode(
+                st["probs"].data_ptr(), st["row_off"].data_ptr(), st["T"].data_ptr(), st["n"],
+                self.model.no, THRESHOLD, st["dec_t"].data_ptr(), st["dec_c"].data_ptr(),
+                st["dec_n"].data_ptr(), st["row_off"].data_ptr(), stream), "ta_decode")
+
+    def decoded(self, st):
+        """Host lists [(t, class), ...] per line (translate_back order)."""
+        if st["n"] == 0:
+            return []
+        dt = st["dec_t"].cpu().numpy()
+        dc = st["dec_c"].cpu().numpy()
+        dn = st["dec_n"].cpu().numpy()
+        out = []
+        for b in range(st["n"]):
+            o = int(st["row_off_host"][b])
+            k = int(dn[b])
+            out.append([(int(dt[o + i]), int(dc[o + i])) for i in range(k)])
+        return out
+
+    def recognise(self, lines, want_probs=False):
+        st = self.prepare(lines)
+        self.run(st, want_logits=want_probs)
+        dec = self.decoded(st)
+        if not want_probs:
+            return dec
+        probs = st["probs"].cpu().numpy()
+        logits = st["logits"].cpu().numpy()
+        states = st["hout"].cpu().numpy()
+        sl = [slice(int(st["row_off_host"][b]), int(st["row_off_host"][b + 1])) for b in range(st["n"])]
+        return dec, [probs[s] for s in sl], [logits[s] for s in sl], [states[s] for s in sl]
+
+    # ---- wire format ------------------------------------------------------------------------
+    def llocs(self, decoded, T, raw_width):
+        """(char, x) pairs of ocropus-rpred's --llocs output for one line: x in raw strip pixels
+        from the strip's left edge (parsed at reference alignToOCR.py:157-170)."""
+        scale = float(raw_width) / (T - 2 * PAD)
+        return [(self.model.codec[c], (t - PAD) * scale) for (t, c) in decoded]
+
+
+def llocs_text(llocs):
+    return "".join("%s\t%.1f\n" % (ch, x) for ch, x in llocs)
