@@ -1,0 +1,113 @@
+"""Host-side glue of the page driver against golden vectors captured from the reference's
+alignToOCR.process / to_JSON_dict / rotate_bbox and latinSyllabification (tools/gen_golden.py).
+The NW step inside process() needs the GPU, so the end-to-end cases are marked gpu; the pure
+host pieces run everywhere."""
+import json
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+
+def test_syllabifier_golden():
+    from text_alignment_amd import latinSyllabification as ls
+    g = load_golden("glue.json")
+    assert ls.syllabify_text(g["syllabify_demo"]["inp"]) == g["syllabify_demo"]["syls"]
+    for c in g["syllabify_cases"]:
+        assert ls.syllabify_text(c["inp"]) == c["syls"], c
+    for c in g["syllabify_words"]:
+        assert ls.syllabify_word(c["inp"]) == c["syls"], c
+    assert list(ls.abbreviations.items()) == list(g["abbreviations"].items())
+
+
+def test_syllabifier_vowelless_words_terminate():
+    from text_alignment_amd import latinSyllabification as ls
+    for w in ("b", "dns", "st", "x1", "qu"):
+        assert ls.syllabify_word(w) == [w]          # the reference never returns on these
+    assert ls.syllabify_text("dns meus") == ["dns", "me", "us"]
+
+
+def test_rotate_bbox_golden():
+    from text_alignment_amd import alignToOCR as atocr
+    from text_alignment_amd.page import Dim
+    for c in load_golden("glue.json")["rotate_cases"]:
+        r = atocr.rotate_bbox(atocr.CharBox('x', c["ul"], c["lr"]), c["angle"],
+                              Dim(*c["orig_dim"]), Dim(*c["target_dim"]))
+        assert [int(r.ul[0]), int(r.ul[1])] == c["out_ul"] and [int(r.lr[0]), int(r.lr[1])] == c["out_lr"], c
+
+
+def test_rotate_bbox_floor_division_on_odd_sizes():
+    # Python-2 semantics of the reference (alignToOCR.py:91,95-96): floor division
+    from text_alignment_amd import alignToOCR as atocr
+    from text_alignment_amd.page import Dim
+    r = atocr.rotate_bbox(atocr.CharBox('x', (10, 10), (20, 20)), 0, Dim(1001, 801), Dim(1000, 800))
+    assert (int(r.ul[0]), int(r.ul[1])) == (10, 10)      # dx = dy = 0 under floor division
+    r = atocr.rotate_bbox(atocr.CharBox('x', (10, 10), (20, 20)), 0, Dim(1000, 800), Dim(1003, 801))
+    assert (int(r.ul[0]), int(r.ul[1])) == (12, 11)      # (1000-1003)//2 = -2, (800-801)//2 = -1
+
+
+def test_charbox_and_helpers(tmp_path):
+    from text_alignment_amd import alignToOCR as atocr
+    b = atocr.CharBox('a', (1, 2), (4, 8))
+    assert (b.ulx, b.uly, b.lrx, b.lry, b.width, b.height) == (1, 2, 4, 8, 3, 6)
+    assert repr(b) == 'a: (1, 2), (4, 8)'
+    gap = atocr.CharBox('_')
+    assert gap.ul is None and gap.lr is None and repr(gap) == '_: empty' and not hasattr(gap, 'ulx')
+    b2, g2 = pickle.loads(pickle.dumps([b, gap], -1))
+    assert b2.lr == (4, 8) and g2.ul is None
+    assert atocr.clean_special_chars('a~b~') == 'ab'
+    f = tmp_path / "t.txt"
+    f.write_text("# comment\ndominus dixit | \nad me\r\n")
+    assert atocr.read_file(str(f)) == "dominus dixit  ad me"
+    assert atocr.parallel == 2 and atocr.median_line_mult == 2
+
+
+def test_chars_from_llocs_half_to_even_and_rejects():
+    from text_alignment_amd import alignToOCR as atocr
+    out = []
+    atocr.chars_from_llocs([('a', 10.46), ('~', 20.0), ('', 25.0), ('b', 30.5), ('c', 31.5)], 100, 7, 47, out)
+    assert [(c.char, c.ul, c.lr) for c in out] == [
+        ('a', (100, 7), (110, 47)),          # 10.46 -> "10.5" -> 110.5 rounds half-to-even to 110
+        ('b', (125, 7), (130, 47)),          # '~' and '' advance the left edge but are dropped
+        ('c', (130, 7), (132, 47))]
+
+
+def test_to_json_dict_quantile():
+    from text_alignment_amd import alignToOCR as atocr
+    d = atocr.to_JSON_dict([atocr.CharBox('do', (50, 90), (68, 130))], [100, 220, 340, 470])
+    assert d == {'median_line_spacing': 125.0, 'syl_boxes': [{'syl': 'do', 'ul': [50, 90], 'lr': [68, 130]}]}
+    json.dumps({'syl_boxes': d['syl_boxes'], 'median_line_spacing': float(d['median_line_spacing'])})
+
+
+def test_expand_abbreviations_golden_strings():
+    from text_alignment_amd import alignToOCR as atocr
+    for c in load_golden("glue.json")["process_cases"]:
+        chars = [atocr.CharBox(ch, ul, lr) for ch, ul, lr in c["chars"]]
+        out = atocr.expand_abbreviations(chars)
+        assert ''.join(x.char for x in out) == c["expanded_ocr"], c["name"]
+
+
+@pytest.mark.gpu
+def test_process_golden_end_to_end():
+    """process() -> to_JSON_dict() with the OCR characters canned (as in the golden capture):
+    exercises abbreviation expansion, the HIP aligner, gap insertion, syllable grouping, rotation
+    and the JSON layout against the reference's own output."""
+    from text_alignment_amd import alignToOCR as atocr
+    from text_alignment_amd.page import PreparedPage
+    g = load_golden("glue.json")
+    for c in g["process_cases"]:
+        chars = [atocr.CharBox(ch, ul, lr) for ch, ul, lr in c["chars"]]
+        page = PreparedPage(c["img_dim"], c["raw_dim"], c["angle"], [], c["peak_locs"])
+        saved = atocr.perform_ocr_with_ocropus
+        atocr.perform_ocr_with_ocropus = lambda strips, model, wkdir_name=None, parallel=2: list(chars)
+        try:
+            res = atocr.process(page, c["transcript"], None, seq_align_params=c["params"])
+        finally:
+            atocr.perform_ocr_with_ocropus = saved
+        syl_boxes, image, peaks, all_chars = res
+        js = atocr.to_JSON_dict(syl_boxes, peaks)
+        js["median_line_spacing"] = float(js["median_line_spacing"])
+        assert js == c["json"], c["name"]
+        assert ''.join(x.char for x in all_chars) == c["expanded_ocr"]

@@ -1,0 +1,89 @@
+"""Row N1: .pyrnn.gz loader and line normaliser -- CPU tests.  The
+model files of the reference are absent, so the loader is exercised on a pickle this test writes
+itself with stand-in classes named like ocrolib's (protocol 2, gzip)."""
+import gzip
+import pickle
+import sys
+import types
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+
+def _write_fake_pyrnn(path, module_name="ocrolib.lstm"):
+    mod = types.ModuleType(module_name)
+    names = ["SeqRecognizer", "Stacked", "Parallel", "Reversed", "LSTM", "Softmax", "Codec"]
+    cls = {}
+    for n in names:
+        cls[n] = type(n, (object,), {"__module__": module_name})
+        setattr(mod, n, cls[n])
+    sys.modules[module_name] = mod
+    pkg = module_name.split(".")[0]
+    if "." in module_name:
+        parent = types.ModuleType(pkg)
+        parent.__path__ = []
+        setattr(parent, module_name.split(".")[1], mod)
+        sys.modules[pkg] = parent
+    rng = np.random.default_rng(3)
+
+    def lstm():
+        o = cls["LSTM"]()
+        for k in ("WGI", "WGF", "WGO", "WCI"):
+            setattr(o, k, rng.uniform(-0.5, 0.5, size=(100, 149)))
+        for k in ("WIP", "WFP", "WOP"):
+            setattr(o, k, rng.uniform(-0.5, 0.5, size=(100,)))
+        o.dims = (48, 100)
+        return o
+    f, r = lstm(), lstm()
+    rev = cls["Reversed"](); rev.net = r
+    par = cls["Parallel"](); par.nets = [f, rev]
+    sm = cls["Softmax"](); sm.W2 = rng.uniform(-1, 1, size=(7, 201))
+    st = cls["Stacked"](); st.nets = [par, sm]
+    codec = cls["Codec"](); codec.code2char = {0: u"", 1: u" ", 2: u"~", 3: u"a", 4: u"b", 5: u"ā"}
+    rec = cls["SeqRecognizer"](); rec.lstm = st; rec.codec = codec; rec.Ni, rec.Ns, rec.No = 48, 100, 7
+    try:
+        with gzip.open(path, "wb") as fh:
+            pickle.dump(rec, fh, protocol=2)
+    finally:
+        del sys.modules[module_name]
+        if "." in module_name:
+            sys.modules.pop(pkg, None)
+    return f, r, sm.W2
+
+
+@pytest.mark.parametrize("module_name", ["ocrolib.lstm", "lstm.lstm"])
+def test_load_pyrnn_roundtrip(tmp_path, module_name):
+    from text_alignment_amd import model_io
+    path = str(tmp_path / "m.pyrnn.gz")
+    f, r, W2 = _write_fake_pyrnn(path, module_name)
+    m = model_io.load_pyrnn(path)
+    assert m.no == 7 and m.codec == ["", " ", "~", "a", "b", u"ā", "~"]
+    assert np.array_equal(m.fwd["WGI"], f.WGI) and np.array_equal(m.rev["WOP"], r.WOP)
+    assert np.array_equal(m.W2, W2)
+
+
+def test_restricted_unpickler_rejects_other_globals(tmp_path):
+    from text_alignment_amd import model_io
+    path = str(tmp_path / "evil.pyrnn.gz")
+    with gzip.open(path, "wb") as fh:
+        pickle.dump(print, fh, protocol=2)            # any global outside the allow-list
+    with pytest.raises(pickle.UnpicklingError):
+        model_io.load_pyrnn(path)
+
+
+def test_line_normaliser_shapes_and_polarity():
+    from text_alignment_amd import lineest
+    rng = np.random.default_rng(0)
+    img = np.ones((70, 300))                           # white page, a dark band of "text"
+    band = rng.random((24, 300)) < 0.4
+    img[22:46][band] = 0.0
+    xs = lineest.prepare_raw_strip((img * 255).astype(np.uint8))
+    assert xs.shape[1] == 48 and xs.shape[0] > 32
+    assert (xs[:16] == 0).all() and (xs[-16:] == 0).all()
+    assert 0.0 <= xs.min() and xs.max() <= 1.0 + 1e-6
+    core = xs[16:-16]
+    assert core[:, 12:36].mean() > 4 * max(core[:, :6].mean(), 1e-3)      # ink sits in the middle rows
+    with pytest.raises(ValueError):
+        lineest.prepare_raw_strip(np.full((40, 100), 255, np.uint8))

@@ -1,0 +1,81 @@
+"""End-to-end page test (BASELINE.json configs[2] shape: ~30 line strips + one NW alignment):
+process() with BOTH kernels live, against the same pipeline driven by the CPU oracles
+(float64 OCR restatement + C NW restatement) through the reference-pinned glue."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+VOCAB = ("dominus deus meus alleluia gloria patri et filio spiritui sancto sicut erat in principio "
+         "nunc semper saecula saeculorum amen laudate eum omnes gentes quoniam confirmata est "
+         "super nos misericordia eius veritas manet aeternum").split()
+
+
+def _page(seed, nlines, R, page_mod):
+    rng = np.random.default_rng(seed)
+    strips = []
+    for k in range(nlines):
+        w = int(rng.integers(150, 420))
+        xs = R.synthetic_line(seed * 1000 + k, width=w)
+        strips.append(page_mod.Strip(offset_x=40 + int(rng.integers(0, 30)), offset_y=100 + 120 * k,
+                                     height=60, width=2 * w, prepared=xs))
+    peaks = [130 + 120 * k for k in range(nlines + 1)]
+    transcript = " ".join(VOCAB[int(i)] for i in rng.integers(0, len(VOCAB), size=6 * nlines))
+    return page_mod.PreparedPage((2200, 3300), (2200, 3300), 0, strips, peaks), transcript
+
+
+def _expected(page, transcript, om, R, atocr, nw_oracle, params=None):
+    chars = []
+    for s in page.strips:
+        ref = R.recognise(om, s.prepared, raw_width=s.width)
+        atocr.chars_from_llocs(ref["llocs"], s.offset_x, s.offset_y, s.offset_y + s.height, chars)
+    expanded = atocr.expand_abbreviations(list(chars))
+    ocr = [c.char for c in expanded]
+    alignment = nw_oracle.perform_alignment(list(transcript), ocr, params)
+    boxes, _ = atocr.align_page(transcript, chars, page.angle, page.image.dim, page.dim, params,
+                                alignment=alignment)
+    return atocr.to_JSON_dict(boxes, page.lines_peak_locs), "".join(ocr)
+
+
+def test_single_page_process_matches_oracle_pipeline():
+    from oracle import nw_oracle, ocr_ref_f64 as R
+    from text_alignment_amd import alignToOCR as atocr, ocr, page as page_mod
+    om = R.synthetic_model(7001, no=40)             # small class count: mostly letters come out
+    om.W2[0, 0] += 4.0                              # favour blanks -> many short runs -> many characters
+    pm = ocr.LineModel(om.fwd, om.rev, om.W2, om.codec)
+    pg, transcript = _page(3, 30, R, page_mod)
+    params = [8, -1, -9, -9, -4, -4]     # cheap mismatches: the random model's text pairs up with the transcript
+    res = atocr.process(pg, transcript, pm, seq_align_params=params)
+    assert res is not None
+    syl_boxes, image, peaks, all_chars = res
+    got = atocr.to_JSON_dict(syl_boxes, peaks)
+    want, want_ocr = _expected(pg, transcript, om, R, atocr, nw_oracle, params)
+    assert "".join(c.char for c in all_chars) == want_ocr
+    assert got == want
+    assert len(got["syl_boxes"]) > 50
+
+
+def test_process_batch_equals_process_and_sharded_driver():
+    from oracle import ocr_ref_f64 as R
+    from text_alignment_amd import alignToOCR as atocr, ocr, page as page_mod, sharding
+    om = R.synthetic_model(7002, no=40)
+    om.W2[0, 0] += 4.0
+    rec = ocr.LineRecognizer(ocr.LineModel(om.fwd, om.rev, om.W2, om.codec))
+    pages, trs = zip(*[_page(10 + k, 4 + 3 * k, R, page_mod) for k in range(4)])
+    params = [10, -5, -7, -7]
+    single = [atocr.to_JSON_dict(*(atocr.process(p, t, rec, seq_align_params=params)[i] for i in (0, 2)))
+              for p, t in zip(pages, trs)]
+    batch = atocr.process_batch(list(pages), list(trs), rec, seq_align_params=params)
+    assert [atocr.to_JSON_dict(b[0], b[2]) for b in batch] == single
+    out = sharding.process_pages(list(pages), list(trs), rec, seq_align_params=params)   # world size 1
+    assert [out[k] for k in range(4)] == single
+
+
+def test_ocr_failure_returns_none(capsys):
+    from text_alignment_amd import alignToOCR as atocr, ocr, page as page_mod
+    pm = ocr.LineModel.random(1, no=20)
+    strip = page_mod.Strip(0, 0, 60, width=100, prepared=np.zeros((5200, 48)))    # too long for the LSTM
+    pg = page_mod.PreparedPage((1000, 800), (1000, 800), 0, [strip], [100, 220])
+    assert atocr.process(pg, "dominus", pm) is None
+    assert "OCRopus failed! Skipping current file." in capsys.readouterr().out

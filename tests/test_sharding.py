@@ -1,0 +1,73 @@
+"""Multi-process (gloo, world_size 2, CPU) test of the page sharding + gather path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from text_alignment_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    costs = [5.0, 1.0, 9.0, 3.0, 7.0, 2.0, 8.0]
+    mine = sharding.shard_indices(costs, world, rank)
+    recs = []
+    for pid in mine:                       # page pid emits pid + 1 boxes (rank 1 may hold fewer)
+        for k in range(pid + 1):
+            recs.append((pid, k, 10 * pid + k, 90, 10 * pid + k + 8, 130))
+    local = np.array(recs, dtype=np.int32).reshape(-1, 6)
+    allrec = sharding.gather_records(local)
+    empty = sharding.gather_records(np.zeros((0, 6), np.int32) if rank == 1 else local)
+    if rank == 0:
+        q.put((mine, allrec.tolist(), empty.shape[0]))
+    else:
+        q.put((mine, None, None))
+    dist.destroy_process_group()
+
+
+def test_shard_and_gather_world2():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shards = sorted((g[0] for g in got), key=lambda s: s[0])
+    assert sorted(shards[0] + shards[1]) == list(range(7))            # a partition of the pages
+    assert sorted([shards[0], shards[1]]) == sorted([[2, 4, 3, 1], [6, 0, 5]])   # heaviest first, dealt
+    allrec = [g[1] for g in got if g[1] is not None][0]
+    assert len(allrec) == sum(p + 1 for p in range(7))
+    by_page = {}
+    for r in allrec:
+        by_page.setdefault(r[0], []).append(r)
+    for pid, rows in by_page.items():
+        assert [r[1] for r in rows] == list(range(pid + 1))
+        assert all(r[2] == 10 * pid + r[1] for r in rows)
+    n_empty = [g[2] for g in got if g[2] is not None][0]
+    assert n_empty == sum(p + 1 for p in [2, 4, 3, 1]) or n_empty == sum(p + 1 for p in [6, 0, 5])
+
+
+def test_single_process_passthrough_and_cost():
+    from text_alignment_amd import sharding
+    local = np.arange(12, dtype=np.int32).reshape(2, 6)
+    assert np.array_equal(sharding.gather_records(local), local)
+    assert sharding.shard_indices([1, 5, 3], 1, 0) == [1, 2, 0]
+    assert sharding.page_cost([100, 200], 800) > sharding.page_cost([100], 800)

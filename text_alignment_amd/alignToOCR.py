@@ -1,0 +1,332 @@
+# -*- coding: utf-8 -*-
+"""Page driver -- drop-in for the reference module of the same name (reference
+alignToOCR.py:24-351): same `process` / `perform_ocr_with_ocropus` / `to_JSON_dict` /
+`CharBox` / `rotate_bbox` / `read_file` surface, same `syl_boxes` JSON.
+
+What changed underneath (and nothing else): the OCR seam no longer writes PNG strips and shells
+out to `ocropus-rpred` (alignToOCR.py:131-147) -- text-line strips go through the HIP line
+recogniser in-process (text_alignment_amd.ocr) -- and the transcript/OCR alignment runs in the
+HIP Needleman-Wunsch kernels (text_alignment_amd.textSeqCompare).  The glue between the two
+kernels (abbreviation expansion, gap insertion, syllable grouping, rotation, JSON) is host-side
+string/box work restated from the reference.
+
+Gamera (the reference's image toolkit, alignToOCR.py:3-5) is not needed: pages arrive as
+`text_alignment_amd.page.PreparedPage` objects carrying their text-line strips; `preproc`
+below adapts them to the two preprocessing calls `process` makes (alignToOCR.py:216-218).
+"""
+import io
+import json  # noqa: F401  (callers json.dump the result of to_JSON_dict, alignToOCR.py:434)
+import os
+import pickle
+import re
+
+import numpy as np
+
+from . import latinSyllabification as latsyl
+from . import textSeqCompare as tsc
+from . import page as preproc
+
+parallel = 2                # kept for signature compatibility (alignToOCR.py:24): one GPU batch
+median_line_mult = 2        # alignToOCR.py:25
+
+
+class CharBox(object):
+    __slots__ = ['char', 'ul', 'lr', 'ulx', 'lrx', 'uly', 'lry', 'width', 'height']
+
+    def __init__(self, char, ul=None, lr=None):
+        self.char = char
+        if (ul is None) or (lr is None):        # a gap marker: no geometry (alignToOCR.py:41-44)
+            self.ul = None
+            self.lr = None
+            return
+        self.ul, self.lr = tuple(ul), tuple(lr)
+        self.ulx, self.uly = ul[0], ul[1]
+        self.lrx, self.lry = lr[0], lr[1]
+        self.width = lr[0] - ul[0]
+        self.height = lr[1] - ul[1]
+
+    def __repr__(self):
+        if self.ul and self.lr:
+            return '{}: {}, {}'.format(self.char, self.ul, self.lr)
+        return '{}: empty'.format(self.char)
+
+    # __slots__ classes pickle by slot; unset geometry of gap markers is skipped
+    def __getstate__(self):
+        return {k: getattr(self, k) for k in self.__slots__ if hasattr(self, k)}
+
+    def __setstate__(self, state):
+        for k, v in state.items():
+            setattr(self, k, v)
+
+
+def clean_special_chars(inp):
+    '''drops the reject class '~' from OCR output (alignToOCR.py:61-72)'''
+    return inp.replace('~', '')
+
+
+def read_file(fname):
+    '''plaintext transcript of a page -> one string (alignToOCR.py:75-87)'''
+    with open(fname, 'r') as f:
+        rows = f.readlines()
+    text = ' '.join(r for r in rows if not r[0] == '#')
+    for junk in ('\n', '\r', '| '):
+        text = text.replace(junk, '')
+    return text
+
+
+def rotate_bbox(cbox, angle, orig_dim, target_dim, radians=False):
+    '''rotate a box about the centre of `orig_dim` and shift by half the size difference to
+    `target_dim` (alignToOCR.py:90-125).  The reference runs on Python 2, where the three
+    divisions at alignToOCR.py:91,95-96 are integer floor divisions.'''
+    px, py = orig_dim.ncols // 2, orig_dim.nrows // 2
+    dx = (orig_dim.ncols - target_dim.ncols) // 2
+    dy = (orig_dim.nrows - target_dim.nrows) // 2
+    if not radians:
+        angle = angle * np.pi / 180
+    s, c = np.sin(angle), np.cos(angle)
+
+    def turn(x, y):
+        x, y = x - px, y - py
+        return (x * c) - (y * s) + (px - dx), (x * s) + (y * c) + (py - dy)
+
+    ulx, uly = turn(cbox.ulx, cbox.uly)
+    lrx, lry = turn(cbox.lrx, cbox.lry)
+    new_ul = np.round([ulx, uly]).astype('int16')
+    new_lr = np.round([lrx, lry]).astype('int16')
+    return CharBox(cbox.char, new_ul, new_lr)
+
+
+# --------------------------------------------------------------------------- OCR seam
+_recognizers = {}
+
+
+def _recognizer_for(ocropus_model):
+    """`ocropus_model` as the reference passes it is a model file path (alignToOCR.py:390-405);
+    a LineModel or a ready LineRecognizer is accepted as well."""
+    from . import ocr
+    if isinstance(ocropus_model, ocr.LineRecognizer):
+        return ocropus_model
+    key = id(ocropus_model) if not isinstance(ocropus_model, str) else os.path.abspath(ocropus_model)
+    if key not in _recognizers:
+        if isinstance(ocropus_model, str):
+            from . import model_io
+            model = model_io.load_pyrnn(ocropus_model)
+        else:
+            model = ocropus_model
+        _recognizers[key] = (ocropus_model, ocr.LineRecognizer(model))
+    return _recognizers[key][1]
+
+
+def chars_from_llocs(llocs, x_min, y_min, y_max, all_chars):
+    """One strip's (char, x) list -> CharBoxes appended to all_chars (alignToOCR.py:160-182).
+    ocropus reports the RIGHT edge of each character, so a character's box runs from the
+    previous character's position to its own; '~' and '' still advance the position."""
+    prev_xpos = x_min
+    for ch, x in llocs:
+        x_text = '%.1f' % x                       # the value as the .llocs file carries it
+        cur_xpos = int(np.round(float(x_text) + x_min))
+        ul, lr = (prev_xpos, y_min), (cur_xpos, y_max)
+        if not (ch == '~' or ch == ''):
+            all_chars.append(CharBox(clean_special_chars(ch), ul, lr))
+        prev_xpos = cur_xpos
+
+
+def perform_ocr_with_ocropus(cc_strips, ocropus_model, wkdir_name=None, parallel=parallel):
+    """Recognise every text-line strip of a page and return its characters in reading order
+    (strip order, then x), as reference alignToOCR.py:128-184 does through `ocropus-rpred`.
+
+    cc_strips: objects with offset_x, offset_y, height and either `prepared` (a (T, 48) array,
+    ink = 1, already normalised and padded) or `pixels` (raw strip, normalised on the host by
+    text_alignment_amd.lineest).  wkdir_name / parallel are accepted and unused: all strips of
+    the page go to the GPU in one batch.
+    """
+    from . import ocr
+    rec = _recognizer_for(ocropus_model)
+    lines, widths = [], []
+    for strip in cc_strips:
+        xs, raw_w = preproc.prepared_line(strip)
+        lines.append(xs)
+        widths.append(raw_w)
+    decoded = rec.recognise(lines)
+    all_chars = []
+    for strip, xs, raw_w, dec in zip(cc_strips, lines, widths, decoded):
+        llocs = rec.llocs(dec, xs.shape[0], raw_w)
+        chars_from_llocs(llocs, strip.offset_x, strip.offset_y, strip.offset_y + strip.height, all_chars)
+    return all_chars
+
+
+# --------------------------------------------------------------------------- alignment glue
+def expand_abbreviations(all_chars):
+    """Replace every occurrence of an abbreviation in the OCR character list by its expansion;
+    character k of the abbreviation lends its box to all letters of segment k
+    (alignToOCR.py:251-264)."""
+    for abb, segments in latsyl.abbreviations.items():
+        while True:
+            ocr_str = ''.join(str(x.char) for x in all_chars)
+            idx = ocr_str.find(abb)
+            if idx == -1:
+                break
+            ins = []
+            for k, segment in enumerate(segments):
+                donor = all_chars[k + idx]
+                ins += [CharBox(ch, donor.ul, donor.lr) for ch in segment]
+            all_chars = all_chars[:idx] + ins + all_chars[idx + len(abb):]
+    return all_chars
+
+
+def syllable_boxes(syls, tra_align, all_chars, indices=None):
+    """For each syllable of the transcript, the union of the OCR character boxes it is aligned
+    to (alignToOCR.py:297-324).  `indices`, if given, receives for every emitted box the index of
+    its syllable among the non-empty syllables of the transcript."""
+    out = []
+    offset = 0
+    which = -1
+    for syl in syls:
+        if len(syl) < 1:
+            continue
+        which += 1
+        if len(syl) == 1:
+            pattern = syl
+        else:
+            pattern = syl[0] + syl[1:-1].replace('', '_*') + syl[-1]
+        hit = re.search(pattern, tra_align[offset:])
+        start, end = hit.start() + offset, hit.end() + offset
+        offset = end
+        boxes = [b for b in all_chars[start:end] if b.lr is not None]
+        if not boxes:
+            continue                          # aligned to nothing in the OCR
+        if len(set(b.uly for b in boxes)) > 1:
+            lowest = max(b.uly for b in boxes)       # spans two text lines: keep the lower one
+            boxes = [b for b in boxes if b.uly == lowest]
+        ul = (min(b.ulx for b in boxes), min(b.uly for b in boxes))
+        lr = (max(b.lrx for b in boxes), max(b.lry for b in boxes))
+        out.append(CharBox(syl, ul, lr))
+        if indices is not None:
+            indices.append(which)
+    return out
+
+
+def align_page(transcript, all_chars, angle, image_dim, raw_dim, seq_align_params=None,
+               alignment=None, indices=None):
+    """Everything `process` does after OCR (alignToOCR.py:247-328), on plain data.  `alignment`
+    may carry a precomputed (tra_align, ocr_align) of the transcript against the expanded OCR
+    string (the batched driver aligns all pages in one launch)."""
+    all_chars = expand_abbreviations(list(all_chars))
+    ocr = ''.join(x.char for x in all_chars)
+    all_chars_copy = list(all_chars)
+
+    if alignment is None:
+        alignment = tsc.perform_alignment(list(transcript), list(ocr),
+                                          scoring_system=seq_align_params, verbose=False)
+    tra_align, ocr_align = alignment
+    tra_align = ''.join(tra_align)
+    ocr_align = ''.join(ocr_align)
+    syls = latsyl.syllabify_text(transcript)
+
+    for k, ch in enumerate(ocr_align):          # gaps of the OCR side get placeholder boxes
+        if ch == '_':
+            all_chars.insert(k, CharBox('_'))
+    assert len(all_chars) == len(tra_align), 'all_chars not same length as alignment: ' \
+        '{} vs {}'.format(len(all_chars), len(tra_align))
+
+    syl_boxes = syllable_boxes(syls, tra_align, all_chars, indices)
+    syl_boxes = [rotate_bbox(b, -1 * angle, image_dim, raw_dim) for b in syl_boxes]
+    return syl_boxes, all_chars_copy
+
+
+def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indices_out=None):
+    """`process` for many pages at once: the strips of ALL pages go through the line recogniser
+    in one batch and the transcript/OCR alignments of all pages run in one NW launch -- the shape
+    in which a GPU is worth using.  Per page the result equals process(page, transcript, model,
+    seq_align_params).  Returns a list of (syl_boxes, image, lines_peak_locs, all_chars)."""
+    from . import ocr
+    rec = _recognizer_for(ocropus_model)
+    prep = [(preproc.preprocess_images(pg), ) for pg in pages]
+    strips_per_page, peaks = [], []
+    for (image, eroded, angle), in prep:
+        cc_strips, lines_peak_locs, _ = preproc.identify_text_lines(image, eroded)
+        strips_per_page.append(cc_strips)
+        peaks.append(lines_peak_locs)
+    lines, widths = [], []
+    for strips in strips_per_page:
+        for strip in strips:
+            xs, raw_w = preproc.prepared_line(strip)
+            lines.append(xs)
+            widths.append(raw_w)
+    decoded = rec.recognise(lines)
+    chars_per_page, k = [], 0
+    for strips in strips_per_page:
+        all_chars = []
+        for strip in strips:
+            llocs = rec.llocs(decoded[k], lines[k].shape[0], widths[k])
+            chars_from_llocs(llocs, strip.offset_x, strip.offset_y, strip.offset_y + strip.height, all_chars)
+            k += 1
+        chars_per_page.append(expand_abbreviations(all_chars))
+    pairs = [(list(tr), [c.char for c in chars]) for tr, chars in zip(transcripts, chars_per_page)]
+    alignments = tsc.perform_alignment_batch(pairs, seq_align_params)
+    results = []
+    for pg, ((image, eroded, angle), ), tr, chars, lp, al in zip(pages, prep, transcripts,
+                                                                chars_per_page, peaks, alignments):
+        idx = [] if indices_out is not None else None
+        syl_boxes, all_chars_copy = align_page(tr, chars, angle, image.dim, pg.dim,
+                                               seq_align_params, alignment=al, indices=idx)
+        if indices_out is not None:
+            indices_out.append(idx)
+        results.append((syl_boxes, image, lp, all_chars_copy))
+    return results
+
+
+def process(raw_image,
+            transcript,
+            ocropus_model,
+            seq_align_params=None,
+            wkdir_name='wkdir_ocropy',
+            parallel=parallel,
+            median_line_mult=median_line_mult,
+            existing_ocr_pickle=None,
+            existing_preproc_images=None,
+            verbose=True):
+    '''
+    given a text layer @raw_image and a string transcript @transcript, performs OCR on the text
+    lines and aligns the results to the transcript text (reference alignToOCR.py:187-330).
+    Returns (syl_boxes, image, lines_peak_locs, all_chars), or None when OCR fails.
+    '''
+    image, eroded, angle = preproc.preprocess_images(raw_image)
+    cc_strips, lines_peak_locs, _ = preproc.identify_text_lines(image, eroded)
+
+    all_chars = []
+    if existing_ocr_pickle:
+        try:
+            with open(existing_ocr_pickle, 'rb') as f:
+                all_chars = pickle.load(f)
+            print('using pickled ocr results in {}...'.format(existing_ocr_pickle))
+        except IOError:
+            print('Pickle file {} not found - performing ocr instead'.format(existing_ocr_pickle))
+        except AttributeError:
+            print('Pickle error: re-performing ocr')
+
+    if not all_chars:
+        from . import ocr
+        try:
+            all_chars = perform_ocr_with_ocropus(cc_strips, ocropus_model, wkdir_name=wkdir_name,
+                                                 parallel=parallel)
+        except ocr.RecognitionError:
+            print('OCRopus failed! Skipping current file.')
+            return None
+
+    syl_boxes, all_chars_copy = align_page(transcript, all_chars, angle, image.dim, raw_image.dim,
+                                           seq_align_params)
+    return syl_boxes, image, lines_peak_locs, all_chars_copy
+
+
+def to_JSON_dict(syl_boxes, lines_peak_locs):
+    '''
+    output of process() -> the dict the MEI-encoding job consumes (alignToOCR.py:333-351).
+    'median_line_spacing' is the 75th percentile of the line gaps, as in the reference.
+    '''
+    data = {'median_line_spacing': np.quantile(np.diff(lines_peak_locs), 0.75), 'syl_boxes': []}
+    for s in syl_boxes:
+        data['syl_boxes'].append({'syl': s.char,
+                                  'ul': [int(s.ul[0]), int(s.ul[1])],
+                                  'lr': [int(s.lr[0]), int(s.lr[1])]})
+    return data
