@@ -1,8 +1,16 @@
 #!/usr/bin/env python3
-"""bench.py -- NW DP cells/s of the HIP hot path (see DESIGN.md "Measurement").
+"""bench.py -- throughput of the HIP hot path (DESIGN.md "Measurement").
 
-One "step" = fill + traceback of one batch of synthetic NW problems (default scoring,
-SURVEY.md section 8d generator) already resident in HBM.  Prints ONE JSON line on rank 0.
+Headline (the JSON line's `value`): NW DP cells/s.  One "step" = fill + traceback of one batch
+of synthetic 4096 x 4096 affine-gap problems per GPU (default scoring, SURVEY.md section 8d
+generator), inputs resident in HBM, plus -- with more than one GPU -- the single gather of
+syllable-box records to rank 0 (the only collective on the path).  Pages/problems shard across
+ranks with no other communication, so scaling is "weak": every rank runs the same batch size.
+
+Also on the line: `roofline` for the dominant kernel (nw_fill_kernel, HIP events around its
+launches on the launch stream), `cpu_baseline` (the reference's algorithm on this host's cores,
+bounded sample, rank 0 only) and `ocr` (text-lines/s of the line recogniser on synthetic pages,
+timed separately, with its own MFMA roofline).
 """
 import argparse
 import json
@@ -16,19 +24,33 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+F32_MFMA_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA peak (spec)
+DEFAULT_SYS = [8, -4, -7, -7, -3, 0]
 
 
-def make_batch(tsc, nprob, n, m, seed0, distinct):
-    from oracle.synth import synth_pair_ids      # input generator only (shared with the tests)
+def make_nw_batch(tsc, nprob, n, m, seed0, distinct=32):
+    from oracle.synth import synth_pair_ids      # seeded input generator shared with the tests
     uniq = [synth_pair_ids(n, m, seed0 + k) for k in range(min(nprob, distinct))]
     probs = [uniq[k % len(uniq)] for k in range(nprob)]
-    return tsc.NWBatch([p[0] for p in probs], [p[1] for p in probs], [8, -4, -7, -7, -3, 0]), uniq
+    return tsc.NWBatch([p[0] for p in probs], [p[1] for p in probs], DEFAULT_SYS), uniq
 
 
-def cpu_baseline(seconds=15.0):
-    """The reference's algorithm on this box's host cores: oracle/nw_ref_py.py, a behavioural
-    port of textSeqCompare.py:13-177 (pure-Python loop over float64 numpy matrices), one core."""
+def synthetic_lines(nlines, seed0):
+    """Already-normalised strips 48 x W', W' ~ U[800, 2000]: (T, 48)."""
+    rng = np.random.default_rng(seed0)
+    lines = []
+    for _ in range(nlines):
+        w = int(rng.integers(800, 2001))
+        xs = np.zeros((w + 32, 48), dtype=np.float32)
+        xs[16:16 + w] = (rng.random((w, 48)) < 0.15) * rng.random((w, 48))
+        lines.append(xs)
+    return lines
+
+
+def cpu_baseline(seconds=12.0):
+    """oracle/nw_ref_py.py -- behavioural port of textSeqCompare.py:13-177 (per-cell Python loop
+    over float64 numpy matrices) -- on one host core, config-1-shaped problems."""
     from oracle import nw_ref_py, nw_oracle
     from oracle.synth import synth_pair
     n = m = 500
@@ -40,10 +62,59 @@ def cpu_baseline(seconds=15.0):
         dt = time.perf_counter() - t0
         if dt > seconds or done >= 64:
             break
-    c_rate = nw_oracle.fill_only_rate(2048, 2048)
     return {"value": done * n * m / dt, "unit": "cells/s", "cores": 1, "kind": "port",
-            "sample": "%d problems of %dx%d (config 1 shape), oracle/nw_ref_py.py, %.1f s" % (done, n, m, dt),
-            "c_restatement_cells_per_s": c_rate}
+            "sample": "%d problems of %dx%d (BASELINE configs[0] shape) through oracle/nw_ref_py.py, "
+                      "%.1f s" % (done, n, m, dt),
+            "c_restatement_cells_per_s": nw_oracle.fill_only_rate(2048, 2048)}
+
+
+def ocr_cpu_baseline(model_seed, no, seconds=8.0):
+    from oracle import ocr_ref_f64 as R
+    om = R.synthetic_model(model_seed, no=no)
+    done, steps, t0 = 0, 0, time.perf_counter()
+    while True:
+        xs = R.synthetic_line(8000 + done, width=1000)
+        R.recognise(om, xs)
+        done += 1
+        steps += xs.shape[0]
+        dt = time.perf_counter() - t0
+        if dt > seconds:
+            break
+    return {"value": done / dt, "unit": "lines/s", "cores": 1, "kind": "port",
+            "sample": "%d lines of width 1000 (T = 1032) through oracle/ocr_ref_f64.py, %.1f s" % (done, dt)}
+
+
+def bench_ocr(args, rank):
+    from text_alignment_amd import ocr
+    no = 96
+    rec = ocr.LineRecognizer(ocr.LineModel.random(7001, no=no))
+    lines = synthetic_lines(args.ocr_lines, 8000 + 7919 * rank)
+    st = rec.prepare(lines)
+    tsteps = int(st["rows"])
+    for _ in range(2):
+        rec.run(st)
+    torch.cuda.synchronize()
+    reps = 3
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
+    t0 = time.perf_counter()
+    for r in range(reps):
+        ev[r][0].record(); rec.run(st, lstm=True, output=False, decode=False)
+        ev[r][1].record(); rec.run(st, lstm=False, output=True, decode=False)
+        ev[r][2].record(); rec.run(st, lstm=False, output=False, decode=True)
+        ev[r][3].record()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    lstm_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+    out_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    dec_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
+    flops_lstm = tsteps * 238400.0                    # 2 dirs x 4 gates x 100 x 149 x 2
+    tf = flops_lstm / (lstm_ms * 1e-3) / 1e12
+    return {"lines_per_s": args.ocr_lines / dt, "timesteps_per_s": tsteps / dt, "lines": args.ocr_lines,
+            "timesteps": tsteps, "classes": no, "dtype": "f32",
+            "ms": {"lstm": lstm_ms, "output_softmax": out_ms, "decode": dec_ms},
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": tf / F32_MFMA_PEAK_TF, "traffic": None, "kernel": "lstm_seq_kernel",
+                         "algorithmic_flops_per_timestep": 238400}}
 
 
 def main():
@@ -53,8 +124,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--m", type=int, default=4096)
-    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=1024, help="NW problems per GPU per step")
+    ap.add_argument("--ocr-lines", type=int, default=1920, help="text lines per GPU (64 pages x 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ocr", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,26 +139,36 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    from text_alignment_amd import textSeqCompare as tsc
-    batch, uniq = make_batch(tsc, args.batch, args.n, args.m, 1234 + rank * 100000, distinct=32)
+    from text_alignment_amd import sharding, textSeqCompare as tsc
+    batch, uniq = make_nw_batch(tsc, args.batch, args.n, args.m, 1234 + rank * 100000)
+    # the records a page driver would gather: ~150 syllable boxes per page/problem
+    recs = np.zeros((150 * args.batch, sharding.RECORD_FIELDS), dtype=np.int32)
+    recs[:, 0] = np.repeat(np.arange(args.batch) + rank * args.batch, 150)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step(timed=None):
+        if timed is not None:
+            timed[0].record()
+        batch.run(fill=True, traceback=False)
+        if timed is not None:
+            timed[1].record()
+        batch.run(fill=False, traceback=True)
+        if timed is not None:
+            timed[2].record()
+        if dist is not None:
+            sharding.gather_records(recs)
+
     for _ in range(args.warmup):
-        batch.run()
+        step()
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-           torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()
-        batch.run(fill=True, traceback=False)
-        ev[k][1].record()
-        batch.run(fill=False, traceback=True)
-        ev[k][2].record()
+        step(ev[k])
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -95,36 +178,49 @@ def main():
     fill_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     tb_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
 
-    # bit-exact spot check of the timed output against the oracle (checker only)
-    ok = True
-    if rank == 0:
-        from oracle import nw_oracle
-        res = batch.results()
-        for k in (0, len(uniq) - 1):
-            want = nw_oracle.align_ids(uniq[k][0], uniq[k][1], [8, -4, -7, -7, -3, 0])
-            ok = ok and res[k].tolist() == want.tolist()
+    ocr_res = None
+    if not args.no_ocr:
+        ocr_res = bench_ocr(args, rank)
+        if dist is not None:
+            agg = torch.tensor([ocr_res["lines_per_s"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+            ocr_res["lines_per_s_all_gpus"] = float(agg.item())
 
     if rank == 0:
+        # bit-exact spot check of the timed output against the oracle (checker only)
+        from oracle import nw_oracle
+        res = batch.results()
+        ok = True
+        for k in (0, len(uniq) - 1):
+            want = nw_oracle.align_ids(uniq[k][0], uniq[k][1], DEFAULT_SYS)
+            ok = ok and res[k].tolist() == want.tolist()
         cells_step = batch.cells * world
-        value = cells_step * args.steps / dt
         fill_rate = batch.cells / (fill_ms * 1e-3)
         out = {
-            "metric": "nw_dp_cells_per_s", "value": value, "unit": "cells/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
-            "data": "synthetic",
-            "config": {"workload": "affine-gap NW, %d problems of %dx%d per GPU, default scoring "
-                                   "[8,-4,-7,-7,-3,0], fill + traceback" % (args.batch, args.n, args.m),
-                       "cells_per_step": cells_step, "bit_exact_vs_oracle": ok},
-            "roofline": {"bound": "hbm", "achieved": fill_rate * 1.0 / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": fill_rate / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "metric": "nw_dp_cells_per_s", "value": cells_step * args.steps / dt, "unit": "cells/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "affine-gap NW, %d problems of %dx%d per GPU per step, default "
+                                   "scoring [8,-4,-7,-7,-3,0], fill + traceback%s"
+                                   % (args.batch, args.n, args.m,
+                                      " + gather of syllable-box records" if world > 1 else ""),
+                       "cells_per_step": cells_step, "parallelism": "pages sharded x%d" % world,
+                       "bit_exact_vs_oracle": ok},
+            "roofline": {"bound": "hbm", "achieved": fill_rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": fill_rate / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "nw_fill_kernel", "kernel_ms": fill_ms, "traceback_ms": tb_ms,
                          "algorithmic_bytes_per_cell": 1},
         }
+        if ocr_res is not None:
+            out["ocr"] = ocr_res
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            if ocr_res is not None:
+                out["ocr"]["cpu_baseline"] = ocr_cpu_baseline(7001, 96)
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

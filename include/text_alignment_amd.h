@@ -117,17 +117,25 @@ int ta_nw_general(const int32_t* t, int32_t n, const int32_t* o, int32_t m,
  *          W_gate[unit 16*wave + lane%16][kp 4*kstep + lane/16], kp: 0 bias, 1..48 x,
  *          49..51 zero, 52..151 h; units >= 100 zero.
  *   peep = float[2][3][112]: WIP, WFP, WOP per direction, units >= 100 zero.
- * ta_lstm_output: w2p = float[204][16*ceil(no/16)], row kp = W2[:, kp] for kp <= 200
- *   (kp 0 = bias column), zero elsewhere.  no <= 128.
- * ta_decode: translate_back(outputs, threshold) per line; line b writes dec_n[b] (t, class)
- *   pairs at dec_t/dec_c + dec_off[b] (capacity (T[b] + 1) / 2 entries).
+ * ta_lstm_output: w2p = float[201][16*ceil(no/16)] (classes beyond `no` zero): row 0 = bias
+ *   column W2[:, 0]; row 1 + 4*kk + kq = W2[:, 1 + 50*kq + kk] (kk < 50, kq < 4) -- the k order
+ *   in which the kernel consumes a row of hout.  no <= 128.  probs / logits / summary are each
+ *   optional (at least one of probs, summary): summary = float[rows][4] =
+ *   {P(class 0), best P, best class (integer bits), 0}, all the decoder needs.
+ * ta_decode / ta_decode_summary: translate_back(outputs, threshold) per line, from the full
+ *   probabilities or from the summaries; line b writes dec_n[b] (t, class) pairs at
+ *   dec_t/dec_c + dec_off[b] (capacity (T[b] + 1) / 2 entries).
  */
 int32_t ta_lstm_packed_weight_floats(void);
 int ta_lstm_forward(const float* x, const int64_t* row_off, const int32_t* T,
                     const int32_t* group_lines, int32_t ngroups,
                     const float* wp, const float* peep, float* hout, void* stream);
 int ta_lstm_output(const float* y, int64_t rows, const float* w2p, int32_t no,
-                   float* probs, float* logits, void* stream);
+                   float* probs, float* logits, float* summary, void* stream);
+int ta_decode_summary(const float* summary, const int64_t* row_off, const int32_t* T,
+                      int32_t nlines, float threshold,
+                      int32_t* dec_t, int32_t* dec_c, int32_t* dec_n, const int64_t* dec_off,
+                      void* stream);
 int ta_decode(const float* probs, const int64_t* row_off, const int32_t* T,
               int32_t nlines, int32_t no, float threshold,
               int32_t* dec_t, int32_t* dec_c, int32_t* dec_n, const int64_t* dec_off,

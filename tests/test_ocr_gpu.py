@@ -27,6 +27,7 @@ def test_lines_vs_f64_oracle(seed, no):
     lines = [R.synthetic_line(8000 + k, width=w) for k, w in enumerate(widths)]
     rec = ocr.LineRecognizer(pm)
     dec, probs, logits, states = rec.recognise(lines, want_probs=True)
+    assert rec.recognise(lines, from_probs=True) == dec        # K5 from full probabilities == from summaries
     worst = 0.0
     errs = []
     for k, xs in enumerate(lines):

@@ -51,7 +51,9 @@ def _load():
     lib.ta_lstm_forward.restype = ctypes.c_int
     lib.ta_lstm_forward.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.ta_lstm_output.restype = ctypes.c_int
-    lib.ta_lstm_output.argtypes = [vp, i64, vp, i32, vp, vp, vp]
+    lib.ta_lstm_output.argtypes = [vp, i64, vp, i32, vp, vp, vp, vp]
+    lib.ta_decode_summary.restype = ctypes.c_int
+    lib.ta_decode_summary.argtypes = [vp, vp, vp, i32, f32, vp, vp, vp, vp, vp]
     lib.ta_decode.restype = ctypes.c_int
     lib.ta_decode.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp]
     return lib
@@ -61,7 +63,8 @@ lib = _load()
 
 EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch",
            "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general",
-           "ta_lstm_packed_weight_floats", "ta_lstm_forward", "ta_lstm_output", "ta_decode"]
+           "ta_lstm_packed_weight_floats", "ta_lstm_forward", "ta_lstm_output", "ta_decode",
+           "ta_decode_summary"]
 
 
 def check(rc, what):

@@ -179,65 +179,72 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_kernel(LstmArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // K4: z = W2 . [1, y_t]  (No x 201), p = softmax(clip(z, -100, 100))   (Appendix B.4)
-constexpr int kOK = 204;           // 1 + 200 + 3 pads
-constexpr int kOKS = kOK / 4;      // 51 k-steps
+//
+// One wave per tile of 16 timesteps.  The sum over k may run in any order, so lane
+// (row = lane & 15, kq = lane >> 4) takes the CONTIGUOUS quarter y[row][50*kq .. 50*kq + 49] of
+// its row straight from HBM into registers (no LDS staging of A); k-step kk of the MFMA then
+// multiplies y[.][50*kq + kk] with the matching row of W2^T, which sits in LDS in that order.
+// The bias column seeds the accumulators.  Softmax runs on the accumulator tile; besides the
+// probabilities the kernel can emit a 16-byte per-timestep summary (P(blank), best probability,
+// best class) that is all the decoder needs.
+constexpr int kOKS = 50;           // k-steps: 200 = 4 x 50
 constexpr int kOWaves = 4;
 constexpr int kMaxCT = 8;          // up to 128 classes
 
 struct OutArgs {
     const float* y;        // [rows][200]
     int64_t rows;
-    const float* w2p;      // [51][4][NoP]  (kp-major, classes padded to NoP = 16*nct, zero filled)
+    const float* w2p;      // [1 + 200][nop]: row 0 = bias, row 1 + 4*kk + kq = W2[:, 1 + 50*kq + kk]
     int no, nct;
-    float* probs;          // [rows][no]
+    float* probs;          // optional [rows][no]
     float* logits;         // optional [rows][no]
+    float4* summary;       // optional [rows]: {P(class 0), best P, best class as float bits, 0}
 };
 
+template <int NCT>
 __global__ __launch_bounds__(kOWaves * 64) void lstm_output_kernel(OutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float osm[];
-    const int nop = a.nct * 16;
-    float* w2 = osm;                                        // [204][nop]
-    float* ytile = osm + (size_t)kOK * nop;                 // [4 waves][16][204]
+    constexpr int nop = NCT * 16;
+    float* w2 = osm;                                        // [201][nop]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int e = tid; e < kOK * nop; e += kOWaves * 64) w2[e] = a.w2p[e];
-    float* yt = ytile + (size_t)wave * 16 * kOK;
+    for (int e = tid; e < 201 * nop; e += kOWaves * 64) w2[e] = a.w2p[e];
     __syncthreads();
+    const int kq = lane >> 4, rr = lane & 15;
 
     const int64_t ntiles = (a.rows + 15) / 16;
     for (int64_t tile = (int64_t)blockIdx.x * kOWaves + wave; tile < ntiles;
          tile += (int64_t)gridDim.x * kOWaves) {
         const int64_t r0 = tile * 16;
-        // stage [16][204] = [1, y(200), 0, 0, 0] per row, coalesced along the row
-        for (int e = lane; e < 16 * kOK; e += 64) {
-            const int rr = e / kOK, kp = e % kOK;
-            float v = 0.f;
-            if (kp == 0) v = 1.f;
-            else if (kp <= 200 && r0 + rr < a.rows) v = a.y[(r0 + rr) * 200 + (kp - 1)];
-            yt[rr * kOK + kp] = v;
-        }
-        // (a wave's LDS instructions execute in order: its reads below see these writes)
-        f32x4 acc[kMaxCT];
+        const int64_t myrow = (r0 + rr < a.rows) ? r0 + rr : a.rows - 1;      // clamp: tail rows are not stored
+        float A[kOKS];
+        {
+            const float2* src = reinterpret_cast<const float2*>(a.y + myrow * 200 + kq * kOKS);
 #pragma unroll
-        for (int ct = 0; ct < kMaxCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 3
+            for (int q = 0; q < kOKS / 2; ++q) { const float2 v = src[q]; A[2 * q] = v.x; A[2 * q + 1] = v.y; }
+        }
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const float b = w2[ct * 16 + rr];                                   // bias row
+            acc[ct] = (f32x4){b, b, b, b};
+        }
+#pragma unroll
         for (int kk = 0; kk < kOKS; ++kk) {
-            const float av = yt[(lane & 15) * kOK + 4 * kk + (lane >> 4)];
-            const float* bp = w2 + (size_t)(4 * kk + (lane >> 4)) * nop + (lane & 15);
+            const float* bp = w2 + (size_t)(1 + 4 * kk + kq) * nop + rr;
 #pragma unroll
-            for (int ct = 0; ct < kMaxCT; ++ct)
-                if (ct < a.nct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bp[ct * 16], acc[ct], 0, 0, 0);
+            for (int ct = 0; ct < NCT; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], bp[ct * 16], acc[ct], 0, 0, 0);
         }
-        // rows (lane>>4)*4 + r, classes ct*16 + (lane&15)
+        // accumulator rows (lane>>4)*4 + r, classes ct*16 + (lane&15)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t row = r0 + (lane >> 4) * 4 + r;
             float zmax = -3.0e38f;
 #pragma unroll
-            for (int ct = 0; ct < kMaxCT; ++ct) {
-                const int cls = ct * 16 + (lane & 15);
-                if (ct < a.nct && cls < a.no) {
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int cls = ct * 16 + rr;
+                if (cls < a.no) {
                     if (a.logits && row < a.rows) a.logits[row * a.no + cls] = acc[ct][r];
                     const float z = fminf(fmaxf(acc[ct][r], -100.f), 100.f);
                     acc[ct][r] = z;
@@ -248,10 +255,10 @@ __global__ __launch_bounds__(kOWaves * 64) void lstm_output_kernel(OutArgs a) {
             for (int d = 1; d < 16; d <<= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, d, 16));
             float sum = 0.f;
 #pragma unroll
-            for (int ct = 0; ct < kMaxCT; ++ct) {
-                const int cls = ct * 16 + (lane & 15);
-                if (ct < a.nct && cls < a.no) {
-                    const float e = __expf(acc[ct][r] - zmax);
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int cls = ct * 16 + rr;
+                if (cls < a.no) {
+                    const float e = expf(acc[ct][r] - zmax);
                     acc[ct][r] = e;
                     sum += e;
                 }
@@ -259,10 +266,32 @@ __global__ __launch_bounds__(kOWaves * 64) void lstm_output_kernel(OutArgs a) {
 #pragma unroll
             for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d, 16);
             const float inv = 1.0f / sum;
+            unsigned long long key = 0ull;           // larger P wins, then the smaller class
 #pragma unroll
-            for (int ct = 0; ct < kMaxCT; ++ct) {
-                const int cls = ct * 16 + (lane & 15);
-                if (ct < a.nct && cls < a.no && row < a.rows) a.probs[row * a.no + cls] = acc[ct][r] * inv;
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int cls = ct * 16 + rr;
+                if (cls < a.no) {
+                    const float pr = acc[ct][r] * inv;
+                    if (a.probs && row < a.rows) a.probs[row * a.no + cls] = pr;
+                    const unsigned long long k =
+                        ((unsigned long long)__float_as_uint(pr) << 32) | (unsigned)(0xFFFFFFFFu - cls);
+                    key = k > key ? k : key;
+                    if (ct == 0) acc[0][r] = pr;     // lane rr == 0 keeps P(class 0)
+                }
+            }
+            if (a.summary) {
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    const unsigned lo = __shfl_xor((unsigned)key, d, 16);
+                    const unsigned hi = __shfl_xor((unsigned)(key >> 32), d, 16);
+                    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                    key = other > key ? other : key;
+                }
+                if (rr == 0 && row < a.rows) {
+                    const unsigned cls = 0xFFFFFFFFu - (unsigned)key;
+                    a.summary[row] = make_float4(acc[0][r], __uint_as_float((unsigned)(key >> 32)),
+                                                 __uint_as_float(cls), 0.f);
+                }
             }
         }
     }
@@ -319,6 +348,53 @@ __global__ __launch_bounds__(64) void decode_kernel(DecArgs a) {
     if (lane == 0) a.dec_n[line] = n;
 }
 
+// K5': the same decode from K4's per-timestep summaries (16 B per timestep instead of a row of
+// probabilities).  One lane per line would do; a wave scans 64 timesteps at a time.
+struct DecSumArgs {
+    const float4* summary; const int64_t* row_off; const int32_t* T; int nlines;
+    float threshold;
+    int32_t* dec_t; int32_t* dec_c; int32_t* dec_n; const int64_t* dec_off;
+};
+
+__global__ __launch_bounds__(64) void decode_summary_kernel(DecSumArgs a) {
+    const int line = blockIdx.x, lane = threadIdx.x;
+    const int T = a.T[line];
+    const float4* s = a.summary + a.row_off[line];
+    int32_t* out_t = a.dec_t + a.dec_off[line];
+    int32_t* out_c = a.dec_c + a.dec_off[line];
+    int n = 0;
+    bool in_run = false;
+    unsigned long long best = 0ull;
+    int best_t = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        float4 v = make_float4(1.f, 0.f, 0.f, 0.f);          // beyond T: not in a run
+        if (t < T) v = s[t];
+        const unsigned long long key =
+            ((unsigned long long)__float_as_uint(v.y) << 32) | (0xFFFFFFFFu - __float_as_uint(v.z));
+        const unsigned long long below = __ballot(v.x < a.threshold);
+        const int cnt = min(64, T - t0);
+        for (int q = 0; q < cnt; ++q) {                        // uniform scan of the 64 entries
+            const unsigned klo = __builtin_amdgcn_readlane((unsigned)key, q);
+            const unsigned khi = __builtin_amdgcn_readlane((unsigned)(key >> 32), q);
+            const unsigned long long kq = ((unsigned long long)khi << 32) | klo;
+            if ((below >> q) & 1ull) {
+                if (!in_run) { in_run = true; best = 0ull; best_t = t0 + q; }
+                if (kq > best) { best = kq; best_t = t0 + q; }
+            } else if (in_run) {
+                if (lane == 0) { out_t[n] = best_t; out_c[n] = (int)(0xFFFFFFFFu - (unsigned)best); }
+                ++n;
+                in_run = false;
+            }
+        }
+    }
+    if (in_run) {
+        if (lane == 0) { out_t[n] = best_t; out_c[n] = (int)(0xFFFFFFFFu - (unsigned)best); }
+        ++n;
+    }
+    if (lane == 0) a.dec_n[line] = n;
+}
+
 }  // namespace ta
 
 using namespace ta;
@@ -340,27 +416,64 @@ extern "C" int ta_lstm_forward(const float* x, const int64_t* row_off, const int
     return TA_OK;
 }
 
+template <int NCT>
+static hipError_t launch_output(const OutArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    if (lds > 64 * 1024) {          // above the default dynamic-LDS limit
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_output_kernel<NCT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(lstm_output_kernel<NCT>, grid, dim3(kOWaves * 64), lds, st, a);
+    return hipSuccess;
+}
+
 extern "C" int ta_lstm_output(const float* y, int64_t rows, const float* w2p, int32_t no,
-                              float* probs, float* logits, void* stream) {
+                              float* probs, float* logits, float* summary, void* stream) {
     if (rows < 0 || no <= 0 || no > 16 * kMaxCT) return ta_fail(TA_EINVAL, "bad rows / class count");
     if (rows == 0) return TA_OK;
-    if (!y || !w2p || !probs) return ta_fail(TA_EINVAL, "null pointer argument");
+    if (!y || !w2p || !(probs || summary)) return ta_fail(TA_EINVAL, "null pointer argument");
     const int nct = (no + 15) / 16;
-    OutArgs a{y, rows, w2p, no, nct, probs, logits};
-    const size_t lds = ((size_t)kOK * nct * 16 + (size_t)kOWaves * 16 * kOK) * sizeof(float);
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_output_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return ta_fail_hip(e, "hipFuncSetAttribute");
-        raised = true;
-    }
+    OutArgs a{y, rows, w2p, no, nct, probs, logits, reinterpret_cast<float4*>(summary)};
+    const size_t lds = (size_t)201 * nct * 16 * sizeof(float);
     const int64_t ntiles = (rows + 15) / 16;
-    const int grid = (int)((ntiles + kOWaves - 1) / kOWaves < 512 ? (ntiles + kOWaves - 1) / kOWaves : 512);
-    hipLaunchKernelGGL(lstm_output_kernel, dim3(grid), dim3(kOWaves * 64), lds,
-                       reinterpret_cast<hipStream_t>(stream), a);
+    const int64_t want = (ntiles + kOWaves - 1) / kOWaves;
+    const dim3 grid((unsigned)(want < 1024 ? want : 1024));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t pre = hipSuccess;
+    switch (nct) {
+        case 1: pre = launch_output<1>(a, grid, lds, st); break;
+        case 2: pre = launch_output<2>(a, grid, lds, st); break;
+        case 3: pre = launch_output<3>(a, grid, lds, st); break;
+        case 4: pre = launch_output<4>(a, grid, lds, st); break;
+        case 5: pre = launch_output<5>(a, grid, lds, st); break;
+        case 6: pre = launch_output<6>(a, grid, lds, st); break;
+        case 7: pre = launch_output<7>(a, grid, lds, st); break;
+        default: pre = launch_output<8>(a, grid, lds, st); break;
+    }
+    if (pre != hipSuccess) return ta_fail_hip(pre, "hipFuncSetAttribute(lstm_output_kernel)");
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ta_fail_hip(e, "lstm_output_kernel launch");
+    return TA_OK;
+}
+
+extern "C" int ta_decode_summary(const float* summary, const int64_t* row_off, const int32_t* T,
+                                 int32_t nlines, float threshold,
+                                 int32_t* dec_t, int32_t* dec_c, int32_t* dec_n, const int64_t* dec_off,
+                                 void* stream) {
+    if (nlines < 0) return ta_fail(TA_EINVAL, "bad line count");
+    if (nlines == 0) return TA_OK;
+    if (!summary || !row_off || !T || !dec_t || !dec_c || !dec_n || !dec_off)
+        return ta_fail(TA_EINVAL, "null pointer argument");
+    DecSumArgs a{reinterpret_cast<const float4*>(summary), row_off, T, nlines, threshold,
+                 dec_t, dec_c, dec_n, dec_off};
+    hipLaunchKernelGGL(decode_summary_kernel, dim3(nlines), dim3(64), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ta_fail_hip(e, "decode_summary_kernel launch");
     return TA_OK;
 }
 

@@ -81,8 +81,12 @@ def _pack_lstm(model):
         for q, name in enumerate(("WIP", "WFP", "WOP")):
             peep[d, q, :NS] = np.asarray(w[name], dtype=np.float64)
     nct = (model.no + 15) // 16
-    w2p = np.zeros((204, nct * 16), dtype=np.float32)
-    w2p[0:201, :model.no] = np.asarray(model.W2, dtype=np.float64).T
+    W2 = np.asarray(model.W2, dtype=np.float64)
+    w2p = np.zeros((201, nct * 16), dtype=np.float32)
+    w2p[0, :model.no] = W2[:, 0]                                   # bias seeds the accumulators
+    for kk in range(50):
+        for kq in range(4):
+            w2p[1 + 4 * kk + kq, :model.no] = W2[:, 1 + 50 * kq + kk]
     return wp, peep, w2p
 
 
@@ -121,15 +125,18 @@ class LineRecognizer(object):
         st["T"] = torch.from_numpy(T.astype(np.int32) if len(lines) else np.zeros(1, np.int32)).to(dev)
         st["group_lines"] = torch.from_numpy(group_lines).to(dev)
         st["hout"] = torch.empty((max(rows, 1), 2 * NS), dtype=torch.float32, device=dev)
-        st["probs"] = torch.empty((max(rows, 1), self.model.no), dtype=torch.float32, device=dev)
+        st["probs"] = None            # full probabilities only on request (tests, inspection)
         st["logits"] = None
+        st["summary"] = torch.empty((max(rows, 1), 4), dtype=torch.float32, device=dev)
         st["dec_t"] = torch.zeros(max(rows, 1), dtype=torch.int32, device=dev)
         st["dec_c"] = torch.zeros(max(rows, 1), dtype=torch.int32, device=dev)
         st["dec_n"] = torch.zeros(max(len(lines), 1), dtype=torch.int32, device=dev)
         return st
 
-    def run(self, st, want_logits=False, lstm=True, output=True, decode=True):
-        """Enqueue K3, K4, K5 on torch's current stream."""
+    def run(self, st, want_logits=False, lstm=True, output=True, decode=True, from_probs=False):
+        """Enqueue K3, K4, K5 on torch's current stream.  By default K4 emits only the 16-byte
+        per-timestep summaries and K5 decodes from them; want_logits / from_probs also
+        materialise the (rows, No) probabilities (and logits) and decode from those."""
         if st["n"] == 0:
             return
         lib = _native.lib
@@ -139,18 +146,27 @@ class LineRecognizer(object):
                 st["x"].data_ptr(), st["row_off"].data_ptr(), st["T"].data_ptr(),
                 st["group_lines"].data_ptr(), st["ngroups"], self.wp.data_ptr(),
                 self.peep.data_ptr(), st["hout"].data_ptr(), stream), "ta_lstm_forward")
+        full = want_logits or from_probs
+        if full and st["probs"] is None:
+            shape = (max(st["rows"], 1), self.model.no)
+            st["probs"] = torch.empty(shape, dtype=torch.float32, device=self.device)
+            st["logits"] = torch.empty(shape, dtype=torch.float32, device=self.device)
         if output:
-            if want_logits and st["logits"] is None:
-                st["logits"] = torch.empty_like(st["probs"])
             _native.check(lib.ta_lstm_output(
                 st["hout"].data_ptr(), st["rows"], self.w2p.data_ptr(), self.model.no,
-                st["probs"].data_ptr(), st["logits"].data_ptr() if want_logits else None, stream),
-                "ta_lstm_output")
-        if decode:
+                st["probs"].data_ptr() if full else None,
+                st["logits"].data_ptr() if full else None,
+                st["summary"].data_ptr(), stream), "ta_lstm_output")
+        if decode and from_probs:
             _native.check(lib.ta_decode(
                 st["probs"].data_ptr(), st["row_off"].data_ptr(), st["T"].data_ptr(), st["n"],
                 self.model.no, THRESHOLD, st["dec_t"].data_ptr(), st["dec_c"].data_ptr(),
                 st["dec_n"].data_ptr(), st["row_off"].data_ptr(), stream), "ta_decode")
+        elif decode:
+            _native.check(lib.ta_decode_summary(
+                st["summary"].data_ptr(), st["row_off"].data_ptr(), st["T"].data_ptr(), st["n"],
+                THRESHOLD, st["dec_t"].data_ptr(), st["dec_c"].data_ptr(),
+                st["dec_n"].data_ptr(), st["row_off"].data_ptr(), stream), "ta_decode_summary")
 
     def decoded(self, st):
         """Host lists [(t, class), ...] per line (translate_back order)."""
@@ -166,9 +182,9 @@ class LineRecognizer(object):
             out.append([(int(dt[o + i]), int(dc[o + i])) for i in range(k)])
         return out
 
-    def recognise(self, lines, want_probs=False):
+    def recognise(self, lines, want_probs=False, from_probs=False):
         st = self.prepare(lines)
-        self.run(st, want_logits=want_probs)
+        self.run(st, want_logits=want_probs, from_probs=from_probs)
         dec = self.decoded(st)
         if not want_probs:
             return dec
