@@ -309,32 +309,81 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
     }
 }
 
-// K2: pointer walk, textSeqCompare.py:96-170.  One wave per problem; lane 0 walks.
+// K2: pointer walk, textSeqCompare.py:96-170.  One wave per problem.
+//
+// A walk step needs one pointer byte, and the next address depends on it, so reading HBM per
+// step costs a full memory latency (~200 ns) each.  The wave instead pulls a WINDOW of the
+// strip layout into LDS -- all 64 lanes (the strip's 256 rows) x kTbGroups groups (4 skewed
+// steps each), i.e. kTbGroups fully coalesced 1 KiB loads -- and walks inside it from LDS.
+// Both window coordinates only ever decrease along the walk (row up => lane down, and the
+// skewed step k = (j-1) + lane never grows), so a window is left exactly once: through the
+// top of the strip or through its low-k side.
+constexpr int kTbGroups = 32;                 // window depth in groups (128 skewed steps)
+constexpr int kTbOps = 512;                   // alignment columns buffered per window
+
 template <int R>
 __global__ __launch_bounds__(64) void nw_traceback_kernel(NwArgs a) {
+    static_assert(R == 4, "window walk is written for 4 rows per lane");
     using L = PtrLayout<R>;
-    const int p = blockIdx.x;
-    if (threadIdx.x != 0) return;
+    __shared__ uint4 win[kTbGroups * 64];
+    __shared__ uint8_t opsbuf[kTbOps];
+    const int p = blockIdx.x, lane = threadIdx.x;
     const int n = (int)(a.t_off[p + 1] - a.t_off[p]);
     const int m = (int)(a.o_off[p + 1] - a.o_off[p]);
     const uint8_t* ws_p = a.ws + a.ws_off[p];
     uint8_t* ops = a.ops_out + a.ops_off[p];
     const int cap = n + m;
+    const int64_t strip_bytes = L::strip_bytes(m);
     int x = n, y = m, len = 0;
     int st = 0;
-    if (n > 0 && m > 0) st = ptr_pm(ws_p[L::addr(n, m, m)]);     // start state, textSeqCompare.py:102
+    bool first = true;
     while (x > 0 && y > 0) {
-        const unsigned b = ws_p[L::addr(x, y, m)];
-        int op;
-        if (st == 0) { op = 0; st = ptr_pm(b); --x; --y; }
-        else if (st == 1) { op = 1; st = ptr_px(b); --x; }
-        else { op = 2; st = ptr_py(b); --y; }
-        ops[cap - 1 - len] = (uint8_t)op;
-        ++len;
+        // position in layout coordinates
+        int strip = (x - 1) / L::SR;
+        int l = ((x - 1) % L::SR) / R;
+        int r = (x - 1) % R;
+        int k = (y - 1) + l;
+        const int g_hi = k >> 2;
+        const int g_lo = max(0, g_hi - (kTbGroups - 1));
+        {   // load the window: piece (g, lane) -> win[(g - g_lo) * 64 + lane]
+            const uint8_t* base = ws_p + (int64_t)strip * strip_bytes + (int64_t)lane * 16;
+#pragma unroll 8
+            for (int it = 0; it <= g_hi - g_lo; ++it)
+                win[it * 64 + lane] = *reinterpret_cast<const uint4*>(base + (int64_t)(g_lo + it) * 1024);
+        }
+        __syncthreads();
+        const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
+        if (first) {                                              // start state, textSeqCompare.py:102
+            st = ptr_pm(wb[(((k >> 2) - g_lo) * 64 + l) * 16 + (k & 3) * R + r]);
+            first = false;
+        }
+        // walk while inside this window: a branch-free scalar state machine (every lane runs it
+        // on wave-uniform values).  In state st the step emits op = st, moves up unless st == 2
+        // and left unless st == 1 (textSeqCompare.py:115-145), and the next state is the pointer
+        // field of this byte that belongs to the current state: bits 2*st, 2*st+1.
+        int cnt = 0;
+        bool inside = true;
+        while (inside) {
+            const unsigned b = wb[(((k >> 2) - g_lo) * 64 + l) * 16 + (k & 3) * R + r];
+            opsbuf[cnt++] = (uint8_t)st;
+            const int up = (st != 2), left = (st != 1);
+            st = 2 - (int)((b >> (2 * st)) & 3u);
+            const int wrap = up & (r == 0);                       // leaves this lane's rows: lane - 1
+            r = (r - up) & (R - 1);
+            x -= up;
+            y -= left;
+            k -= left + wrap;
+            l -= wrap;
+            inside = (x > 0) & (y > 0) & (l >= 0) & ((k >> 2) >= g_lo) & (cnt < kTbOps);
+        }
+        __syncthreads();
+        for (int i = lane; i < cnt; i += 64) ops[cap - 1 - (len + i)] = opsbuf[i];
+        len += cnt;
+        __syncthreads();
     }
-    while (y > 0) { ops[cap - 1 - len] = 2; ++len; --y; }          // textSeqCompare.py:154-158
-    while (x > 0) { ops[cap - 1 - len] = 1; ++len; --x; }          // textSeqCompare.py:160-164
-    a.ops_len[p] = len;
+    while (y > 0) { if (lane == 0) ops[cap - 1 - len] = 2; ++len; --y; }          // textSeqCompare.py:154-158
+    while (x > 0) { if (lane == 0) ops[cap - 1 - len] = 1; ++len; --x; }          // textSeqCompare.py:160-164
+    if (lane == 0) a.ops_len[p] = len;
 }
 
 }  // namespace ta
