@@ -29,6 +29,21 @@ F32_MFMA_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA peak (spec)
 DEFAULT_SYS = [8, -4, -7, -7, -3, 0]
 
 
+def measured_traffic(batch, n, m):
+    """HBM bytes per nw_fill_kernel launch from the rocprofv3 PMC passes kept under profiles/
+    (WRITE_SIZE + 2 x FETCH_SIZE, MI355X_MICROARCH.md HBM section); None for other configs."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_nw_hbm_traffic.json")) as f:
+            d = json.load(f)
+        if d["config"] == {"batch": batch, "n": n, "m": m}:
+            for k, v in d["kernels"].items():
+                if "nw_fill_kernel" in k:
+                    return v["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def make_nw_batch(tsc, nprob, n, m, seed0, distinct=32):
     from oracle.synth import synth_pair_ids      # seeded input generator shared with the tests
     uniq = [synth_pair_ids(n, m, seed0 + k) for k in range(min(nprob, distinct))]
@@ -208,7 +223,8 @@ def main():
                        "cells_per_step": cells_step, "parallelism": "pages sharded x%d" % world,
                        "bit_exact_vs_oracle": ok},
             "roofline": {"bound": "hbm", "achieved": fill_rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": fill_rate / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": fill_rate / 1e9 / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(args.batch, args.n, args.m),
                          "kernel": "nw_fill_kernel", "kernel_ms": fill_ms, "traceback_ms": tb_ms,
                          "algorithmic_bytes_per_cell": 1},
         }
