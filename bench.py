@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--ocr-lines", type=int, default=1920, help="text lines per GPU (64 pages x 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ocr", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group even at world size 1 (rehearses the RCCL path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,15 +152,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_dist and "RANK" in os.environ):
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from text_alignment_amd import sharding, textSeqCompare as tsc
     batch, uniq = make_nw_batch(tsc, args.batch, args.n, args.m, 1234 + rank * 100000)
-    # the records a page driver would gather: ~150 syllable boxes per page/problem
+    # the records a page driver would gather: ~150 syllable boxes per page/problem, packed at a
+    # fixed capacity so the gather is one collective with no size exchange (sharding.py)
     recs = np.zeros((150 * args.batch, sharding.RECORD_FIELDS), dtype=np.int32)
     recs[:, 0] = np.repeat(np.arange(args.batch) + rank * args.batch, 150)
+    packed = sharding.pack_records_device(recs, 150 * args.batch, torch.device("cuda", local))
+    pending = []
 
     def barrier():
         if dist is not None:
@@ -174,16 +179,21 @@ def main():
         batch.run(fill=False, traceback=True)
         if timed is not None:
             timed[2].record()
-        if dist is not None:
-            sharding.gather_records(recs)
+        if dist is not None:           # asynchronous: overlaps the next step's fill
+            pending.append(sharding.gather_to_root(packed, async_op=True))
 
     for _ in range(args.warmup):
         step()
+    for work, _ in pending:
+        work.wait()
+    del pending[:]
     barrier()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(ev[k])
+    for work, _ in pending:
+        work.wait()
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -209,6 +219,10 @@ def main():
         for k in (0, len(uniq) - 1):
             want = nw_oracle.align_ids(uniq[k][0], uniq[k][1], DEFAULT_SYS)
             ok = ok and res[k].tolist() == want.tolist()
+        gathered_ok = True
+        if pending:
+            got = sharding.unpack_gathered(pending[-1][1])
+            gathered_ok = got.shape[0] == 150 * args.batch * world
         cells_step = batch.cells * world
         fill_rate = batch.cells / (fill_ms * 1e-3)
         out = {
@@ -221,7 +235,8 @@ def main():
                                    % (args.batch, args.n, args.m,
                                       " + gather of syllable-box records" if world > 1 else ""),
                        "cells_per_step": cells_step, "parallelism": "pages sharded x%d" % world,
-                       "bit_exact_vs_oracle": ok},
+                       "bit_exact_vs_oracle": ok,
+                       "gather_ok": gathered_ok},
             "roofline": {"bound": "hbm", "achieved": fill_rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": fill_rate / 1e9 / HBM_PEAK_GBS,
                          "traffic": measured_traffic(args.batch, args.n, args.m),

@@ -31,6 +31,14 @@ def _worker(rank, world, port, q):
     local = np.array(recs, dtype=np.int32).reshape(-1, 6)
     allrec = sharding.gather_records(local)
     empty = sharding.gather_records(np.zeros((0, 6), np.int32) if rank == 1 else local)
+    # fixed-capacity form: one gather to rank 0, no size exchange, asynchronous
+    packed = sharding.pack_records_device(local, 64, torch.device("cpu"))
+    work, out = sharding.gather_to_root(packed, async_op=True)
+    work.wait()
+    if rank == 0:
+        assert sharding.unpack_gathered(out).tolist() == allrec.tolist()
+    else:
+        assert out is None
     if rank == 0:
         q.put((mine, allrec.tolist(), empty.shape[0]))
     else:

@@ -67,6 +67,42 @@ def gather_records(local, group=None, device=None):
     return np.concatenate([allrec_h[r, :int(counts_h[r])] for r in range(world)], axis=0)
 
 
+def pack_records_device(local, cap, device):
+    """Host records -> a device tensor of fixed capacity [cap + 1, 6] whose row 0 carries the
+    record count.  With a capacity agreed beforehand (pages per rank x an upper bound of boxes per
+    page) the gather needs no size exchange and no host synchronisation."""
+    local = np.ascontiguousarray(local, dtype=np.int32).reshape(-1, RECORD_FIELDS)
+    if local.shape[0] > cap:
+        raise ValueError("more records (%d) than the agreed capacity (%d)" % (local.shape[0], cap))
+    buf = np.zeros((cap + 1, RECORD_FIELDS), dtype=np.int32)
+    buf[0, 0] = local.shape[0]
+    buf[1:1 + local.shape[0]] = local
+    return torch.from_numpy(buf).to(device)
+
+
+def gather_to_root(packed, group=None, dst=0, async_op=False):
+    """The single collective of the path: gather every rank's packed record tensor
+    ([cap + 1, 6] int32, see pack_records_device) to rank `dst`.  Returns (work, out): `out` is
+    the [world, cap + 1, 6] tensor on `dst` (None elsewhere); with async_op=True the caller
+    waits on `work` before reading it, so the gather overlaps whatever is enqueued next."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None, packed.unsqueeze(0)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    out, parts = None, None
+    if rank == dst:
+        out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+        parts = [out[r] for r in range(world)]
+    work = dist.gather(packed, parts, dst=dst, group=group, async_op=async_op)
+    return work, out
+
+
+def unpack_gathered(out):
+    """[world, cap + 1, 6] gathered tensor -> concatenated host records in rank order."""
+    h = out.cpu().numpy()
+    return np.concatenate([h[r, 1:1 + int(h[r, 0, 0])] for r in range(h.shape[0])], axis=0)
+
+
 def records_to_json(records, transcripts, lines_peak_locs):
     """Rank-0 side: the gathered records -> {page_id: dict laid out as alignToOCR.to_JSON_dict}.
     transcripts[page_id] is the page's transcript string; syllable texts are recomputed here."""
