@@ -173,6 +173,32 @@ def test_config2_batch_properties(tsc):
     assert all(np.array_equal(a, b) for a, b in zip(res, res2))
 
 
+def test_large_token_alphabets_and_hashable_tokens(tsc):
+    """Tokens are arbitrary hashables compared with == (textSeqCompare.py:32): tuples, ints,
+    strings; thousands of distinct ids go through the u16 code path."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(21)
+    t = [(int(a), "x") for a in rng.integers(0, 3000, size=700)]
+    o = [tok if rng.random() < 0.7 else (int(rng.integers(0, 3000)), "x") for tok in t[:650]]
+    o += [int(v) for v in rng.integers(0, 50, size=40)]
+    assert tsc.perform_alignment(t, o) == nw_oracle.perform_alignment(t, o)
+    assert tsc.perform_alignment(t, o, [3, -2, -4, -1, -1, -2]) == nw_oracle.perform_alignment(t, o, [3, -2, -4, -1, -1, -2])
+
+
+def test_random_scoring_systems_one_launch(tsc):
+    """The parameter grid of evaluate_text_alignment.py:181-198 in one launch: 243 scoring systems
+    drawn from the reference's 3^6 grid against one page-sized pair."""
+    from oracle import nw_oracle
+    from oracle.synth import synth_pair
+    grid = [(m1, m2, gx, gy, ex, ey) for m1 in (5, 8, 11) for m2 in (-10, -7, -4)
+            for gx in (-7, -5, -2) for gy in (-7, -5, -2) for ex in (-5, -3, 0) for ey in (0,)]
+    t, o = synth_pair(420, 390, 77)
+    res = tsc.perform_alignment_batch([(t, o)] * len(grid), [list(g) for g in grid])
+    for g, (tra, ocr) in list(zip(grid, res))[::9]:
+        assert (tra, ocr) == nw_oracle.perform_alignment(t, o, list(g)), g
+    assert len(res) == 243
+
+
 def test_overflow_guard_routes_to_general_kernel(tsc):
     from oracle import nw_oracle
     t, o = list("abcabcabc"), list("abcbcaabc")

@@ -6,6 +6,11 @@ raises -- there is no CPU fallback anywhere in the package.
 import ctypes
 import os
 
+# torch first: its wheel bundles the HIP runtime (libamdhip64, soname .so.7).  Loading
+# libta_hip.so before torch would pull in /opt/rocm's copy and leave two HIP runtimes in one
+# process (kernel launches then fail with "no ROCm-capable device").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libta_hip.so")
 
