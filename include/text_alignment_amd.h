@@ -112,10 +112,15 @@ int ta_nw_general(const int32_t* t, int32_t n, const int32_t* o, int32_t m,
  *
  * ta_lstm_forward: group_lines = int32[ngroups][16] line ids (-1 = empty slot); one workgroup
  *   runs the 16 lines of a group in lockstep, so groups should hold lines of similar length.
- *   wp   = ta_lstm_packed_weight_floats() floats: MFMA B fragments
+ *   mode 0: exact f32 MFMA chain.  wp = ta_lstm_packed_weight_floats(0) floats: B fragments
  *          [dir 2][wave 7][gate GI,GF,GO,CI][k-step 38][lane 64] =
  *          W_gate[unit 16*wave + lane%16][kp 4*kstep + lane/16], kp: 0 bias, 1..48 x,
  *          49..51 zero, 52..151 h; units >= 100 zero.
+ *   mode 1: bf16 matrix cores on 3-way split operands (W = W_hi + W_mid in bf16, activations
+ *          three bf16 terms, f32 accumulation).  wp = ta_lstm_packed_weight_floats(1) 4-byte
+ *          units holding bf16 [dir 2][wave 7][plane hi,mid][gate 4][k-step 5][lane 64][8] =
+ *          plane of W_gate[unit 16*wave + lane%16][kp 32*kstep + 8*(lane/16) + j], kp as above
+ *          padded with zeros to 160.
  *   peep = float[2][3][112]: WIP, WFP, WOP per direction, units >= 100 zero.
  * ta_lstm_output: w2p = float[201][16*ceil(no/16)] (classes beyond `no` zero): row 0 = bias
  *   column W2[:, 0]; row 1 + 4*kk + kq = W2[:, 1 + 50*kq + kk] (kk < 50, kq < 4) -- the k order
@@ -126,10 +131,10 @@ int ta_nw_general(const int32_t* t, int32_t n, const int32_t* o, int32_t m,
  *   probabilities or from the summaries; line b writes dec_n[b] (t, class) pairs at
  *   dec_t/dec_c + dec_off[b] (capacity (T[b] + 1) / 2 entries).
  */
-int32_t ta_lstm_packed_weight_floats(void);
+int32_t ta_lstm_packed_weight_floats(int32_t mode);
 int ta_lstm_forward(const float* x, const int64_t* row_off, const int32_t* T,
                     const int32_t* group_lines, int32_t ngroups,
-                    const float* wp, const float* peep, float* hout, void* stream);
+                    const float* wp, const float* peep, float* hout, int32_t mode, void* stream);
 int ta_lstm_output(const float* y, int64_t rows, const float* w2p, int32_t no,
                    float* probs, float* logits, float* summary, void* stream);
 int ta_decode_summary(const float* summary, const int64_t* row_off, const int32_t* T,

@@ -33,10 +33,10 @@ def _models(seed, no):
     return R, ocr, om, pm
 
 
-def _check_lines(R, ocr, om, widths, tol, check_decode=True):
+def _check_lines(R, ocr, om, widths, tol, check_decode=True, precision="f32"):
     pm = ocr.LineModel(om.fwd, om.rev, om.W2, om.codec)
     lines = [R.synthetic_line(8000 + k, width=w) for k, w in enumerate(widths)]
-    rec = ocr.LineRecognizer(pm)
+    rec = ocr.LineRecognizer(pm, precision=precision)
     dec, probs, logits, states = rec.recognise(lines, want_probs=True)
     assert rec.recognise(lines, from_probs=True) == dec        # K5 from full probabilities == from summaries
     errs = []
@@ -74,6 +74,18 @@ def test_stable_model_long_lines(seed, no):
     errs = _check_lines(R, ocr, _tame(R.synthetic_model(seed, no=no)),
                         [499, 500, 501, 777, 800, 900, 1000, 1200, 1600, 2000], TOL)
     assert max(errs) < 2e-4
+
+
+def test_bf16x3_mode():
+    """The split-bf16 fast mode: 1e-3 on the contractive model at benchmark widths (decode
+    identical); on the chaotic spec model only short lines, at a looser bound."""
+    from oracle import ocr_ref_f64 as R
+    from text_alignment_amd import ocr
+    errs = _check_lines(R, ocr, _tame(R.synthetic_model(7001, no=96)), [100, 500, 1000, 2000], TOL,
+                        precision="bf16x3")
+    assert max(errs) < 3e-4
+    _check_lines(R, ocr, R.synthetic_model(7001, no=96), [1, 17, 40, 64, 100], 1e-2,
+                 check_decode=False, precision="bf16x3")
 
 
 def test_spec_model_long_lines_bounded():

@@ -52,9 +52,9 @@ def _load():
     lib.ta_nw_general.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     f32 = ctypes.c_float
     lib.ta_lstm_packed_weight_floats.restype = i32
-    lib.ta_lstm_packed_weight_floats.argtypes = []
+    lib.ta_lstm_packed_weight_floats.argtypes = [i32]
     lib.ta_lstm_forward.restype = ctypes.c_int
-    lib.ta_lstm_forward.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    lib.ta_lstm_forward.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, i32, vp]
     lib.ta_lstm_output.restype = ctypes.c_int
     lib.ta_lstm_output.argtypes = [vp, i64, vp, i32, vp, vp, vp, vp]
     lib.ta_decode_summary.restype = ctypes.c_int

@@ -198,6 +198,165 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_kernel(LstmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// K3 (bf16 x 3): the same recurrence on the bf16 matrix cores.  v_mfma_f32_16x16x32_bf16 runs at
+// 16x the rate of the f32-input MFMA, so f32 operands are split into bf16 terms whose products
+// are accumulated in f32: activations a = a_hi + a_mid + a_lo (exact to 24 bits), weights
+// W = W_hi + W_mid (16 mantissa bits, relative error 2^-17), five products per k-step
+//   W_hi.(a_hi + a_mid + a_lo) + W_mid.(a_hi + a_mid)
+// i.e. 100 MFMAs of 16 cycles per wave and timestep instead of 152 of 32.  The split of h is done
+// once where it is produced (gate math) and stored as three bf16 planes in LDS, so consumers
+// load ready A fragments (one ds_read_b128 per plane and k-step).
+constexpr int kKP2 = 160;          // [1, x(48), 3 pads, h(100), 8 pads]
+constexpr int kKS2 = kKP2 / 32;    // 5 k-steps of 32
+constexpr int kRS2 = 168;          // LDS row stride in bf16 (336 B: conflict-free b128 reads)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float v, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    const __bf16 l = (__bf16)r2;
+    hi = __builtin_bit_cast(unsigned short, h);
+    mid = __builtin_bit_cast(unsigned short, m);
+    lo = __builtin_bit_cast(unsigned short, l);
+}
+
+__global__ __launch_bounds__(kWaves * 64) void lstm_seq_bf16x3_kernel(LstmArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short srcp[2][3][kLines][kRS2];
+    __shared__ int s_T[kLines];
+    __shared__ long long s_row[kLines];
+
+    const int grp = blockIdx.x, dir = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    if (tid < kLines) {
+        const int id = a.group_lines[grp * kLines + tid];
+        s_T[tid] = id >= 0 ? a.T[id] : 0;
+        s_row[tid] = id >= 0 ? a.row_off[id] : 0;
+    }
+    for (int e = tid; e < 2 * 3 * kLines * kRS2; e += kWaves * 64) (&srcp[0][0][0][0])[e] = 0;
+    __syncthreads();
+    int Tmax = 0;
+#pragma unroll
+    for (int s = 0; s < kLines; ++s) Tmax = max(Tmax, s_T[s]);
+
+    // B fragments: [dir][wave][plane 2][gate 4][kstep 5][lane 64] x 8 bf16 (16 bytes)
+    bf16x8 Bf[2][4][kKS2];
+    {
+        const uint4* wp = reinterpret_cast<const uint4*>(a.wp) +
+                          ((size_t)(dir * kWaves + wave) * 2 * 4 * kKS2) * 64 + lane;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int ks = 0; ks < kKS2; ++ks) {
+                    const uint4 v = wp[((size_t)(pl * 4 + g4) * kKS2 + ks) * 64];
+                    Bf[pl][g4][ks] = __builtin_bit_cast(bf16x8, v);
+                }
+    }
+    const int unit = wave * 16 + (lane & 15);
+    const float wip = a.peep[(dir * 3 + 0) * 112 + unit];
+    const float wfp = a.peep[(dir * 3 + 1) * 112 + unit];
+    const float wop = a.peep[(dir * 3 + 2) * 112 + unit];
+
+    int myT[4];
+    long long myrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int slot = (lane >> 4) * 4 + r;
+        myT[r] = s_T[slot];
+        myrow[r] = s_row[slot];
+    }
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+
+    constexpr int kXE = kLines * kXK;                      // 832 elements of [16][52]
+    auto x_value = [&](int e, int t) -> float {
+        const int slot = e / kXK, kp = e % kXK;
+        if (kp == 0) return 1.0f;
+        if (kp > kNi) return 0.0f;
+        const int Tl = s_T[slot];
+        if (Tl <= 0) return 0.0f;
+        int tt = t < Tl ? t : Tl - 1;
+        if (dir) tt = Tl - 1 - tt;
+        return a.x[(s_row[slot] + tt) * kNi + (kp - 1)];
+    };
+    auto x_store = [&](int e, int buf, float v) {
+        const int slot = e / kXK, kp = e % kXK;
+        unsigned short hi, mid, lo;
+        split3(v, hi, mid, lo);
+        srcp[buf][0][slot][kp] = hi;
+        srcp[buf][1][slot][kp] = mid;
+        srcp[buf][2][slot][kp] = lo;
+    };
+    for (int e = tid; e < kXE; e += kWaves * 64) x_store(e, 0, x_value(e, 0));
+    __syncthreads();
+
+    const int e0 = tid, e1 = tid + kWaves * 64;
+    for (int t = 0; t < Tmax; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        float xn0 = 0.f, xn1 = 0.f;
+        if (t + 1 < Tmax) {
+            xn0 = x_value(e0, t + 1);
+            if (e1 < kXE) xn1 = x_value(e1, t + 1);
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) acc[g4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < kKS2; ++ks) {
+            const int off = 32 * ks + 8 * (lane >> 4);
+            const bf16x8 ahi = *reinterpret_cast<const bf16x8*>(&srcp[cur][0][lane & 15][off]);
+            const bf16x8 amid = *reinterpret_cast<const bf16x8*>(&srcp[cur][1][lane & 15][off]);
+            const bf16x8 alo = *reinterpret_cast<const bf16x8*>(&srcp[cur][2][lane & 15][off]);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v = acc[g4];
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, Bf[0][g4][ks], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(amid, Bf[1][g4][ks], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(amid, Bf[0][g4][ks], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, Bf[1][g4][ks], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, Bf[0][g4][ks], v, 0, 0, 0);
+                acc[g4] = v;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float gi = acc[0][r], gf = acc[1][r], go = acc[2][r];
+            const float ci = tanh_fast(acc[3][r]);
+            if (t > 0) { gi += wip * c[r]; gf += wfp * c[r]; }
+            gi = sigmoid_clip(gi);
+            gf = sigmoid_clip(gf);
+            float cn = ci * gi;
+            if (t > 0) { cn += gf * c[r]; go += wop * cn; }
+            go = sigmoid_clip(go);
+            const float h = tanh_fast(cn) * go;
+            c[r] = cn;
+            if (unit < kNs) {
+                const int slot = (lane >> 4) * 4 + r;
+                unsigned short hi, mid, lo;
+                split3(h, hi, mid, lo);
+                srcp[nxt][0][slot][kXK + unit] = hi;
+                srcp[nxt][1][slot][kXK + unit] = mid;
+                srcp[nxt][2][slot][kXK + unit] = lo;
+                if (t < myT[r]) {
+                    const int tt = dir ? myT[r] - 1 - t : t;
+                    a.hout[(myrow[r] + tt) * (2 * kNs) + dir * kNs + unit] = h;
+                }
+            }
+        }
+        if (t + 1 < Tmax) {
+            x_store(e0, nxt, xn0);
+            if (e1 < kXE) x_store(e1, nxt, xn1);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4: z = W2 . [1, y_t]  (No x 201), p = softmax(clip(z, -100, 100))   (Appendix B.4)
 //
 // One wave per tile of 16 timesteps.  The sum over k may run in any order, so lane
@@ -419,18 +578,27 @@ __global__ __launch_bounds__(64) void decode_summary_kernel(DecSumArgs a) {
 
 using namespace ta;
 
-extern "C" int32_t ta_lstm_packed_weight_floats(void) { return 2 * kWaves * 4 * kKS * 64; }
+extern "C" int32_t ta_lstm_packed_weight_floats(int32_t mode) {
+    // mode 0: f32 fragments [2][7][4][38][64]; mode 1: bf16 pairs [2][7][2][4][5][64][8] (as 4-byte units)
+    return mode == 0 ? 2 * kWaves * 4 * kKS * 64 : 2 * kWaves * 2 * 4 * kKS2 * 64 * 4;
+}
 
 extern "C" int ta_lstm_forward(const float* x, const int64_t* row_off, const int32_t* T,
                                const int32_t* group_lines, int32_t ngroups,
-                               const float* wp, const float* peep, float* hout, void* stream) {
+                               const float* wp, const float* peep, float* hout, int32_t mode,
+                               void* stream) {
     if (ngroups < 0) return ta_fail(TA_EINVAL, "negative group count");
     if (ngroups == 0) return TA_OK;
     if (!x || !row_off || !T || !group_lines || !wp || !peep || !hout)
         return ta_fail(TA_EINVAL, "null pointer argument");
+    if (mode != 0 && mode != 1) return ta_fail(TA_EINVAL, "mode must be 0 (f32 MFMA) or 1 (bf16 x 3)");
     LstmArgs a{x, row_off, T, group_lines, wp, peep, hout};
-    hipLaunchKernelGGL(lstm_seq_kernel, dim3(ngroups, 2), dim3(kWaves * 64), 0,
-                       reinterpret_cast<hipStream_t>(stream), a);
+    if (mode == 1)
+        hipLaunchKernelGGL(lstm_seq_bf16x3_kernel, dim3(ngroups, 2), dim3(kWaves * 64), 0,
+                           reinterpret_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(lstm_seq_kernel, dim3(ngroups, 2), dim3(kWaves * 64), 0,
+                           reinterpret_cast<hipStream_t>(stream), a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ta_fail_hip(e, "lstm_seq_kernel launch");
     return TA_OK;
