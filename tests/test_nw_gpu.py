@@ -199,6 +199,29 @@ def test_random_scoring_systems_one_launch(tsc):
     assert len(res) == 243
 
 
+def test_fuzz_2000_problems_one_launch(tsc):
+    """2000 random ragged problems (sizes 0..700, alphabets 2/4/27, 10 scoring systems incl.
+    positive gap scores and all-zero) in one launch, every alignment against the oracle."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(2026)
+    t_list, o_list, prm = [], [], []
+    for k in range(2000):
+        big = (k % 10 == 0)
+        n = int(rng.integers(0, 700 if big else 120))
+        m = int(rng.integers(0, 700 if big else 120))
+        t, o = _random_problem(rng, n, m, [2, 4, 27][k % 3], k % 2 == 0)
+        t_list.append(t); o_list.append(o); prm.append(SYSTEMS[int(rng.integers(0, len(SYSTEMS)))])
+    batch = tsc.NWBatch(t_list, o_list, prm)
+    batch.run()
+    res = batch.results()
+    bad = []
+    for k in range(2000):
+        want = nw_oracle.align_ids(t_list[k], o_list[k], prm[k])
+        if res[k].tolist() != want.tolist():
+            bad.append(k)
+    assert not bad, bad[:10]
+
+
 def test_overflow_guard_routes_to_general_kernel(tsc):
     from oracle import nw_oracle
     t, o = list("abcabcabc"), list("abcbcaabc")
