@@ -44,11 +44,11 @@ def measured_traffic(batch, n, m):
     return None
 
 
-def make_nw_batch(tsc, nprob, n, m, seed0, distinct=32):
+def make_nw_batch(tsc, nprob, n, m, seed0, distinct=32, two_phase=False):
     from oracle.synth import synth_pair_ids      # seeded input generator shared with the tests
     uniq = [synth_pair_ids(n, m, seed0 + k) for k in range(min(nprob, distinct))]
     probs = [uniq[k % len(uniq)] for k in range(nprob)]
-    return tsc.NWBatch([p[0] for p in probs], [p[1] for p in probs], DEFAULT_SYS), uniq
+    return tsc.NWBatch([p[0] for p in probs], [p[1] for p in probs], DEFAULT_SYS, two_phase=two_phase), uniq
 
 
 def synthetic_lines(nlines, seed0):
@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--ocr-lines", type=int, default=1920, help="text lines per GPU (64 pages x 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ocr", action="store_true")
+    ap.add_argument("--one-pass", action="store_true",
+                    help="use the single-pass fill (1 B/cell pointer matrix) instead of the two-phase aligner")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group even at world size 1 (rehearses the RCCL path)")
     args = ap.parse_args()
@@ -158,7 +160,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from text_alignment_amd import sharding, textSeqCompare as tsc
-    batch, uniq = make_nw_batch(tsc, args.batch, args.n, args.m, 1234 + rank * 100000)
+    batch, uniq = make_nw_batch(tsc, args.batch, args.n, args.m, 1234 + rank * 100000,
+                               two_phase=not args.one_pass)
     # the records a page driver would gather: ~150 syllable boxes per page/problem, packed at a
     # fixed capacity so the gather is one collective with no size exchange (sharding.py)
     recs = np.zeros((150 * args.batch, sharding.RECORD_FIELDS), dtype=np.int32)

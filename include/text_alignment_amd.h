@@ -81,6 +81,22 @@ int ta_nw_batch(const int32_t* t_codes, const int64_t* t_off,
                 uint32_t flags, void* stream);
 
 /*
+ * ta_nw2_batch: the same aligner in two phases -- a score-only wavefront fill that leaves
+ * checkpoints, then a traceback that re-derives pointers only in windows around the path
+ * (csrc/ta_nw2.hip).  Arguments and results exactly as ta_nw_batch, except that `ws` regions are
+ * ta_nw2_workspace_bytes(n, m) long (checkpoints + a 128 KiB window scratch instead of the
+ * 1 B/cell pointer matrix).  TA_NW_FILL = phase 1, TA_NW_TRACEBACK = phase 2.
+ */
+int64_t ta_nw2_workspace_bytes(int32_t n, int32_t m);
+int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
+                 const int32_t* o_codes, const int64_t* o_off, int32_t nprob,
+                 const int32_t* params, int32_t params_stride,
+                 uint8_t* ws, const int64_t* ws_off,
+                 uint8_t* ops_out, const int64_t* ops_off, int32_t* ops_len,
+                 int32_t max_n, int32_t max_m, int64_t score_bound,
+                 uint32_t flags, void* stream);
+
+/*
  * ta_nw_general: the same aligner for scoring systems the integer kernel does not take --
  * a caller-supplied scoring function (textSeqCompare.py:27-29; the host tabulates it over
  * the distinct tokens into `table`, row-major [t id][o id], row length tm) or non-integral

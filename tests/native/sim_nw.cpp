@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../../text_alignment_amd/csrc/nw_cell.h"
@@ -108,6 +109,206 @@ static int run(const int32_t* t, int n, const int32_t* o, int m, const int* p,
     for (int a = 0; a < len; ++a) ops_out[a] = rev[len - 1 - a];
     *ops_len = len;
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two-phase aligner: phase 1 fills scores only (raw integers, no pointer bytes) and checkpoints
+// (a) every KCG groups the whole lane state of the strip's wave and (b) per strip three planes of
+// lane 63's last two rows; phase 2 walks back strip by strip, re-running the TAGGED fill only over
+// a window of skewed steps [g0*SPG, k_in] restarted from a checkpoint (two halo steps make the
+// winner tags of the restart state irrelevant) and walking the pointer bytes of that window.
+template <int R>
+static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, int KCG, int GSPAN,
+                uint8_t* ops_out, int* ops_len) {
+    using L = PtrLayout<R>;
+    constexpr int SPG = L::SPG;
+    const CellConsts c = make_consts(p[0], p[1], p[2], p[3], p[4], p[5]);
+    const int cmat_raw = p[0] - p[4] - p[5], cmis_raw = p[1] - p[4] - p[5];
+    const int nstrips = L::nstrips(n), ngroups = L::ngroups(m);
+    const int nck = ngroups / KCG + 1;
+    struct State { int D[kLanes][R], H[kLanes][R], Vlast[kLanes], dsave[kLanes]; };
+    std::vector<State> ck((size_t)std::max(nstrips, 1) * nck);
+    // row planes of lane 63: index [strip][j], j = 0..m
+    std::vector<int> RV2((size_t)std::max(nstrips, 1) * (m + 2)), RD2(RV2.size()), RH3(RV2.size());
+
+    // ---------------- phase 1: raw fill ----------------
+    {
+        std::vector<int> hv(m + 2), hd(m + 2);
+        for (int j = 0; j <= m; ++j) { hv[j] = raw_of(bnd_V_row0(c, j)); hd[j] = raw_of(bnd_D_row0(c, j)); }
+        for (int s = 0; s < nstrips; ++s) {
+            int D[kLanes][R], V[kLanes][R], H[kLanes][R], tcode[kLanes][R], dsave[kLanes];
+            for (int l = 0; l < kLanes; ++l) {
+                for (int r = 0; r < R; ++r) {
+                    const int i = s * L::SR + l * R + r + 1;
+                    D[l][r] = raw_of(bnd_D_col0(c, i)); H[l][r] = raw_of(bnd_H_col0(c, i)); V[l][r] = 0;
+                    tcode[l][r] = (i <= n) ? t[i - 1] : -1;
+                }
+                dsave[l] = raw_of(bnd_D_col0(c, s * L::SR + l * R));
+            }
+            for (int g = 0; g < ngroups; ++g) {
+                if (g > 0 && g % KCG == 0) {
+                    State& st = ck[(size_t)s * nck + g / KCG];
+                    for (int l = 0; l < kLanes; ++l) {
+                        for (int r = 0; r < R; ++r) { st.D[l][r] = D[l][r]; st.H[l][r] = H[l][r]; }
+                        st.Vlast[l] = V[l][R - 1]; st.dsave[l] = dsave[l];
+                    }
+                }
+                for (int q = 0; q < SPG; ++q) {
+                    const int k = g * SPG + q;
+                    int vup[kLanes], dnext[kLanes];
+                    for (int l = 0; l < kLanes; ++l) {
+                        const int j = k - l + 1;
+                        if (l == 0) { const int jj = (j >= 1 && j <= m) ? j : 0; vup[l] = hv[jj]; dnext[l] = hd[jj]; }
+                        else { vup[l] = V[l - 1][R - 1]; dnext[l] = D[l - 1][R - 1]; }
+                    }
+                    int nD[kLanes][R], nV[kLanes][R], nH[kLanes][R];
+                    bool act[kLanes];
+                    for (int l = 0; l < kLanes; ++l) {
+                        const int j = k - l + 1;
+                        act[l] = (j >= 1 && j <= m);
+                        if (!act[l]) continue;
+                        int d_ul = dsave[l], v_u = vup[l];
+                        for (int r = 0; r < R; ++r) {
+                            const int cs = (tcode[l][r] == o[j - 1]) ? cmat_raw : cmis_raw;
+                            int d, v, h;
+                            cell_update_raw(d_ul, v_u, H[l][r], cs, c.gox, c.goy, d, v, h);
+                            d_ul = D[l][r]; v_u = v;
+                            nD[l][r] = d; nV[l][r] = v; nH[l][r] = h;
+                        }
+                    }
+                    for (int l = 0; l < kLanes; ++l) {
+                        if (!act[l]) continue;
+                        for (int r = 0; r < R; ++r) { D[l][r] = nD[l][r]; V[l][r] = nV[l][r]; H[l][r] = nH[l][r]; }
+                        dsave[l] = dnext[l];
+                        if (l == kLanes - 1) {
+                            const int j = k - l + 1;
+                            hv[j] = V[l][R - 1]; hd[j] = D[l][R - 1];
+                            const size_t b = (size_t)s * (m + 2) + j;
+                            RV2[b] = V[l][R - 2]; RD2[b] = D[l][R - 2]; RH3[b] = H[l][R - 1];
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---------------- phase 2: windowed tagged re-fill + walk ----------------
+    std::vector<uint8_t> rev;
+    int x = n, y = m, st = 0;
+    bool first = true;
+    int guard = 0;
+    while (x > 0 && y > 0) {
+        if (++guard > 4 * (n + m) + 16) return -9;
+        const int s = (x - 1) / L::SR;
+        int l = ((x - 1) % L::SR) / R, r = (x - 1) % R, k = (y - 1) + l;
+        const int g_in = k / SPG;
+        const int g0 = KCG * (std::max(0, g_in - GSPAN) / KCG);
+        const int k0 = g0 * SPG;
+        const int kvalid = g0 > 0 ? k0 + 2 : 0;
+        const int i_h = s * L::SR;                        // row above the strip (1-based index)
+        // tagged hand-off row for columns k0 .. min(m, (g_in+1)*SPG)
+        const int jhi = std::min(m, (g_in + 1) * SPG);
+        std::vector<int> hvt(m + 2, 0), hdt(m + 2, 0);
+        for (int j = std::max(0, k0); j <= jhi; ++j) {
+            if (s == 0) { hvt[j] = bnd_V_row0(c, j); hdt[j] = bnd_D_row0(c, j); continue; }
+            if (j == 0) { hdt[0] = bnd_D_col0(c, i_h); continue; }
+            const size_t b = (size_t)(s - 1) * (m + 2);
+            const int d_ul = (j - 1 >= 1) ? RD2[b + j - 1] : raw_of(bnd_D_col0(c, i_h - 1));
+            const int v_u = RV2[b + j];
+            const int h_l = (j - 1 >= 1) ? RH3[b + j - 1] : raw_of(bnd_H_col0(c, i_h));
+            const int cs = (t[i_h - 1] == o[j - 1]) ? c.cmatch : c.cmismatch;
+            int d, v, h;
+            cell_update(enc_of(d_ul), enc_of(v_u), enc_of(h_l), cs, c.gox6, c.goy6, d, v, h);
+            hvt[j] = v; hdt[j] = d;
+        }
+        // lane state at the start of group g0
+        int D[kLanes][R], V[kLanes][R], H[kLanes][R], tcode[kLanes][R], dsave[kLanes];
+        for (int ll = 0; ll < kLanes; ++ll) {
+            for (int rr = 0; rr < R; ++rr) {
+                const int i = s * L::SR + ll * R + rr + 1;
+                tcode[ll][rr] = (i <= n) ? t[i - 1] : -1;
+                V[ll][rr] = 0;
+                if (g0 == 0) { D[ll][rr] = bnd_D_col0(c, i); H[ll][rr] = bnd_H_col0(c, i); }
+            }
+            if (g0 == 0) dsave[ll] = bnd_D_col0(c, s * L::SR + ll * R);
+        }
+        if (g0 > 0) {
+            const State& cs0 = ck[(size_t)s * nck + g0 / KCG];
+            for (int ll = 0; ll < kLanes; ++ll) {
+                for (int rr = 0; rr < R; ++rr) { D[ll][rr] = enc_of(cs0.D[ll][rr]); H[ll][rr] = enc_of(cs0.H[ll][rr]); }
+                V[ll][R - 1] = enc_of(cs0.Vlast[ll]); dsave[ll] = enc_of(cs0.dsave[ll]);
+            }
+        }
+        // tagged fill of groups g0..g_in into a window buffer
+        std::vector<uint8_t> wbuf((size_t)(g_in - g0 + 1) * 1024, 0xEE);
+        for (int g = g0; g <= g_in; ++g) {
+            uint8_t acc[kLanes][16];
+            memset(acc, 0xEE, sizeof(acc));
+            for (int q = 0; q < SPG; ++q) {
+                const int kk = g * SPG + q;
+                int vup[kLanes], dnext[kLanes];
+                for (int ll = 0; ll < kLanes; ++ll) {
+                    const int j = kk - ll + 1;
+                    if (ll == 0) { const int jj = std::min(std::max(j, 0), m); vup[ll] = hvt[jj]; dnext[ll] = hdt[jj]; }
+                    else { vup[ll] = V[ll - 1][R - 1]; dnext[ll] = D[ll - 1][R - 1]; }
+                }
+                int nD[kLanes][R], nV[kLanes][R], nH[kLanes][R];
+                bool act[kLanes];
+                for (int ll = 0; ll < kLanes; ++ll) {
+                    const int j = kk - ll + 1;
+                    act[ll] = (j >= 1 && j <= m);
+                    if (!act[ll]) continue;
+                    int d_ul = dsave[ll], v_u = vup[ll];
+                    for (int rr = 0; rr < R; ++rr) {
+                        const int cs = (tcode[ll][rr] == o[j - 1]) ? c.cmatch : c.cmismatch;
+                        int d, v, h;
+                        const unsigned b = cell_update(d_ul, v_u, H[ll][rr], cs, c.gox6, c.goy6, d, v, h);
+                        acc[ll][q * R + rr] = (uint8_t)(b & 0x3F);
+                        d_ul = D[ll][rr]; v_u = v;
+                        nD[ll][rr] = d; nV[ll][rr] = v; nH[ll][rr] = h;
+                    }
+                }
+                for (int ll = 0; ll < kLanes; ++ll) {
+                    if (!act[ll]) continue;
+                    for (int rr = 0; rr < R; ++rr) { D[ll][rr] = nD[ll][rr]; V[ll][rr] = nV[ll][rr]; H[ll][rr] = nH[ll][rr]; }
+                    dsave[ll] = dnext[ll];
+                }
+            }
+            for (int ll = 0; ll < kLanes; ++ll) memcpy(&wbuf[((size_t)(g - g0) * 64 + ll) * 16], acc[ll], 16);
+        }
+        auto byte_at = [&](int ll, int rr, int kk) -> unsigned {
+            return wbuf[((size_t)(kk / SPG - g0) * 64 + ll) * 16 + (kk % SPG) * R + rr];
+        };
+        if (first) { st = ptr_pm(byte_at(l, r, k)); first = false; }
+        int steps = 0;
+        while (x > 0 && y > 0 && l >= 0 && k >= kvalid) {
+            const unsigned b = byte_at(l, r, k);
+            if (b == 0xEE) return -7;
+            const int up = (st != 2), left = (st != 1);
+            rev.push_back((uint8_t)st);
+            st = 2 - (int)((b >> (2 * st)) & 3u);
+            const int wrap = up & (r == 0);
+            r = (r - up) & (R - 1);
+            x -= up; y -= left; k -= left + wrap; l -= wrap;
+            ++steps;
+        }
+        if (steps == 0) return -8;
+    }
+    while (y > 0) { rev.push_back(2); --y; }
+    while (x > 0) { rev.push_back(1); --x; }
+    const int len = (int)rev.size();
+    for (int a = 0; a < len; ++a) ops_out[a] = rev[len - 1 - a];
+    *ops_len = len;
+    return 0;
+}
+
+extern "C" int sim_nw2(const int32_t* t, int n, const int32_t* o, int m, const int* params, int R,
+                       int KCG, int GSPAN, uint8_t* ops_out, int* ops_len) {
+    switch (R) {
+        case 4: return run2<4>(t, n, o, m, params, KCG, GSPAN, ops_out, ops_len);
+        case 8: return run2<8>(t, n, o, m, params, KCG, GSPAN, ops_out, ops_len);
+        default: return -1;
+    }
 }
 
 extern "C" int sim_nw(const int32_t* t, int n, const int32_t* o, int m, const int* params, int R,

@@ -25,7 +25,23 @@ def sim():
     lib.sim_nw.restype = ctypes.c_int
     lib.sim_nw.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                            ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    lib.sim_nw2.restype = ctypes.c_int
+    lib.sim_nw2.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                            ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                            ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
     return lib
+
+
+def _sim2_ops(lib, t, o, params, R, kcg, gspan):
+    t = np.ascontiguousarray(t, dtype=np.int32)
+    o = np.ascontiguousarray(o, dtype=np.int32)
+    p = np.asarray(params, dtype=np.int32)
+    ops = np.zeros(len(t) + len(o) + 1, dtype=np.uint8)
+    ln = ctypes.c_int(0)
+    rc = lib.sim_nw2(t.ctypes.data, len(t), o.ctypes.data, len(o), p.ctypes.data, R, kcg, gspan,
+                     ops.ctypes.data, ctypes.byref(ln))
+    assert rc == 0, rc
+    return ops[:ln.value]
 
 
 def _sim_ops(lib, t, o, params, R):
@@ -69,3 +85,27 @@ def test_sim_matches_oracle_synth(sim, R):
         want = nw_oracle.align_ids(t, o, [8, -4, -7, -7, -3, 0])
         got = _sim_ops(sim, t, o, [8, -4, -7, -7, -3, 0], R)
         assert got.tolist() == want.tolist(), (R, n, m, seed)
+
+
+@pytest.mark.parametrize("kcg,gspan", [(1, 1), (2, 3), (4, 8), (32, 96)])
+def test_two_phase_sim_matches_oracle(sim, kcg, gspan):
+    """Checkpointed score-only fill + windowed tagged re-fill (the two-phase aligner's data flow):
+    tiny checkpoint periods and spans force many restarts, multi-window strips and halo steps."""
+    rng = np.random.default_rng(500 + kcg)
+    for k in range(60):
+        asz = [2, 4, 27][k % 3]
+        n = int(rng.integers(1, 90)) if k % 4 else int(rng.integers(200, 700))
+        m = int(rng.integers(1, 90)) if k % 5 else int(rng.integers(100, 500))
+        t = rng.integers(0, asz, size=n)
+        o = rng.integers(0, asz, size=m)
+        if k % 2 == 0:
+            kk = min(n, m)
+            o[:kk] = np.where(rng.random(kk) < 0.8, t[:kk], o[:kk])
+        sc = SYSTEMS[k % len(SYSTEMS)]
+        want = nw_oracle.align_ids(t, o, sc)
+        got = _sim2_ops(sim, t, o, sc, 4, kcg, gspan)
+        assert got.tolist() == want.tolist(), (n, m, sc, kcg, gspan)
+    for n, m, seed in [(500, 500, 1234), (300, 700, 1236), (1030, 515, 7)]:
+        t, o = synth_pair_ids(n, m, seed)
+        want = nw_oracle.align_ids(t, o, SYSTEMS[0])
+        assert _sim2_ops(sim, t, o, SYSTEMS[0], 4, kcg, gspan).tolist() == want.tolist()

@@ -109,6 +109,21 @@ TA_HD unsigned cell_update(int d_ul, int v_u, int h_l, int cs, int gox6, int goy
     return ((unsigned)d_ul & 0x03u) | (inner & ~0x03u);                           // v_bfi_b32
 }
 
+// ---- score-only cell (no tags, no pointer byte): same three maxima on raw integers ----
+// Used by the checkpointing fill (phase 1 of the two-phase aligner); the tagged cell above
+// produces the same scores in its upper 26 bits: cell_update(...) >> 6 == cell_update_raw(...).
+TA_HD void cell_update_raw(int d_ul, int v_u, int h_l, int cs, int gox, int goy,
+                           int& d, int& v, int& h) {
+    const int mr = d_ul + cs;
+    const int xg = v_u + gox;
+    const int yg = h_l + goy;
+    d = max3i(mr, xg, yg);
+    v = max3i(mr, v_u, yg);
+    h = max3i(mr, xg, h_l);
+}
+TA_HD int raw_of(int enc) { return enc >> kShift; }            // arithmetic shift: floor
+TA_HD int enc_of(int raw) { return raw * 64; }                 // tag field zero
+
 // ---- pointer-matrix layout (library-internal; the traceback kernel is its only reader) ----
 // A strip is kLanes*R consecutive rows handled by one wave; lane l owns rows
 // strip*SR + l*R + r (r < R).  The wave sweeps skewed steps k = (j-1) + l, so all lanes of a

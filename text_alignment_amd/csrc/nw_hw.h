@@ -1,0 +1,103 @@
+// nw_hw.h -- device-side helpers shared by the NW kernels (ta_nw.hip, ta_nw2.hip): kernel
+// argument block, single-instruction inline-asm helpers, LDS carve of the fill kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nw_cell.h"
+
+namespace ta {
+
+struct NwArgs {
+    const int32_t* t_codes; const int64_t* t_off;
+    const int32_t* o_codes; const int64_t* o_off;
+    const int32_t* params; int32_t params_stride;
+    uint8_t* ws; const int64_t* ws_off;
+    uint8_t* ops_out; const int64_t* ops_off; int32_t* ops_len;
+    int32_t nprob;
+};
+
+// ---- single-instruction helpers.  Inline asm pins the instruction selection: left to
+// itself hipcc un-folds the pre-shifted constants and splits max3 / bfi (25 VALU per cell
+// instead of 16, see DESIGN.md "K1 instruction budget").  Non-volatile: each is a pure
+// register op the compiler may schedule freely.
+__device__ __forceinline__ int v_max3(int a, int b, int c) {
+    int d;
+    asm("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ int v_and_or_x(int a, int mask) {            // (a & mask) | kTagX
+    int d;
+    asm("v_and_or_b32 %0, %1, %2, 21" : "=v"(d) : "v"(a), "s"(mask));
+    return d;
+}
+__device__ __forceinline__ unsigned v_bfi3(unsigned a, unsigned b) {    // (a & 3) | (b & ~3)
+    unsigned d;
+    asm("v_bfi_b32 %0, 3, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ unsigned v_bfi12(unsigned a, unsigned b) {   // (a & 12) | (b & ~12)
+    unsigned d;
+    asm("v_bfi_b32 %0, 12, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// t == o ? hit : miss   (textSeqCompare.py:32)
+__device__ __forceinline__ int v_score(int t, int o, int miss, int hit) {
+    int d;
+    asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %4, vcc"
+        : "=v"(d) : "v"(t), "v"(o), "v"(miss), "v"(hit) : "vcc");
+    return d;
+}
+// lane l receives lane l-1's value; lane 0 keeps what the destination held (DPP wave_shr:1,
+// bound_ctrl off).  The leading s_nop covers the VALU-write -> DPP-read wait states (2) that
+// hipcc cannot see across asm statements; NOPS = 4 also covers an EXEC write before a DPP.
+template <int NOPS>
+__device__ __forceinline__ void wave_shr1_pair(int& a_io, int a_src, int& b_io, int b_src) {
+    asm volatile("s_nop %4\n\t"
+                 "v_mov_b32_dpp %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf"
+                 : "+v"(a_io), "+v"(b_io) : "v"(a_src), "v"(b_src), "n"(NOPS));
+}
+
+constexpr int kOPad = 64;     // o-code padding in front (lanes that have not started yet)
+constexpr int kOTail = 80;    // steps run to m + 62 (+ group round-up) past the last code
+constexpr int kCheck = 16;    // hand-off progress is checked / published every kCheck groups
+
+// LDS carve (dynamic): int2 hvd[m+2] | int2 dummy[64*4] | uint16 ocode[kOPad+m+kOTail] | int prog[16]
+struct NwLds {
+    size_t hvd_bytes, dummy_bytes, oc_bytes, total;
+    __host__ __device__ explicit NwLds(int m) {
+        hvd_bytes = ((size_t)(m + 2) * 8 + 15) & ~(size_t)15;
+        dummy_bytes = 64 * 4 * 8;
+        oc_bytes = ((size_t)(kOPad + m + kOTail) * 2 + 15) & ~(size_t)15;
+        total = hvd_bytes + dummy_bytes + oc_bytes + 64;
+    }
+};
+
+// One interior cell on the encoded values: the arithmetic of ta::cell_update (nw_cell.h,
+// checked on the CPU by the lane simulator), one VALU instruction per line.
+struct CellRegs {
+    int cmis, cmat, gox6, goy6, clean;    // clean = ~kTagMask, wave-uniform
+};
+__device__ __forceinline__ unsigned cell_hw(const CellRegs& k, int d_ul, int v_u, int h_l,
+                                            int t, int o, int& d, int& v, int& h) {
+    const int cs = v_score(t, o, k.cmis, k.cmat);        // v_cmp_eq + v_cndmask
+    const int mr = (d_ul & k.clean) + cs;                 // v_and, v_add
+    const int xr = v_and_or_x(v_u, k.clean);              // v_and_or
+    const int yr = h_l & k.clean;                         // v_and
+    const int xg = xr + k.gox6;                           // v_add
+    const int yg = yr + k.goy6;                           // v_add
+    d = v_max3(mr, xg, yg);
+    v = v_max3(mr, xr, yg);
+    h = v_max3(mr, xg, yr);
+    return v_bfi3((unsigned)d_ul, v_bfi12((unsigned)v_u, (unsigned)h_l));
+}
+
+// pack the low bytes of four values into one dword (3 v_perm_b32)
+__device__ __forceinline__ unsigned pack4(unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
+    const unsigned lo = __builtin_amdgcn_perm(b1, b0, 0x0C0C0400u);
+    const unsigned hi = __builtin_amdgcn_perm(b3, b2, 0x0C0C0400u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+}  // namespace ta

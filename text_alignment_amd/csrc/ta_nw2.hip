@@ -1,0 +1,554 @@
+// ta_nw2.hip -- two-phase form of the affine-gap aligner (same results as ta_nw.hip, bit for bit).
+//
+// The single-pass fill kernel (ta_nw.hip) is bound by VALU issue, and 40 % of its instructions only
+// serve the pointer byte (tag clean-up, two v_bfi, byte packing).  The reference needs pointers
+// only along the traceback path (textSeqCompare.py:96-164), so:
+//
+//  phase 1  nw_score_kernel   the same strip / lane / skew wavefront on RAW integer scores: per cell
+//           v_cmp + v_cndmask, 3 v_add, 3 v_max3_i32 and nothing else; no pointer byte is formed
+//           or stored.  It leaves checkpoints in HBM (0.13 B per cell): every kCkGroups groups the
+//           wave's whole lane state, and per strip three planes of lane 63's last two rows.
+//  phase 2  nw_trace2_kernel  one wave per problem walks back strip by strip.  For the strip the
+//           walk is in, it re-runs the TAGGED fill (ta_nw.hip's cell) over a window of skewed steps
+//           restarted from the nearest state checkpoint (two halo steps make the missing winner
+//           tags of the restart state irrelevant; the row above the strip is re-derived with tags
+//           from the three planes), writes that window's pointer bytes to a small scratch and
+//           walks them.  About 10 % of the cells are recomputed.
+//
+// Data flow and the halo argument are replayed on the CPU by tests/native/sim_nw.cpp (run2).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "nw_cell.h"
+#include "nw_hw.h"
+#include "ta_common.h"
+
+namespace ta {
+
+constexpr int kCkGroups = 16;                 // state checkpoint every 16 groups (64 skewed steps)
+constexpr int kSpanGroups = 84;               // phase 2 restarts >= this many groups before the entry
+constexpr int kWinGroups = kCkGroups + kSpanGroups;     // upper bound of a window, in groups
+constexpr int kStateInts = 10;                // D[4], H[4], V[3], dsave
+
+// per-problem layout of the phase-1/2 workspace (all offsets in bytes, 16-byte aligned)
+struct Ws2 {
+    int nstrips, ngroups, nck, mrow;
+    int64_t rowck, stck, scratch, total;
+    __host__ __device__ Ws2(int n, int m) {
+        using L = PtrLayout<4>;
+        nstrips = L::nstrips(n);
+        ngroups = L::ngroups(m);
+        nck = ngroups / kCkGroups + 1;
+        mrow = (m + 8 + 3) & ~3;
+        rowck = 0;
+        stck = rowck + (int64_t)nstrips * 3 * mrow * 4;
+        scratch = stck + (int64_t)nstrips * nck * kStateInts * 64 * 4;
+        total = scratch + (int64_t)kWinGroups * 1024;
+    }
+    __host__ __device__ int64_t row_plane(int s, int plane) const {       // int index base, entry j at +j+2
+        return rowck + ((int64_t)(s * 3 + plane) * mrow) * 4;
+    }
+    __host__ __device__ int64_t state(int s, int ck) const {
+        return stck + ((int64_t)(s * nck + ck) * kStateInts * 64) * 4;
+    }
+};
+
+struct RawRegs { int cmis, cmat, gox, goy; };
+
+__device__ __forceinline__ void cell_raw_hw(const RawRegs& k, int d_ul, int v_u, int h_l, int t, int o,
+                                            int& d, int& v, int& h) {
+    const int cs = v_score(t, o, k.cmis, k.cmat);
+    const int mr = d_ul + cs;
+    const int xg = v_u + k.gox;
+    const int yg = h_l + k.goy;
+    d = v_max3(mr, xg, yg);
+    v = v_max3(mr, v_u, yg);
+    h = v_max3(mr, xg, h_l);
+}
+
+// ---------------------------------------------------------------------------------------------
+// phase 1
+template <int W>
+__global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
+    constexpr int R = 4;
+    using L = PtrLayout<R>;
+    constexpr int SPG = L::SPG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int p = blockIdx.x;
+    const int64_t t0 = a.t_off[p], o0 = a.o_off[p];
+    const int n = (int)(a.t_off[p + 1] - t0);
+    const int m = (int)(a.o_off[p + 1] - o0);
+    if (n <= 0 || m <= 0) return;
+
+    const int32_t* prm = a.params + (size_t)p * a.params_stride;
+    const CellConsts c = make_consts(prm[0], prm[1], prm[2], prm[3], prm[4], prm[5]);
+    RawRegs kr;
+    kr.cmis = prm[1] - prm[4] - prm[5]; kr.cmat = prm[0] - prm[4] - prm[5];
+    kr.gox = prm[2]; kr.goy = prm[3];
+
+    const NwLds lds(m);
+    int2* hvd = reinterpret_cast<int2*>(smem);
+    int2* dummy = reinterpret_cast<int2*>(smem + lds.hvd_bytes);
+    uint16_t* ocode = reinterpret_cast<uint16_t*>(smem + lds.hvd_bytes + lds.dummy_bytes);
+    int* prog = reinterpret_cast<int*>(smem + lds.hvd_bytes + lds.dummy_bytes + lds.oc_bytes);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int j = tid; j < kOPad + m + kOTail; j += W * 64) {
+        const int src = j - kOPad;
+        ocode[j] = (src >= 0 && src < m) ? (uint16_t)a.o_codes[o0 + src] : (uint16_t)0xFFFF;
+    }
+    for (int j = tid; j <= m; j += W * 64)
+        hvd[j] = make_int2(raw_of(bnd_V_row0(c, j)), raw_of(bnd_D_row0(c, j)));
+    if (tid < 16) prog[tid] = 0;
+    __syncthreads();
+
+    const Ws2 ws(n, m);
+    uint8_t* const ws_p = a.ws + a.ws_off[p];
+    const int nstrips = ws.nstrips, ngroups = ws.ngroups;
+    const int prev_wave = (wave + W - 1) % W;
+    const int g_lo = (63 + SPG - 1) / SPG;
+    const int g_hi = m / SPG;
+    int pass = 0;
+
+    for (int s = wave; s < nstrips; s += W, ++pass) {
+        int D[R], V[R], H[R], tc[R];
+        const int row0 = s * L::SR + lane * R;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = row0 + r + 1;
+            D[r] = raw_of(bnd_D_col0(c, i));
+            H[r] = raw_of(bnd_H_col0(c, i));
+            V[r] = 0;
+            tc[r] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
+        }
+        int dsave = raw_of(bnd_D_col0(c, row0));
+        const bool lane_has_rows = row0 < n;
+        const int prod_pass = (wave == 0) ? pass - 1 : pass;
+        int* const plane_v = reinterpret_cast<int*>(ws_p + ws.row_plane(s, 0));
+        int* const plane_d = reinterpret_cast<int*>(ws_p + ws.row_plane(s, 1));
+        int* const plane_h = reinterpret_cast<int*>(ws_p + ws.row_plane(s, 2));
+
+        auto wait_span = [&](int g_first) {
+            if (W == 1 || s == 0) return;
+            const int k_last = min((g_first + kCheck + 1) * SPG - 1, L::nsteps(m) - 1);
+            const int col = min(k_last + 1, m);
+            const int need_groups = min(ngroups, (col + 62) / SPG + 1);
+            const int need = prod_pass * ngroups + need_groups;
+            while (true) {
+                const int have = __hip_atomic_load(&prog[prev_wave], __ATOMIC_ACQUIRE,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__builtin_amdgcn_readfirstlane(have) >= need) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        };
+        auto publish = [&](int g) {
+            if (W == 1) return;
+            if ((g % kCheck) == kCheck - 1 || g == ngroups - 1) {
+                if (lane == 63)
+                    __hip_atomic_store(&prog[wave], pass * ngroups + g + 1, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        int oc_next[SPG];
+        int2 hd_next[SPG];
+        auto load_group = [&](int g) {
+            const int idx = kOPad + g * SPG - lane;
+#pragma unroll
+            for (int q = 0; q < SPG; ++q) {
+                oc_next[q] = ocode[idx + q];
+                hd_next[q] = hvd[min(g * SPG + q + 1, m)];
+            }
+        };
+        auto prefetch = [&](int g) {
+            if (g + 1 < ngroups) {
+                if (((g + 1) % kCheck) == 0) wait_span(g + 1);
+                load_group(g + 1);
+            }
+        };
+        // whole lane state, taken BEFORE group g runs: what phase 2 restarts from
+        auto checkpoint = [&](int g) {
+            if (g > 0 && (g % kCkGroups) == 0) {
+                int* st = reinterpret_cast<int*>(ws_p + ws.state(s, g / kCkGroups)) + lane;
+#pragma unroll
+                for (int r = 0; r < R; ++r) { st[r * 64] = D[r]; st[(R + r) * 64] = H[r]; }
+                st[8 * 64] = V[R - 1];
+                st[9 * 64] = dsave;
+            }
+        };
+        // lane 63's last two rows: V~ and D of row R-2, H~ of row R-1, per column (entry j at j+2)
+        auto store_planes = [&](int g, const int (&rv)[SPG], const int (&rd)[SPG], const int (&rh)[SPG]) {
+            if (lane == 63 && g >= 15) {
+                const int base = 4 * (g - 15);
+                *reinterpret_cast<int4*>(plane_v + base) = make_int4(rv[0], rv[1], rv[2], rv[3]);
+                *reinterpret_cast<int4*>(plane_d + base) = make_int4(rd[0], rd[1], rd[2], rd[3]);
+                *reinterpret_cast<int4*>(plane_h + base) = make_int4(rh[0], rh[1], rh[2], rh[3]);
+            }
+        };
+        auto group_edge = [&](int g) {
+            checkpoint(g);
+            int oc[SPG];
+            int2 hd[SPG];
+#pragma unroll
+            for (int q = 0; q < SPG; ++q) { oc[q] = oc_next[q]; hd[q] = hd_next[q]; }
+            prefetch(g);
+            int rv[SPG], rd[SPG], rh[SPG];
+#pragma unroll
+            for (int q = 0; q < SPG; ++q) {
+                const int k = g * SPG + q;
+                const int j = k - lane + 1;
+                const bool active = (j >= 1) && (j <= m) && lane_has_rows;
+                int v_up = hd[q].x, d_next = hd[q].y;
+                wave_shr1_pair<4>(v_up, V[R - 1], d_next, D[R - 1]);
+                if (active) {
+                    int d_ul = dsave, v_u = v_up;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int d_old = D[r];
+                        cell_raw_hw(kr, d_ul, v_u, H[r], tc[r], oc[q], D[r], V[r], H[r]);
+                        d_ul = d_old;
+                        v_u = V[r];
+                    }
+                    dsave = d_next;
+                    if (lane == 63) hvd[j] = make_int2(V[R - 1], D[R - 1]);
+                }
+                rv[q] = V[R - 2]; rd[q] = D[R - 2]; rh[q] = H[R - 1];
+            }
+            store_planes(g, rv, rd, rh);
+            publish(g);
+        };
+
+        wait_span(0);
+        load_group(0);
+        int g = 0;
+        const int e1 = min(g_lo, ngroups);
+        for (; g < e1; ++g) group_edge(g);
+
+        if (g < g_hi) {
+            int2* wptr = (lane == 63) ? (hvd + (g * SPG - 62)) : (dummy + lane * SPG);
+            const int winc = (lane == 63) ? SPG : 0;
+            for (; g < g_hi; ++g) {
+                checkpoint(g);
+                int oc[SPG];
+                int2 hd[SPG];
+#pragma unroll
+                for (int q = 0; q < SPG; ++q) { oc[q] = oc_next[q]; hd[q] = hd_next[q]; }
+                prefetch(g);
+                int rv[SPG], rd[SPG], rh[SPG];
+#pragma unroll
+                for (int q = 0; q < SPG; ++q) {
+                    int v_up = hd[q].x, d_next = hd[q].y;
+                    wave_shr1_pair<1>(v_up, V[R - 1], d_next, D[R - 1]);
+                    int d_ul = dsave, v_u = v_up;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int d_old = D[r];
+                        cell_raw_hw(kr, d_ul, v_u, H[r], tc[r], oc[q], D[r], V[r], H[r]);
+                        d_ul = d_old;
+                        v_u = V[r];
+                    }
+                    dsave = d_next;
+                    wptr[q] = make_int2(V[R - 1], D[R - 1]);
+                    rv[q] = V[R - 2]; rd[q] = D[R - 2]; rh[q] = H[R - 1];
+                }
+                wptr += winc;
+                store_planes(g, rv, rd, rh);
+                publish(g);
+            }
+        }
+        for (; g < ngroups; ++g) group_edge(g);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// phase 2
+constexpr int kTb2Groups = 32;                // walk sub-window staged in LDS, in groups
+constexpr int kTb2Ops = 512;
+
+__global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
+    constexpr int R = 4;
+    using L = PtrLayout<R>;
+    constexpr int SPG = L::SPG;
+    constexpr int kSteps = kWinGroups * SPG;                    // 512 skewed steps per window at most
+    __shared__ int2 hvt[kSteps + 8];                            // tagged (V~, D) of the row above, columns k0..
+    __shared__ uint16_t ow[kSteps + 64 + 8];                    // OCR codes, o index (k0 - 63) + i
+    __shared__ uint4 win[kTb2Groups * 64];
+    __shared__ uint8_t opsbuf[kTb2Ops];
+
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int64_t t0 = a.t_off[p], o0 = a.o_off[p];
+    const int n = (int)(a.t_off[p + 1] - t0);
+    const int m = (int)(a.o_off[p + 1] - o0);
+    uint8_t* ops = a.ops_out + a.ops_off[p];
+    const int cap = n + m;
+    int x = n, y = m, len = 0, st = 0;
+    bool first = true;
+
+    const int32_t* prm = a.params + (size_t)p * a.params_stride;
+    const CellConsts c = make_consts(prm[0], prm[1], prm[2], prm[3], prm[4], prm[5]);
+    CellRegs kr;
+    kr.cmis = c.cmismatch; kr.cmat = c.cmatch; kr.gox6 = c.gox6; kr.goy6 = c.goy6;
+    kr.clean = ~kTagMask;
+    const Ws2 ws(max(n, 1), max(m, 1));
+    uint8_t* const ws_p = a.ws + a.ws_off[p];
+    uint8_t* const scratch = ws_p + ws.scratch;
+
+    while (x > 0 && y > 0) {
+        const int s = (x - 1) / L::SR;
+        int l = ((x - 1) % L::SR) / R;
+        int r = (x - 1) % R;
+        int k = (y - 1) + l;
+        const int g_in = k >> 2;
+        const int g0 = kCkGroups * (max(0, g_in - kSpanGroups) / kCkGroups);
+        const int k0 = g0 * SPG;
+        const int kvalid = g0 > 0 ? k0 + 2 : 0;
+        const int i_h = s * L::SR;                              // 1-based index of the row above the strip
+        const int nsteps_w = (g_in - g0 + 1) * SPG;
+
+        // (a) OCR codes of the window: ow[i] = o[(k0 - 63) + i]
+        // (fixed trip counts, fully unrolled: all loads of a stage are in flight together)
+#pragma unroll
+        for (int it = 0; it < (kSteps + 64 + 63) / 64; ++it) {
+            const int i = it * 64 + lane;
+            const int src = k0 - 63 + i;
+            if (i < nsteps_w + 64)
+                ow[i] = (src >= 0 && src < m) ? (uint16_t)a.o_codes[o0 + src] : (uint16_t)0xFFFF;
+        }
+        // (b) the row above the strip with winner tags, columns k0 .. min(m, k0 + nsteps_w)
+        {
+            const int jhi = min(m, k0 + nsteps_w);
+            const int* pv = reinterpret_cast<const int*>(ws_p + ws.row_plane(max(s - 1, 0), 0)) + 2;
+            const int* pd = reinterpret_cast<const int*>(ws_p + ws.row_plane(max(s - 1, 0), 1)) + 2;
+            const int* ph = reinterpret_cast<const int*>(ws_p + ws.row_plane(max(s - 1, 0), 2)) + 2;
+            const int t_h = (s > 0) ? a.t_codes[t0 + i_h - 1] : -1;
+            if (s == 0) {
+                for (int j = k0 + lane; j <= jhi; j += 64)
+                    hvt[j - k0] = make_int2(bnd_V_row0(c, j), bnd_D_row0(c, j));
+            } else {
+                constexpr int kIt = (kSteps + 1 + 63) / 64;
+                int rd_[kIt], rv_[kIt], rh_[kIt], ro_[kIt];
+#pragma unroll
+                for (int it = 0; it < kIt; ++it) {                 // issue every load first
+                    const int j = min(k0 + it * 64 + lane, jhi);
+                    const int jm = max(j - 1, 0);
+                    rd_[it] = pd[jm]; rv_[it] = pv[j]; rh_[it] = ph[jm];
+                    ro_[it] = a.o_codes[o0 + jm];
+                }
+#pragma unroll
+                for (int it = 0; it < kIt; ++it) {
+                    const int j = k0 + it * 64 + lane;
+                    if (j > jhi) continue;
+                    int2 e;
+                    if (j == 0) {
+                        e = make_int2(0, bnd_D_col0(c, i_h));
+                    } else {
+                        const int d_ul = (j - 1 >= 1) ? rd_[it] : raw_of(bnd_D_col0(c, i_h - 1));
+                        const int h_l = (j - 1 >= 1) ? rh_[it] : raw_of(bnd_H_col0(c, i_h));
+                        const int cs = (t_h == ro_[it]) ? c.cmatch : c.cmismatch;
+                        int d, v, h;
+                        cell_update(enc_of(d_ul), enc_of(rv_[it]), enc_of(h_l), cs, c.gox6, c.goy6, d, v, h);
+                        e = make_int2(v, d);
+                    }
+                    hvt[j - k0] = e;
+                }
+            }
+        }
+        // (c) lane state at the start of group g0
+        int D[R], V[R], H[R], tc[R];
+        int dsave;
+        const int row0 = s * L::SR + lane * R;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int i = row0 + rr + 1;
+            tc[rr] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
+            V[rr] = 0;
+            D[rr] = bnd_D_col0(c, i);
+            H[rr] = bnd_H_col0(c, i);
+        }
+        dsave = bnd_D_col0(c, row0);
+        if (g0 > 0) {
+            const int* stp = reinterpret_cast<const int*>(ws_p + ws.state(s, g0 / kCkGroups)) + lane;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) { D[rr] = enc_of(stp[rr * 64]); H[rr] = enc_of(stp[(R + rr) * 64]); }
+            V[R - 1] = enc_of(stp[8 * 64]);
+            dsave = enc_of(stp[9 * 64]);
+        }
+        const bool lane_has_rows = row0 < n;
+        __syncthreads();
+
+        // (d) tagged fill of groups g0 .. g_in into the scratch (strip layout, group index g - g0);
+        // inputs of group g+1 are fetched from LDS while group g computes, and groups in which
+        // every lane is inside 1 <= j <= m run without EXEC changes (as in ta_nw.hip)
+        {
+            int oc_next[SPG];
+            int2 hd_next[SPG];
+            auto load_group = [&](int g) {
+#pragma unroll
+                for (int q = 0; q < SPG; ++q) {
+                    const int kk = g * SPG + q;
+                    oc_next[q] = ow[kk - k0 + 63 - lane];
+                    hd_next[q] = hvt[min(kk + 1, m) - k0];
+                }
+            };
+            load_group(g0);
+            const int gs_lo = (63 + SPG - 1) / SPG, gs_hi = m / SPG;     // steady groups [gs_lo, gs_hi)
+            for (int g = g0; g <= g_in; ++g) {
+                int oc[SPG];
+                int2 hd[SPG];
+#pragma unroll
+                for (int q = 0; q < SPG; ++q) { oc[q] = oc_next[q]; hd[q] = hd_next[q]; }
+                if (g < g_in) load_group(g + 1);
+                unsigned acc[4] = {0u, 0u, 0u, 0u};
+                if (g >= gs_lo && g < gs_hi) {
+#pragma unroll
+                    for (int q = 0; q < SPG; ++q) {
+                        int v_up = hd[q].x, d_next = hd[q].y;
+                        wave_shr1_pair<1>(v_up, V[R - 1], d_next, D[R - 1]);
+                        int d_ul = dsave, v_u = v_up;
+                        unsigned b[R];
+#pragma unroll
+                        for (int rr = 0; rr < R; ++rr) {
+                            const int d_old = D[rr];
+                            b[rr] = cell_hw(kr, d_ul, v_u, H[rr], tc[rr], oc[q], D[rr], V[rr], H[rr]);
+                            d_ul = d_old;
+                            v_u = V[rr];
+                        }
+                        acc[q] = pack4(b[0], b[1], b[2], b[3]);
+                        dsave = d_next;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < SPG; ++q) {
+                        const int kk = g * SPG + q;
+                        const int j = kk - lane + 1;
+                        const bool active = (j >= 1) && (j <= m) && lane_has_rows;
+                        int v_up = hd[q].x, d_next = hd[q].y;
+                        wave_shr1_pair<4>(v_up, V[R - 1], d_next, D[R - 1]);
+                        if (active) {
+                            int d_ul = dsave, v_u = v_up;
+                            unsigned b[R];
+#pragma unroll
+                            for (int rr = 0; rr < R; ++rr) {
+                                const int d_old = D[rr];
+                                b[rr] = cell_hw(kr, d_ul, v_u, H[rr], tc[rr], oc[q], D[rr], V[rr], H[rr]);
+                                d_ul = d_old;
+                                v_u = V[rr];
+                            }
+                            acc[q] = pack4(b[0], b[1], b[2], b[3]);
+                            dsave = d_next;
+                        }
+                    }
+                }
+                *reinterpret_cast<uint4*>(scratch + ((int64_t)(g - g0) * 64 + lane) * 16) =
+                    make_uint4(acc[0], acc[1], acc[2], acc[3]);
+            }
+        }
+        __threadfence();            // the walk below re-reads these bytes: make them visible past L1
+        __syncthreads();
+
+        // (e) walk the window (LDS-staged sub-windows of kTb2Groups groups)
+        bool leave = false;
+        while (!leave) {
+            const int gw_hi = k >> 2;
+            const int gw_lo = max(g0, gw_hi - (kTb2Groups - 1));
+            const int klow = max(kvalid, gw_lo * SPG);
+#pragma unroll 8
+            for (int it = 0; it <= gw_hi - gw_lo; ++it)
+                win[it * 64 + lane] = *reinterpret_cast<const uint4*>(
+                    scratch + ((int64_t)(gw_lo + it - g0) * 64 + lane) * 16);
+            __syncthreads();
+            const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
+            if (first) {                                       // start state, textSeqCompare.py:102
+                st = ptr_pm(wb[(((k >> 2) - gw_lo) * 64 + l) * 16 + (k & 3) * R + r]);
+                first = false;
+            }
+            int cnt = 0;
+            bool inside = (k >= klow);
+            while (inside) {
+                const unsigned b = wb[(((k >> 2) - gw_lo) * 64 + l) * 16 + (k & 3) * R + r];
+                opsbuf[cnt++] = (uint8_t)st;
+                const int up = (st != 2), left = (st != 1);
+                st = 2 - (int)((b >> (2 * st)) & 3u);
+                const int wrap = up & (r == 0);
+                r = (r - up) & (R - 1);
+                x -= up;
+                y -= left;
+                k -= left + wrap;
+                l -= wrap;
+                inside = (x > 0) & (y > 0) & (l >= 0) & (k >= klow) & (cnt < kTb2Ops);
+            }
+            __syncthreads();
+            for (int i = lane; i < cnt; i += 64) ops[cap - 1 - (len + i)] = opsbuf[i];
+            len += cnt;
+            __syncthreads();
+            // leave this fill window when the walk left the strip, finished, or ran below the valid steps
+            leave = (x <= 0) | (y <= 0) | (l < 0) | (k < kvalid) | (cnt == 0);
+        }
+    }
+    while (y > 0) { if (lane == 0) ops[cap - 1 - len] = 2; ++len; --y; }
+    while (x > 0) { if (lane == 0) ops[cap - 1 - len] = 1; ++len; --x; }
+    if (lane == 0) a.ops_len[p] = len;
+}
+
+}  // namespace ta
+
+using namespace ta;
+
+extern "C" int64_t ta_nw2_workspace_bytes(int32_t n, int32_t m) {
+    if (n <= 0 || m <= 0) return 16;
+    return (Ws2(n, m).total + 15) & ~(int64_t)15;
+}
+
+template <int W>
+static hipError_t launch_score(const NwArgs& a, int max_m, hipStream_t st) {
+    const size_t lds = NwLds(max_m).total;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nw_score_kernel<W>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL((nw_score_kernel<W>), dim3(a.nprob), dim3(W * 64), lds, st, a);
+    return hipGetLastError();
+}
+
+extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
+                            const int32_t* o_codes, const int64_t* o_off, int32_t nprob,
+                            const int32_t* params, int32_t params_stride,
+                            uint8_t* ws, const int64_t* ws_off,
+                            uint8_t* ops_out, const int64_t* ops_off, int32_t* ops_len,
+                            int32_t max_n, int32_t max_m, int64_t score_bound,
+                            uint32_t flags, void* stream) {
+    if (nprob < 0 || max_n < 0 || max_m < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (nprob == 0) return TA_OK;
+    if (!t_off || !o_off || !params || !ws_off || !ops_off || !ops_len)
+        return ta_fail(TA_EINVAL, "null pointer argument");
+    if (params_stride != 0 && params_stride != 6) return ta_fail(TA_EINVAL, "params_stride must be 0 or 6");
+    if (score_bound < 0 || score_bound >= (1ll << 23))
+        return ta_fail(TA_ERANGE, "(n+m+2)*max|param| does not fit the 32-bit encoded scores");
+    if (max_m > ta_nw_max_m()) return ta_fail(TA_ELIMIT, "m exceeds the LDS hand-off row capacity");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    NwArgs a{t_codes, t_off, o_codes, o_off, params, params_stride, ws, ws_off,
+             ops_out, ops_off, ops_len, nprob};
+    if ((flags & TA_NW_FILL) && max_n > 0 && max_m > 0) {
+        if (!t_codes || !o_codes || !ws) return ta_fail(TA_EINVAL, "null code/workspace pointer");
+        const int nstrips = PtrLayout<4>::nstrips(max_n);
+        hipError_t e;
+        if (nstrips >= 8) e = launch_score<8>(a, max_m, st);
+        else if (nstrips >= 4) e = launch_score<4>(a, max_m, st);
+        else if (nstrips >= 2) e = launch_score<2>(a, max_m, st);
+        else e = launch_score<1>(a, max_m, st);
+        if (e != hipSuccess) return ta_fail_hip(e, "nw_score_kernel launch");
+    }
+    if (flags & TA_NW_TRACEBACK) {
+        if (!ops_out && (max_n + max_m) > 0) return ta_fail(TA_EINVAL, "null ops_out");
+        hipLaunchKernelGGL(nw_trace2_kernel, dim3(nprob), dim3(64), 0, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return ta_fail_hip(e, "nw_trace2_kernel launch");
+    }
+    return TA_OK;
+}

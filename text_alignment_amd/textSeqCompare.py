@@ -87,7 +87,7 @@ class NWBatch(object):
     `run()` only enqueues kernels on torch's current stream.
     """
 
-    def __init__(self, t_list, o_list, params, device="cuda"):
+    def __init__(self, t_list, o_list, params, device="cuda", two_phase=None):
         assert len(t_list) == len(o_list)
         self.device = torch.device(device)
         self.nprob = len(t_list)
@@ -96,6 +96,12 @@ class NWBatch(object):
         self.max_n = int(self.n.max()) if self.nprob else 0
         self.max_m = int(self.m.max()) if self.nprob else 0
         self.cells = int((self.n * self.m).sum())
+        # two-phase aligner (score-only fill + windowed pointer re-derivation, csrc/ta_nw2.hip):
+        # faster and 8x lighter on HBM once problems span several 256-row strips; the one-pass
+        # kernel (1 B/cell pointer matrix) wins on page-sized problems
+        if two_phase is None:
+            two_phase = self.max_n * self.max_m >= (1 << 21)
+        self.two_phase = bool(two_phase)
         p = np.asarray(params, dtype=np.int64)
         if p.ndim == 1:
             p = p.reshape(1, 6)
@@ -110,8 +116,8 @@ class NWBatch(object):
         lib = _native.lib
         t_off = np.zeros(self.nprob + 1, dtype=np.int64); np.cumsum(self.n, out=t_off[1:])
         o_off = np.zeros(self.nprob + 1, dtype=np.int64); np.cumsum(self.m, out=o_off[1:])
-        ws_sizes = np.array([lib.ta_nw_workspace_bytes(int(a), int(b))
-                             for a, b in zip(self.n, self.m)], dtype=np.int64)
+        ws_fn = lib.ta_nw2_workspace_bytes if self.two_phase else lib.ta_nw_workspace_bytes
+        ws_sizes = np.array([ws_fn(int(a), int(b)) for a, b in zip(self.n, self.m)], dtype=np.int64)
         ws_off = np.zeros(self.nprob + 1, dtype=np.int64); np.cumsum(ws_sizes, out=ws_off[1:])
         self.ws_bytes = int(ws_off[-1])
         cap = self.n + self.m
@@ -141,14 +147,15 @@ class NWBatch(object):
             return
         flags = (_native.TA_NW_FILL if fill else 0) | (_native.TA_NW_TRACEBACK if traceback else 0)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = _native.lib.ta_nw_batch(
+        entry = _native.lib.ta_nw2_batch if self.two_phase else _native.lib.ta_nw_batch
+        rc = entry(
             self.t_codes.data_ptr(), self.t_off.data_ptr(),
             self.o_codes.data_ptr(), self.o_off.data_ptr(), self.nprob,
             self.params.data_ptr(), self.params_stride,
             self.ws.data_ptr(), self.ws_off.data_ptr(),
             self.ops.data_ptr(), self.ops_off.data_ptr(), self.ops_len.data_ptr(),
             self.max_n, self.max_m, self.score_bound, flags, stream)
-        _native.check(rc, "ta_nw_batch")
+        _native.check(rc, "ta_nw2_batch" if self.two_phase else "ta_nw_batch")
 
     def results(self):
         """Host copies of the alignment columns, one uint8 array per problem."""
