@@ -29,15 +29,17 @@ F32_MFMA_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA peak (spec)
 DEFAULT_SYS = [8, -4, -7, -7, -3, 0]
 
 
-def measured_traffic(batch, n, m):
-    """HBM bytes per nw_fill_kernel launch from the rocprofv3 PMC passes kept under profiles/
-    (WRITE_SIZE + 2 x FETCH_SIZE, MI355X_MICROARCH.md HBM section); None for other configs."""
+def measured_traffic(batch, n, m, kernel):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes kept under
+    profiles/ (WRITE_SIZE + 2 x FETCH_SIZE, MI355X_MICROARCH.md HBM section); None for configs
+    that were not profiled."""
+    name = "r01_nw2_hbm_traffic.json" if kernel == "nw_score_kernel" else "r01_nw_hbm_traffic.json"
     try:
-        with open(os.path.join(REPO, "profiles", "r01_nw_hbm_traffic.json")) as f:
+        with open(os.path.join(REPO, "profiles", name)) as f:
             d = json.load(f)
         if d["config"] == {"batch": batch, "n": n, "m": m}:
             for k, v in d["kernels"].items():
-                if "nw_fill_kernel" in k:
+                if kernel in k:
                     return v["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -161,7 +163,7 @@ def main():
 
     from text_alignment_amd import sharding, textSeqCompare as tsc
     batch, uniq = make_nw_batch(tsc, args.batch, args.n, args.m, 1234 + rank * 100000,
-                               two_phase=not args.one_pass)
+                               two_phase=False if args.one_pass else None)
     # the records a page driver would gather: ~150 syllable boxes per page/problem, packed at a
     # fixed capacity so the gather is one collective with no size exchange (sharding.py)
     recs = np.zeros((150 * args.batch, sharding.RECORD_FIELDS), dtype=np.int32)
@@ -230,6 +232,7 @@ def main():
         if pending:
             got = sharding.unpack_gathered(pending[-1][1])
             gathered_ok = got.shape[0] == 150 * args.batch * world
+        kname = "nw_score_kernel" if batch.two_phase else "nw_fill_kernel"
         cells_step = batch.cells * world
         fill_rate = batch.cells / (fill_ms * 1e-3)
         out = {
@@ -238,16 +241,19 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "affine-gap NW, %d problems of %dx%d per GPU per step, default "
-                                   "scoring [8,-4,-7,-7,-3,0], fill + traceback%s"
+                                   "scoring [8,-4,-7,-7,-3,0], %s%s"
                                    % (args.batch, args.n, args.m,
+                                      "two-phase (score fill + windowed traceback)" if batch.two_phase
+                                      else "one-pass fill + traceback",
                                       " + gather of syllable-box records" if world > 1 else ""),
                        "cells_per_step": cells_step, "parallelism": "pages sharded x%d" % world,
                        "bit_exact_vs_oracle": ok,
                        "gather_ok": gathered_ok},
             "roofline": {"bound": "hbm", "achieved": fill_rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": fill_rate / 1e9 / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.batch, args.n, args.m),
-                         "kernel": "nw_fill_kernel", "kernel_ms": fill_ms, "traceback_ms": tb_ms,
+                         "traffic": measured_traffic(args.batch, args.n, args.m, kname),
+                         "kernel": kname, "kernel_ms": fill_ms, "traceback_ms": tb_ms,
+                         "traceback_kernel": "nw_trace2_kernel" if batch.two_phase else "nw_traceback_kernel",
                          "algorithmic_bytes_per_cell": 1},
         }
         if ocr_res is not None:
