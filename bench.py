@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--ocr-lines", type=int, default=1920, help="text lines per GPU (64 pages x 30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ocr", action="store_true")
+    ap.add_argument("--pages", type=int, default=64,
+                    help="synthetic pages per GPU for the end-to-end process_batch timing (0 = skip)")
     ap.add_argument("--one-pass", action="store_true",
                     help="use the single-pass fill (1 B/cell pointer matrix) instead of the two-phase aligner")
     ap.add_argument("--force-dist", action="store_true",
@@ -220,6 +222,11 @@ def main():
             dist.all_reduce(agg, op=dist.ReduceOp.SUM)
             ocr_res["lines_per_s_all_gpus"] = float(agg.item())
 
+    pages_res = None
+    if args.pages > 0 and not args.no_ocr:
+        from tools import pages_bench
+        pages_res = pages_bench.run(args.pages, seed0=100 + 1000 * rank)
+
     if rank == 0:
         # bit-exact spot check of the timed output against the oracle (checker only)
         from oracle import nw_oracle
@@ -258,6 +265,8 @@ def main():
         }
         if ocr_res is not None:
             out["ocr"] = ocr_res
+        if pages_res is not None:
+            out["pages_end_to_end"] = pages_res
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             if ocr_res is not None:

@@ -48,6 +48,25 @@ def test_rotate_bbox_floor_division_on_odd_sizes():
     assert (int(r.ul[0]), int(r.ul[1])) == (12, 11)      # (1000-1003)//2 = -2, (800-801)//2 = -1
 
 
+def test_rotate_bboxes_equals_rotate_bbox_and_round_semantics():
+    from text_alignment_amd import alignToOCR as atocr
+    from text_alignment_amd.page import Dim
+    rng = np.random.default_rng(0)
+    for _ in range(60):
+        ang = float(rng.choice([0, 0.5, -1.25, 2.5, 90, 33.3]))
+        od = Dim(int(rng.integers(500, 3000)), int(rng.integers(500, 3000)))
+        td = Dim(od.ncols - int(rng.integers(-41, 41)), od.nrows - int(rng.integers(-41, 41)))
+        boxes = [atocr.CharBox('x', (int(rng.integers(0, 3000)), int(rng.integers(0, 3000))),
+                               (int(rng.integers(0, 3000)), int(rng.integers(0, 3000)))) for _ in range(12)]
+        one = [atocr.rotate_bbox(b, ang, od, td) for b in boxes]
+        many = atocr.rotate_bboxes(boxes, ang, od, td)
+        assert [(int(b.ul[0]), int(b.ul[1]), int(b.lr[0]), int(b.lr[1])) for b in one] == \
+               [(int(b.ul[0]), int(b.ul[1]), int(b.lr[0]), int(b.lr[1])) for b in many]
+    # Python round == numpy round (half to even) on the values chars_from_llocs sees
+    for v in list(rng.uniform(0, 5000, 2000).round(1)) + [0.5, 1.5, 2.5, 110.5, 111.5]:
+        assert int(round(float(v))) == int(np.round(float(v)))
+
+
 def test_charbox_and_helpers(tmp_path):
     from text_alignment_amd import alignToOCR as atocr
     b = atocr.CharBox('a', (1, 2), (4, 8))

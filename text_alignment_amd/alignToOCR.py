@@ -96,6 +96,28 @@ def rotate_bbox(cbox, angle, orig_dim, target_dim, radians=False):
     return CharBox(cbox.char, new_ul, new_lr)
 
 
+def rotate_bboxes(boxes, angle, orig_dim, target_dim, radians=False):
+    """rotate_bbox over a whole page's boxes at once: the same float64 arithmetic element by
+    element (one numpy pass instead of four np.round calls per box)."""
+    if not boxes:
+        return []
+    px, py = orig_dim.ncols // 2, orig_dim.nrows // 2
+    dx = (orig_dim.ncols - target_dim.ncols) // 2
+    dy = (orig_dim.nrows - target_dim.nrows) // 2
+    if not radians:
+        angle = angle * np.pi / 180
+    s, c = np.sin(angle), np.cos(angle)
+    pts = np.array([[b.ulx, b.uly, b.lrx, b.lry] for b in boxes])
+    x = pts[:, 0::2] - px
+    y = pts[:, 1::2] - py
+    nx = (x * c) - (y * s) + (px - dx)
+    ny = (x * s) + (y * c) + (py - dy)
+    rx = np.round(nx).astype('int16')
+    ry = np.round(ny).astype('int16')
+    return [CharBox(b.char, np.array([rx[k, 0], ry[k, 0]]), np.array([rx[k, 1], ry[k, 1]]))
+            for k, b in enumerate(boxes)]
+
+
 # --------------------------------------------------------------------------- OCR seam
 _recognizers = {}
 
@@ -124,7 +146,9 @@ def chars_from_llocs(llocs, x_min, y_min, y_max, all_chars):
     prev_xpos = x_min
     for ch, x in llocs:
         x_text = '%.1f' % x                       # the value as the .llocs file carries it
-        cur_xpos = int(np.round(float(x_text) + x_min))
+        # int(np.round(v)) of the reference (alignToOCR.py:170): round half to even, which is
+        # what Python's round() does on a float as well (and 20x cheaper per character)
+        cur_xpos = int(round(float(x_text) + x_min))
         ul, lr = (prev_xpos, y_min), (cur_xpos, y_max)
         if not (ch == '~' or ch == ''):
             all_chars.append(CharBox(clean_special_chars(ch), ul, lr))
@@ -230,7 +254,7 @@ def align_page(transcript, all_chars, angle, image_dim, raw_dim, seq_align_param
         '{} vs {}'.format(len(all_chars), len(tra_align))
 
     syl_boxes = syllable_boxes(syls, tra_align, all_chars, indices)
-    syl_boxes = [rotate_bbox(b, -1 * angle, image_dim, raw_dim) for b in syl_boxes]
+    syl_boxes = rotate_bboxes(syl_boxes, -1 * angle, image_dim, raw_dim)
     return syl_boxes, all_chars_copy
 
 

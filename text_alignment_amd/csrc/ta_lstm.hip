@@ -166,6 +166,12 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_kernel(LstmArgs a) {
             for (int g4 = 0; g4 < 4; ++g4)
                 acc[g4] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], Bf[g4][kk], acc[g4], 0, 0, 0);
         }
+        // next step's inputs go to LDS BEFORE this step's output stores are issued: the wait for
+        // the prefetched loads would otherwise also wait for those stores (vmcnt counts both)
+        if (t + 1 < Tmax) {
+            x_store(e0, nxt, xn0);
+            if (e1 < kXE) x_store(e1, nxt, xn1);
+        }
         // gates: acc[0..3] = WGI, WGF, WGO, WCI . src
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -188,10 +194,6 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_kernel(LstmArgs a) {
                     a.hout[(myrow[r] + tt) * (2 * kNs) + dir * kNs + unit] = h;
                 }
             }
-        }
-        if (t + 1 < Tmax) {
-            x_store(e0, nxt, xn0);
-            if (e1 < kXE) x_store(e1, nxt, xn1);
         }
         __syncthreads();
     }
@@ -323,6 +325,10 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_bf16x3_kernel(LstmArgs a
                 acc[g4] = v;
             }
         }
+        if (t + 1 < Tmax) {                    // before the output stores (see the f32 kernel)
+            x_store(e0, nxt, xn0);
+            if (e1 < kXE) x_store(e1, nxt, xn1);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float gi = acc[0][r], gf = acc[1][r], go = acc[2][r];
@@ -347,10 +353,6 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_bf16x3_kernel(LstmArgs a
                     a.hout[(myrow[r] + tt) * (2 * kNs) + dir * kNs + unit] = h;
                 }
             }
-        }
-        if (t + 1 < Tmax) {
-            x_store(e0, nxt, xn0);
-            if (e1 < kXE) x_store(e1, nxt, xn1);
         }
         __syncthreads();
     }

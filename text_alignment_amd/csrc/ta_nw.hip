@@ -87,6 +87,10 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
             tc[r] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
         }
         int dsave = bnd_D_col0(c, row0);
+        // retire the transcript-code loads before the group loops (keeps s_waitcnt vmcnt(0), which
+        // would also drain the pointer stores, out of the loop body)
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("" :: "v"(tc[r]));
         const bool lane_has_rows = row0 < n;
         uint8_t* out = ws_p + (int64_t)s * strip_bytes + (int64_t)lane * 16;
         const int prod_pass = (wave == 0) ? pass - 1 : pass;   // pass in which prev_wave did strip s-1

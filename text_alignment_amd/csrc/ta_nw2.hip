@@ -126,6 +126,11 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
             tc[r] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
         }
         int dsave = raw_of(bnd_D_col0(c, row0));
+        // retire the transcript-code loads here: otherwise hipcc parks their s_waitcnt vmcnt(0) at
+        // the first use INSIDE the group loop, where it also drains every checkpoint / plane store
+        // of the previous group
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("" :: "v"(tc[r]));
         const bool lane_has_rows = row0 < n;
         const int prod_pass = (wave == 0) ? pass - 1 : pass;
         int* const plane_v = reinterpret_cast<int*>(ws_p + ws.row_plane(s, 0));

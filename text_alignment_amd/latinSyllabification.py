@@ -57,6 +57,9 @@ def _units(word):
     return out
 
 
+_memo = {}
+
+
 def syllabify_word(inp):
     '''
     Units that are a vowel or a diphthong seed a syllable; every other unit first sticks to the
@@ -65,6 +68,9 @@ def syllabify_word(inp):
     '''
     if inp in _FIXED:
         return list(_FIXED[inp])
+    hit = _memo.get(inp)
+    if hit is not None:
+        return list(hit)
     units = _units(inp)
     seeded = [u in _NUCLEI for u in units]
     if units and not any(seeded):
@@ -85,6 +91,8 @@ def syllabify_word(inp):
                 flags.append(seeded[k])
                 k += 1
             units, seeded = merged, flags
+    if len(_memo) < 100000:
+        _memo[inp] = tuple(units)
     return units
 
 

@@ -221,7 +221,7 @@ class LineRecognizer(object):
         for b in range(st["n"]):
             o = int(st["row_off_host"][b])
             k = int(dn[b])
-            out.append([(int(dt[o + i]), int(dc[o + i])) for i in range(k)])
+            out.append(list(zip(dt[o:o + k].tolist(), dc[o:o + k].tolist())))
         return out
 
     def recognise(self, lines, want_probs=False, from_probs=False):

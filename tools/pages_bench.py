@@ -1,0 +1,69 @@
+"""End-to-end timing of alignToOCR.process_batch on synthetic pages (BASELINE configs[2]/[4]
+shape): 30 strips per page of 800-2000 columns, ~1200-character transcripts.
+
+    python tools/pages_bench.py [npages] [--profile]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+VOCAB = ("dominus deus meus alleluia gloria patri et filio spiritui sancto sicut erat in principio "
+         "nunc semper saecula saeculorum amen laudate eum omnes gentes quoniam confirmata est "
+         "super nos misericordia eius veritas manet aeternum").split()
+PARAMS = [8, -1, -9, -9, -4, -4]     # cheap mismatches: a random-weight model's text still pairs up
+
+
+def make_page(seed, nlines=30):
+    from text_alignment_amd import page as page_mod
+    rng = np.random.default_rng(seed)
+    strips = []
+    for k in range(nlines):
+        w = int(rng.integers(800, 2001))
+        xs = np.zeros((w + 32, 48), dtype=np.float32)
+        xs[16:16 + w] = (rng.random((w, 48)) < 0.15) * rng.random((w, 48))
+        strips.append(page_mod.Strip(40, 100 + 120 * k, 60, width=2 * w, prepared=xs))
+    peaks = [130 + 120 * k for k in range(nlines + 1)]
+    tr = " ".join(VOCAB[int(i)] for i in rng.integers(0, len(VOCAB), size=180))
+    return page_mod.PreparedPage((2200, 3300), (2200, 3300), 0, strips, peaks), tr
+
+
+def make_recognizer():
+    from text_alignment_amd import ocr
+    model = ocr.LineModel.random(7001, no=40)
+    model.W2[0, 0] += 4.0            # favour blanks: many short runs -> many characters
+    return ocr.LineRecognizer(model)
+
+
+def run(npages, seed0=100):
+    import torch
+    from text_alignment_amd import alignToOCR as atocr
+    rec = make_recognizer()
+    pages, trs = zip(*[make_page(seed0 + k) for k in range(npages)])
+    atocr.process_batch(list(pages[:2]), list(trs[:2]), rec, PARAMS)          # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = atocr.process_batch(list(pages), list(trs), rec, PARAMS)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"pages": npages, "seconds": dt, "pages_per_s": npages / dt, "lines_per_s": npages * 30 / dt,
+            "syllable_boxes": sum(len(r[0]) for r in res),
+            "note": "process_batch end to end: host upload + K3/K4/K5 + NW + host glue (Python)"}
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 64
+    print(run(n))
+    if "--profile" in sys.argv:
+        import cProfile
+        import pstats
+        from text_alignment_amd import alignToOCR as atocr
+        rec = make_recognizer()
+        pages, trs = zip(*[make_page(100 + k) for k in range(n)])
+        pr = cProfile.Profile()
+        pr.enable()
+        atocr.process_batch(list(pages), list(trs), rec, PARAMS)
+        pr.disable()
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
