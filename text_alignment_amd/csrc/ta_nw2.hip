@@ -451,7 +451,8 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
                     make_uint4(acc[0], acc[1], acc[2], acc[3]);
             }
         }
-        __threadfence();            // the walk below re-reads these bytes: make them visible past L1
+        // the walk below re-reads these bytes: same wave, same CU -- workgroup-scope ordering (the
+        // barrier's vmcnt wait) is enough; an agent-scope fence would write back the XCD's L2 per window
         __syncthreads();
 
         // (e) walk the window (LDS-staged sub-windows of kTb2Groups groups)
