@@ -97,10 +97,12 @@ class NWBatch(object):
         self.max_m = int(self.m.max()) if self.nprob else 0
         self.cells = int((self.n * self.m).sum())
         # two-phase aligner (score-only fill + windowed pointer re-derivation, csrc/ta_nw2.hip):
-        # faster and 8x lighter on HBM once problems span several 256-row strips; the one-pass
-        # kernel (1 B/cell pointer matrix) wins on page-sized problems
+        # its fill is ~30 % cheaper per cell, its traceback costs ~60 us more per 256-row strip of
+        # the tallest problem (one wave walks the strips one after the other), and its workspace
+        # is 8x smaller.  Measured break-even on MI355X: total cells ~ 6e8 x strips.
         if two_phase is None:
-            two_phase = self.max_n * self.max_m >= (1 << 21)
+            nstrips = (self.max_n + 255) // 256
+            two_phase = (self.cells > 6e8 * nstrips) or (self.cells > 64e9)
         self.two_phase = bool(two_phase)
         p = np.asarray(params, dtype=np.int64)
         if p.ndim == 1:
