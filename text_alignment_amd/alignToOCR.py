@@ -10,9 +10,10 @@ HIP Needleman-Wunsch kernels (text_alignment_amd.textSeqCompare).  The glue betw
 kernels (abbreviation expansion, gap insertion, syllable grouping, rotation, JSON) is host-side
 string/box work restated from the reference.
 
-Gamera (the reference's image toolkit, alignToOCR.py:3-5) is not needed: pages arrive as
-`text_alignment_amd.page.PreparedPage` objects carrying their text-line strips; `preproc`
-below adapts them to the two preprocessing calls `process` makes (alignToOCR.py:216-218).
+Gamera (the reference's image toolkit, alignToOCR.py:3-5) is not needed: a page arrives either
+as a `text_alignment_amd.page.PreparedPage` carrying its text-line strips, or as a raw text-layer
+image (numpy array), which `preproc` (text_alignment_amd.textAlignPreprocessing, scipy-based)
+binarises, deskews and cuts into lines -- the two calls `process` makes at alignToOCR.py:216-218.
 """
 import io
 import json  # noqa: F401  (callers json.dump the result of to_JSON_dict, alignToOCR.py:434)
@@ -24,7 +25,8 @@ import numpy as np
 
 from . import latinSyllabification as latsyl
 from . import textSeqCompare as tsc
-from . import page as preproc
+from . import page as page_mod
+from . import textAlignPreprocessing as preproc
 
 parallel = 2                # kept for signature compatibility (alignToOCR.py:24): one GPU batch
 median_line_mult = 2        # alignToOCR.py:25
@@ -168,7 +170,7 @@ def perform_ocr_with_ocropus(cc_strips, ocropus_model, wkdir_name=None, parallel
     rec = _recognizer_for(ocropus_model)
     lines, widths = [], []
     for strip in cc_strips:
-        xs, raw_w = preproc.prepared_line(strip)
+        xs, raw_w = page_mod.prepared_line(strip)
         lines.append(xs)
         widths.append(raw_w)
     decoded = rec.recognise(lines)
@@ -274,7 +276,7 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     lines, widths = [], []
     for strips in strips_per_page:
         for strip in strips:
-            xs, raw_w = preproc.prepared_line(strip)
+            xs, raw_w = page_mod.prepared_line(strip)
             lines.append(xs)
             widths.append(raw_w)
     decoded = rec.recognise(lines)

@@ -1,0 +1,254 @@
+"""Gamera-free preprocessing and text-line finding -- host side,
+numpy / scipy.ndimage.  Counterpart of the reference module of the same name
+(reference textAlignPreprocessing.py:38-285), so that `alignToOCR.process` can start from a
+raw text-layer image (a numpy array) instead of a `page.PreparedPage`.
+
+Two kinds of code live here, with different parity status:
+
+* The projection / peak-finding numerics (`moving_avg_filter` :147, `calculate_peak_prominence`
+  :59, `find_peak_locations` :113, `vertically_coincide` :38 of the reference) are plain numpy in
+  the reference too; they are restated here and PINNED to golden vectors captured from the
+  imported reference (tests/golden/preproc.json).
+* The image operations the reference delegates to the Gamera C++ toolkit (`to_onebit`,
+  `despeckle`, `cc_analysis`, `rotation_angle_projections`, `rotate`, `filter_short_runs`,
+  `filter_narrow_runs`, `projection_rows`, `draw_line`, `subimage`; reference :167-195, :212-253)
+  are re-expressed with scipy.ndimage from Gamera's documented behaviour.  Gamera is not
+  installed here, so these are PARITY UNPINNED: same pipeline, same parameters, not bit-checked.
+
+Images are numpy arrays; a "onebit" image is a bool array with True = ink (Gamera's black).
+"""
+import numpy as np
+from scipy import ndimage
+
+from . import page as page_mod
+
+# PARAMETERS FOR PREPROCESSING (reference textAlignPreprocessing.py:12-16)
+saturation_thresh = 0.9
+sat_area_thresh = 150
+despeckle_amt = 100
+noise_area_thresh = 100
+
+# PARAMETERS FOR TEXT LINE SEGMENTATION (reference :18-22)
+filter_size = 30
+prominence_tolerance = 0.70
+collision_strip_scale = 1
+remove_capitals_scale = 10000
+
+_EIGHT = np.ones((3, 3), dtype=bool)          # Gamera labels connected components 8-connected
+
+
+# --------------------------------------------------------------------------- pinned numerics
+def vertically_coincide(hline_position, comp_offset, comp_nrows, collision,
+                        collision_scale=collision_strip_scale):
+    """True if any part of a component (rows comp_offset .. comp_offset + comp_nrows) lies within
+    the horizontal strip of height `collision` centred on hline_position (reference :38-56)."""
+    collision *= collision_strip_scale
+    top, bottom = comp_offset, comp_offset + comp_nrows
+    strip_top = hline_position - int(collision / 2)
+    strip_bottom = hline_position + int(collision / 2)
+    above = top < strip_top and bottom < strip_top
+    below = top > strip_bottom and bottom > strip_bottom
+    return (not above and not below)
+
+
+def calculate_peak_prominence(data, index):
+    '''log of the prominence of the peak at `index`: isolated peaks score high, peaks in the
+    foothills of larger ones low (reference :59-110).'''
+    here = data[index]
+    if (index == 0 or index == len(data) - 1 or data[index - 1] > here or data[index + 1] > here or
+            (data[index - 1] == here and data[index + 1] == here)):
+        return 0
+    if here == max(data):
+        return np.log(here)
+    higher = [i for i, v in enumerate(data) if v > here]
+    right = [i for i in higher if i > index]
+    left = [i for i in higher if i < index]
+    nearest_right = min(right) if right else np.inf
+    nearest_left = max(left) if left else -np.inf
+    nearest = nearest_left if (nearest_right - index) > (index - nearest_left) else nearest_right
+    lo, hi = min(nearest, index), max(nearest, index)
+    key_col = min(data[lo:hi])
+    return np.log(data[index] - key_col + 1)
+
+
+def find_peak_locations(data, tol=prominence_tolerance, ranked=False):
+    '''indices of the prominent peaks of a row projection (reference :113-144)'''
+    proms = [(i, calculate_peak_prominence(data, i)) for i in range(len(data))]
+    top = max([p[1] for p in proms])
+    if top == 0 or len(proms) == 0:
+        return []
+    proms = [(i, v / top) for i, v in proms]
+    peaks = [p for p in proms if p[1] > tol]
+    # both corners of a flat-topped peak are prominent: drop the first of two equal neighbours
+    dupes = [peaks[i] for i in range(len(peaks) - 2) if peaks[i][1] == peaks[i + 1][1]]
+    for d in dupes:
+        peaks.remove(d)
+    if ranked:
+        peaks.sort(key=lambda p: p[1] * -1)
+        return peaks
+    return [p[0] for p in peaks]
+
+
+def moving_avg_filter(data, filter_size=filter_size):
+    '''moving average over filter_size samples to either side; the ends stay zero (reference :147-157)'''
+    smoothed = np.zeros(len(data))
+    for n in range(filter_size, len(data) - filter_size):
+        smoothed[n] = np.mean(data[n - filter_size: n + filter_size + 1])
+    return smoothed
+
+
+# --------------------------------------------------------------------------- image operations
+def otsu_threshold(grey):
+    """Otsu's threshold of a uint8 image (Gamera's to_onebit on a greyscale image)."""
+    hist = np.bincount(grey.ravel(), minlength=256).astype(np.float64)
+    total = hist.sum()
+    cum = np.cumsum(hist)
+    mean_cum = np.cumsum(hist * np.arange(256))
+    mean_all = mean_cum[-1]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        between = (mean_all * cum - mean_cum * total) ** 2 / (cum * (total - cum))
+    between[~np.isfinite(between)] = 0
+    return int(np.argmax(between))
+
+
+def to_onebit(image):
+    """RGB / greyscale / bool array -> bool array, True = ink."""
+    a = np.asarray(image)
+    if a.dtype == bool:
+        return a.copy()
+    if a.ndim == 3:
+        a = a[..., :3].mean(axis=2)
+    if a.dtype != np.uint8:
+        a = np.clip(a * (255.0 if a.max() <= 1.0 else 1.0), 0, 255).astype(np.uint8)
+    return a <= otsu_threshold(a)
+
+
+def despeckle(onebit, size):
+    """remove ink components of fewer than `size` pixels"""
+    lab, n = ndimage.label(onebit, structure=_EIGHT)
+    if n == 0:
+        return onebit
+    area = np.bincount(lab.ravel(), minlength=n + 1)
+    keep = area >= size
+    keep[0] = False
+    return keep[lab]
+
+
+def components(onebit):
+    """[(label slice pair, label id)] of the 8-connected ink components, plus the label image"""
+    lab, n = ndimage.label(onebit, structure=_EIGHT)
+    return lab, ndimage.find_objects(lab)
+
+
+def rotation_angle_projections(onebit, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
+    """angle in [lo, hi] degrees whose rotation makes the row projection sharpest (largest
+    variance), found on a decimated copy: coarse sweep, then a fine sweep around the best"""
+    step = max(1, int(max(onebit.shape) / 1200))
+    small = onebit[::step, ::step].astype(np.float32)
+
+    def score(ang):
+        rot = ndimage.rotate(small, ang, reshape=False, order=1, mode='constant', cval=0.0)
+        return float(np.var(rot.sum(axis=1)))
+    grid = np.arange(lo, hi + 1e-9, coarse)
+    best = grid[int(np.argmax([score(a) for a in grid]))]
+    grid = np.arange(best - coarse, best + coarse + 1e-9, fine)
+    best = grid[int(np.argmax([score(a) for a in grid]))]
+    return float(np.round(best, 3))
+
+
+def rotate(onebit, angle):
+    """rotate about the centre, growing the canvas to hold the whole page (as Gamera's rotate;
+    alignToOCR.rotate_bbox undoes exactly this padding, reference alignToOCR.py:93-96)"""
+    if angle == 0:
+        return onebit.copy()
+    rot = ndimage.rotate(onebit.astype(np.float32), angle, reshape=True, order=1, mode='constant', cval=0.0)
+    return rot > 0.5
+
+
+def _filter_runs(onebit, length, axis):
+    """remove ink runs shorter than `length` along `axis`"""
+    if length <= 1:
+        return onebit
+    structure = np.ones((length, 1), bool) if axis == 0 else np.ones((1, length), bool)
+    return ndimage.binary_opening(onebit, structure=structure)
+
+
+def filter_short_runs(onebit, length):      # vertical runs (Gamera: filter_short_runs)
+    return _filter_runs(onebit, length, 0)
+
+
+def filter_narrow_runs(onebit, length):     # horizontal runs (Gamera: filter_narrow_runs)
+    return _filter_runs(onebit, length, 1)
+
+
+# --------------------------------------------------------------------------- the two entry points
+class BinImage(page_mod.Image):
+    """A onebit page image with the `dim` / `ncols` / `nrows` attributes `process` reads."""
+
+    def __init__(self, ink):
+        page_mod.Image.__init__(self, ink.shape[1], ink.shape[0])
+        self.ink = ink
+
+
+def preprocess_images(input_image, despeckle_amt=despeckle_amt, filter_runs=1, filter_runs_amt=2,
+                      correct_rotation=True):
+    '''denoise and deskew the text layer before text-line segmentation (reference :160-195).
+    Returns (image_bin, image_eroded, angle).  A PreparedPage passes straight through.'''
+    if isinstance(input_image, page_mod.PreparedPage):
+        return page_mod.preprocess_images(input_image)
+    ink = to_onebit(getattr(input_image, "pixels", input_image))
+    ink = despeckle(ink, despeckle_amt)
+    ink = ~despeckle(~ink, despeckle_amt)                      # fill small holes
+    lab, objs = components(ink)
+    for k, sl in enumerate(objs):                              # drop components taller than the threshold
+        if sl is not None and sat_area_thresh < (sl[0].stop - sl[0].start):
+            ink[sl][lab[sl] == k + 1] = False
+    angle = rotation_angle_projections(ink, -6, 6)
+    if correct_rotation:
+        ink = rotate(ink, angle)
+    eroded = ink.copy()
+    for _ in range(filter_runs):
+        eroded = filter_short_runs(eroded, filter_runs_amt)
+        eroded = filter_narrow_runs(eroded, filter_runs_amt)
+    return BinImage(ink), BinImage(eroded), angle
+
+
+def identify_text_lines(image_bin, image_eroded):
+    '''text lines of a preprocessed page (reference :198-285): peaks of the smoothed row
+    projection; a white line at the projection minimum between neighbouring peaks; connected
+    components; per peak the union of the components a strip around the peak touches.
+    Returns (line_strips, peak_locations, smoothed_projection).'''
+    if hasattr(image_bin, "_page"):
+        return page_mod.identify_text_lines(image_bin, image_eroded)
+    ink = image_eroded.ink.copy()
+    project = ink.sum(axis=1)
+    smoothed = moving_avg_filter(project, filter_size)
+    peaks = find_peak_locations(smoothed)
+    for a, b in zip(peaks[:-1], peaks[1:]):
+        idx = int(np.argmin(smoothed[a:b])) + a
+        ink[max(idx - 1, 0):idx + 1, :] = False                # 2-pixel white line
+    lab, objs = components(ink)
+    comps = []
+    for k, sl in enumerate(objs):
+        if sl is None:
+            continue
+        area = int((lab[sl] == k + 1).sum())
+        if area > noise_area_thresh:
+            comps.append((sl[1].start, sl[0].start, sl[1].stop - 1, sl[0].stop - 1))   # ulx, uly, lrx, lry
+    if not comps:
+        return [], peaks, smoothed
+    heights = [c[3] - c[1] + 1 for c in comps]
+    med = np.median(heights)
+    comps = [c for c, h in zip(comps, heights) if h < med * remove_capitals_scale]
+    cc_median_height = np.median([c[3] - c[1] + 1 for c in comps])
+    strips = []
+    for loc in peaks:
+        hit = [c for c in comps if vertically_coincide(loc, c[1], c[3] - c[1] + 1, cc_median_height)]
+        if not hit:
+            continue
+        ulx, uly = min(c[0] for c in hit), min(c[1] for c in hit)
+        lrx, lry = max(c[2] for c in hit), max(c[3] for c in hit)
+        sub = image_bin.ink[uly:lry + 1, ulx:lrx + 1]
+        pixels = np.where(sub, 0, 255).astype(np.uint8)        # as the saved PNG: ink black on white
+        strips.append(page_mod.Strip(ulx, uly, lry - uly + 1, width=lrx - ulx + 1, pixels=pixels))
+    return strips, peaks, smoothed

@@ -338,6 +338,45 @@ def gen_glue(latsyl, atocr):
     return out
 
 
+def gen_preproc():
+    """Pure-numpy helpers of textAlignPreprocessing.py (no Gamera call inside them):
+    moving_avg_filter :147, calculate_peak_prominence :59, find_peak_locations :113,
+    vertically_coincide :38 -- captured on seeded projection profiles."""
+    import textAlignPreprocessing as preproc
+    rng = np.random.default_rng(777)
+    out = {"profiles": [], "coincide": []}
+    for k in range(6):
+        nrows = int(rng.integers(300, 800))
+        nlines = int(rng.integers(3, 14))
+        y = np.zeros(nrows)
+        centers = np.sort(rng.integers(40, nrows - 40, size=nlines))
+        for c0 in centers:                      # text lines: bumps of ink in the row projection
+            wdt = float(rng.integers(6, 20))
+            amp = float(rng.integers(100, 900))
+            y += amp * np.exp(-0.5 * ((np.arange(nrows) - c0) / wdt) ** 2)
+        y += rng.integers(0, 30, size=nrows)
+        y = np.floor(y)
+        fs = [30, 30, 10, 5][k % 4]
+        sm = preproc.moving_avg_filter(y, fs)
+        peaks = preproc.find_peak_locations(sm)
+        peaks_tol = preproc.find_peak_locations(sm, tol=0.5)
+        ranked = preproc.find_peak_locations(sm, ranked=True)
+        proms = [float(preproc.calculate_peak_prominence(sm, i)) for i in range(0, nrows, 7)]
+        out["profiles"].append(dict(data=[int(v) for v in y], filter_size=fs,
+                                    smoothed=[float(v) for v in sm], peaks=[int(p) for p in peaks],
+                                    peaks_tol05=[int(p) for p in peaks_tol],
+                                    ranked=[[int(a), float(b)] for a, b in ranked],
+                                    prominence_every7=proms))
+    for k in range(60):
+        a = [int(rng.integers(0, 500)), int(rng.integers(0, 500)), int(rng.integers(1, 120)), int(rng.integers(1, 80))]
+        out["coincide"].append(dict(args=a, result=bool(preproc.vertically_coincide(*a))))
+    for flat in ([5, 5, 5, 5], [1, 2, 3, 4, 5], [0, 3, 3, 0, 1, 0], [0, 0, 0]):
+        out["profiles"].append(dict(data=flat, filter_size=0, smoothed=None,
+                                    peaks=[int(p) for p in preproc.find_peak_locations(np.array(flat, float))],
+                                    peaks_tol05=None, ranked=None, prominence_every7=None))
+    return out
+
+
 def speed_check(tsc):
     from oracle import nw_ref_py
     for n, m in [(500, 500), (1000, 1000)]:
@@ -375,6 +414,8 @@ def main():
         dump("nw_random_small.json", gen_nw_random(tsc))
     if not only or "glue" in only:
         dump("glue.json", gen_glue(latsyl, atocr))
+    if not only or "preproc" in only:
+        dump("preproc.json", gen_preproc())
     if not only or "synth" in only:
         dump("nw_synth.json", gen_nw_synth(tsc, big=args.big))
 
