@@ -31,6 +31,7 @@ extern "C" {
 /* bit flags for ta_nw_batch */
 #define TA_NW_FILL 1u
 #define TA_NW_TRACEBACK 2u
+#define TA_NW_CODES8 4u      /* caller asserts every token id < 255: 1-byte codes in LDS (ta_nw2_batch) */
 
 int ta_version(void);
 const char* ta_last_error(void);

@@ -66,10 +66,10 @@ constexpr int kCheck = 16;    // hand-off progress is checked / published every 
 // LDS carve (dynamic): int2 hvd[m+2] | int2 dummy[64*4] | uint16 ocode[kOPad+m+kOTail] | int prog[16]
 struct NwLds {
     size_t hvd_bytes, dummy_bytes, oc_bytes, total;
-    __host__ __device__ explicit NwLds(int m) {
+    __host__ __device__ explicit NwLds(int m, int code_bytes = 2) {
         hvd_bytes = ((size_t)(m + 2) * 8 + 15) & ~(size_t)15;
         dummy_bytes = 64 * 4 * 8;
-        oc_bytes = ((size_t)(kOPad + m + kOTail) * 2 + 15) & ~(size_t)15;
+        oc_bytes = ((size_t)(kOPad + m + kOTail) * code_bytes + 15) & ~(size_t)15;
         total = hvd_bytes + dummy_bytes + oc_bytes + 64;
     }
 };

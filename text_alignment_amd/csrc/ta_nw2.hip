@@ -68,7 +68,10 @@ __device__ __forceinline__ void cell_raw_hw(const RawRegs& k, int d_ul, int v_u,
 
 // ---------------------------------------------------------------------------------------------
 // phase 1
-template <int W>
+// OC = uint8_t when every token id of the batch is below 255 (alphabets like the reference's 27
+// symbols): the OCR codes then take 1 byte each in LDS and a 4096-column problem fits four
+// workgroups per CU instead of three.
+template <int W, typename OC>
 __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
     constexpr int R = 4;
     using L = PtrLayout<R>;
@@ -87,10 +90,10 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
     kr.cmis = prm[1] - prm[4] - prm[5]; kr.cmat = prm[0] - prm[4] - prm[5];
     kr.gox = prm[2]; kr.goy = prm[3];
 
-    const NwLds lds(m);
+    const NwLds lds(m, (int)sizeof(OC));
     int2* hvd = reinterpret_cast<int2*>(smem);
     int2* dummy = reinterpret_cast<int2*>(smem + lds.hvd_bytes);
-    uint16_t* ocode = reinterpret_cast<uint16_t*>(smem + lds.hvd_bytes + lds.dummy_bytes);
+    OC* ocode = reinterpret_cast<OC*>(smem + lds.hvd_bytes + lds.dummy_bytes);
     int* prog = reinterpret_cast<int*>(smem + lds.hvd_bytes + lds.dummy_bytes + lds.oc_bytes);
 
     const int tid = threadIdx.x;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
 
     for (int j = tid; j < kOPad + m + kOTail; j += W * 64) {
         const int src = j - kOPad;
-        ocode[j] = (src >= 0 && src < m) ? (uint16_t)a.o_codes[o0 + src] : (uint16_t)0xFFFF;
+        ocode[j] = (src >= 0 && src < m) ? (OC)a.o_codes[o0 + src] : (OC)~(OC)0;   // pad: never a valid id
     }
     for (int j = tid; j <= m; j += W * 64)
         hvd[j] = make_int2(raw_of(bnd_V_row0(c, j)), raw_of(bnd_D_row0(c, j)));
@@ -508,18 +511,23 @@ extern "C" int64_t ta_nw2_workspace_bytes(int32_t n, int32_t m) {
     return (Ws2(n, m).total + 15) & ~(int64_t)15;
 }
 
-template <int W>
-static hipError_t launch_score(const NwArgs& a, int max_m, hipStream_t st) {
-    const size_t lds = NwLds(max_m).total;
+template <int W, typename OC>
+static hipError_t launch_score_oc(const NwArgs& a, int max_m, hipStream_t st) {
+    const size_t lds = NwLds(max_m, (int)sizeof(OC)).total;
     static bool raised = false;
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nw_score_kernel<W>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nw_score_kernel<W, OC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL((nw_score_kernel<W>), dim3(a.nprob), dim3(W * 64), lds, st, a);
+    hipLaunchKernelGGL((nw_score_kernel<W, OC>), dim3(a.nprob), dim3(W * 64), lds, st, a);
     return hipGetLastError();
+}
+
+template <int W>
+static hipError_t launch_score(const NwArgs& a, int max_m, bool codes8, hipStream_t st) {
+    return codes8 ? launch_score_oc<W, uint8_t>(a, max_m, st) : launch_score_oc<W, uint16_t>(a, max_m, st);
 }
 
 extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
@@ -544,10 +552,11 @@ extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
         if (!t_codes || !o_codes || !ws) return ta_fail(TA_EINVAL, "null code/workspace pointer");
         const int nstrips = PtrLayout<4>::nstrips(max_n);
         hipError_t e;
-        if (nstrips >= 8) e = launch_score<8>(a, max_m, st);
-        else if (nstrips >= 4) e = launch_score<4>(a, max_m, st);
-        else if (nstrips >= 2) e = launch_score<2>(a, max_m, st);
-        else e = launch_score<1>(a, max_m, st);
+        const bool codes8 = (flags & TA_NW_CODES8) != 0;
+        if (nstrips >= 8) e = launch_score<8>(a, max_m, codes8, st);
+        else if (nstrips >= 4) e = launch_score<4>(a, max_m, codes8, st);
+        else if (nstrips >= 2) e = launch_score<2>(a, max_m, codes8, st);
+        else e = launch_score<1>(a, max_m, codes8, st);
         if (e != hipSuccess) return ta_fail_hip(e, "nw_score_kernel launch");
     }
     if (flags & TA_NW_TRACEBACK) {

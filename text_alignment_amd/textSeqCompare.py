@@ -133,6 +133,7 @@ class NWBatch(object):
         cat_o = np.concatenate(o_list) if self.nprob and o_off[-1] else np.zeros(1, np.int32)
         if (cat_t.max(initial=0) >= 65535) or (cat_o.max(initial=0) >= 65535):
             raise OverflowError("more than 65534 distinct tokens in one batch")
+        self.codes8 = bool(max(cat_t.max(initial=0), cat_o.max(initial=0)) < 255)
         self.t_codes = dev(cat_t.astype(np.int32))
         self.o_codes = dev(cat_o.astype(np.int32))
         self.t_off = dev(t_off)
@@ -148,6 +149,8 @@ class NWBatch(object):
         if self.nprob == 0:
             return
         flags = (_native.TA_NW_FILL if fill else 0) | (_native.TA_NW_TRACEBACK if traceback else 0)
+        if self.codes8:
+            flags |= _native.TA_NW_CODES8
         stream = torch.cuda.current_stream(self.device).cuda_stream
         entry = _native.lib.ta_nw2_batch if self.two_phase else _native.lib.ta_nw_batch
         rc = entry(
