@@ -100,4 +100,52 @@ __device__ __forceinline__ unsigned pack4(unsigned b0, unsigned b1, unsigned b2,
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
+// ---- vectorised traceback walk inside an LDS-staged window of the strip layout (R = 4) ----
+// textSeqCompare.py:110-145.  In state st a step emits op = st, moves up unless st == 2 and left
+// unless st == 1, and the next state is the 2-bit pointer field of the cell's byte that belongs to
+// st (bits 2*st, 2*st+1; field f means state 2 - f).  Alignments are made of RUNS -- matches stay
+// in state 0 along a diagonal, gaps in state 1 / 2 along a column / row -- so instead of one
+// dependent step at a time, lane i looks at the cell i steps further along the current direction
+// and reports whether the walk would still be in state st there; one ballot gives the run
+// length, and the whole run (plus the step that changes state) is taken at once.
+//
+// win: window of 16-byte pieces [(group - gw_lo) * 64 + lane]; x_lo: row index just above the
+// strip (cells with x > x_lo are in it); klow: smallest valid skewed step.  Returns the number
+// of ops appended to opsbuf; updates x, y, st.  The walk stops when it leaves the strip, the
+// valid steps, the table (x == 0 or y == 0) or after max_ops.
+__device__ __forceinline__ int walk_window_vec(const uint4* win, int gw_lo, int klow, int x_lo,
+                                               int& x, int& y, int& st, uint8_t* opsbuf, int max_ops,
+                                               int lane) {
+    const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
+    int cnt = 0;
+    while (true) {
+        const int up = (st != 2), left = (st != 1);
+        const int xi = x - lane * up, yi = y - lane * left;
+        const int li = (xi - 1 - x_lo) >> 2;
+        const int ki = (yi - 1) + li;
+        const bool valid = (xi > x_lo) & (yi > 0) & (ki >= klow);
+        unsigned b = 0;
+        if (valid) b = wb[((ki >> 2) - gw_lo) * 1024 + li * 16 + (ki & 3) * 4 + ((xi - 1) & 3)];
+        const int nxt = 2 - (int)((b >> (2 * st)) & 3u);
+        const unsigned long long vmask = __ballot(valid);
+        if ((vmask & 1ull) == 0ull) break;                       // lane 0 (the current cell) is out
+        const unsigned long long cmask = __ballot(valid && nxt == st);
+        int run = (~cmask == 0ull) ? 64 : (int)__builtin_ctzll(~cmask);   // lanes 0..run-1 stay in st
+        int steps = run, st_new = st;
+        if (run < 64 && ((vmask >> run) & 1ull)) {               // the step that leaves state st
+            steps = run + 1;
+            st_new = __builtin_amdgcn_readlane(nxt, run);
+        }
+        steps = min(steps, max_ops - cnt);
+        if (steps < run + 1) st_new = st;                         // truncated inside the run
+        if (lane < steps) opsbuf[cnt + lane] = (uint8_t)st;
+        cnt += steps;
+        x -= steps * up;
+        y -= steps * left;
+        st = st_new;
+        if (cnt >= max_ops) break;
+    }
+    return cnt;
+}
+
 }  // namespace ta

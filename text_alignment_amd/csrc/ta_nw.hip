@@ -270,25 +270,8 @@ __global__ __launch_bounds__(64) void nw_traceback_kernel(NwArgs a) {
             st = ptr_pm(wb[(((k >> 2) - g_lo) * 64 + l) * 16 + (k & 3) * R + r]);
             first = false;
         }
-        // walk while inside this window: a branch-free scalar state machine (every lane runs it
-        // on wave-uniform values).  In state st the step emits op = st, moves up unless st == 2
-        // and left unless st == 1 (textSeqCompare.py:115-145), and the next state is the pointer
-        // field of this byte that belongs to the current state: bits 2*st, 2*st+1.
-        int cnt = 0;
-        bool inside = true;
-        while (inside) {
-            const unsigned b = wb[(((k >> 2) - g_lo) * 64 + l) * 16 + (k & 3) * R + r];
-            opsbuf[cnt++] = (uint8_t)st;
-            const int up = (st != 2), left = (st != 1);
-            st = 2 - (int)((b >> (2 * st)) & 3u);
-            const int wrap = up & (r == 0);                       // leaves this lane's rows: lane - 1
-            r = (r - up) & (R - 1);
-            x -= up;
-            y -= left;
-            k -= left + wrap;
-            l -= wrap;
-            inside = (x > 0) & (y > 0) & (l >= 0) & ((k >> 2) >= g_lo) & (cnt < kTbOps);
-        }
+        // walk while inside this window, a run at a time (nw_hw.h: walk_window_vec)
+        const int cnt = walk_window_vec(win, g_lo, g_lo * 4, strip * L::SR, x, y, st, opsbuf, kTbOps, lane);
         __syncthreads();
         for (int i = lane; i < cnt; i += 64) ops[cap - 1 - (len + i)] = opsbuf[i];
         len += cnt;

@@ -474,25 +474,15 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
                 st = ptr_pm(wb[(((k >> 2) - gw_lo) * 64 + l) * 16 + (k & 3) * R + r]);
                 first = false;
             }
-            int cnt = 0;
-            bool inside = (k >= klow);
-            while (inside) {
-                const unsigned b = wb[(((k >> 2) - gw_lo) * 64 + l) * 16 + (k & 3) * R + r];
-                opsbuf[cnt++] = (uint8_t)st;
-                const int up = (st != 2), left = (st != 1);
-                st = 2 - (int)((b >> (2 * st)) & 3u);
-                const int wrap = up & (r == 0);
-                r = (r - up) & (R - 1);
-                x -= up;
-                y -= left;
-                k -= left + wrap;
-                l -= wrap;
-                inside = (x > 0) & (y > 0) & (l >= 0) & (k >= klow) & (cnt < kTb2Ops);
-            }
+            const int cnt = walk_window_vec(win, gw_lo, klow, s * L::SR, x, y, st, opsbuf, kTb2Ops, lane);
             __syncthreads();
             for (int i = lane; i < cnt; i += 64) ops[cap - 1 - (len + i)] = opsbuf[i];
             len += cnt;
             __syncthreads();
+            // position in layout coordinates after the walk
+            l = (x > s * L::SR) ? ((x - 1) % L::SR) / R : -1;
+            r = (x - 1) & (R - 1);
+            k = (y - 1) + l;
             // leave this fill window when the walk left the strip, finished, or ran below the valid steps
             leave = (x <= 0) | (y <= 0) | (l < 0) | (k < kvalid) | (cnt == 0);
         }
