@@ -89,6 +89,9 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
     RawRegs kr;
     kr.cmis = prm[1] - prm[4] - prm[5]; kr.cmat = prm[0] - prm[4] - prm[5];
     kr.gox = prm[2]; kr.goy = prm[3];
+    // keep the two select constants resident in VGPRs (hipcc otherwise re-materialises them with
+    // two v_mov per step, 8 % of the loop's VALU instructions)
+    asm volatile("" : "+v"(kr.cmis), "+v"(kr.cmat));
 
     const NwLds lds(m, (int)sizeof(OC));
     int2* hvd = reinterpret_cast<int2*>(smem);
@@ -236,15 +239,28 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
         for (; g < e1; ++g) group_edge(g);
 
         if (g < g_hi) {
+            // ---- steady state: every lane is inside 1 <= j <= m, no EXEC changes.  Two groups per
+            // iteration with two input buffers (A / B), so the LDS prefetch of the next group lands
+            // in the other buffer and no register copies are needed at the loop back-edge. ----
             int2* wptr = (lane == 63) ? (hvd + (g * SPG - 62)) : (dummy + lane * SPG);
             const int winc = (lane == 63) ? SPG : 0;
-            for (; g < g_hi; ++g) {
-                checkpoint(g);
-                int oc[SPG];
-                int2 hd[SPG];
+            int ocA[SPG], ocB[SPG];
+            int2 hdA[SPG], hdB[SPG];
 #pragma unroll
-                for (int q = 0; q < SPG; ++q) { oc[q] = oc_next[q]; hd[q] = hd_next[q]; }
-                prefetch(g);
+            for (int q = 0; q < SPG; ++q) { ocA[q] = oc_next[q]; hdA[q] = hd_next[q]; }
+            auto fetch = [&](int gn, int (&oc)[SPG], int2 (&hd)[SPG]) {       // inputs of group gn
+                if (gn < ngroups) {
+                    if ((gn % kCheck) == 0) wait_span(gn);
+                    const int idx = kOPad + gn * SPG - lane;
+#pragma unroll
+                    for (int q = 0; q < SPG; ++q) {
+                        oc[q] = ocode[idx + q];
+                        hd[q] = hvd[min(gn * SPG + q + 1, m)];
+                    }
+                }
+            };
+            auto steady = [&](int gg, const int (&oc)[SPG], const int2 (&hd)[SPG]) {
+                checkpoint(gg);
                 int rv[SPG], rd[SPG], rh[SPG];
 #pragma unroll
                 for (int q = 0; q < SPG; ++q) {
@@ -263,8 +279,25 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
                     rv[q] = V[R - 2]; rd[q] = D[R - 2]; rh[q] = H[R - 1];
                 }
                 wptr += winc;
-                store_planes(g, rv, rd, rh);
-                publish(g);
+                store_planes(gg, rv, rd, rh);
+                publish(gg);
+            };
+            while (g + 1 < g_hi) {
+                fetch(g + 1, ocB, hdB);
+                steady(g, ocA, hdA);
+                fetch(g + 2, ocA, hdA);
+                steady(g + 1, ocB, hdB);
+                g += 2;
+            }
+            if (g < g_hi) {
+                fetch(g + 1, ocB, hdB);
+                steady(g, ocA, hdA);
+                ++g;
+#pragma unroll
+                for (int q = 0; q < SPG; ++q) { oc_next[q] = ocB[q]; hd_next[q] = hdB[q]; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < SPG; ++q) { oc_next[q] = ocA[q]; hd_next[q] = hdA[q]; }
             }
         }
         for (; g < ngroups; ++g) group_edge(g);
