@@ -44,6 +44,9 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
     CellRegs kr;
     kr.cmis = c.cmismatch; kr.cmat = c.cmatch; kr.gox6 = c.gox6; kr.goy6 = c.goy6;
     kr.clean = ~kTagMask;
+    // keep the two select constants resident in VGPRs (hipcc otherwise re-materialises them with
+    // two v_mov per step)
+    asm volatile("" : "+v"(kr.cmis), "+v"(kr.cmat));
 
     const NwLds lds(m);
     int2* hvd = reinterpret_cast<int2*>(smem);
@@ -182,17 +185,29 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
 
         if (g < g_hi) {
             // ---- steady state: straight-line code, no EXEC changes.  Lanes whose rows lie
-            // below row n compute don't-care values that never reach a valid row. ----
+            // below row n compute don't-care values that never reach a valid row.  Two groups per
+            // iteration with two input buffers (A / B): the LDS prefetch of the next group lands in
+            // the other buffer, so the loop back-edge needs no register copies. ----
             // lane 63 publishes its bottom row to hvd[j], j = k - 62; the other lanes write a
             // private dummy slot so the store needs no EXEC mask
             int2* wptr = (lane == 63) ? (hvd + (g * SPG - 62)) : (dummy + lane * SPG);
             const int winc = (lane == 63) ? SPG : 0;
-            for (; g < g_hi; ++g) {
-                int oc[SPG];
-                int2 hd[SPG];
+            int ocA[SPG], ocB[SPG];
+            int2 hdA[SPG], hdB[SPG];
 #pragma unroll
-                for (int q = 0; q < SPG; ++q) { oc[q] = oc_next[q]; hd[q] = hd_next[q]; }
-                prefetch(g);
+            for (int q = 0; q < SPG; ++q) { ocA[q] = oc_next[q]; hdA[q] = hd_next[q]; }
+            auto fetch = [&](int gn, int (&oc)[SPG], int2 (&hd)[SPG]) {       // inputs of group gn
+                if (gn < ngroups) {
+                    if ((gn % kCheck) == 0) wait_span(gn);
+                    const int idx = kOPad + gn * SPG - lane;
+#pragma unroll
+                    for (int q = 0; q < SPG; ++q) {
+                        oc[q] = ocode[idx + q];
+                        hd[q] = hvd[min(gn * SPG + q + 1, m)];
+                    }
+                }
+            };
+            auto steady = [&](int gg, const int (&oc)[SPG], const int2 (&hd)[SPG]) {
                 unsigned acc[4];
 #pragma unroll
                 for (int q = 0; q < SPG; ++q) {
@@ -214,8 +229,25 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
                     wptr[q] = make_int2(V[R - 1], D[R - 1]);
                 }
                 wptr += winc;
-                *reinterpret_cast<uint4*>(out + (int64_t)g * 1024) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
-                publish(g);
+                *reinterpret_cast<uint4*>(out + (int64_t)gg * 1024) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+                publish(gg);
+            };
+            while (g + 1 < g_hi) {
+                fetch(g + 1, ocB, hdB);
+                steady(g, ocA, hdA);
+                fetch(g + 2, ocA, hdA);
+                steady(g + 1, ocB, hdB);
+                g += 2;
+            }
+            if (g < g_hi) {
+                fetch(g + 1, ocB, hdB);
+                steady(g, ocA, hdA);
+                ++g;
+#pragma unroll
+                for (int q = 0; q < SPG; ++q) { oc_next[q] = ocB[q]; hd_next[q] = hdB[q]; }
+            } else {
+#pragma unroll
+                for (int q = 0; q < SPG; ++q) { oc_next[q] = ocA[q]; hd_next[q] = hdA[q]; }
             }
         }
         for (; g < ngroups; ++g) group_edge(g);
