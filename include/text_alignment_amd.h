@@ -32,6 +32,8 @@ extern "C" {
 #define TA_NW_FILL 1u
 #define TA_NW_TRACEBACK 2u
 #define TA_NW_CODES8 4u      /* caller asserts every token id < 255: 1-byte codes in LDS (ta_nw2_batch) */
+#define TA_NW_WIDE 8u        /* ta_nw_batch: force one problem over several workgroups (HBM hand-off rows) */
+#define TA_NW_NARROW 16u     /* ta_nw_batch: force one workgroup per problem; default: wide iff nprob < 256 */
 
 int ta_version(void);
 const char* ta_last_error(void);
@@ -41,7 +43,8 @@ const char* ta_last_error(void);
  * (reference textSeqCompare.py:13-177; called from alignToOCR.py:273).
  *
  * ta_nw_workspace_bytes: bytes of pointer-matrix workspace one n x m problem needs
- * (1 byte per DP cell plus the skew padding of the strip layout, multiple of 1024).
+ * (1 byte per DP cell plus the skew padding of the strip layout, plus one 8(m+2)-byte hand-off row
+ * per 1024 transcript rows for the wide launch; multiple of 1024).
  */
 int64_t ta_nw_workspace_bytes(int32_t n, int32_t m);
 

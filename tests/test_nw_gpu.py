@@ -123,6 +123,34 @@ def test_ragged_batch_vs_oracle_full_pointer_matrix(tsc, two_phase):
             assert np.array_equal(got_ptr, want_ptr[1:, 1:]), (k, n, m, prm[k])
 
 
+@pytest.mark.parametrize("wide", [True, False], ids=["wide", "narrow"])
+def test_one_pass_launch_shapes(tsc, wide):
+    """The one-pass fill spread over several workgroups per problem (hand-off rows in HBM, the
+    default for batches smaller than the CU count) against one workgroup per problem: whole
+    pointer matrices and alignments vs the oracle, ragged strip counts in one launch."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(23)
+    sizes = [(1030, 70), (1300, 3000), (5000, 2000), (8192, 300), (2049, 64), (1024, 1024), (1025, 1),
+             (4100, 4100), (300, 300), (0, 7), (2560, 129)]
+    t_list, o_list, prm = [], [], []
+    for k, (n, m) in enumerate(sizes):
+        t, o = _random_problem(rng, n, m, [2, 4, 27][k % 3], k % 2 == 0)
+        t_list.append(t); o_list.append(o); prm.append(SYSTEMS[k % len(SYSTEMS)])
+    batch = tsc.NWBatch(t_list, o_list, prm, two_phase=False, wide=wide)
+    for _ in range(2):                       # second run: progress words are re-armed per launch
+        batch.run()
+    torch.cuda.synchronize()
+    res = batch.results()
+    ws = batch.ws.cpu().numpy()
+    ws_off = batch.ws_off.cpu().numpy()
+    for k, (n, m) in enumerate(sizes):
+        want_ops, want_ptr, _ = nw_oracle.align_ids(t_list[k], o_list[k], prm[k], want_ptr=True)
+        assert res[k].tolist() == want_ops.tolist(), (k, n, m, prm[k])
+        if n and m:
+            got_ptr = _decode_ptr(ws[ws_off[k]:], n, m)
+            assert np.array_equal(got_ptr, want_ptr[1:, 1:]), (k, n, m, prm[k])
+
+
 def test_waves_per_problem_variants(tsc, two_phase):
     """Same problems through batches whose largest problem selects W = 1, 2, 4, 8 waves."""
     from oracle import nw_oracle

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libta_hip.so")
 
 TA_OK = 0
 TA_EINVAL, TA_ERANGE, TA_EHIP, TA_ELIMIT = -1, -2, -3, -4
-TA_NW_FILL, TA_NW_TRACEBACK, TA_NW_CODES8 = 1, 2, 4
+TA_NW_FILL, TA_NW_TRACEBACK, TA_NW_CODES8, TA_NW_WIDE, TA_NW_NARROW = 1, 2, 4, 8, 16
 
 
 class NativeLibraryError(RuntimeError):

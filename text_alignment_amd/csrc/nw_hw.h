@@ -15,6 +15,7 @@ struct NwArgs {
     uint8_t* ws; const int64_t* ws_off;
     uint8_t* ops_out; const int64_t* ops_off; int32_t* ops_len;
     int32_t nprob;
+    int32_t wide_stride;          // wide one-pass launch only: block index = chunk * wide_stride + p
 };
 
 // ---- single-instruction helpers.  Inline asm pins the instruction selection: left to

@@ -26,18 +26,58 @@
 
 namespace ta {
 
-template <int R, int W>
+// Hand-off rows in HBM for the wide launch (a problem spread over several workgroups): one row of
+// (V, D) pairs below every kWideW-th strip, and one progress word per row, behind the pointer bytes.
+constexpr int kWideW = 4;                         // waves (strips) per workgroup of the wide launch
+template <int R>
+struct WideWs {
+    int64_t rows_off, prog_off, total;
+    int row_elems, nrows;
+    __host__ __device__ WideWs(int n, int m) {
+        using L = PtrLayout<R>;
+        nrows = L::nstrips(n) / kWideW;           // boundaries below strips kWideW-1, 2 kWideW-1, ...
+        row_elems = (m + 2 + 1) & ~1;             // int2 entries, 16-byte multiple
+        rows_off = L::total_bytes(n, m);
+        prog_off = rows_off + (int64_t)nrows * row_elems * 8;
+        total = (prog_off + (int64_t)nrows * 4 + 1023) & ~(int64_t)1023;
+    }
+};
+
+template <int R>
+__global__ __launch_bounds__(64) void nw_wide_init_kernel(NwArgs a) {
+    const int p = blockIdx.x;
+    const int n = (int)(a.t_off[p + 1] - a.t_off[p]);
+    const int m = (int)(a.o_off[p + 1] - a.o_off[p]);
+    if (n <= 0 || m <= 0) return;
+    const WideWs<R> wl(n, m);
+    int* gprog = reinterpret_cast<int*>(a.ws + a.ws_off[p] + wl.prog_off);
+    for (int i = threadIdx.x; i < wl.nrows; i += 64) gprog[i] = 0;
+}
+
+// WIDE = false: one workgroup per problem, wave w takes strips w, w+W, ... (hand-off in LDS only).
+// WIDE = true:  workgroup (chunk, p) takes strips chunk*W .. chunk*W+W-1 of problem p; the bottom
+// row of a workgroup's last strip goes to the next workgroup through HBM (exported from the LDS
+// hand-off row every kCheck groups, progress word released at agent scope).  A workgroup only ever
+// waits for a workgroup with a smaller block index, so in-order dispatch guarantees progress.
+template <int R, int W, bool WIDE>
 __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
     using L = PtrLayout<R>;
     constexpr int SPG = L::SPG;
+    // groups between two looks at the LDS progress word of the strip above.  The wide launch is
+    // for latency (one problem, every strip on a SIMD of its own): a finer grain lets a strip
+    // follow the one above at 21 groups instead of 33
+    constexpr int CHK = WIDE ? 4 : kCheck;
     constexpr int DW = R / 4;                     // dwords of pointer bytes per step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int p = blockIdx.x;
+    const int p = WIDE ? (int)(blockIdx.x % a.wide_stride) : (int)blockIdx.x;
+    const int chunk = WIDE ? (int)(blockIdx.x / a.wide_stride) : 0;
+    if (WIDE && p >= a.nprob) return;
     const int64_t t0 = a.t_off[p], o0 = a.o_off[p];
     const int n = (int)(a.t_off[p + 1] - t0);
     const int m = (int)(a.o_off[p + 1] - o0);
     if (n <= 0 || m <= 0) return;                 // nothing to fill; traceback emits pure gaps
+    if (WIDE && chunk * W >= L::nstrips(n)) return;
 
     const int32_t* prm = a.params + (size_t)p * a.params_stride;
     const CellConsts c = make_consts(prm[0], prm[1], prm[2], prm[3], prm[4], prm[5]);
@@ -71,13 +111,17 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
     const int ngroups = L::ngroups(m);
     const int64_t strip_bytes = L::strip_bytes(m);
     uint8_t* const ws_p = a.ws + a.ws_off[p];
+    const WideWs<R> wl(n, m);
+    int2* const xrows = reinterpret_cast<int2*>(ws_p + wl.rows_off);
+    int* const gprog = reinterpret_cast<int*>(ws_p + wl.prog_off);
+    int imp_hi = 0, exp_hi = 0;                   // hand-off columns imported / exported so far (WIDE)
     const int prev_wave = (wave + W - 1) % W;
     // groups [g_lo, g_hi) are "steady": every lane is inside 1 <= j <= m on every step
     const int g_lo = (63 + SPG - 1) / SPG;
     const int g_hi = m / SPG;
     int pass = 0;
 
-    for (int s = wave; s < nstrips; s += W, ++pass) {
+    for (int s = chunk * W + wave; s < nstrips; s += (WIDE ? nstrips : W), ++pass) {
         // ---- per-strip lane state: column-0 boundary (textSeqCompare.py:53-56) ----
         int D[R], V[R], H[R], tc[R];
         const int row0 = s * L::SR + lane * R;            // 0-based index of this lane's first row
@@ -101,12 +145,31 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
         // the strip above must be kCheck+1 groups ahead before this wave touches a span:
         // the hand-off entries of group g+1 are prefetched while group g is computed
         auto wait_span = [&](int g_first) {
-            if (W == 1 || s == 0) return;
-            // the last step of groups [g_first, g_first + kCheck] reads hand-off column
+            if (s == 0 || (W == 1 && !WIDE)) return;
+            // the last step of groups [g_first, g_first + CHK] reads hand-off column
             // min(k_last + 1, m), written by the producer's lane 63 at its step col + 62
-            const int k_last = min((g_first + kCheck + 1) * SPG - 1, L::nsteps(m) - 1);
+            const int k_last = min((g_first + CHK + 1) * SPG - 1, L::nsteps(m) - 1);
             const int col = min(k_last + 1, m);
             const int need_groups = min(ngroups, (col + 62) / SPG + 1);
+            if (WIDE && wave == 0) {
+                // the strip above belongs to the previous workgroup: wait for its progress word,
+                // then pull every newly final column from its HBM row into the LDS hand-off row
+                if (imp_hi >= col) return;
+                const int row = s / W - 1;
+                int have;
+                while (true) {
+                    have = __builtin_amdgcn_readfirstlane(
+                        __hip_atomic_load(&gprog[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (have >= need_groups) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const int cfin = (have >= ngroups) ? m : min(m, have * SPG - 1 - 62);
+                const int2* src = xrows + (int64_t)row * wl.row_elems;
+                for (int j = imp_hi + 1 + lane; j <= cfin; j += 64) hvd[j] = src[j];
+                imp_hi = cfin;
+                return;
+            }
             const int need = prod_pass * ngroups + need_groups;
             while (true) {
                 const int have = __hip_atomic_load(&prog[prev_wave], __ATOMIC_ACQUIRE,
@@ -115,9 +178,23 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
                 __builtin_amdgcn_s_sleep(2);
             }
         };
+        // progress is published after groups 0, CHK, 2 CHK, ...: the consumer's needs are 1 mod CHK
         auto publish = [&](int g) {
+            if (WIDE && wave == W - 1) {
+                if (((g % kCheck) == 0 || g == ngroups - 1) && s + 1 < nstrips) {
+                    // lane 63 has finished columns <= k - 62 of this strip's bottom row
+                    const int cfin = (g == ngroups - 1) ? m : min(m, (g + 1) * SPG - 1 - 62);
+                    int2* dst = xrows + (int64_t)(s / W) * wl.row_elems;
+                    for (int j = exp_hi + 1 + lane; j <= cfin; j += 64) dst[j] = hvd[j];
+                    exp_hi = max(exp_hi, cfin);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (lane == 0)
+                        __hip_atomic_store(&gprog[s / W], g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;
+            }
             if (W == 1) return;
-            if ((g % kCheck) == kCheck - 1 || g == ngroups - 1) {
+            if ((g % CHK) == 0 || g == ngroups - 1) {
                 if (lane == 63)
                     __hip_atomic_store(&prog[wave], pass * ngroups + g + 1, __ATOMIC_RELEASE,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -136,7 +213,7 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
         };
         auto prefetch = [&](int g) {
             if (g + 1 < ngroups) {
-                if (((g + 1) % kCheck) == 0) wait_span(g + 1);
+                if (((g + 1) % CHK) == 0) wait_span(g + 1);
                 load_group(g + 1);
             }
         };
@@ -198,7 +275,7 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
             for (int q = 0; q < SPG; ++q) { ocA[q] = oc_next[q]; hdA[q] = hd_next[q]; }
             auto fetch = [&](int gn, int (&oc)[SPG], int2 (&hd)[SPG]) {       // inputs of group gn
                 if (gn < ngroups) {
-                    if ((gn % kCheck) == 0) wait_span(gn);
+                    if ((gn % CHK) == 0) wait_span(gn);
                     const int idx = kOPad + gn * SPG - lane;
 #pragma unroll
                     for (int q = 0; q < SPG; ++q) {
@@ -322,7 +399,7 @@ constexpr int kR = 4;          // rows per lane of the production kernel
 
 extern "C" int64_t ta_nw_workspace_bytes(int32_t n, int32_t m) {
     if (n <= 0 || m <= 0) return 0;
-    return PtrLayout<kR>::total_bytes(n, m);
+    return WideWs<kR>(n, m).total;
 }
 
 extern "C" int32_t ta_nw_max_m(void) {
@@ -335,12 +412,32 @@ static hipError_t launch_fill(const NwArgs& a, int max_m, hipStream_t st) {
     const size_t lds = NwLds(max_m).total;
     static bool raised = false;         // allow > 64 KiB of dynamic LDS, once per process
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nw_fill_kernel<kR, W>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nw_fill_kernel<kR, W, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         raised = true;
     }
-    hipLaunchKernelGGL((nw_fill_kernel<kR, W>), dim3(a.nprob), dim3(W * 64), lds, st, a);
+    hipLaunchKernelGGL((nw_fill_kernel<kR, W, false>), dim3(a.nprob), dim3(W * 64), lds, st, a);
+    return hipGetLastError();
+}
+
+// few tall problems: spread each over ceil(nstrips / kWideW) workgroups so that every strip has a
+// SIMD of its own.  Block index = chunk * stride + p with stride a multiple of 8: workgroups are
+// dealt round-robin to the 8 XCDs, so all chunks of a problem share one L2 for the HBM hand-off rows.
+static hipError_t launch_fill_wide(NwArgs a, int nstrips, int max_m, hipStream_t st) {
+    const size_t lds = NwLds(max_m).total;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nw_fill_kernel<kR, kWideW, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    a.wide_stride = (a.nprob + 7) & ~7;
+    const int chunks = (nstrips + kWideW - 1) / kWideW;
+    hipLaunchKernelGGL((nw_wide_init_kernel<kR>), dim3(a.nprob), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((nw_fill_kernel<kR, kWideW, true>), dim3(a.wide_stride * chunks), dim3(kWideW * 64),
+                       lds, st, a);
     return hipGetLastError();
 }
 
@@ -367,7 +464,10 @@ extern "C" int ta_nw_batch(const int32_t* t_codes, const int64_t* t_off,
             if (!t_codes || !o_codes || !ws) return ta_fail(TA_EINVAL, "null code/workspace pointer");
             const int nstrips = PtrLayout<kR>::nstrips(max_n);
             hipError_t e;
-            if (nstrips >= 8) e = launch_fill<8>(a, max_m, st);
+            const bool wide = (flags & TA_NW_WIDE) ? true : (flags & TA_NW_NARROW) ? false
+                              : (nprob < 256 && nstrips > kWideW);
+            if (wide && nstrips > kWideW) e = launch_fill_wide(a, nstrips, max_m, st);
+            else if (nstrips >= 8) e = launch_fill<8>(a, max_m, st);
             else if (nstrips >= 4) e = launch_fill<4>(a, max_m, st);
             else if (nstrips >= 2) e = launch_fill<2>(a, max_m, st);
             else e = launch_fill<1>(a, max_m, st);

@@ -87,7 +87,7 @@ class NWBatch(object):
     `run()` only enqueues kernels on torch's current stream.
     """
 
-    def __init__(self, t_list, o_list, params, device="cuda", two_phase=None):
+    def __init__(self, t_list, o_list, params, device="cuda", two_phase=None, wide=None):
         assert len(t_list) == len(o_list)
         self.device = torch.device(device)
         self.nprob = len(t_list)
@@ -104,6 +104,9 @@ class NWBatch(object):
             nstrips = (self.max_n + 255) // 256
             two_phase = (self.cells > 6e8 * nstrips) or (self.cells > 64e9)
         self.two_phase = bool(two_phase)
+        # one-pass launch shape: None = library default (a problem is spread over several
+        # workgroups when the batch has fewer problems than the GPU has CUs), True / False force it
+        self.wide = wide
         p = np.asarray(params, dtype=np.int64)
         if p.ndim == 1:
             p = p.reshape(1, 6)
@@ -151,6 +154,8 @@ class NWBatch(object):
         flags = (_native.TA_NW_FILL if fill else 0) | (_native.TA_NW_TRACEBACK if traceback else 0)
         if self.codes8:
             flags |= _native.TA_NW_CODES8
+        if self.wide is not None and not self.two_phase:
+            flags |= _native.TA_NW_WIDE if self.wide else _native.TA_NW_NARROW
         stream = torch.cuda.current_stream(self.device).cuda_stream
         entry = _native.lib.ta_nw2_batch if self.two_phase else _native.lib.ta_nw_batch
         rc = entry(
