@@ -141,19 +141,29 @@ def _recognizer_for(ocropus_model):
     return _recognizers[key][1]
 
 
+def _edge_positions(xs, x_min):
+    """int(np.round(float('%.1f' % x) + x_min)) of the reference (alignToOCR.py:167-170) for a
+    whole line at once: x as the .llocs file carries it (one decimal), then round half to even."""
+    v = np.asarray(xs, dtype=np.float64)
+    t = v * 10.0
+    f = np.floor(t)
+    frac = t - f
+    one_dec = np.where(frac > 0.5, f + 1.0, f) / 10.0
+    for i in np.nonzero(np.abs(frac - 0.5) < 1e-6)[0]:          # (near-)ties: let printf decide
+        one_dec[i] = float('%.1f' % v[i])
+    return np.rint(one_dec + x_min).astype(np.int64).tolist()
+
+
 def chars_from_llocs(llocs, x_min, y_min, y_max, all_chars):
     """One strip's (char, x) list -> CharBoxes appended to all_chars (alignToOCR.py:160-182).
     ocropus reports the RIGHT edge of each character, so a character's box runs from the
     previous character's position to its own; '~' and '' still advance the position."""
+    if not llocs:
+        return
     prev_xpos = x_min
-    for ch, x in llocs:
-        x_text = '%.1f' % x                       # the value as the .llocs file carries it
-        # int(np.round(v)) of the reference (alignToOCR.py:170): round half to even, which is
-        # what Python's round() does on a float as well (and 20x cheaper per character)
-        cur_xpos = int(round(float(x_text) + x_min))
-        ul, lr = (prev_xpos, y_min), (cur_xpos, y_max)
+    for (ch, _), cur_xpos in zip(llocs, _edge_positions([x for _, x in llocs], x_min)):
         if not (ch == '~' or ch == ''):
-            all_chars.append(CharBox(clean_special_chars(ch), ul, lr))
+            all_chars.append(CharBox(clean_special_chars(ch), (prev_xpos, y_min), (cur_xpos, y_max)))
         prev_xpos = cur_xpos
 
 
@@ -185,18 +195,18 @@ def perform_ocr_with_ocropus(cc_strips, ocropus_model, wkdir_name=None, parallel
 def expand_abbreviations(all_chars):
     """Replace every occurrence of an abbreviation in the OCR character list by its expansion;
     character k of the abbreviation lends its box to all letters of segment k
-    (alignToOCR.py:251-264)."""
+    (alignToOCR.py:251-264).  String positions index the character list, as in the reference."""
+    ocr_str = ''.join(str(x.char) for x in all_chars)
     for abb, segments in latsyl.abbreviations.items():
-        while True:
-            ocr_str = ''.join(str(x.char) for x in all_chars)
-            idx = ocr_str.find(abb)
-            if idx == -1:
-                break
+        idx = ocr_str.find(abb)
+        while idx != -1:
             ins = []
             for k, segment in enumerate(segments):
                 donor = all_chars[k + idx]
                 ins += [CharBox(ch, donor.ul, donor.lr) for ch in segment]
             all_chars = all_chars[:idx] + ins + all_chars[idx + len(abb):]
+            ocr_str = ''.join(str(x.char) for x in all_chars)        # only after a replacement
+            idx = ocr_str.find(abb)
     return all_chars
 
 
@@ -233,11 +243,11 @@ def syllable_boxes(syls, tra_align, all_chars, indices=None):
 
 
 def align_page(transcript, all_chars, angle, image_dim, raw_dim, seq_align_params=None,
-               alignment=None, indices=None):
+               alignment=None, indices=None, expanded=False):
     """Everything `process` does after OCR (alignToOCR.py:247-328), on plain data.  `alignment`
     may carry a precomputed (tra_align, ocr_align) of the transcript against the expanded OCR
     string (the batched driver aligns all pages in one launch)."""
-    all_chars = expand_abbreviations(list(all_chars))
+    all_chars = list(all_chars) if expanded else expand_abbreviations(list(all_chars))
     ocr = ''.join(x.char for x in all_chars)
     all_chars_copy = list(all_chars)
 
@@ -249,11 +259,13 @@ def align_page(transcript, all_chars, angle, image_dim, raw_dim, seq_align_param
     ocr_align = ''.join(ocr_align)
     syls = latsyl.syllabify_text(transcript)
 
-    for k, ch in enumerate(ocr_align):          # gaps of the OCR side get placeholder boxes
-        if ch == '_':
-            all_chars.insert(k, CharBox('_'))
-    assert len(all_chars) == len(tra_align), 'all_chars not same length as alignment: ' \
-        '{} vs {}'.format(len(all_chars), len(tra_align))
+    # gaps of the OCR side get placeholder boxes (alignToOCR.py:285-292; a literal '_' in the OCR
+    # text counts as a gap there too and trips the same assertion)
+    ngaps = ocr_align.count('_')
+    assert len(all_chars) + ngaps == len(tra_align), 'all_chars not same length as alignment: ' \
+        '{} vs {}'.format(len(all_chars) + ngaps, len(tra_align))
+    boxes = iter(all_chars)
+    all_chars = [CharBox('_') if ch == '_' else next(boxes) for ch in ocr_align]
 
     syl_boxes = syllable_boxes(syls, tra_align, all_chars, indices)
     syl_boxes = rotate_bboxes(syl_boxes, -1 * angle, image_dim, raw_dim)
@@ -295,7 +307,7 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
                                                                 chars_per_page, peaks, alignments):
         idx = [] if indices_out is not None else None
         syl_boxes, all_chars_copy = align_page(tr, chars, angle, image.dim, pg.dim,
-                                               seq_align_params, alignment=al, indices=idx)
+                                               seq_align_params, alignment=al, indices=idx, expanded=True)
         if indices_out is not None:
             indices_out.append(idx)
         results.append((syl_boxes, image, lp, all_chars_copy))

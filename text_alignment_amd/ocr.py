@@ -241,7 +241,8 @@ class LineRecognizer(object):
         """(char, x) pairs of ocropus-rpred's --llocs output for one line: x in raw strip pixels
         from the strip's left edge (parsed at reference alignToOCR.py:157-170)."""
         scale = float(raw_width) / (T - 2 * PAD)
-        return [(self.model.codec[c], (t - PAD) * scale) for (t, c) in decoded]
+        codec = self.model.codec
+        return [(codec[c], (t - PAD) * scale) for (t, c) in decoded]
 
 
 def llocs_text(llocs):
