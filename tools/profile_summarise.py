@@ -1,0 +1,57 @@
+"""Turns the rocprofv3 CSVs written by tools/profile_round.sh into the small summaries kept under
+profiles/: per-kernel mean WRITE_SIZE / FETCH_SIZE and HBM bytes per launch
+(WRITE_SIZE*1024 + 2*FETCH_SIZE*1024: counter unit KiB, gfx950 FETCH_SIZE correction, see
+MI355X_MICROARCH.md HBM section), and a copy of the kernel-stats table."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def counter_means(path, counter):
+    acc = {}
+    for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] != counter:
+                    continue
+                name = row["Kernel_Name"]
+                if "nw_" not in name:
+                    continue
+                s = acc.setdefault(name, [0.0, 0])
+                s[0] += float(row["Counter_Value"])
+                s[1] += 1
+    return {k: v[0] / v[1] for k, v in acc.items()}
+
+
+def main():
+    rnd, out = sys.argv[1], sys.argv[2]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(repo, "profiles")
+    stats = glob.glob(os.path.join(out, "kt", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(prof, "%s_kernel_stats_bench_default.csv" % rnd))
+    for mode, fname, desc in (("two", "%s_nw2_hbm_traffic.json", "two-phase aligner"),
+                              ("one", "%s_nw_hbm_traffic.json", "one-pass aligner (--one-pass)")):
+        wr = counter_means(os.path.join(out, mode + "_WRITE_SIZE"), "WRITE_SIZE")
+        rd = counter_means(os.path.join(out, mode + "_FETCH_SIZE"), "FETCH_SIZE")
+        kernels = {}
+        for k in sorted(set(wr) | set(rd)):
+            w, r = wr.get(k, 0.0), rd.get(k, 0.0)
+            kernels[k] = {"WRITE_SIZE_KiB_mean": w, "FETCH_SIZE_KiB_mean": r,
+                          "hbm_bytes_per_launch": w * 1024 + 2 * r * 1024}
+        doc = {"command": "rocprofv3 --pmc WRITE_SIZE (and, separately, FETCH_SIZE) --output-format csv -- python3 "
+                          "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ocr%s   [1024 problems of "
+                          "4096x4096, %s]" % (" --one-pass" if mode == "one" else "", desc),
+               "units": "counter values are KiB (x1024 -> bytes); FETCH_SIZE is doubled for wide coalesced reads "
+                        "per MI355X_MICROARCH.md (HBM section); WRITE_SIZE is exact for 16-B-per-lane streaming stores",
+               "config": {"batch": 1024, "n": 4096, "m": 4096}, "kernels": kernels}
+        with open(os.path.join(prof, fname % rnd), "w") as fh:
+            json.dump(doc, fh, indent=1)
+    print("profiles updated")
+
+
+if __name__ == "__main__":
+    main()
