@@ -260,3 +260,16 @@ def test_overflow_guard_routes_to_general_kernel(tsc):
     t, o = list("abcabcabc"), list("abcbcaabc")
     big = [2 ** 21, -2 ** 20, -7, -7, -3, 0]
     assert tsc.perform_alignment(t, o, big) == nw_oracle.perform_alignment(t, o, big)
+
+
+def test_ocr_longer_than_lds_row_routes_to_general_kernel(tsc):
+    """m beyond ta_nw_max_m() (the LDS hand-off row) still aligns, through the float64 kernel."""
+    from oracle import nw_oracle
+    from oracle.synth import synth_pair
+    from text_alignment_amd import _native
+    m = _native.lib.ta_nw_max_m() + 500
+    t, o = synth_pair(700, m, 77)
+    assert tsc.perform_alignment(t, o) == nw_oracle.perform_alignment(t, o)
+    res = tsc.perform_alignment_batch([(t, o), (list("abc"), list("abd"))])
+    assert res[0] == nw_oracle.perform_alignment(t, o)
+    assert res[1] == nw_oracle.perform_alignment(list("abc"), list("abd"))

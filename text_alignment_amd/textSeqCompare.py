@@ -117,6 +117,10 @@ class NWBatch(object):
         self.score_bound = (self.max_n + self.max_m + 2) * (3 * pmax + 2)
         if np.abs(p).max(initial=0) > 2 ** 20:
             raise OverflowError("scoring parameters too large for the integer kernels")
+        if self.score_bound >= 2 ** 23:
+            raise OverflowError("(n+m+2)*max|param| does not fit the 32-bit encoded scores")
+        if self.max_m > _native.lib.ta_nw_max_m():
+            raise OverflowError("OCR string longer than the LDS hand-off row of the integer kernels")
 
         lib = _native.lib
         t_off = np.zeros(self.nprob + 1, dtype=np.int64); np.cumsum(self.n, out=t_off[1:])
@@ -211,7 +215,10 @@ def perform_alignment_batch(pairs, scoring_systems=None):
     params = np.array([[int(v) for v in p] for p, _ in parsed], dtype=np.int64)
     if len(pairs) and (params == params[0]).all():
         params = params[:1]
-    batch = NWBatch(t_list, o_list, params)
+    try:
+        batch = NWBatch(t_list, o_list, params)
+    except OverflowError:           # some problem exceeds the integer kernels' limits: one by one
+        return [perform_alignment(t, o, s) for (t, o), s in zip(pairs, systems)]
     batch.run()
     return [ops_to_alignment(ops, t, o) for ops, (t, o) in zip(batch.results(), pairs)]
 
