@@ -266,8 +266,8 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
             // iteration with two input buffers (A / B): the LDS prefetch of the next group lands in
             // the other buffer, so the loop back-edge needs no register copies. ----
             // lane 63 publishes its bottom row to hvd[j], j = k - 62; the other lanes write a
-            // private dummy slot so the store needs no EXEC mask
-            int2* wptr = (lane == 63) ? (hvd + (g * SPG - 62)) : (dummy + lane * SPG);
+            // private dummy slot (8-byte lane stride: bank-conflict free) so the store needs no EXEC mask
+            int2* wptr = (lane == 63) ? (hvd + (g * SPG - 62)) : (dummy + lane);
             const int winc = (lane == 63) ? SPG : 0;
             int ocA[SPG], ocB[SPG];
             int2 hdA[SPG], hdB[SPG];

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
             // ---- steady state: every lane is inside 1 <= j <= m, no EXEC changes.  Two groups per
             // iteration with two input buffers (A / B), so the LDS prefetch of the next group lands
             // in the other buffer and no register copies are needed at the loop back-edge. ----
-            int2* wptr = (lane == 63) ? (hvd + (g * SPG - 62)) : (dummy + lane * SPG);
+            int2* wptr = (lane == 63) ? (hvd + (g * SPG - 62)) : (dummy + lane);
             const int winc = (lane == 63) ? SPG : 0;
             int ocA[SPG], ocB[SPG];
             int2 hdA[SPG], hdB[SPG];
