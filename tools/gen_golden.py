@@ -377,6 +377,75 @@ def gen_preproc():
     return out
 
 
+MEI_DOC = """<?xml version="1.0" encoding="UTF-8"?>
+<mei xmlns="http://www.music-encoding.org/ns/mei" meiversion="3.9.9">
+<music><facsimile><surface xml:id="surf1">
+%s
+</surface></facsimile>
+<body><mdiv><score><section><staff n="1"><layer n="1">
+%s
+</layer></staff></section></score></mdiv></body></music></mei>
+"""
+
+
+def mei_case(seed, nsyl):
+    """A synthetic Neon-style MEI page: neume components with zones, one <syllable> per neume,
+    and text boxes below some of them (others share a text box or have none)."""
+    rng = np.random.default_rng(seed)
+    zones, syls, boxes = [], [], []
+    x, y, zid = 100, 300, 0
+    for k in range(nsyl):
+        ncs = []
+        for _ in range(int(rng.integers(1, 4))):
+            zid += 1
+            w, h = int(rng.integers(20, 40)), int(rng.integers(20, 40))
+            yy = y + int(rng.integers(-30, 30))
+            zones.append('<zone xml:id="z%d" ulx="%d" uly="%d" lrx="%d" lry="%d"/>' % (zid, x, yy, x + w, yy + h))
+            ncs.append('<nc xml:id="nc%d" facs="z%d"/>' % (zid, zid))
+            x += w + int(rng.integers(0, 10))
+        syls.append('<syllable xml:id="syl%d"><neume xml:id="n%d">%s</neume></syllable>' % (k, k, "".join(ncs)))
+        x += int(rng.integers(10, 60))
+        if x > 1500:
+            x, y = 100, y + 400
+    # text boxes: one per two or three neumes, placed a line below; some stretches have none
+    text = "do mi nus de us me us al le lu ia glo ri a pa tri".split()
+    bx, by, k = 100, 300, 0
+    while by < y + 1 and k < 60:
+        w = int(rng.integers(60, 220))
+        if rng.random() < 0.8:
+            boxes.append([text[k % len(text)], [bx, by + 110], [bx + w, by + 170]])
+        bx += w + int(rng.integers(0, 40))
+        k += 1
+        if bx > 1500:
+            bx, by = 100, by + 400
+    return MEI_DOC % ("\n".join(zones), "\n".join(syls)), boxes
+
+
+def gen_mei():
+    """writeToMEI.add_text_to_mei_file (writeToMEI.py:41-145) on synthetic MEI documents.  The
+    reference indexes syllable boxes as (text, ul, lr) sequences; ids come from np.random, seeded."""
+    import xml.etree.ElementTree as ET
+    sys.modules["xml.etree.cElementTree"] = ET            # removed in Python 3.9
+    import writeToMEI as mei
+    cases = []
+    for seed, nsyl, spacing in [(1, 12, 240.0), (2, 30, 250.5), (3, 45, 180.0), (4, 6, 400.0)]:
+        doc, boxes = mei_case(seed, nsyl)
+        ET.register_namespace('', 'http://www.music-encoding.org/ns/mei')
+        root = ET.fromstring(doc)
+        tree = ET.ElementTree(root)
+        np.random.seed(1000 + seed)
+        syl_boxes = [(b[0], tuple(b[1]), tuple(b[2])) for b in boxes]
+        tree, all_bboxes, assign_lines = mei.add_text_to_mei_file(tree, syl_boxes, spacing)
+        cases.append({"seed": 1000 + seed, "doc": doc, "boxes": boxes, "med_line_spacing": spacing,
+                      "xml": ET.tostring(tree.getroot(), encoding="unicode"),
+                      "all_bboxes": all_bboxes, "assign_lines": assign_lines})
+    broken = '<mei xmlns="http://www.music-encoding.org/ns/mei" meiversion="3.9.9"><a xlink:href="x"/></mei>'
+    return {"cases": cases, "repair": {"in": broken, "out": mei.repair_xml(broken)},
+            "intersect": [[a, b, c, d, mei.intersect(a, b, c, d)] for a, b, c, d in
+                          [((0, 0), (10, 10), (5, 5), (20, 8)), ((0, 0), (10, 10), (10, 10), (20, 20)),
+                           ((0, 0), (4, 9), (1, 2), (3, 5)), ((5, 5), (6, 6), (0, 0), (1, 1))]]}
+
+
 def speed_check(tsc):
     from oracle import nw_ref_py
     for n, m in [(500, 500), (1000, 1000)]:
@@ -416,6 +485,8 @@ def main():
         dump("glue.json", gen_glue(latsyl, atocr))
     if not only or "preproc" in only:
         dump("preproc.json", gen_preproc())
+    if not only or "mei" in only:
+        dump("mei.json", gen_mei())
     if not only or "synth" in only:
         dump("nw_synth.json", gen_nw_synth(tsc, big=args.big))
 
