@@ -76,7 +76,9 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_kernel(LstmArgs a) {
     __shared__ int s_T[kLines];
     __shared__ long long s_row[kLines];
 
-    const int grp = blockIdx.x, dir = blockIdx.y;
+    // groups arrive longest first; both directions of a group are neighbours in dispatch order, so
+    // with more workgroups than CUs the long ones start first (longest-processing-time order)
+    const int grp = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -230,7 +232,9 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_bf16x3_kernel(LstmArgs a
     __shared__ int s_T[kLines];
     __shared__ long long s_row[kLines];
 
-    const int grp = blockIdx.x, dir = blockIdx.y;
+    // groups arrive longest first; both directions of a group are neighbours in dispatch order, so
+    // with more workgroups than CUs the long ones start first (longest-processing-time order)
+    const int grp = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -382,6 +386,44 @@ struct OutArgs {
     float4* summary;       // optional [rows]: {P(class 0), best P, best class as float bits, 0}
 };
 
+// reductions over the 16 lanes of a DPP row (= the 16 class columns of an accumulator row): two
+// quad permutes, then half-row and row mirrors; every lane ends with the result.  No LDS traffic
+// (__shfl_xor compiles to ds_bpermute_b32).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<kDppXor1>(v));
+    v = fmaxf(v, dpp_f<kDppXor2>(v));
+    v = fmaxf(v, dpp_f<kDppHalfMirror>(v));
+    return fmaxf(v, dpp_f<kDppMirror>(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    // fixed association ((lane pairs) quads) halves) row: the same tree on every lane
+    v += dpp_f<kDppXor1>(v);
+    v += dpp_f<kDppXor2>(v);
+    v += dpp_f<kDppHalfMirror>(v);
+    return v + dpp_f<kDppMirror>(v);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long k) {
+    const unsigned lo = dpp_u<CTRL>((unsigned)k), hi = dpp_u<CTRL>((unsigned)(k >> 32));
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    return o > k ? o : k;
+}
+__device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long k) {
+    k = dpp_max_u64<kDppXor1>(k);
+    k = dpp_max_u64<kDppXor2>(k);
+    k = dpp_max_u64<kDppHalfMirror>(k);
+    return dpp_max_u64<kDppMirror>(k);
+}
+
 template <int NCT>
 __global__ __launch_bounds__(kOWaves * 64) void lstm_output_kernel(OutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float osm[];
@@ -394,16 +436,19 @@ __global__ __launch_bounds__(kOWaves * 64) void lstm_output_kernel(OutArgs a) {
     const int kq = lane >> 4, rr = lane & 15;
 
     const int64_t ntiles = (a.rows + 15) / 16;
-    for (int64_t tile = (int64_t)blockIdx.x * kOWaves + wave; tile < ntiles;
-         tile += (int64_t)gridDim.x * kOWaves) {
-        const int64_t r0 = tile * 16;
-        const int64_t myrow = (r0 + rr < a.rows) ? r0 + rr : a.rows - 1;      // clamp: tail rows are not stored
-        float A[kOKS];
-        {
-            const float2* src = reinterpret_cast<const float2*>(a.y + myrow * 200 + kq * kOKS);
+    const int64_t stride = (int64_t)gridDim.x * kOWaves;
+    // this lane's quarter row of a tile; rows past the end are clamped (read, never stored)
+    auto load_tile = [&](int64_t tile, float (&dst)[kOKS]) {
+        const int64_t row = min(min(tile, ntiles - 1) * 16 + rr, a.rows - 1);
+        const float2* src = reinterpret_cast<const float2*>(a.y + row * 200 + kq * kOKS);
 #pragma unroll
-            for (int q = 0; q < kOKS / 2; ++q) { const float2 v = src[q]; A[2 * q] = v.x; A[2 * q + 1] = v.y; }
-        }
+        for (int q = 0; q < kOKS / 2; ++q) { const float2 v = src[q]; dst[2 * q] = v.x; dst[2 * q + 1] = v.y; }
+    };
+    float A[kOKS], An[kOKS];
+    load_tile((int64_t)blockIdx.x * kOWaves + wave, A);
+    for (int64_t tile = (int64_t)blockIdx.x * kOWaves + wave; tile < ntiles; tile += stride) {
+        const int64_t r0 = tile * 16;
+        load_tile(tile + stride, An);          // next tile's rows fly under this tile's MFMAs
         f32x4 acc[NCT];
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
@@ -432,20 +477,18 @@ __global__ __launch_bounds__(kOWaves * 64) void lstm_output_kernel(OutArgs a) {
                     zmax = fmaxf(zmax, z);
                 }
             }
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, d, 16));
+            zmax = row16_max(zmax);
             float sum = 0.f;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 const int cls = ct * 16 + rr;
                 if (cls < a.no) {
-                    const float e = expf(acc[ct][r] - zmax);
+                    const float e = exp_fast(fmaxf(acc[ct][r] - zmax, -87.0f));
                     acc[ct][r] = e;
                     sum += e;
                 }
             }
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) sum += __shfl_xor(sum, d, 16);
+            sum = row16_sum(sum);
             const float inv = 1.0f / sum;
             unsigned long long key = 0ull;           // larger P wins, then the smaller class
 #pragma unroll
@@ -461,13 +504,7 @@ __global__ __launch_bounds__(kOWaves * 64) void lstm_output_kernel(OutArgs a) {
                 }
             }
             if (a.summary) {
-#pragma unroll
-                for (int d = 1; d < 16; d <<= 1) {
-                    const unsigned lo = __shfl_xor((unsigned)key, d, 16);
-                    const unsigned hi = __shfl_xor((unsigned)(key >> 32), d, 16);
-                    const unsigned long long other = ((unsigned long long)hi << 32) | lo;
-                    key = other > key ? other : key;
-                }
+                key = row16_max_u64(key);
                 if (rr == 0 && row < a.rows) {
                     const unsigned cls = 0xFFFFFFFFu - (unsigned)key;
                     a.summary[row] = make_float4(acc[0][r], __uint_as_float((unsigned)(key >> 32)),
@@ -475,6 +512,8 @@ __global__ __launch_bounds__(kOWaves * 64) void lstm_output_kernel(OutArgs a) {
                 }
             }
         }
+#pragma unroll
+        for (int q = 0; q < kOKS; ++q) A[q] = An[q];
     }
 }
 
@@ -596,10 +635,10 @@ extern "C" int ta_lstm_forward(const float* x, const int64_t* row_off, const int
     if (mode != 0 && mode != 1) return ta_fail(TA_EINVAL, "mode must be 0 (f32 MFMA) or 1 (bf16 x 3)");
     LstmArgs a{x, row_off, T, group_lines, wp, peep, hout};
     if (mode == 1)
-        hipLaunchKernelGGL(lstm_seq_bf16x3_kernel, dim3(ngroups, 2), dim3(kWaves * 64), 0,
+        hipLaunchKernelGGL(lstm_seq_bf16x3_kernel, dim3(2 * ngroups), dim3(kWaves * 64), 0,
                            reinterpret_cast<hipStream_t>(stream), a);
     else
-        hipLaunchKernelGGL(lstm_seq_kernel, dim3(ngroups, 2), dim3(kWaves * 64), 0,
+        hipLaunchKernelGGL(lstm_seq_kernel, dim3(2 * ngroups), dim3(kWaves * 64), 0,
                            reinterpret_cast<hipStream_t>(stream), a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ta_fail_hip(e, "lstm_seq_kernel launch");
