@@ -101,11 +101,12 @@ def ocr_cpu_baseline(model_seed, no, seconds=8.0):
             "sample": "%d lines of width 1000 (T = 1032) through oracle/ocr_ref_f64.py, %.1f s" % (done, dt)}
 
 
-def bench_ocr(args, rank, precision="f32"):
+def bench_ocr(args, rank, precision="f32", nlines=None):
     from text_alignment_amd import ocr
     no = 96
+    nlines = args.ocr_lines if nlines is None else nlines
     rec = ocr.LineRecognizer(ocr.LineModel.random(7001, no=no), precision=precision)
-    lines = synthetic_lines(args.ocr_lines, 8000 + 7919 * rank)
+    lines = synthetic_lines(nlines, 8000 + 7919 * rank)
     st = rec.prepare(lines)
     tsteps = int(st["rows"])
     for _ in range(2):
@@ -126,7 +127,7 @@ def bench_ocr(args, rank, precision="f32"):
     dec_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
     flops_lstm = tsteps * 238400.0                    # 2 dirs x 4 gates x 100 x 149 x 2
     tf = flops_lstm / (lstm_ms * 1e-3) / 1e12
-    return {"lines_per_s": args.ocr_lines / dt, "timesteps_per_s": tsteps / dt, "lines": args.ocr_lines,
+    return {"lines_per_s": nlines / dt, "timesteps_per_s": tsteps / dt, "lines": nlines,
             "timesteps": tsteps, "classes": no,
             "dtype": "f32" if precision == "f32" else "bf16x3 (split operands, f32 accumulate)",
             "ms": {"lstm": lstm_ms, "output_softmax": out_ms, "decode": dec_ms},
@@ -144,6 +145,8 @@ def main():
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=1024, help="NW problems per GPU per step")
     ap.add_argument("--ocr-lines", type=int, default=1920, help="text lines per GPU (64 pages x 30)")
+    ap.add_argument("--ocr-lines-large", type=int, default=5760,
+                    help="second OCR measurement with more lines than CUs x 16 (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ocr", action="store_true")
     ap.add_argument("--pages", type=int, default=64,
@@ -217,6 +220,12 @@ def main():
         fast = bench_ocr(args, rank, precision="bf16x3")
         ocr_res["bf16x3_mode"] = {"lines_per_s": fast["lines_per_s"], "ms": fast["ms"],
                                   "note": "optional fast mode, not the parity mode"}
+        if args.ocr_lines_large > args.ocr_lines:
+            # 240 workgroups on 256 CUs leave the longest line group in charge of the time; with
+            # several workgroups per CU (longest first) the same kernels fill the chip
+            big = bench_ocr(args, rank, nlines=args.ocr_lines_large)
+            ocr_res["large_batch"] = {"lines": big["lines"], "lines_per_s": big["lines_per_s"], "ms": big["ms"],
+                                      "mfma_frac": big["roofline"]["frac"]}
         if dist is not None:
             agg = torch.tensor([ocr_res["lines_per_s"]], dtype=torch.float64, device="cuda")
             dist.all_reduce(agg, op=dist.ReduceOp.SUM)
