@@ -276,7 +276,7 @@ def main():
             out["ocr"] = ocr_res
         if pages_res is not None:
             out["pages_end_to_end"] = pages_res
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
             if ocr_res is not None:
                 out["ocr"]["cpu_baseline"] = ocr_cpu_baseline(7001, 96)
