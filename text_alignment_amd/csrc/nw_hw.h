@@ -42,11 +42,15 @@ __device__ __forceinline__ unsigned v_bfi12(unsigned a, unsigned b) {   // (a & 
     asm("v_bfi_b32 %0, 12, %1, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
-// t == o ? hit : miss   (textSeqCompare.py:32)
+// t == o ? hit : miss   (textSeqCompare.py:32).  The lane mask goes to an SGPR pair of the
+// compiler's choosing, not VCC: the compares of a group depend only on codes that are known
+// before the group starts, so they can be hoisted off the max3 dependency chain, and the selects
+// do not serialise on one mask register (5 % on the score-only cell, tools/ubench/valu_rate.hip).
 __device__ __forceinline__ int v_score(int t, int o, int miss, int hit) {
+    unsigned long long mask;
     int d;
-    asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_cndmask_b32 %0, %3, %4, vcc"
-        : "=v"(d) : "v"(t), "v"(o), "v"(miss), "v"(hit) : "vcc");
+    asm("v_cmp_eq_u32 %0, %1, %2" : "=s"(mask) : "v"(t), "v"(o));
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(miss), "v"(hit), "s"(mask));
     return d;
 }
 // lane l receives lane l-1's value; lane 0 keeps what the destination held (DPP wave_shr:1,

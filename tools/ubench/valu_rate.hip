@@ -34,6 +34,33 @@ __global__ __launch_bounds__(512) void k(int* out, int iters, int seed) {
         if (OP == 16) { REP8(asm volatile("v_max_f32 %0, %0, %4\n v_max_f32 %1, %1, %4\n v_max_f32 %2, %2, %4\n v_max_f32 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
         if (OP == 17) { REP8(asm volatile("v_pk_max_f16 %0, %0, %4\n v_pk_max_f16 %1, %1, %4\n v_pk_max_f16 %2, %2, %4\n v_pk_max_f16 %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
         if (OP == 18) { REP8(asm volatile("v_pk_sub_i16 %0, %0, %4 clamp\n v_pk_sub_i16 %1, %1, %4 clamp\n v_pk_sub_i16 %2, %2, %4 clamp\n v_pk_sub_i16 %3, %3, %4 clamp" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0));) }
+        // mixes: does the 2-cycle rate of add survive between 4-cycle instructions?
+        if (OP == 20) { REP8(asm volatile("v_add_u32 %0, %0, %4\n v_max3_i32 %1, %1, %5, %6\n v_add_u32 %2, %2, %4\n v_max3_i32 %3, %3, %5, %6" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(b0), "v"(b1));) }
+        if (OP == 21) { REP8(asm volatile("v_add_u32 %0, %0, %4\n v_add_u32 %2, %2, %4\n v_max3_i32 %1, %1, %5, %6\n v_max3_i32 %3, %3, %5, %6" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(b0), "v"(b1));) }
+        // the score-only cell of nw_score_kernel, 4 rows chained as in the kernel (8 instructions per cell)
+        if (OP == 22) { REP8(asm volatile(
+            "v_cmp_eq_u32 vcc, %4, %5\n v_cndmask_b32 %0, %6, %7, vcc\n v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %6\n v_add_u32 %3, %3, %7\n"
+            "v_max3_i32 %1, %0, %2, %3\n v_max3_i32 %2, %0, %2, %3\n v_max3_i32 %3, %0, %1, %3\n"
+            "v_cmp_eq_u32 vcc, %4, %6\n v_cndmask_b32 %0, %6, %7, vcc\n v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %6\n v_add_u32 %3, %3, %7\n"
+            "v_max3_i32 %1, %0, %2, %3\n v_max3_i32 %2, %0, %2, %3\n v_max3_i32 %3, %0, %1, %3\n"
+            "v_cmp_eq_u32 vcc, %4, %7\n v_cndmask_b32 %0, %6, %7, vcc\n v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %6\n v_add_u32 %3, %3, %7\n"
+            "v_max3_i32 %1, %0, %2, %3\n v_max3_i32 %2, %0, %2, %3\n v_max3_i32 %3, %0, %1, %3\n"
+            "v_cmp_eq_u32 vcc, %5, %7\n v_cndmask_b32 %0, %6, %7, vcc\n v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %6\n v_add_u32 %3, %3, %7\n"
+            "v_max3_i32 %1, %0, %2, %3\n v_max3_i32 %2, %0, %2, %3\n v_max3_i32 %3, %0, %1, %3"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(b0), "v"(b1), "v"(b2) : "vcc");) }
+        // the same cell with the compare result in an SGPR pair and the select folded into VOP3
+        if (OP == 23) { REP8(asm volatile(
+            "v_cmp_eq_u32 s[20:21], %4, %5\n v_cndmask_b32 %0, %6, %7, s[20:21]\n v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %6\n v_add_u32 %3, %3, %7\n"
+            "v_max3_i32 %1, %0, %2, %3\n v_max3_i32 %2, %0, %2, %3\n v_max3_i32 %3, %0, %1, %3\n"
+            "v_cmp_eq_u32 s[22:23], %4, %6\n v_cndmask_b32 %0, %6, %7, s[22:23]\n v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %6\n v_add_u32 %3, %3, %7\n"
+            "v_max3_i32 %1, %0, %2, %3\n v_max3_i32 %2, %0, %2, %3\n v_max3_i32 %3, %0, %1, %3\n"
+            "v_cmp_eq_u32 s[24:25], %4, %7\n v_cndmask_b32 %0, %6, %7, s[24:25]\n v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %6\n v_add_u32 %3, %3, %7\n"
+            "v_max3_i32 %1, %0, %2, %3\n v_max3_i32 %2, %0, %2, %3\n v_max3_i32 %3, %0, %1, %3\n"
+            "v_cmp_eq_u32 s[26:27], %5, %7\n v_cndmask_b32 %0, %6, %7, s[26:27]\n v_add_u32 %0, %0, %1\n v_add_u32 %2, %2, %6\n v_add_u32 %3, %3, %7\n"
+            "v_max3_i32 %1, %0, %2, %3\n v_max3_i32 %2, %0, %2, %3\n v_max3_i32 %3, %0, %1, %3"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c), "v"(b0), "v"(b1), "v"(b2) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");) }
+        if (OP == 24) { REP8(asm volatile("v_cmp_eq_u32 vcc, %0, %4\n v_cmp_eq_u32 vcc, %1, %4\n v_cmp_eq_u32 vcc, %2, %4\n v_cmp_eq_u32 vcc, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0) : "vcc");) }
+        if (OP == 25) { REP8(asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b0) : "vcc");) }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + b2 + b3;
 }
@@ -65,5 +92,8 @@ int main() {
     run<12>("v_pk_add_f32", 16);
     run<7>("v_pk_add_u16", 32); run<8>("v_pk_max_i16", 32); run<15>("v_pk_mad_i16", 32);
     run<18>("v_pk_sub_i16 clamp", 32); run<17>("v_pk_max_f16", 32);
+    run<20>("add,max3 alternating", 32); run<21>("add,add,max3,max3", 32);
+    run<24>("v_cmp_eq_u32 alone", 32); run<25>("v_cndmask_b32 alone", 32);
+    run<22>("score-only cell x4 (vcc), per instr", 8 * 32); run<23>("score-only cell x4 (sgpr mask), per instr", 8 * 32);
     return 0;
 }
