@@ -87,3 +87,29 @@ def test_line_normaliser_shapes_and_polarity():
     assert core[:, 12:36].mean() > 4 * max(core[:, :6].mean(), 1e-3)      # ink sits in the middle rows
     with pytest.raises(ValueError):
         lineest.prepare_raw_strip(np.full((40, 100), 255, np.uint8))
+
+
+def test_normaliser_pool_matches_inline():
+    """page.prepared_lines: raw strips normalised in spawned worker processes (the reference's
+    `parallel` = number of ocropus workers, alignToOCR.py:24, :142-147) give exactly what the
+    in-process path gives; prepared strips pass through untouched."""
+    import numpy as np
+    from text_alignment_amd import page as page_mod
+    rng = np.random.default_rng(3)
+    strips = []
+    for k in range(6):
+        h, w = int(rng.integers(40, 70)), int(rng.integers(200, 400))
+        ink = np.zeros((h, w), bool)
+        ink[h // 3: 2 * h // 3] = rng.random((2 * h // 3 - h // 3, w)) < 0.4
+        strips.append(page_mod.Strip(10, 20 * k, h, pixels=np.where(ink, 0, 255).astype(np.uint8)))
+    ready = np.zeros((100, 48), np.float32)
+    strips.insert(2, page_mod.Strip(0, 0, 48, width=136, prepared=ready))
+    try:
+        pooled = page_mod.prepared_lines(strips, workers=2)
+    finally:
+        page_mod.close_pool()
+    inline = page_mod.prepared_lines(strips, workers=1)
+    assert len(pooled) == len(inline) == 7
+    for (a, wa), (b, wb) in zip(pooled, inline):
+        assert wa == wb and a.shape == b.shape and np.array_equal(a, b)
+    assert pooled[2][0] is ready and pooled[2][1] == 136

@@ -173,16 +173,15 @@ def perform_ocr_with_ocropus(cc_strips, ocropus_model, wkdir_name=None, parallel
 
     cc_strips: objects with offset_x, offset_y, height and either `prepared` (a (T, 48) array,
     ink = 1, already normalised and padded) or `pixels` (raw strip, normalised on the host by
-    text_alignment_amd.lineest).  wkdir_name / parallel are accepted and unused: all strips of
-    the page go to the GPU in one batch.
+    text_alignment_amd.lineest).  wkdir_name is accepted and unused: all strips of
+    the page go to the GPU in one batch.  `parallel` (the reference's number of ocropus worker
+    processes) is the number of host processes that normalise raw strips.
     """
     from . import ocr
     rec = _recognizer_for(ocropus_model)
-    lines, widths = [], []
-    for strip in cc_strips:
-        xs, raw_w = page_mod.prepared_line(strip)
-        lines.append(xs)
-        widths.append(raw_w)
+    prepared = page_mod.prepared_lines(list(cc_strips), workers=parallel)
+    lines = [xs for xs, _ in prepared]
+    widths = [w for _, w in prepared]
     decoded = rec.recognise(lines)
     all_chars = []
     for strip, xs, raw_w, dec in zip(cc_strips, lines, widths, decoded):
@@ -272,7 +271,8 @@ def align_page(transcript, all_chars, angle, image_dim, raw_dim, seq_align_param
     return syl_boxes, all_chars_copy
 
 
-def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indices_out=None):
+def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indices_out=None,
+                  parallel=parallel):
     """`process` for many pages at once: the strips of ALL pages go through the line recogniser
     in one batch and the transcript/OCR alignments of all pages run in one NW launch -- the shape
     in which a GPU is worth using.  Per page the result equals process(page, transcript, model,
@@ -285,12 +285,9 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
         cc_strips, lines_peak_locs, _ = preproc.identify_text_lines(image, eroded)
         strips_per_page.append(cc_strips)
         peaks.append(lines_peak_locs)
-    lines, widths = [], []
-    for strips in strips_per_page:
-        for strip in strips:
-            xs, raw_w = page_mod.prepared_line(strip)
-            lines.append(xs)
-            widths.append(raw_w)
+    prepared = page_mod.prepared_lines([st for strips in strips_per_page for st in strips], workers=parallel)
+    lines = [xs for xs, _ in prepared]
+    widths = [w for _, w in prepared]
     decoded = rec.recognise(lines)
     chars_per_page, k = [], 0
     for strips in strips_per_page:

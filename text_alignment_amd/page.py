@@ -78,3 +78,56 @@ def prepared_line(strip):
     from . import lineest
     xs = lineest.prepare_raw_strip(strip.pixels)
     return xs, int(strip.pixels.shape[1])
+
+
+# ---- host-side line normalisation in worker processes -----------------------------------------
+# The reference hands its strips to `ocropus-rpred -Q <parallel>` (alignToOCR.py:142-147), whose
+# worker processes spend most of their time in the line normaliser; here the recogniser runs on the
+# GPU and `parallel` keeps its meaning for the part that is still host work (lineest, ~50 ms per
+# raw strip in scipy).  Workers are spawned (never forked: the parent may hold a GPU context), only
+# import numpy/scipy, and stay alive for the next page.
+_pool = None
+_pool_size = 0
+
+
+def _normaliser_pool(workers):
+    global _pool, _pool_size
+    if _pool is None or _pool_size != workers:
+        close_pool()
+        import atexit
+        import multiprocessing
+        _pool = multiprocessing.get_context("spawn").Pool(workers)
+        _pool_size = workers
+        atexit.register(close_pool)
+    return _pool
+
+
+def close_pool():
+    global _pool, _pool_size
+    if _pool is not None:
+        _pool.terminate()
+        _pool.join()
+        _pool, _pool_size = None, 0
+
+
+def prepared_lines(strips, workers=1, min_batch=4):
+    """[(xs, raw_width)] for a list of strips.  Strips that carry `.prepared` pass through; raw
+    strips are normalised on the host, in `workers` processes when there are enough of them."""
+    out = [None] * len(strips)
+    raw = []
+    for k, strip in enumerate(strips):
+        if getattr(strip, "prepared", None) is not None:
+            out[k] = prepared_line(strip)
+        else:
+            raw.append(k)
+    if workers > 1 and len(raw) >= min_batch:
+        from . import lineest
+        pool = _normaliser_pool(int(workers))
+        done = pool.map(lineest.prepare_raw_strip, [strips[k].pixels for k in raw],
+                        chunksize=max(1, len(raw) // (4 * int(workers))))
+        for k, xs in zip(raw, done):
+            out[k] = (xs, int(strips[k].pixels.shape[1]))
+    else:
+        for k in raw:
+            out[k] = prepared_line(strips[k])
+    return out
