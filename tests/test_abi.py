@@ -84,3 +84,36 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(root, f), encoding="utf-8").read()
                 assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", ""), f
+
+
+# ---- the C ABI from plain C (no Python, no torch): tests/native/abi_c_example.c ---------------
+_C_SRC = os.path.join(REPO, "tests", "native", "abi_c_example.c")
+_C_BIN = os.path.join(REPO, "tests", "native", "build", "abi_c_example")
+
+
+def _build_c_example():
+    import subprocess
+    os.makedirs(os.path.dirname(_C_BIN), exist_ok=True)
+    libdir = os.path.join(REPO, "text_alignment_amd")
+    subprocess.check_call(
+        ["gcc", "-std=c99", "-Wall", "-I", os.path.join(REPO, "include"), "-I", "/opt/rocm/include",
+         "-D__HIP_PLATFORM_AMD__", _C_SRC, "-L", libdir, "-lta_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+         "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", _C_BIN])
+    return _C_BIN
+
+
+def test_c_example_builds_against_header(native):
+    """the header is C (not C++), self-contained, and the library links from gcc"""
+    assert os.path.exists(_build_c_example())
+
+
+@pytest.mark.gpu
+def test_c_example_runs_and_matches_oracle(native):
+    import subprocess
+    from oracle import nw_oracle
+    exe = _build_c_example()
+    for t, o in [("dominus deus meus", "domnus dcus  meuss"), ("abc", "xbcd"), ("aaaa", "a"),
+                 ("quoniam confirmata est super nos misericordia eius", "quonia cofirmata est supcr nos miscricordia cius")]:
+        out = subprocess.run([exe, t, o], check=True, capture_output=True, text=True, timeout=120).stdout.split("\n")
+        tra, ocr = nw_oracle.perform_alignment(list(t), list(o))
+        assert out[0] == "".join(tra) and out[1] == "".join(ocr), (t, o, out)

@@ -48,7 +48,15 @@ def run(npages, seed0=100):
     res = atocr.process_batch(list(pages), list(trs), rec, PARAMS)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # BASELINE configs[2]: one page end to end (30 strips + one NW problem), latency of a lone call
+    lat = []
+    for k in range(3):
+        t1 = time.perf_counter()
+        atocr.process_batch([pages[k]], [trs[k]], rec, PARAMS)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t1)
     return {"pages": npages, "seconds": dt, "pages_per_s": npages / dt, "lines_per_s": npages * 30 / dt,
+            "single_page_ms": 1e3 * sorted(lat)[1],
             "syllable_boxes": sum(len(r[0]) for r in res),
             "note": "process_batch end to end: host upload + K3/K4/K5 + NW + host glue (Python)"}
 
