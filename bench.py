@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--m", type=int, default=4096)
-    ap.add_argument("--batch", type=int, default=1024, help="NW problems per GPU per step")
+    ap.add_argument("--batch", type=int, default=4096, help="NW problems per GPU per step")
     ap.add_argument("--ocr-lines", type=int, default=1920, help="text lines per GPU (64 pages x 30)")
     ap.add_argument("--ocr-lines-large", type=int, default=5760,
                     help="second OCR measurement with more lines than CUs x 16 (0 = skip)")

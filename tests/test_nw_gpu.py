@@ -273,3 +273,22 @@ def test_ocr_longer_than_lds_row_routes_to_general_kernel(tsc):
     res = tsc.perform_alignment_batch([(t, o), (list("abc"), list("abd"))])
     assert res[0] == nw_oracle.perform_alignment(t, o)
     assert res[1] == nw_oracle.perform_alignment(list("abc"), list("abd"))
+
+
+def test_two_phase_many_problems_small_walk_window(tsc):
+    """Batches of >= 2048 problems use the small LDS walk sub-window in phase 2 (several walkers
+    per SIMD): ragged sizes, a few problems large enough for multi-strip, multi-window walks."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(31)
+    sizes = [(int(rng.integers(1, 400)), int(rng.integers(1, 400))) for _ in range(2060)]
+    sizes[7] = (2100, 1900); sizes[500] = (1500, 3000); sizes[2059] = (3000, 700); sizes[1000] = (0, 9)
+    t_list, o_list = [], []
+    for k, (n, m) in enumerate(sizes):
+        t, o = _random_problem(rng, n, m, [2, 4, 27][k % 3], k % 2 == 0)
+        t_list.append(t); o_list.append(o)
+    batch = tsc.NWBatch(t_list, o_list, SYSTEMS[0], two_phase=True)
+    batch.run()
+    res = batch.results()
+    for k in list(range(0, 2060, 41)) + [7, 500, 1000, 2059]:
+        want = nw_oracle.align_ids(t_list[k], o_list[k], SYSTEMS[0])
+        assert res[k].tolist() == want.tolist(), (k, sizes[k])

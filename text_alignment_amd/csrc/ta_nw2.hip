@@ -306,9 +306,15 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // phase 2
-constexpr int kTb2Groups = 32;                // walk sub-window staged in LDS, in groups
+// Walk sub-window staged in LDS, in groups (1 KiB each).  The sub-window is what limits how many
+// problems a CU holds at once (32 groups: 38 KB per workgroup -> one wave per SIMD).  A lone wave
+// issues only every ~8 cycles, so batches with more problems than the GPU has SIMDs use a small
+// sub-window: more loads and barriers per strip, but several walkers per SIMD.
+constexpr int kTb2GroupsFew = 32, kTb2GroupsMany = 8;
+constexpr int kTb2ManyProblems = 2048;
 constexpr int kTb2Ops = 512;
 
+template <int kTb2Groups>
 __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
     constexpr int R = 4;
     using L = PtrLayout<R>;
@@ -584,7 +590,10 @@ extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
     }
     if (flags & TA_NW_TRACEBACK) {
         if (!ops_out && (max_n + max_m) > 0) return ta_fail(TA_EINVAL, "null ops_out");
-        hipLaunchKernelGGL(nw_trace2_kernel, dim3(nprob), dim3(64), 0, st, a);
+        if (nprob >= kTb2ManyProblems)
+            hipLaunchKernelGGL(nw_trace2_kernel<kTb2GroupsMany>, dim3(nprob), dim3(64), 0, st, a);
+        else
+            hipLaunchKernelGGL(nw_trace2_kernel<kTb2GroupsFew>, dim3(nprob), dim3(64), 0, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return ta_fail_hip(e, "nw_trace2_kernel launch");
     }

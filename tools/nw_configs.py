@@ -2,7 +2,7 @@
 checked bit-exact against the C oracle (checker only):
 
   C1  1 x 500^2 (the reference's own CPU-runnable case)      C2  1024 x 2048^2
-  headline 1 x 4096^2 and 64 x 4096^2 (and the bench default 1024 x 4096^2)
+  headline 1 x 4096^2 and 64 x 4096^2 (and 1024 / 4096 x 4096^2, the latter is the bench default)
   C4  1 x 8192^2 (and 64 x 8192^2)
   N2  the evaluation grid search (reference evaluate_text_alignment.py:178-198): 2187 page-sized
       problems (3 pages x the 729 scoring systems of :181-188), per-problem parameters, one launch
@@ -92,8 +92,9 @@ def main():
     run("C2 1024x2048^2 (two-phase forced)", 1024, 2048, 2048, two_phase=True)
     run("headline 1x4096^2", 1, 4096, 4096)
     run("headline 64x4096^2", 64, 4096, 4096)
-    run("bench default 1024x4096^2", 1024, 4096, 4096)
-    run("bench default 1024x4096^2 (one-pass forced)", 1024, 4096, 4096, two_phase=False)
+    run("1024x4096^2", 1024, 4096, 4096)
+    run("1024x4096^2 (one-pass forced)", 1024, 4096, 4096, two_phase=False)
+    run("bench default 4096x4096^2", 4096, 4096, 4096)
     run("C4 1x8192^2", 1, 8192, 8192)
     run("C4 64x8192^2", 64, 8192, 8192)
     run("C4 512x8192^2", 512, 8192, 8192)

@@ -43,11 +43,11 @@ def main():
             kernels[k] = {"WRITE_SIZE_KiB_mean": w, "FETCH_SIZE_KiB_mean": r,
                           "hbm_bytes_per_launch": w * 1024 + 2 * r * 1024}
         doc = {"command": "rocprofv3 --pmc WRITE_SIZE (and, separately, FETCH_SIZE) --output-format csv -- python3 "
-                          "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ocr%s   [1024 problems of "
+                          "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ocr%s   [4096 problems of "
                           "4096x4096, %s]" % (" --one-pass" if mode == "one" else "", desc),
                "units": "counter values are KiB (x1024 -> bytes); FETCH_SIZE is doubled for wide coalesced reads "
                         "per MI355X_MICROARCH.md (HBM section); WRITE_SIZE is exact for 16-B-per-lane streaming stores",
-               "config": {"batch": 1024, "n": 4096, "m": 4096}, "kernels": kernels}
+               "config": {"batch": 4096, "n": 4096, "m": 4096}, "kernels": kernels}
         with open(os.path.join(prof, fname % rnd), "w") as fh:
             json.dump(doc, fh, indent=1)
     print("profiles updated")
