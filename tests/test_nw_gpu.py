@@ -292,3 +292,27 @@ def test_two_phase_many_problems_small_walk_window(tsc):
     for k in list(range(0, 2060, 41)) + [7, 500, 1000, 2059]:
         want = nw_oracle.align_ids(t_list[k], o_list[k], SYSTEMS[0])
         assert res[k].tolist() == want.tolist(), (k, sizes[k])
+
+
+def test_bench_default_shape_properties(tsc):
+    """The bench's own workload (4096 problems of 4096 x 4096, default scoring, two-phase) through
+    size-independent properties: every token of both strings appears exactly once, no alignment
+    column is a double gap, replicas of a problem give identical bytes, and the seed-1234 problem
+    reproduces the alignment captured from the reference (tests/golden/nw_synth.json)."""
+    from oracle.synth import synth_pair_ids
+    nprob, distinct = 4096, 16
+    uniq = [synth_pair_ids(4096, 4096, 1234 + k) for k in range(distinct)]
+    probs = [uniq[k % distinct] for k in range(nprob)]
+    batch = tsc.NWBatch([p[0] for p in probs], [p[1] for p in probs], SYSTEMS[0])
+    assert batch.two_phase
+    batch.run()
+    res = batch.results()
+    for k, ops in enumerate(res):
+        c = np.bincount(ops, minlength=3)
+        assert len(c) == 3 and c[0] + c[1] == 4096 and c[0] + c[2] == 4096, k
+    for k in range(distinct, nprob):
+        assert np.array_equal(res[k], res[k % distinct]), k
+    g = load_golden("nw_synth.json")
+    c4096 = [c for c in g["cases"] if c["n"] == 4096][0]
+    assert res[0].tolist() == unrle(c4096["ops_rle"])
+    assert len(res[0]) == c4096["align_len"]
