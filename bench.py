@@ -79,10 +79,44 @@ def cpu_baseline(seconds=12.0):
         dt = time.perf_counter() - t0
         if dt > seconds or done >= 64:
             break
-    return {"value": done * n * m / dt, "unit": "cells/s", "cores": 1, "kind": "port",
-            "sample": "%d problems of %dx%d (BASELINE configs[0] shape) through oracle/nw_ref_py.py, "
-                      "%.1f s" % (done, n, m, dt),
-            "c_restatement_cells_per_s": nw_oracle.fill_only_rate(2048, 2048)}
+    out = {"value": done * n * m / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+           "sample": "%d problems of %dx%d (BASELINE configs[0] shape) through oracle/nw_ref_py.py, "
+                     "%.1f s" % (done, n, m, dt),
+           "c_restatement_cells_per_s": nw_oracle.fill_only_rate(2048, 2048),
+           "cpu_model": _cpu_model()}
+    # the same port on every host core this process may use: one plain child interpreter per core
+    # (the reference itself is single-threaded; SURVEY.md 8d asks for both figures)
+    import subprocess
+    cores = len(os.sched_getaffinity(0))
+    per = 4
+    code = ("import sys; sys.path.insert(0, %r); from oracle import nw_ref_py; "
+            "from oracle.synth import synth_pair; s0 = int(sys.argv[1]); "
+            "[nw_ref_py.perform_alignment(*synth_pair(%d, %d, s0 + k)) for k in range(%d)]" % (REPO, n, m, per))
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(5000 + per * k)]) for k in range(cores)]
+    ok = True
+    for pr in procs:
+        try:
+            ok = (pr.wait(timeout=max(1.0, 120.0 - (time.perf_counter() - t0))) == 0) and ok
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            ok = False
+    dt = time.perf_counter() - t0
+    out["all_cores"] = ({"value": cores * per * n * m / dt, "unit": "cells/s", "cores": cores,
+                         "sample": "%d processes x %d problems of %dx%d, %.1f s incl. interpreter start"
+                                   % (cores, per, n, m, dt)} if ok else {"error": "a worker failed or timed out"})
+    return out
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def ocr_cpu_baseline(model_seed, no, seconds=8.0):
