@@ -87,7 +87,7 @@ def cpu_baseline(seconds=12.0):
     # the same port on every host core this process may use: one plain child interpreter per core
     # (the reference itself is single-threaded; SURVEY.md 8d asks for both figures)
     import subprocess
-    cores = len(os.sched_getaffinity(0))
+    cores = _usable_cores()
     per = 4
     code = ("import sys; sys.path.insert(0, %r); from oracle import nw_ref_py; "
             "from oracle.synth import synth_pair; s0 = int(sys.argv[1]); "
@@ -106,6 +106,20 @@ def cpu_baseline(seconds=12.0):
                          "sample": "%d processes x %d problems of %dx%d, %.1f s incl. interpreter start"
                                    % (cores, per, n, m, dt)} if ok else {"error": "a worker failed or timed out"})
     return out
+
+
+def _usable_cores(cap=16):
+    """host cores this job may actually burn: the cgroup CPU quota if there is one, never more
+    than the affinity mask, and at most `cap` (a one-GPU box's share of its host)"""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(cores, cap))
 
 
 def _cpu_model():
