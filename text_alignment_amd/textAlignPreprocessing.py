@@ -141,14 +141,23 @@ def components(onebit):
 
 
 def rotation_angle_projections(onebit, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
-    """angle in [lo, hi] degrees whose rotation makes the row projection sharpest (largest
-    variance), found on a decimated copy: coarse sweep, then a fine sweep around the best"""
-    step = max(1, int(max(onebit.shape) / 1200))
-    small = onebit[::step, ::step].astype(np.float32)
+    """angle in [lo, hi] degrees whose rotation (as `rotate` below applies it) makes the row
+    projection sharpest (largest variance): coarse sweep, then a fine sweep around the best.
+    The projection of the rotated page is formed directly from the ink coordinates -- pixel (y, x)
+    lands on row cy + (y - cy) cos a - (x - cx) sin a -- instead of rotating the image once per
+    candidate angle (60 rotations of a page cost seconds; this costs milliseconds)."""
+    ys, xs = np.nonzero(onebit)
+    if ys.size == 0:
+        return 0.0
+    h, w = onebit.shape
+    cy, cx = (h - 1) / 2.0, (w - 1) / 2.0
+    dy, dx = ys - cy, xs - cx
 
     def score(ang):
-        rot = ndimage.rotate(small, ang, reshape=False, order=1, mode='constant', cval=0.0)
-        return float(np.var(rot.sum(axis=1)))
+        a = np.deg2rad(ang)
+        rows = np.rint(cy + dy * np.cos(a) - dx * np.sin(a)).astype(np.int64)
+        rows = rows[(rows >= 0) & (rows < h)]
+        return float(np.var(np.bincount(rows, minlength=h)))
     grid = np.arange(lo, hi + 1e-9, coarse)
     best = grid[int(np.argmax([score(a) for a in grid]))]
     grid = np.arange(best - coarse, best + coarse + 1e-9, fine)
