@@ -106,3 +106,48 @@ def test_process_from_raw_image():
     assert len(peaks) in (4, 5) and js["median_line_spacing"] > 100
     for b in js["syl_boxes"]:
         assert 0 <= b["ul"][0] <= b["lr"][0] <= image.dim.ncols
+
+
+def test_find_lines_in_worker_processes_matches_inline():
+    """page.map_host: per-page preprocessing + line finding in spawned workers (what process_batch
+    does with `parallel` > 1) returns what the in-process call returns."""
+    from text_alignment_amd import page as page_mod
+    from text_alignment_amd import textAlignPreprocessing as pp
+    pages = [_synthetic_page(4, seed=k)[0] for k in range(3)]
+    inline = [pp.find_lines(pg) for pg in pages]
+    try:
+        pooled = page_mod.map_host(pp.find_lines, pages, workers=2)
+    finally:
+        page_mod.close_pool()
+    for (b0, e0, a0, s0, p0), (b1, e1, a1, s1, p1) in zip(inline, pooled):
+        assert a0 == a1 and list(p0) == list(p1) and len(s0) == len(s1)
+        assert np.array_equal(b0.ink, b1.ink) and np.array_equal(e0.ink, e1.ink)
+        for x, y in zip(s0, s1):
+            assert (x.offset_x, x.offset_y, x.height) == (y.offset_x, y.offset_y, y.height)
+            assert np.array_equal(x.pixels, y.pixels)
+
+
+@pytest.mark.gpu
+def test_process_batch_from_raw_images_with_workers():
+    """process_batch on raw page arrays, host stages in two worker processes: per page the same
+    boxes as process() on that page alone."""
+    from text_alignment_amd import alignToOCR as atocr, ocr, page as page_mod
+    from text_alignment_amd.page import Image
+
+    class Raw(object):
+        def __init__(self, px):
+            self.pixels = px
+            self.dim = Image(px.shape[1], px.shape[0]).dim
+    model = ocr.LineModel.random(5, no=30)
+    model.W2[0, 0] += 4.0
+    rec = ocr.LineRecognizer(model)
+    params = [8, -1, -9, -9, -4, -4]
+    pages = [Raw(_synthetic_page(4, seed=k)[0]) for k in range(3)]
+    trs = ["dominus dixit ad me filius meus es tu", "ego hodie genui te alleluia", "quare fremuerunt gentes"]
+    try:
+        batch = atocr.process_batch(pages, trs, rec, params, parallel=2)
+    finally:
+        page_mod.close_pool()
+    for pg, tr, got in zip(pages, trs, batch):
+        alone = atocr.process(pg, tr, rec, seq_align_params=params, verbose=False)
+        assert atocr.to_JSON_dict(got[0], got[2]) == atocr.to_JSON_dict(alone[0], alone[2])

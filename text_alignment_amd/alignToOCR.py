@@ -279,12 +279,10 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     seq_align_params).  Returns a list of (syl_boxes, image, lines_peak_locs, all_chars)."""
     from . import ocr
     rec = _recognizer_for(ocropus_model)
-    prep = [(preproc.preprocess_images(pg), ) for pg in pages]
-    strips_per_page, peaks = [], []
-    for (image, eroded, angle), in prep:
-        cc_strips, lines_peak_locs, _ = preproc.identify_text_lines(image, eroded)
-        strips_per_page.append(cc_strips)
-        peaks.append(lines_peak_locs)
+    found = page_mod.map_host(preproc.find_lines, list(pages), workers=parallel)
+    prep = [((image, eroded, angle), ) for (image, eroded, angle, _, _) in found]
+    strips_per_page = [f[3] for f in found]
+    peaks = [f[4] for f in found]
     prepared = page_mod.prepared_lines([st for strips in strips_per_page for st in strips], workers=parallel)
     lines = [xs for xs, _ in prepared]
     widths = [w for _, w in prepared]

@@ -110,6 +110,24 @@ def close_pool():
         _pool, _pool_size = None, 0
 
 
+def map_host(fn, items, workers=1, min_batch=2):
+    """[fn(x) for x in items] for a picklable module-level fn of pure host work; raw page arrays
+    go to the worker pool when there are enough of them, PreparedPages (nothing to compute) and
+    small jobs stay in-process."""
+    heavy = [k for k, it in enumerate(items) if not isinstance(it, PreparedPage)]
+    if workers > 1 and len(heavy) >= min_batch:
+        out = [None] * len(items)
+        # workers get the bare pixel array (callers' page objects need not be picklable)
+        done = _normaliser_pool(int(workers)).map(fn, [getattr(items[k], "pixels", items[k]) for k in heavy])
+        for k, r in zip(heavy, done):
+            out[k] = r
+        for k, it in enumerate(items):
+            if out[k] is None:
+                out[k] = fn(it)
+        return out
+    return [fn(it) for it in items]
+
+
 def prepared_lines(strips, workers=1, min_batch=4):
     """[(xs, raw_width)] for a list of strips.  Strips that carry `.prepared` pass through; raw
     strips are normalised on the host, in `workers` processes when there are enough of them."""

@@ -222,6 +222,15 @@ def preprocess_images(input_image, despeckle_amt=despeckle_amt, filter_runs=1, f
     return BinImage(ink), BinImage(eroded), angle
 
 
+def find_lines(input_image):
+    """preprocess_images + identify_text_lines of one page in one call (a unit of host work the
+    batched page driver can hand to a worker process): (image_bin, image_eroded, angle, line
+    strips, peak locations)."""
+    image_bin, image_eroded, angle = preprocess_images(input_image)
+    strips, peaks, _ = identify_text_lines(image_bin, image_eroded)
+    return image_bin, image_eroded, angle, strips, peaks
+
+
 def identify_text_lines(image_bin, image_eroded):
     '''text lines of a preprocessed page (reference :198-285): peaks of the smoothed row
     projection; a white line at the projection minimum between neighbouring peaks; connected
