@@ -52,6 +52,19 @@ def test_argument_errors_without_gpu(native):
         native.check(rc, "ta_nw_batch")
     assert lib.ta_nw_batch(None, None, None, None, -1, None, 0, None, None, None, None, None,
                            0, 0, 0, 3, None) == native.TA_EINVAL
+    # every other entry point refuses null pointers the same way, before touching the device
+    calls = [
+        lambda: lib.ta_nw2_batch(None, None, None, None, 1, None, 0, None, None, None, None, None, 10, 10, 100, 3, None),
+        lambda: lib.ta_nw_general(None, 3, None, 3, None, None, 0, None, None, None, None, None),
+        lambda: lib.ta_lstm_forward(None, None, None, None, 1, None, None, None, 0, None),
+        lambda: lib.ta_lstm_output(None, 16, None, 96, None, None, None, None),
+        lambda: lib.ta_decode_summary(None, None, None, 1, 0.7, None, None, None, None, None),
+        lambda: lib.ta_decode(None, None, None, 1, 96, 0.7, None, None, None, None, None),
+    ]
+    for call in calls:
+        assert call() == native.TA_EINVAL
+        assert b"null" in lib.ta_last_error()
+    assert lib.ta_lstm_packed_weight_floats(0) == 2 * 7 * 4 * 38 * 64
 
 
 def test_scoring_parse_and_errors():
