@@ -63,10 +63,9 @@ template <int R, int W, bool WIDE>
 __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
     using L = PtrLayout<R>;
     constexpr int SPG = L::SPG;
-    // groups between two looks at the LDS progress word of the strip above.  The wide launch is
-    // for latency (one problem, every strip on a SIMD of its own): a finer grain lets a strip
-    // follow the one above at 21 groups instead of 33
-    constexpr int CHK = WIDE ? 4 : kCheck;
+    // groups between two looks at the LDS progress word of the strip above: a strip follows the one
+    // above at CHK + 17 groups (the wide launch exports to HBM every kCheck groups regardless)
+    constexpr int CHK = 4;
     constexpr int DW = R / 4;                     // dwords of pointer bytes per step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 

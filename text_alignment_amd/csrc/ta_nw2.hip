@@ -76,6 +76,13 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
     constexpr int R = 4;
     using L = PtrLayout<R>;
     constexpr int SPG = L::SPG;
+#ifndef TA_P1_CHK
+#define TA_P1_CHK 4
+#endif
+    // groups between two looks at the progress word of the strip above: a strip follows the one
+    // above at CHK + 17 groups, and the ramp of a workgroup (wave w idles w x that lag at the start,
+    // the waves above idle as long at the end) is what a finer grain buys back
+    constexpr int CHK = TA_P1_CHK;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int p = blockIdx.x;
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
 
         auto wait_span = [&](int g_first) {
             if (W == 1 || s == 0) return;
-            const int k_last = min((g_first + kCheck + 1) * SPG - 1, L::nsteps(m) - 1);
+            const int k_last = min((g_first + CHK + 1) * SPG - 1, L::nsteps(m) - 1);
             const int col = min(k_last + 1, m);
             const int need_groups = min(ngroups, (col + 62) / SPG + 1);
             const int need = prod_pass * ngroups + need_groups;
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
         };
         auto publish = [&](int g) {
             if (W == 1) return;
-            if ((g % kCheck) == kCheck - 1 || g == ngroups - 1) {
+            if ((g % CHK) == 0 || g == ngroups - 1) {     // published values are 1 mod CHK, like the needs
                 if (lane == 63)
                     __hip_atomic_store(&prog[wave], pass * ngroups + g + 1, __ATOMIC_RELEASE,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
         };
         auto prefetch = [&](int g) {
             if (g + 1 < ngroups) {
-                if (((g + 1) % kCheck) == 0) wait_span(g + 1);
+                if (((g + 1) % CHK) == 0) wait_span(g + 1);
                 load_group(g + 1);
             }
         };
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
             for (int q = 0; q < SPG; ++q) { ocA[q] = oc_next[q]; hdA[q] = hd_next[q]; }
             auto fetch = [&](int gn, int (&oc)[SPG], int2 (&hd)[SPG]) {       // inputs of group gn
                 if (gn < ngroups) {
-                    if ((gn % kCheck) == 0) wait_span(gn);
+                    if ((gn % CHK) == 0) wait_span(gn);
                     const int idx = kOPad + gn * SPG - lane;
 #pragma unroll
                     for (int q = 0; q < SPG; ++q) {
