@@ -166,6 +166,36 @@ int ta_decode(const float* probs, const int64_t* row_off, const int32_t* T,
               int32_t* dec_t, int32_t* dec_c, int32_t* dec_n, const int64_t* dec_off,
               void* stream);
 
+/*
+ * Line normaliser: what `ocropus-rpred` does to each PNG strip of alignToOCR.py:131-147 before the
+ * network sees it -- ocropy 1.3.3 CenterNormalizer.measure / dewarp / normalize and prepare_line
+ * (third-party arithmetic).  All pointers [dev].
+ *
+ * Strips are uint8 greyscale images (white background), concatenated: strip b = pix + pix_off[b],
+ * hh[b] rows of ww[b] pixels.  gw holds the gaussian kernels; gw_off[b][3] are the offsets of the
+ * CENTRE taps and gr[b][3] the radii of the three kernels of strip b (sigma 0.5 h along rows,
+ * 1.0 h along columns, 0.3 h for the centre line; scipy's truncate = 4 kernels, computed by the
+ * caller so that they are bit-identical to the host's).  ws: 3 * hh * ww doubles per strip at
+ * ws_off[b]; arg / center: ww[b] ints per strip at col_off[b]; minmax: 2 ints per strip.
+ *
+ * ta_linenorm_measure writes center (the smoothed, truncated centre line), r_out (half-height of
+ * the band cut around it) and wout (normalised width int(48 / (2 r) * w)) -- the caller reads wout
+ * back to size the outputs.  ta_linenorm_resample writes the recogniser's input rows: strip b owns
+ * rows row_off[b] .. row_off[b] + wout[b] + 32 of x [rows][48] (16 zero rows of padding each
+ * side); tmp: 48 * wout[b] floats per strip at tmp_off[b]; omax: one word per strip.
+ */
+int ta_linenorm_measure(const uint8_t* pix, const int64_t* pix_off, const int32_t* hh,
+                        const int32_t* ww, int32_t nlines, const double* gw,
+                        const int64_t* gw_off, const int32_t* gr, double* ws,
+                        const int64_t* ws_off, int32_t* arg, int32_t* center,
+                        const int64_t* col_off, int32_t* minmax, int32_t* r_out,
+                        int32_t* wout, void* stream);
+int ta_linenorm_resample(const uint8_t* pix, const int64_t* pix_off, const int32_t* hh,
+                         const int32_t* ww, int32_t nlines, const int32_t* center,
+                         const int64_t* col_off, const int32_t* minmax, const int32_t* r,
+                         const int32_t* wout, float* tmp, const int64_t* tmp_off,
+                         uint32_t* omax, float* x, const int64_t* row_off, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,81 @@
+"""Device line normaliser (csrc/ta_lineest.hip) against the host restatement
+(text_alignment_amd/lineest.py: scipy.ndimage in float64; ocropy itself
+is absent, so both are parity-unpinned restatements -- this test pins them to each other):
+identical centre line and band height, resampled input rows equal to float32 rounding."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _strip(rng, h, w, wobble=0.0):
+    """word-like ink blobs around a (possibly curved) baseline, grey-level antialiasing"""
+    yy = np.arange(h)[:, None]
+    base = h / 2.0 + wobble * np.sin(np.arange(w) / 97.0)[None, :]
+    dens = 0.6 * np.exp(-0.5 * ((yy - base) / (h / 7.0)) ** 2)
+    ink = rng.random((h, w)) < dens
+    gaps = np.zeros(w, bool)
+    x = int(rng.integers(5, 40))
+    while x < w:
+        g = int(rng.integers(8, 30))
+        gaps[x:x + g] = True
+        x += g + int(rng.integers(40, 120))
+    ink[:, gaps] = False
+    grey = np.where(ink, rng.integers(0, 90, size=(h, w)), rng.integers(235, 256, size=(h, w)))
+    return grey.astype(np.uint8)
+
+
+def test_device_normaliser_matches_host():
+    assert torch.cuda.is_available()
+    from text_alignment_amd import lineest, lineest_gpu
+    rng = np.random.default_rng(5)
+    shapes = [(44, 1216), (61, 900), (70, 1500), (33, 300), (96, 700), (20, 120), (52, 2000), (45, 64)]
+    strips = [_strip(rng, h, w, wobble=(3.0 if k % 2 else 0.0)) for k, (h, w) in enumerate(shapes)]
+    strips.append(np.where(strips[0] < 128, 0, 255).astype(np.uint8))        # bilevel, as the page cutter saves them
+    x, T, dbg = lineest_gpu.normalize_strips(strips, want_debug=True)
+    x = x.cpu().numpy()
+    row = 0
+    for k, s in enumerate(strips):
+        norm = lineest.CenterNormalizer()
+        want = lineest.prepare_raw_strip(s, norm)
+        assert np.array_equal(dbg["center"][k], norm.center), k
+        assert int(dbg["r"][k]) == norm.r, k
+        assert T[k] == want.shape[0], (k, T[k], want.shape)
+        got = x[row:row + T[k]]
+        row += int(T[k])
+        assert got.shape == want.shape
+        assert float(np.abs(got - want.astype(np.float32)).max()) <= 2e-6, k
+    assert row == x.shape[0]
+
+
+def test_device_normaliser_rejects_what_the_host_rejects():
+    from text_alignment_amd import lineest_gpu
+    with pytest.raises(ValueError):
+        lineest_gpu.normalize_strips([np.full((30, 100), 255, np.uint8)])
+    with pytest.raises(TypeError):
+        lineest_gpu.normalize_strips([np.zeros((30, 100), np.float32)])
+    x, T, _ = lineest_gpu.normalize_strips([])
+    assert x.shape == (0, 48) and len(T) == 0
+
+
+def test_recogniser_takes_raw_strips():
+    """LineRecognizer.prepare: raw uint8 strips (device normaliser) mixed with host-prepared lines
+    give the rows the all-host path gives, and the same decoded characters."""
+    from text_alignment_amd import lineest, ocr
+    rng = np.random.default_rng(9)
+    strips = [_strip(rng, h, w) for h, w in [(44, 600), (50, 420), (61, 800), (38, 256), (44, 333)]]
+    host = [lineest.prepare_raw_strip(s).astype(np.float32) for s in strips]
+    model = ocr.LineModel.random(11, no=40)
+    for wts in (model.fwd, model.rev):                         # contractive recurrence: see test_ocr_gpu._tame
+        for name in ("WGI", "WGF", "WGO", "WCI"):
+            wts[name][:, 49:] *= 0.25
+        for name in ("WIP", "WFP", "WOP"):
+            wts[name] *= 0.25
+    rec = ocr.LineRecognizer(model)
+    mixed = [strips[0], host[1], strips[2], strips[3], host[4]]
+    st_m, st_h = rec.prepare(mixed), rec.prepare(host)
+    assert np.array_equal(st_m["T_host"], st_h["T_host"])
+    assert float((st_m["x"] - st_h["x"]).abs().max()) <= 2e-6
+    assert rec.recognise(mixed) == rec.recognise(host)
+    assert list(rec.last_T) == [h.shape[0] for h in host]

@@ -105,10 +105,12 @@ def test_normaliser_pool_matches_inline():
     ready = np.zeros((100, 48), np.float32)
     strips.insert(2, page_mod.Strip(0, 0, 48, width=136, prepared=ready))
     try:
-        pooled = page_mod.prepared_lines(strips, workers=2)
+        pooled = page_mod.prepared_lines(strips, workers=2, device_normaliser=False)
     finally:
         page_mod.close_pool()
-    inline = page_mod.prepared_lines(strips, workers=1)
+    inline = page_mod.prepared_lines(strips, workers=1, device_normaliser=False)
+    handed_on = page_mod.prepared_lines(strips, workers=1)          # default: raw uint8 strips go to the GPU as they are
+    assert handed_on[0][0].dtype == np.uint8 and handed_on[0][1] == strips[0].pixels.shape[1]
     assert len(pooled) == len(inline) == 7
     for (a, wa), (b, wb) in zip(pooled, inline):
         assert wa == wb and a.shape == b.shape and np.array_equal(a, b)

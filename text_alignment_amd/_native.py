@@ -65,6 +65,10 @@ def _load():
     lib.ta_decode_summary.argtypes = [vp, vp, vp, i32, f32, vp, vp, vp, vp, vp]
     lib.ta_decode.restype = ctypes.c_int
     lib.ta_decode.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp]
+    lib.ta_linenorm_measure.restype = ctypes.c_int
+    lib.ta_linenorm_measure.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.ta_linenorm_resample.restype = ctypes.c_int
+    lib.ta_linenorm_resample.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     return lib
 
 
@@ -73,7 +77,7 @@ lib = _load()
 EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_batch",
            "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general",
            "ta_lstm_packed_weight_floats", "ta_lstm_forward", "ta_lstm_output", "ta_decode",
-           "ta_decode_summary"]
+           "ta_decode_summary", "ta_linenorm_measure", "ta_linenorm_resample"]
 
 
 def check(rc, what):

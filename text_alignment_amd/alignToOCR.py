@@ -184,8 +184,8 @@ def perform_ocr_with_ocropus(cc_strips, ocropus_model, wkdir_name=None, parallel
     widths = [w for _, w in prepared]
     decoded = rec.recognise(lines)
     all_chars = []
-    for strip, xs, raw_w, dec in zip(cc_strips, lines, widths, decoded):
-        llocs = rec.llocs(dec, xs.shape[0], raw_w)
+    for k, (strip, raw_w, dec) in enumerate(zip(cc_strips, widths, decoded)):
+        llocs = rec.llocs(dec, int(rec.last_T[k]), raw_w)
         chars_from_llocs(llocs, strip.offset_x, strip.offset_y, strip.offset_y + strip.height, all_chars)
     return all_chars
 
@@ -291,7 +291,7 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     for strips in strips_per_page:
         all_chars = []
         for strip in strips:
-            llocs = rec.llocs(decoded[k], lines[k].shape[0], widths[k])
+            llocs = rec.llocs(decoded[k], int(rec.last_T[k]), widths[k])
             chars_from_llocs(llocs, strip.offset_x, strip.offset_y, strip.offset_y + strip.height, all_chars)
             k += 1
         chars_per_page.append(expand_abbreviations(all_chars))

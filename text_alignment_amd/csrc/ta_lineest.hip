@@ -1,0 +1,342 @@
+// ta_lineest.hip -- text-line height normalisation on the GPU (SURVEY.md section 8f, row N1,
+// "GPU later"): what `ocropus-rpred` does to every PNG strip that reference alignToOCR.py:131-147
+// hands it before the LSTM sees it -- ocropy 1.3.3 CenterNormalizer.measure / dewarp / normalize
+// and prepare_line (third-party arithmetic, parity unpinned).
+//
+// The host restatement (text_alignment_amd/lineest.py, scipy.ndimage in float64) is followed
+// operation by operation, in the same order of floating-point operations as scipy's C loops
+// (correlate1d: centre tap, then tap pairs from the outside in; uniform_filter1d: running sum;
+// integer output of gaussian_filter: truncation; geometric transform: 2 x 2 taps in row-major
+// order), with explicit non-fused multiplies and adds, so that the integer decisions in the
+// middle -- the per-column arg-max of the smoothed image, the truncated centre line, the band
+// half-height r -- come out identical and the resampled line agrees to float32 rounding.
+//
+// Data: one greyscale uint8 strip per line (h x w, white background), concatenated; three float64
+// planes of h x w per line as workspace.  Everything here is bandwidth / latency trivia next to
+// the recogniser: the point is to take 16-50 ms of host CPU per strip off the page pipeline.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ta_common.h"
+
+namespace ta {
+
+constexpr int kLnThreads = 256;
+constexpr int kLnTarget = 48;      // target height
+constexpr int kLnPad = 16;         // prepare_line pad
+
+struct LnArgs {
+    const uint8_t* pix; const int64_t* pix_off;      // [h][w] per line
+    const int32_t* hh; const int32_t* ww;
+    int32_t nlines;
+    const double* gw;                                // gaussian weights, all lines' kernels
+    const int64_t* gw_off;                           // [nlines][3] offset of the CENTRE tap of wy, wx, wc
+    const int32_t* gr;                               // [nlines][3] radii ry, rx, rc
+    double* ws; const int64_t* ws_off;               // 3 planes of h*w doubles per line
+    int32_t* arg; int32_t* center; const int64_t* col_off;   // [w] per line
+    int32_t* minmax;                                 // [nlines][2]
+    int32_t* r_out; int32_t* wout;                   // [nlines]
+    unsigned long long* acc;                         // [nlines][2] mad sum, count
+};
+
+__device__ __forceinline__ double dmul(double a, double b) { return __dmul_rn(a, b); }
+__device__ __forceinline__ double dadd(double a, double b) { return __dadd_rn(a, b); }
+
+// B.0 / prepare_raw_strip: min and max pixel of each strip
+__global__ __launch_bounds__(kLnThreads) void ln_minmax_kernel(LnArgs a) {
+    __shared__ int smin[kLnThreads], smax[kLnThreads];
+    const int line = blockIdx.x, tid = threadIdx.x;
+    const int64_t n = (int64_t)a.hh[line] * a.ww[line];
+    const uint8_t* p = a.pix + a.pix_off[line];
+    int lo = 255, hi = 0;
+    for (int64_t e = tid; e < n; e += kLnThreads) { const int v = p[e]; lo = min(lo, v); hi = max(hi, v); }
+    smin[tid] = lo; smax[tid] = hi;
+    __syncthreads();
+    for (int s = kLnThreads / 2; s > 0; s >>= 1) {
+        if (tid < s) { smin[tid] = min(smin[tid], smin[tid + s]); smax[tid] = max(smax[tid], smax[tid + s]); }
+        __syncthreads();
+    }
+    if (tid == 0) { a.minmax[2 * line] = smin[0]; a.minmax[2 * line + 1] = smax[0]; }
+}
+
+// temp = amax(line) - line; temp = temp / amax(temp), line = pix / 255.0   (plane 0)
+__global__ __launch_bounds__(kLnThreads) void ln_temp_kernel(LnArgs a) {
+    const int line = blockIdx.x;
+    const int64_t n = (int64_t)a.hh[line] * a.ww[line];
+    const uint8_t* p = a.pix + a.pix_off[line];
+    double* A = a.ws + a.ws_off[line];
+    const double amax = (double)a.minmax[2 * line + 1] / 255.0;
+    const double tmax = dadd(amax, -((double)a.minmax[2 * line] / 255.0));
+    for (int64_t e = (int64_t)blockIdx.y * kLnThreads + threadIdx.x; e < n; e += (int64_t)gridDim.y * kLnThreads)
+        A[e] = dadd(amax, -((double)p[e] / 255.0)) / tmax;
+}
+
+// scipy correlate1d with a symmetric kernel, mode 'constant' (zeros): centre tap, then the pairs
+// from the outermost inwards.  AXIS 0: along rows (stride w), AXIS 1: along columns (stride 1).
+template <int AXIS, int SRC, int DST, int WSEL>
+__global__ __launch_bounds__(kLnThreads) void ln_gauss_kernel(LnArgs a) {
+    const int line = blockIdx.x;
+    const int h = a.hh[line], w = a.ww[line];
+    const int64_t n = (int64_t)h * w;
+    const double* S = a.ws + a.ws_off[line] + (int64_t)SRC * n;
+    double* D = a.ws + a.ws_off[line] + (int64_t)DST * n;
+    const double* wc = a.gw + a.gw_off[3 * line + WSEL];
+    const int rad = a.gr[3 * line + WSEL];
+    const int len = AXIS == 0 ? h : w;
+    const int64_t stride = AXIS == 0 ? w : 1;
+    for (int64_t e = (int64_t)blockIdx.y * kLnThreads + threadIdx.x; e < n; e += (int64_t)gridDim.y * kLnThreads) {
+        const int pos = AXIS == 0 ? (int)(e / w) : (int)(e % w);
+        const double* c = S + e;
+        double t = dmul(c[0], wc[0]);
+        const int reach = min(rad, len - 1);               // beyond it both taps of a pair are zeros
+        for (int jj = -reach; jj < 0; ++jj) {
+            const double lo = (pos + jj >= 0) ? c[(int64_t)jj * stride] : 0.0;
+            const double hi = (pos - jj < len) ? c[-(int64_t)jj * stride] : 0.0;
+            t = dadd(t, dmul(dadd(lo, hi), wc[jj]));
+        }
+        D[e] = t;
+    }
+}
+
+// scipy uniform_filter1d, mode 'constant': running sum over the zero-extended line.
+// AXIS 0: one thread per column, size int(0.5 h); AXIS 1: one thread per row, size w.
+template <int AXIS, int SRC, int DST>
+__global__ __launch_bounds__(kLnThreads) void ln_uniform_kernel(LnArgs a) {
+    const int line = blockIdx.x;
+    const int h = a.hh[line], w = a.ww[line];
+    const int64_t n = (int64_t)h * w;
+    const double* S = a.ws + a.ws_off[line] + (int64_t)SRC * n;
+    double* D = a.ws + a.ws_off[line] + (int64_t)DST * n;
+    const int len = AXIS == 0 ? h : w;
+    const int lines = AXIS == 0 ? w : h;
+    const int64_t stride = AXIS == 0 ? w : 1, lstride = AXIS == 0 ? 1 : w;
+    const int size = AXIS == 0 ? (int)(h * 0.5) : w;
+    for (int q = blockIdx.y * kLnThreads + threadIdx.x; q < lines; q += gridDim.y * kLnThreads) {
+        const double* s = S + (int64_t)q * lstride;
+        double* d = D + (int64_t)q * lstride;
+        if (size <= 1) {                                    // scipy skips axes of size <= 1
+            for (int k = 0; k < len; ++k) d[(int64_t)k * stride] = s[(int64_t)k * stride];
+            continue;
+        }
+        const int size1 = size / 2;
+        auto ext = [&](int k) -> double {                   // extended line: size1 zeros in front
+            const int src = k - size1;
+            return (src >= 0 && src < len) ? s[(int64_t)src * stride] : 0.0;
+        };
+        double tmp = 0.0;
+        for (int ll = 0; ll < size; ++ll) tmp = dadd(tmp, ext(ll));
+        d[0] = tmp / (double)size;
+        for (int ll = 1; ll < len; ++ll) {
+            tmp = dadd(tmp, dadd(ext(ll + size - 1), -ext(ll - 1)));
+            d[(int64_t)ll * stride] = tmp / (double)size;
+        }
+    }
+}
+
+// smoothed = G2 + 0.001 * U; a = argmax over rows (first maximum), per column
+template <int G2, int U>
+__global__ __launch_bounds__(kLnThreads) void ln_argmax_kernel(LnArgs a) {
+    const int line = blockIdx.x;
+    const int h = a.hh[line], w = a.ww[line];
+    const int64_t n = (int64_t)h * w;
+    const double* G = a.ws + a.ws_off[line] + (int64_t)G2 * n;
+    const double* Uf = a.ws + a.ws_off[line] + (int64_t)U * n;
+    int32_t* arg = a.arg + a.col_off[line];
+    for (int j = blockIdx.y * kLnThreads + threadIdx.x; j < w; j += gridDim.y * kLnThreads) {
+        double best = dadd(G[j], dmul(0.001, Uf[j]));
+        int bi = 0;
+        for (int i = 1; i < h; ++i) {
+            const double v = dadd(G[(int64_t)i * w + j], dmul(0.001, Uf[(int64_t)i * w + j]));
+            if (v > best) { best = v; bi = i; }
+        }
+        arg[j] = bi;
+    }
+}
+
+// center = int32(gaussian_filter(a, 0.3 h)): integer input, default mode 'reflect', the float64
+// result is truncated towards zero on the way into the integer output array
+__global__ __launch_bounds__(kLnThreads) void ln_center_kernel(LnArgs a) {
+    const int line = blockIdx.x;
+    const int w = a.ww[line];
+    const int32_t* arg = a.arg + a.col_off[line];
+    int32_t* cen = a.center + a.col_off[line];
+    const double* wc = a.gw + a.gw_off[3 * line + 2];
+    const int rad = a.gr[3 * line + 2];
+    auto at = [&](int k) -> double {                        // reflect: (d c b a | a b c d | d c b a)
+        while (k < 0 || k >= w) k = (k < 0) ? (-k - 1) : (2 * w - k - 1);
+        return (double)arg[k];
+    };
+    for (int j = blockIdx.y * kLnThreads + threadIdx.x; j < w; j += gridDim.y * kLnThreads) {
+        double t = dmul((double)arg[j], wc[0]);
+        for (int jj = -rad; jj < 0; ++jj) t = dadd(t, dmul(dadd(at(j + jj), at(j - jj)), wc[jj]));
+        cen[j] = (int32_t)(long long)t;
+    }
+}
+
+// mad = mean |row - center[col]| over ink pixels (temp != 0 <=> pixel below the strip's maximum)
+__global__ __launch_bounds__(kLnThreads) void ln_mad_kernel(LnArgs a) {
+    __shared__ unsigned long long ssum[kLnThreads], scnt[kLnThreads];
+    const int line = blockIdx.x, tid = threadIdx.x;
+    const int h = a.hh[line], w = a.ww[line];
+    const int64_t n = (int64_t)h * w;
+    const uint8_t* p = a.pix + a.pix_off[line];
+    const int32_t* cen = a.center + a.col_off[line];
+    const int pmax = a.minmax[2 * line + 1];
+    unsigned long long sum = 0, cnt = 0;
+    for (int64_t e = tid; e < n; e += kLnThreads) {
+        if (p[e] != pmax) {
+            const int i = (int)(e / w), j = (int)(e % w);
+            sum += (unsigned long long)abs(i - cen[j]);
+            ++cnt;
+        }
+    }
+    ssum[tid] = sum; scnt[tid] = cnt;
+    __syncthreads();
+    for (int s = kLnThreads / 2; s > 0; s >>= 1) {
+        if (tid < s) { ssum[tid] += ssum[tid + s]; scnt[tid] += scnt[tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double mad = (double)ssum[0] / (double)scnt[0];
+        const int r = (int)dadd(1.0, dmul(4.0, mad));
+        a.r_out[line] = r;
+        const double scale = dmul((double)kLnTarget, 1.0) / (double)(2 * r);
+        a.wout[line] = (int)dmul(scale, (double)w);
+    }
+}
+
+struct LnOutArgs {
+    const uint8_t* pix; const int64_t* pix_off;
+    const int32_t* hh; const int32_t* ww;
+    int32_t nlines;
+    const int32_t* center; const int64_t* col_off;
+    const int32_t* minmax; const int32_t* r; const int32_t* wout;
+    float* tmp; const int64_t* tmp_off;              // [48][W'] per line
+    unsigned int* omax;                              // [nlines] bits of the (positive) maximum
+    float* x; const int64_t* row_off;                // LSTM input rows, [W' + 32][48] per line
+};
+
+// dewarp (2r rows around the centre line, white outside) + affine_transform(eye/scale, order 1,
+// mode 'constant', cval = white) to height 48
+__global__ __launch_bounds__(kLnThreads) void ln_resample_kernel(LnOutArgs a) {
+    __shared__ float smax[kLnThreads];
+    const int line = blockIdx.x, tid = threadIdx.x;
+    const int h = a.hh[line], w = a.ww[line], r = a.r[line], wo = a.wout[line];
+    const uint8_t* p = a.pix + a.pix_off[line];
+    const int32_t* cen = a.center + a.col_off[line];
+    float* out = a.tmp + a.tmp_off[line];
+    const float cval = (float)((double)a.minmax[2 * line + 1] / 255.0);
+    const int dh = 2 * r;
+    const double scale = dmul((double)kLnTarget, 1.0) / (double)dh;
+    const double mdiag = 1.0 / scale;
+    auto dewarped = [&](int y, int xx) -> double {          // float32 array in the reference
+        const int row = cen[xx] + y - r;
+        const float v = (row >= 0 && row < h) ? (float)((double)p[(int64_t)row * w + xx] / 255.0) : cval;
+        return (double)v;
+    };
+    float vmax = 0.0f;
+    const int64_t nout = (int64_t)kLnTarget * wo;
+    for (int64_t e = (int64_t)blockIdx.y * kLnThreads + tid; e < nout; e += (int64_t)gridDim.y * kLnThreads) {
+        const int i = (int)(e / wo), j = (int)(e % wo);
+        const double cy = dadd(dadd(0.0, dmul((double)i, mdiag)), dmul((double)j, 0.0));
+        const double cx = dadd(dadd(0.0, dmul((double)i, 0.0)), dmul((double)j, mdiag));
+        float v;
+        if (cy < 0.0 || cy > (double)(dh - 1) || cx < 0.0 || cx > (double)(w - 1)) {
+            v = cval;
+        } else {
+            const int y0 = (int)floor(cy), x0 = (int)floor(cx);
+            const double ty = dadd(cy, -(double)y0), tx = dadd(cx, -(double)x0);
+            const double wy[2] = {dadd(1.0, -ty), ty}, wx[2] = {dadd(1.0, -tx), tx};
+            double t = 0.0;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int yy = min(y0 + dy, dh - 1), xq = min(x0 + dx, w - 1);
+                    t = dadd(t, dmul(dmul(dewarped(yy, xq), wy[dy]), wx[dx]));
+                }
+            v = (float)t;
+        }
+        out[e] = v;
+        vmax = fmaxf(vmax, v);
+    }
+    smax[tid] = vmax;
+    __syncthreads();
+    for (int s = kLnThreads / 2; s > 0; s >>= 1) {
+        if (tid < s) smax[tid] = fmaxf(smax[tid], smax[tid + s]);
+        __syncthreads();
+    }
+    if (tid == 0) atomicMax(a.omax + line, __float_as_uint(smax[0]));   // values are >= 0
+}
+
+// prepare_line: line / amax(line); amax(line) - line; transpose; 16 zero rows before and after
+__global__ __launch_bounds__(kLnThreads) void ln_finish_kernel(LnOutArgs a) {
+    const int line = blockIdx.x;
+    const int wo = a.wout[line];
+    const float* in = a.tmp + a.tmp_off[line];
+    float* x = a.x + a.row_off[line] * kLnTarget;
+    const float amax = __uint_as_float(a.omax[line]);
+    const float top = __fdiv_rn(amax, amax);                 // amax of the divided line
+    const int64_t rows = wo + 2 * kLnPad;
+    for (int64_t e = (int64_t)blockIdx.y * kLnThreads + threadIdx.x; e < rows * kLnTarget;
+         e += (int64_t)gridDim.y * kLnThreads) {
+        const int t = (int)(e / kLnTarget), i = (int)(e % kLnTarget);
+        float v = 0.0f;
+        if (t >= kLnPad && t < kLnPad + wo) v = __fsub_rn(top, __fdiv_rn(in[(int64_t)i * wo + (t - kLnPad)], amax));
+        x[e] = v;
+    }
+}
+
+}  // namespace ta
+
+using namespace ta;
+
+extern "C" int ta_linenorm_measure(const uint8_t* pix, const int64_t* pix_off, const int32_t* hh,
+                                   const int32_t* ww, int32_t nlines, const double* gw,
+                                   const int64_t* gw_off, const int32_t* gr, double* ws,
+                                   const int64_t* ws_off, int32_t* arg, int32_t* center,
+                                   const int64_t* col_off, int32_t* minmax, int32_t* r_out,
+                                   int32_t* wout, void* stream) {
+    if (nlines < 0) return ta_fail(TA_EINVAL, "negative line count");
+    if (nlines == 0) return TA_OK;
+    if (!pix || !pix_off || !hh || !ww || !gw || !gw_off || !gr || !ws || !ws_off || !arg || !center ||
+        !col_off || !minmax || !r_out || !wout)
+        return ta_fail(TA_EINVAL, "null pointer argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    LnArgs a{pix, pix_off, hh, ww, nlines, gw, gw_off, gr, ws, ws_off, arg, center, col_off, minmax,
+             r_out, wout, nullptr};
+    const dim3 one(nlines), wide(nlines, 32), cols(nlines, 8);
+    hipLaunchKernelGGL(ln_minmax_kernel, one, dim3(kLnThreads), 0, st, a);
+    hipLaunchKernelGGL(ln_temp_kernel, wide, dim3(kLnThreads), 0, st, a);
+    hipLaunchKernelGGL((ln_gauss_kernel<0, 0, 1, 0>), wide, dim3(kLnThreads), 0, st, a);      // plane 0 -> 1
+    hipLaunchKernelGGL((ln_gauss_kernel<1, 1, 2, 1>), wide, dim3(kLnThreads), 0, st, a);      // plane 1 -> 2
+    hipLaunchKernelGGL((ln_uniform_kernel<0, 2, 0>), cols, dim3(kLnThreads), 0, st, a);       // plane 2 -> 0
+    hipLaunchKernelGGL((ln_uniform_kernel<1, 0, 1>), one, dim3(kLnThreads), 0, st, a);        // plane 0 -> 1
+    hipLaunchKernelGGL((ln_argmax_kernel<2, 1>), cols, dim3(kLnThreads), 0, st, a);
+    hipLaunchKernelGGL(ln_center_kernel, cols, dim3(kLnThreads), 0, st, a);
+    hipLaunchKernelGGL(ln_mad_kernel, one, dim3(kLnThreads), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ta_fail_hip(e, "line normaliser (measure) launch");
+    return TA_OK;
+}
+
+extern "C" int ta_linenorm_resample(const uint8_t* pix, const int64_t* pix_off, const int32_t* hh,
+                                    const int32_t* ww, int32_t nlines, const int32_t* center,
+                                    const int64_t* col_off, const int32_t* minmax, const int32_t* r,
+                                    const int32_t* wout, float* tmp, const int64_t* tmp_off,
+                                    uint32_t* omax, float* x, const int64_t* row_off, void* stream) {
+    if (nlines < 0) return ta_fail(TA_EINVAL, "negative line count");
+    if (nlines == 0) return TA_OK;
+    if (!pix || !pix_off || !hh || !ww || !center || !col_off || !minmax || !r || !wout || !tmp ||
+        !tmp_off || !omax || !x || !row_off)
+        return ta_fail(TA_EINVAL, "null pointer argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    LnOutArgs a{pix, pix_off, hh, ww, nlines, center, col_off, minmax, r, wout, tmp, tmp_off, omax, x, row_off};
+    hipError_t e = hipMemsetAsync(omax, 0, sizeof(uint32_t) * (size_t)nlines, st);
+    if (e != hipSuccess) return ta_fail_hip(e, "line normaliser memset");
+    hipLaunchKernelGGL(ln_resample_kernel, dim3(nlines, 16), dim3(kLnThreads), 0, st, a);
+    hipLaunchKernelGGL(ln_finish_kernel, dim3(nlines, 16), dim3(kLnThreads), 0, st, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return ta_fail_hip(e, "line normaliser (resample) launch");
+    return TA_OK;
+}

@@ -1,0 +1,99 @@
+"""Device side of the line normaliser (csrc/ta_lineest.hip): raw greyscale strips in, the
+recogniser's input rows out, without a host round trip.  Same arithmetic as `lineest.py` (the
+scipy restatement of ocropy 1.3.3's CenterNormalizer + prepare_line, SURVEY.md Appendix B.0-B.2;
+parity unpinned), which the GPU tests use as the checker.  uint8 greyscale strips only: colour or
+float images take the host path (`lineest.prepare_raw_strip`).
+"""
+import numpy as np
+import torch
+
+from . import _native
+from .lineest import PAD, TARGET_HEIGHT
+
+_kernels = {}
+
+
+def _gauss_weights(sigma):
+    """scipy.ndimage's 1-D gaussian kernel (truncate = 4.0), bit for bit"""
+    radius = int(4.0 * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return phi / phi.sum(), radius
+
+
+def _line_kernels(h):
+    if h not in _kernels:
+        _kernels[h] = [_gauss_weights(s) for s in (h * 0.5, h * 1.0, h * 0.3)]      # rows, columns, centre line
+    return _kernels[h]
+
+
+def normalize_strips(strips, device="cuda", want_debug=False):
+    """strips: list of 2-D uint8 arrays (white background).  Returns (x, T, debug): x = float32
+    device tensor [sum T, 48] (line b owns rows sum(T[:b]) .. + T[b]), T = int64 array of
+    timesteps (normalised width + 32)."""
+    dev = torch.device(device)
+    lib = _native.lib
+    n = len(strips)
+    if n == 0:
+        return torch.zeros((0, TARGET_HEIGHT), dtype=torch.float32, device=dev), np.zeros(0, np.int64), {}
+    hh = np.zeros(n, np.int32); ww = np.zeros(n, np.int32)
+    for k, s in enumerate(strips):
+        s = np.asarray(s)
+        if s.ndim != 2 or s.dtype != np.uint8:
+            raise TypeError("the device normaliser takes 2-D uint8 strips")
+        if s.size == 0 or s.max() == s.min():
+            raise ValueError("empty or constant text-line image")
+        hh[k], ww[k] = s.shape
+    pix_off = np.zeros(n + 1, np.int64); np.cumsum(hh.astype(np.int64) * ww, out=pix_off[1:])
+    col_off = np.zeros(n + 1, np.int64); np.cumsum(ww, out=col_off[1:])
+    pix = np.concatenate([np.ascontiguousarray(s).ravel() for s in strips])
+    # gaussian kernels: one set per distinct strip height, offsets point at the centre taps
+    gw_parts, gw_off, gr, where, pos = [], np.zeros((n, 3), np.int64), np.zeros((n, 3), np.int32), {}, 0
+    for k in range(n):
+        h = int(hh[k])
+        if h not in where:
+            offs = []
+            for wts, rad in _line_kernels(h):
+                gw_parts.append(wts); offs.append((pos + rad, rad)); pos += len(wts)
+            where[h] = offs
+        for q, (o, rad) in enumerate(where[h]):
+            gw_off[k, q], gr[k, q] = o, rad
+    gw = np.concatenate(gw_parts)
+
+    def up(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_pix, d_pix_off, d_hh, d_ww = up(pix), up(pix_off[:-1].copy()), up(hh), up(ww)
+    d_gw, d_gw_off, d_gr, d_col_off = up(gw), up(gw_off), up(gr), up(col_off[:-1].copy())
+    d_ws_off = up(3 * pix_off[:-1])
+    ws = torch.empty(3 * int(pix_off[-1]), dtype=torch.float64, device=dev)
+    arg = torch.empty(int(col_off[-1]), dtype=torch.int32, device=dev)
+    center = torch.empty_like(arg)
+    minmax = torch.empty(2 * n, dtype=torch.int32, device=dev)
+    r = torch.empty(n, dtype=torch.int32, device=dev)
+    wout = torch.empty(n, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _native.check(lib.ta_linenorm_measure(
+        d_pix.data_ptr(), d_pix_off.data_ptr(), d_hh.data_ptr(), d_ww.data_ptr(), n,
+        d_gw.data_ptr(), d_gw_off.data_ptr(), d_gr.data_ptr(), ws.data_ptr(), d_ws_off.data_ptr(),
+        arg.data_ptr(), center.data_ptr(), d_col_off.data_ptr(), minmax.data_ptr(),
+        r.data_ptr(), wout.data_ptr(), stream), "ta_linenorm_measure")
+    wo = wout.cpu().numpy().astype(np.int64)              # output sizes are data-dependent: one small sync
+    del ws
+    T = wo + 2 * PAD
+    row_off = np.zeros(n + 1, np.int64); np.cumsum(T, out=row_off[1:])
+    tmp_off = np.zeros(n + 1, np.int64); np.cumsum(wo * TARGET_HEIGHT, out=tmp_off[1:])
+    tmp = torch.empty(max(int(tmp_off[-1]), 1), dtype=torch.float32, device=dev)
+    omax = torch.empty(n, dtype=torch.int32, device=dev)
+    x = torch.empty((int(row_off[-1]), TARGET_HEIGHT), dtype=torch.float32, device=dev)
+    d_tmp_off, d_row_off = up(tmp_off[:-1].copy()), up(row_off[:-1].copy())     # named: they must outlive the launch
+    _native.check(lib.ta_linenorm_resample(
+        d_pix.data_ptr(), d_pix_off.data_ptr(), d_hh.data_ptr(), d_ww.data_ptr(), n,
+        center.data_ptr(), d_col_off.data_ptr(), minmax.data_ptr(), r.data_ptr(), wout.data_ptr(),
+        tmp.data_ptr(), d_tmp_off.data_ptr(), omax.data_ptr(), x.data_ptr(),
+        d_row_off.data_ptr(), stream), "ta_linenorm_resample")
+    debug = {}
+    if want_debug:
+        c = center.cpu().numpy()
+        debug = {"center": [c[col_off[k]:col_off[k + 1]] for k in range(n)], "r": r.cpu().numpy(),
+                 "arg": [arg.cpu().numpy()[col_off[k]:col_off[k + 1]] for k in range(n)]}
+    return x, T, debug

@@ -145,13 +145,24 @@ class LineRecognizer(object):
 
     # ---- batched device pass -------------------------------------------------------------
     def prepare(self, lines):
-        """Upload prepared lines ((T, 48) arrays, ink = 1) and allocate outputs."""
-        T = np.array([ln.shape[0] for ln in lines], dtype=np.int64)
-        if len(lines) and T.max() > MAX_T:
-            raise RecognitionError("input too large for LSTM model")
-        for ln in lines:
+        """Upload lines and allocate outputs.  A line is either a prepared (T, 48) float array
+        (ink = 1, padded) or a raw 2-D uint8 strip (white background), which is normalised on the
+        device (lineest_gpu, csrc/ta_lineest.hip) without a host round trip."""
+        raw = [k for k, ln in enumerate(lines) if getattr(ln, "dtype", None) == np.uint8]
+        T = np.zeros(len(lines), dtype=np.int64)
+        x_raw, T_raw = None, None
+        if raw:
+            from . import lineest_gpu
+            x_raw, T_raw, _ = lineest_gpu.normalize_strips([lines[k] for k in raw], device=self.device)
+            T[raw] = T_raw
+        for k, ln in enumerate(lines):
+            if getattr(ln, "dtype", None) == np.uint8:
+                continue
             if ln.ndim != 2 or ln.shape[1] != NI:
                 raise ValueError("a prepared line must have shape (T, 48)")
+            T[k] = ln.shape[0]
+        if len(lines) and T.max() > MAX_T:
+            raise RecognitionError("input too large for LSTM model")
         order = np.argsort(-T, kind="stable")
         ngroups = (len(lines) + 15) // 16
         group_lines = np.full((max(ngroups, 1), 16), -1, dtype=np.int32)
@@ -159,10 +170,27 @@ class LineRecognizer(object):
         row_off = np.zeros(len(lines) + 1, dtype=np.int64)
         np.cumsum(T, out=row_off[1:])
         rows = int(row_off[-1])
-        x = np.concatenate(lines, axis=0).astype(np.float32) if rows else np.zeros((1, NI), np.float32)
+        raw_set = set(raw)
+        host = [k for k in range(len(lines)) if k not in raw_set]
+        if not raw:
+            x = np.concatenate(lines, axis=0).astype(np.float32) if rows else np.zeros((1, NI), np.float32)
+            x_dev = torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+        elif not host:
+            x_dev = x_raw
+        else:                                   # mixed batch: stitch the two sources together in line order
+            x_dev = torch.empty((rows, NI), dtype=torch.float32, device=self.device)
+            xh = torch.from_numpy(np.ascontiguousarray(
+                np.concatenate([lines[k] for k in host], axis=0).astype(np.float32))).to(self.device)
+            ph = pr = 0
+            for k in range(len(lines)):
+                t = int(T[k])
+                if k in raw_set:
+                    x_dev[row_off[k]:row_off[k] + t] = x_raw[pr:pr + t]; pr += t
+                else:
+                    x_dev[row_off[k]:row_off[k] + t] = xh[ph:ph + t]; ph += t
         st = {"n": len(lines), "rows": rows, "T_host": T, "row_off_host": row_off, "ngroups": ngroups}
         dev = self.device
-        st["x"] = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        st["x"] = x_dev
         st["row_off"] = torch.from_numpy(row_off[:-1].copy() if len(lines) else row_off).to(dev)
         st["T"] = torch.from_numpy(T.astype(np.int32) if len(lines) else np.zeros(1, np.int32)).to(dev)
         st["group_lines"] = torch.from_numpy(group_lines).to(dev)
@@ -226,6 +254,7 @@ class LineRecognizer(object):
 
     def recognise(self, lines, want_probs=False, from_probs=False):
         st = self.prepare(lines)
+        self.last_T = st["T_host"]              # timesteps per line (raw strips: known only now)
         self.run(st, want_logits=want_probs, from_probs=from_probs)
         dec = self.decoded(st)
         if not want_probs:

@@ -128,14 +128,22 @@ def map_host(fn, items, workers=1, min_batch=2):
     return [fn(it) for it in items]
 
 
-def prepared_lines(strips, workers=1, min_batch=4):
-    """[(xs, raw_width)] for a list of strips.  Strips that carry `.prepared` pass through; raw
-    strips are normalised on the host, in `workers` processes when there are enough of them."""
+def prepared_lines(strips, workers=1, min_batch=4, device_normaliser=True):
+    """[(line, raw_width)] for a list of strips, `line` being what LineRecognizer.prepare takes.
+    Strips that carry `.prepared` pass through.  Raw uint8 greyscale strips are handed on as they
+    are when `device_normaliser` is set (the recogniser normalises them on the GPU); anything else
+    (colour, float) is normalised on the host, in `workers` processes when there are enough."""
     out = [None] * len(strips)
     raw = []
     for k, strip in enumerate(strips):
         if getattr(strip, "prepared", None) is not None:
             out[k] = prepared_line(strip)
+            continue
+        px = np.asarray(strip.pixels)
+        if device_normaliser and px.dtype == np.uint8 and px.ndim == 2:
+            if px.size == 0 or px.max() == px.min():
+                raise ValueError("empty or constant text-line image")
+            out[k] = (px, int(px.shape[1]))
         else:
             raw.append(k)
     if workers > 1 and len(raw) >= min_batch:
