@@ -16,12 +16,20 @@ VOCAB = ("dominus deus meus alleluia gloria patri et filio spiritui sancto sicut
 PARAMS = [8, -1, -9, -9, -4, -4]     # cheap mismatches: a random-weight model's text still pairs up
 
 
-def make_page(seed, nlines=30):
+def make_page(seed, nlines=30, raw=False):
+    """raw = False: strips carry already-normalised (T, 48) rows (SURVEY 8d's OCR input);
+    raw = True: strips are 60-row uint8 images as the page cutter saves them (device normaliser)."""
     from text_alignment_amd import page as page_mod
     rng = np.random.default_rng(seed)
     strips = []
     for k in range(nlines):
         w = int(rng.integers(800, 2001))
+        if raw:
+            yy = np.arange(60)[:, None]
+            dens = 0.6 * np.exp(-0.5 * ((yy - 30.0) / 8.0) ** 2)
+            px = np.where(rng.random((60, w)) < dens, 0, 255).astype(np.uint8)
+            strips.append(page_mod.Strip(40, 100 + 120 * k, 60, width=w, pixels=px))
+            continue
         xs = np.zeros((w + 32, 48), dtype=np.float32)
         xs[16:16 + w] = (rng.random((w, 48)) < 0.15) * rng.random((w, 48))
         strips.append(page_mod.Strip(40, 100 + 120 * k, 60, width=2 * w, prepared=xs))
@@ -55,8 +63,18 @@ def run(npages, seed0=100):
         atocr.process_batch([pages[k]], [trs[k]], rec, PARAMS)
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t1)
+    # the same from raw strips: line normaliser on the device in front of the recogniser
+    rpages, rtrs = zip(*[make_page(seed0 + 5000 + k, raw=True) for k in range(npages)])
+    atocr.process_batch(list(rpages[:2]), list(rtrs[:2]), rec, PARAMS)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    atocr.process_batch(list(rpages), list(rtrs), rec, PARAMS)
+    torch.cuda.synchronize()
+    raw_dt = time.perf_counter() - t2
     return {"pages": npages, "seconds": dt, "pages_per_s": npages / dt, "lines_per_s": npages * 30 / dt,
             "single_page_ms": 1e3 * sorted(lat)[1],
+            "raw_strips": {"pages_per_s": npages / raw_dt, "seconds": raw_dt,
+                           "note": "strips as 60-row uint8 images, normalised by csrc/ta_lineest.hip"},
             "syllable_boxes": sum(len(r[0]) for r in res),
             "note": "process_batch end to end: host upload + K3/K4/K5 + NW + host glue (Python)"}
 
