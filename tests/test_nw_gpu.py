@@ -316,3 +316,20 @@ def test_bench_default_shape_properties(tsc):
     c4096 = [c for c in g["cases"] if c["n"] == 4096][0]
     assert res[0].tolist() == unrle(c4096["ops_rle"])
     assert len(res[0]) == c4096["align_len"]
+
+
+def test_wide_launch_oversubscribed(tsc):
+    """255 problems of 4096 x 4096 take the wide one-pass launch (fewer problems than CUs) with
+    more workgroups (255 x 4 chunks, 41 KB of LDS each) than the GPU holds at once: later chunks
+    wait on earlier ones that must already be resident or done (in-order dispatch)."""
+    from oracle import nw_oracle
+    from oracle.synth import synth_pair_ids
+    distinct = 5
+    uniq = [synth_pair_ids(4096, 4096, 4321 + k) for k in range(distinct)]
+    probs = [uniq[k % distinct] for k in range(255)]
+    batch = tsc.NWBatch([p[0] for p in probs], [p[1] for p in probs], SYSTEMS[0], two_phase=False)
+    batch.run()
+    res = batch.results()
+    want = [nw_oracle.align_ids(t, o, SYSTEMS[0]) for t, o in uniq]
+    for k, ops in enumerate(res):
+        assert np.array_equal(ops, want[k % distinct]), k
