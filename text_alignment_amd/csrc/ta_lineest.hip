@@ -98,6 +98,52 @@ __global__ __launch_bounds__(kLnThreads) void ln_gauss_kernel(LnArgs a) {
     }
 }
 
+// The same correlation along a row (the expensive one: up to 8 h + 1 taps), four adjacent outputs
+// per thread: the two tap windows x[j + jj .. j + jj + 3] and x[j - jj .. j - jj + 3] slide by one
+// element per tap pair, so each pair costs two new loads for four outputs.  Every output still sums
+// its own products in scipy's order.
+template <int SRC, int DST, int WSEL>
+__global__ __launch_bounds__(kLnThreads) void ln_gauss_row_kernel(LnArgs a) {
+    constexpr int NO = 4;
+    const int line = blockIdx.x;
+    const int h = a.hh[line], w = a.ww[line];
+    const int64_t n = (int64_t)h * w;
+    const double* S = a.ws + a.ws_off[line] + (int64_t)SRC * n;
+    double* D = a.ws + a.ws_off[line] + (int64_t)DST * n;
+    const double* wc = a.gw + a.gw_off[3 * line + WSEL];
+    const int rad = a.gr[3 * line + WSEL];
+    const int reach = min(rad, w - 1);
+    const int per_row = (w + NO - 1) / NO;
+    const int64_t ngroups = (int64_t)h * per_row;
+    for (int64_t gidx = (int64_t)blockIdx.y * kLnThreads + threadIdx.x; gidx < ngroups;
+         gidx += (int64_t)gridDim.y * kLnThreads) {
+        const int i = (int)(gidx / per_row), j0 = (int)(gidx % per_row) * NO;
+        const double* row = S + (int64_t)i * w;
+        auto X = [&](int k) -> double { return (k >= 0 && k < w) ? row[k] : 0.0; };
+        double t[NO], lo[NO], hi[NO];
+#pragma unroll
+        for (int q = 0; q < NO; ++q) {
+            t[q] = dmul(X(j0 + q), wc[0]);
+            lo[q] = X(j0 - reach + q);
+            hi[q] = X(j0 + reach + q);
+        }
+        for (int jj = -reach; jj < 0; ++jj) {
+            const double wj = wc[jj];
+#pragma unroll
+            for (int q = 0; q < NO; ++q) t[q] = dadd(t[q], dmul(dadd(lo[q], hi[q]), wj));
+#pragma unroll
+            for (int q = 0; q < NO - 1; ++q) lo[q] = lo[q + 1];
+            lo[NO - 1] = X(j0 + jj + NO);                      // window of tap jj + 1: x[j0 + jj + 1 + q]
+#pragma unroll
+            for (int q = NO - 1; q > 0; --q) hi[q] = hi[q - 1];
+            hi[0] = X(j0 - jj - 1);                            // window of tap jj + 1: x[j0 - jj - 1 + q]
+        }
+#pragma unroll
+        for (int q = 0; q < NO; ++q)
+            if (j0 + q < w) D[(int64_t)i * w + j0 + q] = t[q];
+    }
+}
+
 // scipy uniform_filter1d, mode 'constant': running sum over the zero-extended line.
 // AXIS 0: one thread per column, size int(0.5 h); AXIS 1: one thread per row, size w.
 template <int AXIS, int SRC, int DST>
@@ -309,7 +355,7 @@ extern "C" int ta_linenorm_measure(const uint8_t* pix, const int64_t* pix_off, c
     hipLaunchKernelGGL(ln_minmax_kernel, one, dim3(kLnThreads), 0, st, a);
     hipLaunchKernelGGL(ln_temp_kernel, wide, dim3(kLnThreads), 0, st, a);
     hipLaunchKernelGGL((ln_gauss_kernel<0, 0, 1, 0>), wide, dim3(kLnThreads), 0, st, a);      // plane 0 -> 1
-    hipLaunchKernelGGL((ln_gauss_kernel<1, 1, 2, 1>), wide, dim3(kLnThreads), 0, st, a);      // plane 1 -> 2
+    hipLaunchKernelGGL((ln_gauss_row_kernel<1, 2, 1>), wide, dim3(kLnThreads), 0, st, a);     // plane 1 -> 2
     hipLaunchKernelGGL((ln_uniform_kernel<0, 2, 0>), cols, dim3(kLnThreads), 0, st, a);       // plane 2 -> 0
     hipLaunchKernelGGL((ln_uniform_kernel<1, 0, 1>), one, dim3(kLnThreads), 0, st, a);        // plane 0 -> 1
     hipLaunchKernelGGL((ln_argmax_kernel<2, 1>), cols, dim3(kLnThreads), 0, st, a);
