@@ -333,3 +333,21 @@ def test_wide_launch_oversubscribed(tsc):
     want = [nw_oracle.align_ids(t, o, SYSTEMS[0]) for t, o in uniq]
     for k, ops in enumerate(res):
         assert np.array_equal(ops, want[k % distinct]), k
+
+
+def test_two_phase_with_16_bit_codes(tsc):
+    """Alphabets beyond 254 symbols take the u16 code path of phase 1 (TA_NW_CODES8 unset)."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(77)
+    probs = []
+    for n, m in [(700, 650), (1300, 2100), (300, 5)]:
+        t = rng.integers(0, 3000, size=n).astype(np.int32)
+        o = rng.integers(0, 3000, size=m).astype(np.int32)
+        k = min(n, m)
+        o[:k] = np.where(rng.random(k) < 0.75, t[:k], o[:k])
+        probs.append((t, o))
+    batch = tsc.NWBatch([p[0] for p in probs], [p[1] for p in probs], SYSTEMS[1], two_phase=True)
+    assert not batch.codes8
+    batch.run()
+    for (t, o), got in zip(probs, batch.results()):
+        assert got.tolist() == nw_oracle.align_ids(t, o, SYSTEMS[1]).tolist()
