@@ -36,7 +36,6 @@ struct LnArgs {
     int32_t* arg; int32_t* center; const int64_t* col_off;   // [w] per line
     int32_t* minmax;                                 // [nlines][2]
     int32_t* r_out; int32_t* wout;                   // [nlines]
-    unsigned long long* acc;                         // [nlines][2] mad sum, count
 };
 
 __device__ __forceinline__ double dmul(double a, double b) { return __dmul_rn(a, b); }
@@ -350,7 +349,7 @@ extern "C" int ta_linenorm_measure(const uint8_t* pix, const int64_t* pix_off, c
         return ta_fail(TA_EINVAL, "null pointer argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     LnArgs a{pix, pix_off, hh, ww, nlines, gw, gw_off, gr, ws, ws_off, arg, center, col_off, minmax,
-             r_out, wout, nullptr};
+             r_out, wout};
     const dim3 one(nlines), wide(nlines, 32), cols(nlines, 8);
     hipLaunchKernelGGL(ln_minmax_kernel, one, dim3(kLnThreads), 0, st, a);
     hipLaunchKernelGGL(ln_temp_kernel, wide, dim3(kLnThreads), 0, st, a);
