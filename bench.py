@@ -46,6 +46,19 @@ def measured_traffic(batch, n, m, kernel):
     return None
 
 
+def measured_mfma_busy(kernel):
+    """MFMA pipe utilisation of a recogniser kernel from the counter pass kept under profiles/
+    (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD-cycles, 1920-line workload); None if absent."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_ocr_pmc_mfma.json")) as f:
+            for k, v in json.load(f)["kernels"].items():
+                if kernel in k:
+                    return v["mfma_pipe_utilisation"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def make_nw_batch(tsc, nprob, n, m, seed0, distinct=32, two_phase=False):
     from oracle.synth import synth_pair_ids      # seeded input generator shared with the tests
     uniq = [synth_pair_ids(n, m, seed0 + k) for k in range(min(nprob, distinct))]
@@ -181,6 +194,7 @@ def bench_ocr(args, rank, precision="f32", nlines=None):
             "ms": {"lstm": lstm_ms, "output_softmax": out_ms, "decode": dec_ms},
             "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": tf / F32_MFMA_PEAK_TF, "traffic": None, "kernel": "lstm_seq_kernel",
+                         "mfma_pipe_busy_rocprof": measured_mfma_busy("lstm_seq_kernel") if nlines == 1920 and precision == "f32" else None,
                          "algorithmic_flops_per_timestep": 238400}}
 
 
