@@ -39,37 +39,31 @@ try:
 except ImportError:                 # not running inside Rodan
     RodanTask = None
 
+def _port(name, mime):
+    """one mandatory single-resource Rodan port"""
+    return {'name': name, 'resource_types': [mime], 'minimum': 1, 'maximum': 1, 'is_list': False}
+
+
 if RodanTask is not None:
     class textAlignment(RodanTask):
+        # job metadata as Rodan shows it (names and port layout of reference textAlignment.py:7-49)
         name = 'Text Alignment'
         author = 'Timothy de Reuse'
-        description = 'Given a text layer image and plaintext of some text on that page, finds the ' \
-                      'positions of each syllable of text in the image (MI355X build).'
-        enabled = True
-        category = 'text'
-        interactive = False
+        description = ('Finds the position on the page of every syllable of a known transcript, '
+                       'given the text layer of the page image (MI355X build).')
+        enabled, category, interactive = True, 'text', False
         settings = {
             'title': 'Text Alignment Settings',
             'type': 'object',
             'required': ['MEI Version'],
-            'properties': {
-                'MEI Version': {
-                    'enum': ['4.0.0', '3.9.9'],
-                    'type': 'string',
-                    'default': '3.9.9',
-                    'description': 'Specifies the MEI version, 3.9.9 is the old unofficial MEI standard used by Neon',
-                },
-            },
+            'properties': {'MEI Version': {
+                'type': 'string', 'enum': ['4.0.0', '3.9.9'], 'default': '3.9.9',
+                'description': '3.9.9 is the unofficial MEI flavour Neon reads; 4.0.0 the released standard'}},
         }
-        input_port_types = [
-            {'name': 'Text Layer', 'resource_types': ['image/rgba+png'], 'minimum': 1, 'maximum': 1, 'is_list': False},
-            {'name': 'Transcript', 'resource_types': ['text/plain'], 'minimum': 1, 'maximum': 1, 'is_list': False},
-        ]
-        output_port_types = [
-            {'name': 'JSON', 'resource_types': ['application/JSON'], 'minimum': 1, 'maximum': 1, 'is_list': False},
-        ]
+        input_port_types = [_port('Text Layer', 'image/rgba+png'), _port('Transcript', 'text/plain')]
+        output_port_types = [_port('JSON', 'application/JSON')]
 
         def run_my_task(self, inputs, settings, outputs):
-            return run_alignment(inputs['Text Layer'][0]['resource_path'],
-                                 inputs['Transcript'][0]['resource_path'],
-                                 outputs['JSON'][0]['resource_path'])
+            def path(ports, name):
+                return ports[name][0]['resource_path']
+            return run_alignment(path(inputs, 'Text Layer'), path(inputs, 'Transcript'), path(outputs, 'JSON'))
