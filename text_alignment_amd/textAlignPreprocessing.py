@@ -175,11 +175,21 @@ def rotate(onebit, angle):
 
 
 def _filter_runs(onebit, length, axis):
-    """remove ink runs shorter than `length` along `axis`"""
+    """remove ink runs shorter than `length` along `axis`: a morphological opening with a
+    `length` x 1 line (what scipy.ndimage.binary_opening computes, here with shifted views: a pixel
+    survives iff it lies in a window of `length` consecutive ink pixels)"""
     if length <= 1:
         return onebit
-    structure = np.ones((length, 1), bool) if axis == 0 else np.ones((1, length), bool)
-    return ndimage.binary_opening(onebit, structure=structure)
+    a = np.moveaxis(np.asarray(onebit, dtype=bool), axis, 0)
+    n = a.shape[0]
+    out = np.zeros_like(a)
+    if n >= length:
+        full = a[:n - length + 1].copy()                  # full[i]: a[i .. i+length-1] all ink
+        for k in range(1, length):
+            full &= a[k:n - length + 1 + k]
+        for k in range(length):
+            out[k:n - length + 1 + k] |= full
+    return np.moveaxis(out, 0, axis)
 
 
 def filter_short_runs(onebit, length):      # vertical runs (Gamera: filter_short_runs)
