@@ -196,6 +196,41 @@ int ta_linenorm_resample(const uint8_t* pix, const int64_t* pix_off, const int32
                          const int32_t* wout, float* tmp, const int64_t* tmp_off,
                          uint32_t* omax, float* x, const int64_t* row_off, void* stream);
 
+/*
+ * Page preprocessing primitives: the full-page image passes of textAlignPreprocessing.py:160-285
+ * (Gamera's to_onebit, despeckle, cc_analysis, rotation_angle_projections, rotate,
+ * filter_short_runs / filter_narrow_runs, projection_rows in the reference).  One page at a time;
+ * images are uint8 planes [h][w] (ink = 1).  All pointers [dev].
+ *
+ * ta_pp_label: 8-connected components; lab[p] = linear index of the component's first pixel in
+ *   raster order, -1 on background; stats = int32[5][h*w] = area, x0, y0, x1, y1, indexed by that
+ *   root; flag = one device int.  Synchronises the stream between passes.
+ * ta_pp_components: up to cap records {root, area, x0, y0, x1, y1} (any order), *count = true number.
+ * ta_pp_filter_components: clears components with area < min_area or more than max_height rows.
+ * ta_pp_angle_histograms: hist[a][row] of the page decimated by `step` and rotated by angle a
+ *   (cos_sin = {cos a0, sin a0, ...}): pixel (y, x) lands on row rint(cy + dy cos a - dx sin a).
+ * ta_pp_rotate: (bilinear resample of the 0/1 plane through output -> input map
+ *   in = M out + offset, mo = {m00, m01, m10, m11, off0, off1}, zeros outside) > 0.5.
+ * ta_pp_open_runs: morphological opening with a line of `len` pixels along `axis`.
+ */
+int ta_pp_histogram(const uint8_t* img, int64_t n, uint32_t* hist256, void* stream);
+int ta_pp_threshold(const uint8_t* img, int64_t n, int32_t thr, int32_t invert, uint8_t* ink, void* stream);
+int ta_pp_label(const uint8_t* ink, int32_t h, int32_t w, int32_t* lab, int32_t* stats, int32_t* flag,
+                void* stream);
+int ta_pp_components(const int32_t* lab, const int32_t* stats, int32_t h, int32_t w, int32_t* recs,
+                     int32_t cap, int32_t* count, void* stream);
+int ta_pp_filter_components(uint8_t* ink, const int32_t* lab, const int32_t* stats, int32_t h, int32_t w,
+                            int32_t min_area, int32_t max_height, void* stream);
+int ta_pp_invert(uint8_t* ink, int64_t n, void* stream);
+int ta_pp_angle_histograms(const uint8_t* ink, int32_t h, int32_t w, int32_t step, const double* cos_sin,
+                           int32_t nang, uint32_t* hist, void* stream);
+int ta_pp_rotate(const uint8_t* ink, int32_t h, int32_t w, uint8_t* out, int32_t oh, int32_t ow,
+                 const double* mo, void* stream);
+int ta_pp_open_runs(const uint8_t* in, uint8_t* out, int32_t h, int32_t w, int32_t len, int32_t axis,
+                    void* stream);
+int ta_pp_row_sums(const uint8_t* ink, int32_t h, int32_t w, int32_t* sums, void* stream);
+int ta_pp_clear_rows(uint8_t* ink, int32_t w, const int32_t* rows, int32_t nrows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

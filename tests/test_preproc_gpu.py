@@ -1,0 +1,72 @@
+"""Device page preprocessing (csrc/ta_preproc.hip, preproc_gpu.py) against the host restatement
+(textAlignPreprocessing.py, numpy / scipy.ndimage): same components, same skew angle, same rotated
+and filtered bits, same line strips.  (Gamera is absent: both are parity-unpinned restatements of
+reference textAlignPreprocessing.py:160-285; this pins them to each other.)"""
+import numpy as np
+import pytest
+
+from test_preprocessing import _synthetic_page
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _noisy_page(seed, nlines=6, angle=0.0):
+    img, centres = _synthetic_page(nlines, angle=angle, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    img = img.copy()
+    ys, xs = rng.integers(0, img.shape[0], 400), rng.integers(0, img.shape[1], 400)
+    img[ys, xs] = 0                                         # specks
+    img[200:420, 30:36] = 0                                 # a tall stroke (taller than 150 rows)
+    grey = np.where(img == 0, rng.integers(0, 80, img.shape), rng.integers(180, 256, img.shape)).astype(np.uint8)
+    return grey
+
+
+def test_labels_match_scipy():
+    from scipy import ndimage
+    from text_alignment_amd import preproc_gpu as G
+    rng = np.random.default_rng(1)
+    d = G._Dev()
+    for shape, dens in [((64, 80), 0.5), ((200, 333), 0.3), ((37, 1000), 0.62), ((1, 50), 0.5), ((300, 300), 0.45)]:
+        a = rng.random(shape) < dens
+        if shape == (300, 300):                              # a spiral: many propagation rounds
+            a[:] = False
+            for k in range(0, 140, 4):
+                a[k, k:300 - k] = True; a[k:300 - k, 299 - k] = True
+                a[299 - k, k + 2:300 - k] = True; a[k + 4:300 - k, k + 2] = True
+        ink = torch.from_numpy(a.astype(np.uint8)).cuda()
+        lab, stats = d.label(ink)
+        lab = lab.cpu().numpy()
+        want, n = ndimage.label(a, structure=np.ones((3, 3), bool))
+        assert ((lab >= 0) == a).all()
+        # same partition: our label is the raster-first pixel of the component
+        first = np.full(n + 1, -1, np.int64)
+        flat = want.ravel()
+        idx = np.arange(flat.size)
+        for k in range(flat.size - 1, -1, -1):
+            first[flat[k]] = idx[k]
+        assert np.array_equal(lab.ravel()[flat > 0], first[flat[flat > 0]])
+        recs = d.components(torch.from_numpy(lab).cuda(), stats)
+        assert len(recs) == n
+        area = np.bincount(flat, minlength=n + 1)[1:]
+        assert sorted(recs[:, 1].tolist()) == sorted(area.tolist())
+        objs = ndimage.find_objects(want)
+        boxes = sorted((sl[1].start, sl[0].start, sl[1].stop - 1, sl[0].stop - 1) for sl in objs)
+        assert sorted(map(tuple, recs[:, 2:6].tolist())) == boxes
+
+
+@pytest.mark.parametrize("seed,angle", [(0, 0.0), (3, 2.0), (5, -3.3)])
+def test_preprocess_and_lines_match_host(seed, angle):
+    from text_alignment_amd import preproc_gpu as G
+    from text_alignment_amd import textAlignPreprocessing as H
+    grey = _noisy_page(seed, angle=angle)
+    b0, e0, a0, s0, p0 = H.find_lines(grey)
+    b1, e1, a1, s1, p1 = G.find_lines(grey)
+    assert a0 == a1
+    assert np.array_equal(b0.ink, b1.ink)
+    assert np.array_equal(e0.ink, e1.ink)
+    assert list(p0) == list(p1)
+    assert len(s0) == len(s1) and len(s0) >= 4
+    for x, y in zip(s0, s1):
+        assert (x.offset_x, x.offset_y, x.height, x.width) == (y.offset_x, y.offset_y, y.height, y.width)
+        assert np.array_equal(x.pixels, y.pixels)

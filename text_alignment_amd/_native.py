@@ -69,6 +69,15 @@ def _load():
     lib.ta_linenorm_measure.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.ta_linenorm_resample.restype = ctypes.c_int
     lib.ta_linenorm_resample.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    pp = {"ta_pp_histogram": [vp, i64, vp, vp], "ta_pp_threshold": [vp, i64, i32, i32, vp, vp],
+          "ta_pp_label": [vp, i32, i32, vp, vp, vp, vp], "ta_pp_components": [vp, vp, i32, i32, vp, i32, vp, vp],
+          "ta_pp_filter_components": [vp, vp, vp, i32, i32, i32, i32, vp], "ta_pp_invert": [vp, i64, vp],
+          "ta_pp_angle_histograms": [vp, i32, i32, i32, vp, i32, vp, vp],
+          "ta_pp_rotate": [vp, i32, i32, vp, i32, i32, vp, vp], "ta_pp_open_runs": [vp, vp, i32, i32, i32, i32, vp],
+          "ta_pp_row_sums": [vp, i32, i32, vp, vp], "ta_pp_clear_rows": [vp, i32, vp, i32, vp]}
+    for name, args in pp.items():
+        getattr(lib, name).restype = ctypes.c_int
+        getattr(lib, name).argtypes = args
     return lib
 
 
@@ -77,7 +86,10 @@ lib = _load()
 EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_batch",
            "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general",
            "ta_lstm_packed_weight_floats", "ta_lstm_forward", "ta_lstm_output", "ta_decode",
-           "ta_decode_summary", "ta_linenorm_measure", "ta_linenorm_resample"]
+           "ta_decode_summary", "ta_linenorm_measure", "ta_linenorm_resample",
+           "ta_pp_histogram", "ta_pp_threshold", "ta_pp_label", "ta_pp_components", "ta_pp_filter_components",
+           "ta_pp_invert", "ta_pp_angle_histograms", "ta_pp_rotate", "ta_pp_open_runs", "ta_pp_row_sums",
+           "ta_pp_clear_rows"]
 
 
 def check(rc, what):

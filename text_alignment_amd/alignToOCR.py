@@ -271,6 +271,27 @@ def align_page(transcript, all_chars, angle, image_dim, raw_dim, seq_align_param
     return syl_boxes, all_chars_copy
 
 
+def find_lines_all(pages, workers=1):
+    """preprocessing + text-line finding of every page: (image_bin, image_eroded, angle, strips,
+    peak locations) per page.  Raw uint8 greyscale pages go through the device kernels
+    (preproc_gpu, csrc/ta_preproc.hip); PreparedPages pass through; anything else (colour, float,
+    bool) takes the host restatement, in `workers` processes when there are several."""
+    out = [None] * len(pages)
+    rest = []
+    for k, pg in enumerate(pages):
+        px = getattr(pg, "pixels", pg)
+        if not isinstance(pg, page_mod.PreparedPage) and isinstance(px, np.ndarray) and \
+                px.dtype == np.uint8 and px.ndim == 2:
+            from . import preproc_gpu
+            out[k] = preproc_gpu.find_lines(px)
+        else:
+            rest.append(k)
+    if rest:
+        for k, r in zip(rest, page_mod.map_host(preproc.find_lines, [pages[k] for k in rest], workers=workers)):
+            out[k] = r
+    return out
+
+
 def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indices_out=None,
                   parallel=parallel):
     """`process` for many pages at once: the strips of ALL pages go through the line recogniser
@@ -279,7 +300,7 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     seq_align_params).  Returns a list of (syl_boxes, image, lines_peak_locs, all_chars)."""
     from . import ocr
     rec = _recognizer_for(ocropus_model)
-    found = page_mod.map_host(preproc.find_lines, list(pages), workers=parallel)
+    found = find_lines_all(list(pages), workers=parallel)
     prep = [((image, eroded, angle), ) for (image, eroded, angle, _, _) in found]
     strips_per_page = [f[3] for f in found]
     peaks = [f[4] for f in found]
@@ -324,8 +345,7 @@ def process(raw_image,
     lines and aligns the results to the transcript text (reference alignToOCR.py:187-330).
     Returns (syl_boxes, image, lines_peak_locs, all_chars), or None when OCR fails.
     '''
-    image, eroded, angle = preproc.preprocess_images(raw_image)
-    cc_strips, lines_peak_locs, _ = preproc.identify_text_lines(image, eroded)
+    image, eroded, angle, cc_strips, lines_peak_locs = find_lines_all([raw_image], workers=1)[0]
 
     all_chars = []
     if existing_ocr_pickle:

@@ -1,0 +1,377 @@
+// ta_preproc.hip -- page preprocessing primitives on the GPU: the
+// image operations the reference delegates to the Gamera toolkit in textAlignPreprocessing.py
+// (to_onebit, despeckle, cc_analysis, rotation_angle_projections, rotate, filter_short_runs /
+// filter_narrow_runs, projection_rows; reference :167-195, :212-253), as the host restatement
+// text_alignment_amd/textAlignPreprocessing.py expresses them with numpy / scipy.ndimage.  Gamera is
+// absent, so this is parity-unpinned against the reference; it is pinned to the host restatement
+// (same component sets, same angle, same rotated bits).
+//
+// One page at a time; images are uint8 planes (ink = 1).  All kernels are plain streaming passes
+// (HBM-bound, a few MB per page); connected components use label equivalence: every ink pixel
+// starts as its own label (its linear index), a scan pass lowers the root of a pixel's label to the
+// smallest label among its 8 neighbours, an analysis pass flattens the label trees, until nothing
+// changes.  The final label of a component is the linear index of its first pixel in raster order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ta_common.h"
+
+namespace ta {
+
+constexpr int kPpThreads = 256;
+
+__global__ __launch_bounds__(kPpThreads) void pp_hist_kernel(const uint8_t* img, int64_t n, uint32_t* hist) {
+    __shared__ uint32_t sh[256];
+    sh[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads)
+        atomicAdd(&sh[img[e]], 1u);
+    __syncthreads();
+    if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+}
+
+// ink = (img <= thr), or its complement
+__global__ __launch_bounds__(kPpThreads) void pp_threshold_kernel(const uint8_t* img, int64_t n, int thr,
+                                                                  int invert, uint8_t* ink) {
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
+        const int v = img[e] <= thr;
+        ink[e] = (uint8_t)(invert ? !v : v);
+    }
+}
+
+__global__ __launch_bounds__(kPpThreads) void pp_label_init_kernel(const uint8_t* ink, int64_t n, int32_t* lab) {
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads)
+        lab[e] = ink[e] ? (int32_t)e : -1;
+}
+
+__global__ __launch_bounds__(kPpThreads) void pp_label_scan_kernel(int32_t* lab, int h, int w, int32_t* changed) {
+    const int64_t n = (int64_t)h * w;
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
+        const int32_t mine = lab[e];
+        if (mine < 0) continue;
+        const int y = (int)(e / w), x = (int)(e % w);
+        int32_t m = mine;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = y + dy, xx = x + dx;
+                if ((dy | dx) == 0 || yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+                const int32_t q = lab[(int64_t)yy * w + xx];
+                if (q >= 0 && q < m) m = q;
+            }
+        if (m < mine) {
+            atomicMin(&lab[mine], m);              // lower the root this pixel currently points at
+            *changed = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kPpThreads) void pp_label_flatten_kernel(int32_t* lab, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
+        int32_t r = lab[e];
+        if (r < 0) continue;
+        while (lab[r] != r) r = lab[r];
+        lab[e] = r;
+    }
+}
+
+// per-root statistics: area and bounding box (arrays indexed by the root's linear index)
+__global__ __launch_bounds__(kPpThreads) void pp_stats_kernel(const int32_t* lab, int h, int w, int32_t* area,
+                                                              int32_t* x0, int32_t* y0, int32_t* x1, int32_t* y1) {
+    const int64_t n = (int64_t)h * w;
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
+        const int32_t r = lab[e];
+        if (r < 0) continue;
+        const int y = (int)(e / w), x = (int)(e % w);
+        atomicAdd(&area[r], 1);
+        atomicMin(&x0[r], x); atomicMin(&y0[r], y);
+        atomicMax(&x1[r], x); atomicMax(&y1[r], y);
+    }
+}
+
+// records {root, area, x0, y0, x1, y1} of every component, in no particular order
+__global__ __launch_bounds__(kPpThreads) void pp_collect_kernel(const int32_t* lab, int64_t n, const int32_t* area,
+                                                                const int32_t* x0, const int32_t* y0,
+                                                                const int32_t* x1, const int32_t* y1,
+                                                                int32_t* recs, int32_t cap, int32_t* count) {
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
+        if (lab[e] != (int32_t)e) continue;
+        const int k = atomicAdd(count, 1);
+        if (k < cap) {
+            int32_t* r = recs + (int64_t)k * 6;
+            r[0] = (int32_t)e; r[1] = area[e]; r[2] = x0[e]; r[3] = y0[e]; r[4] = x1[e]; r[5] = y1[e];
+        }
+    }
+}
+
+// ink &= keep(component): area >= min_area and height <= max_height (either bound may be off)
+__global__ __launch_bounds__(kPpThreads) void pp_filter_kernel(uint8_t* ink, const int32_t* lab, int64_t n,
+                                                               const int32_t* area, const int32_t* y0,
+                                                               const int32_t* y1, int min_area, int max_height) {
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
+        const int32_t r = lab[e];
+        if (r < 0) continue;
+        const bool keep = area[r] >= min_area && (y1[r] - y0[r] + 1) <= max_height;
+        if (!keep) ink[e] = 0;
+    }
+}
+
+__global__ __launch_bounds__(kPpThreads) void pp_invert_kernel(uint8_t* ink, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads)
+        ink[e] = !ink[e];
+}
+
+// row histogram of the page rotated by each candidate angle, from the ink coordinates of the
+// decimated page: pixel (y, x) lands on row rint(cy + dy cos a - dx sin a)
+__global__ __launch_bounds__(kPpThreads) void pp_angle_hist_kernel(const uint8_t* ink, int h, int w, int step,
+                                                                   const double* cs, int nang, uint32_t* hist) {
+    const int hs = (h + step - 1) / step, wsm = (w + step - 1) / step;
+    const double cy = (hs - 1) / 2.0, cx = (wsm - 1) / 2.0;
+    const int64_t n = (int64_t)hs * wsm;
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
+        const int ys = (int)(e / wsm), xs = (int)(e % wsm);
+        if (!ink[(int64_t)ys * step * w + (int64_t)xs * step]) continue;
+        const double dy = __dadd_rn((double)ys, -cy), dx = __dadd_rn((double)xs, -cx);
+        for (int a = 0; a < nang; ++a) {
+            const double v = __dadd_rn(__dadd_rn(cy, __dmul_rn(dy, cs[2 * a])), -__dmul_rn(dx, cs[2 * a + 1]));
+            const long long row = (long long)rint(v);
+            if (row >= 0 && row < hs) atomicAdd(&hist[(int64_t)a * hs + row], 1u);
+        }
+    }
+}
+
+// scipy.ndimage.affine_transform(float32(ink), M, offset, order = 1, mode = 'constant', cval = 0) > 0.5
+__global__ __launch_bounds__(kPpThreads) void pp_rotate_kernel(const uint8_t* ink, int h, int w, uint8_t* out,
+                                                               int oh, int ow, const double* mo) {
+    const double m00 = mo[0], m01 = mo[1], m10 = mo[2], m11 = mo[3], off0 = mo[4], off1 = mo[5];
+    const int64_t n = (int64_t)oh * ow;
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
+        const int i = (int)(e / ow), j = (int)(e % ow);
+        const double cy = __dadd_rn(__dadd_rn(off0, __dmul_rn((double)i, m00)), __dmul_rn((double)j, m01));
+        const double cx = __dadd_rn(__dadd_rn(off1, __dmul_rn((double)i, m10)), __dmul_rn((double)j, m11));
+        uint8_t bit = 0;
+        if (!(cy < 0.0 || cy > (double)(h - 1) || cx < 0.0 || cx > (double)(w - 1))) {
+            const int y0 = (int)floor(cy), x0 = (int)floor(cx);
+            const double ty = __dadd_rn(cy, -(double)y0), tx = __dadd_rn(cx, -(double)x0);
+            const double wy[2] = {__dadd_rn(1.0, -ty), ty}, wx[2] = {__dadd_rn(1.0, -tx), tx};
+            double t = 0.0;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int yy = min(y0 + dy, h - 1), xx = min(x0 + dx, w - 1);
+                    const double v = ink[(int64_t)yy * w + xx] ? 1.0 : 0.0;
+                    t = __dadd_rn(t, __dmul_rn(__dmul_rn(v, wy[dy]), wx[dx]));
+                }
+            bit = (float)t > 0.5f;
+        }
+        out[e] = bit;
+    }
+}
+
+// opening with a line of `len` pixels along the axis: a pixel survives iff some window of `len`
+// consecutive pixels containing it is all ink
+__global__ __launch_bounds__(kPpThreads) void pp_open_runs_kernel(const uint8_t* in, uint8_t* out, int h, int w,
+                                                                  int len, int axis) {
+    const int64_t n = (int64_t)h * w;
+    const int L = axis == 0 ? h : w;
+    const int64_t stride = axis == 0 ? w : 1;
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
+        uint8_t keep = 0;
+        if (in[e]) {
+            const int pos = axis == 0 ? (int)(e / w) : (int)(e % w);
+            int before = 0, after = 0;                      // ink run lengths on either side, capped at len - 1
+            while (before < len - 1 && pos - before - 1 >= 0 && in[e - (int64_t)(before + 1) * stride]) ++before;
+            while (after < len - 1 && pos + after + 1 < L && in[e + (int64_t)(after + 1) * stride]) ++after;
+            keep = (before + after + 1) >= len;
+        }
+        out[e] = keep;
+    }
+}
+
+__global__ __launch_bounds__(kPpThreads) void pp_row_sums_kernel(const uint8_t* ink, int h, int w, int32_t* sums) {
+    __shared__ int sh[kPpThreads];
+    const int y = blockIdx.x;
+    int acc = 0;
+    for (int x = threadIdx.x; x < w; x += kPpThreads) acc += ink[(int64_t)y * w + x];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = kPpThreads / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[y] = sh[0];
+}
+
+__global__ __launch_bounds__(kPpThreads) void pp_clear_rows_kernel(uint8_t* ink, int w, const int32_t* rows, int nrows) {
+    const int r = rows[blockIdx.x];
+    for (int x = threadIdx.x; x < w; x += kPpThreads) ink[(int64_t)r * w + x] = 0;
+}
+
+__global__ __launch_bounds__(kPpThreads) void pp_fill_kernel(int32_t* a, int64_t n, int32_t v) {
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) a[e] = v;
+}
+
+static int pp_blocks(int64_t n) {
+    const int64_t b = (n + kPpThreads - 1) / kPpThreads;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace ta
+
+using namespace ta;
+
+#define PP_LAUNCH_CHECK(what) do { hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) return ta_fail_hip(e_, what); } while (0)
+
+extern "C" int ta_pp_histogram(const uint8_t* img, int64_t n, uint32_t* hist256, void* stream) {
+    if (n < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (!img || !hist256) return ta_fail(TA_EINVAL, "null pointer argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(hist256, 0, 256 * sizeof(uint32_t), st);
+    if (e != hipSuccess) return ta_fail_hip(e, "histogram memset");
+    if (n) hipLaunchKernelGGL(pp_hist_kernel, dim3(pp_blocks(n) > 1024 ? 1024 : pp_blocks(n)), dim3(kPpThreads), 0, st, img, n, hist256);
+    PP_LAUNCH_CHECK("pp_hist_kernel");
+    return TA_OK;
+}
+
+extern "C" int ta_pp_threshold(const uint8_t* img, int64_t n, int32_t thr, int32_t invert, uint8_t* ink, void* stream) {
+    if (n < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (!img || !ink) return ta_fail(TA_EINVAL, "null pointer argument");
+    if (n) hipLaunchKernelGGL(pp_threshold_kernel, dim3(pp_blocks(n)), dim3(kPpThreads), 0,
+                              reinterpret_cast<hipStream_t>(stream), img, n, thr, invert, ink);
+    PP_LAUNCH_CHECK("pp_threshold_kernel");
+    return TA_OK;
+}
+
+// 8-connected components of `ink` (h x w): lab[p] = linear index of the component's first pixel,
+// -1 on background.  stats: five int32 arrays of h*w entries (area, x0, y0, x1, y1; indexed by the
+// root).  flag: one device int.  Synchronises the stream between passes (the iteration count is
+// data-dependent).
+extern "C" int ta_pp_label(const uint8_t* ink, int32_t h, int32_t w, int32_t* lab, int32_t* stats,
+                           int32_t* flag, void* stream) {
+    if (h < 0 || w < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (!ink || !lab || !stats || !flag) return ta_fail(TA_EINVAL, "null pointer argument");
+    const int64_t n = (int64_t)h * w;
+    if (n == 0) return TA_OK;
+    if (n >= (1ll << 31)) return ta_fail(TA_ELIMIT, "page too large for 32-bit labels");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nb = pp_blocks(n);
+    hipLaunchKernelGGL(pp_label_init_kernel, dim3(nb), dim3(kPpThreads), 0, st, ink, n, lab);
+    for (int it = 0; it < 100000; ++it) {
+        hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), st);
+        if (e != hipSuccess) return ta_fail_hip(e, "label flag memset");
+        hipLaunchKernelGGL(pp_label_scan_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, h, w, flag);
+        hipLaunchKernelGGL(pp_label_flatten_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, n);
+        int32_t changed = 0;
+        e = hipMemcpyAsync(&changed, flag, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return ta_fail_hip(e, "label iteration");
+        if (!changed) break;
+    }
+    int32_t* area = stats; int32_t* x0 = stats + n; int32_t* y0 = stats + 2 * n;
+    int32_t* x1 = stats + 3 * n; int32_t* y1 = stats + 4 * n;
+    hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, area, n, 0);
+    hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, x0, 2 * n, 0x7fffffff);
+    hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, x1, 2 * n, -1);
+    hipLaunchKernelGGL(pp_stats_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, h, w, area, x0, y0, x1, y1);
+    PP_LAUNCH_CHECK("pp_label kernels");
+    return TA_OK;
+}
+
+// component table: up to `cap` records {root, area, x0, y0, x1, y1}; *count receives the true number
+extern "C" int ta_pp_components(const int32_t* lab, const int32_t* stats, int32_t h, int32_t w,
+                                int32_t* recs, int32_t cap, int32_t* count, void* stream) {
+    if (h < 0 || w < 0 || cap < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (!lab || !stats || !recs || !count) return ta_fail(TA_EINVAL, "null pointer argument");
+    const int64_t n = (int64_t)h * w;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return ta_fail_hip(e, "component count memset");
+    if (n) hipLaunchKernelGGL(pp_collect_kernel, dim3(pp_blocks(n)), dim3(kPpThreads), 0, st, lab, n, stats,
+                              stats + n, stats + 2 * n, stats + 3 * n, stats + 4 * n, recs, cap, count);
+    PP_LAUNCH_CHECK("pp_collect_kernel");
+    return TA_OK;
+}
+
+// drop components with fewer than min_area pixels or taller than max_height rows
+extern "C" int ta_pp_filter_components(uint8_t* ink, const int32_t* lab, const int32_t* stats, int32_t h,
+                                       int32_t w, int32_t min_area, int32_t max_height, void* stream) {
+    if (h < 0 || w < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (!ink || !lab || !stats) return ta_fail(TA_EINVAL, "null pointer argument");
+    const int64_t n = (int64_t)h * w;
+    if (n) hipLaunchKernelGGL(pp_filter_kernel, dim3(pp_blocks(n)), dim3(kPpThreads), 0,
+                              reinterpret_cast<hipStream_t>(stream), ink, lab, n, stats, stats + 2 * n,
+                              stats + 4 * n, min_area, max_height);
+    PP_LAUNCH_CHECK("pp_filter_kernel");
+    return TA_OK;
+}
+
+extern "C" int ta_pp_invert(uint8_t* ink, int64_t n, void* stream) {
+    if (n < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (!ink) return ta_fail(TA_EINVAL, "null pointer argument");
+    if (n) hipLaunchKernelGGL(pp_invert_kernel, dim3(pp_blocks(n)), dim3(kPpThreads), 0,
+                              reinterpret_cast<hipStream_t>(stream), ink, n);
+    PP_LAUNCH_CHECK("pp_invert_kernel");
+    return TA_OK;
+}
+
+// hist[a][row], a < nang, row < ceil(h / step): row projection of the decimated page rotated by
+// angle a; cos_sin = {cos a0, sin a0, cos a1, ...}
+extern "C" int ta_pp_angle_histograms(const uint8_t* ink, int32_t h, int32_t w, int32_t step,
+                                      const double* cos_sin, int32_t nang, uint32_t* hist, void* stream) {
+    if (h < 0 || w < 0 || step < 1 || nang < 0) return ta_fail(TA_EINVAL, "bad size");
+    if (!ink || !cos_sin || !hist) return ta_fail(TA_EINVAL, "null pointer argument");
+    const int hs = (h + step - 1) / step, wsm = (w + step - 1) / step;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(hist, 0, sizeof(uint32_t) * (size_t)nang * hs, st);
+    if (e != hipSuccess) return ta_fail_hip(e, "angle histogram memset");
+    const int64_t n = (int64_t)hs * wsm;
+    if (n && nang) hipLaunchKernelGGL(pp_angle_hist_kernel, dim3(pp_blocks(n)), dim3(kPpThreads), 0, st, ink, h, w,
+                                      step, cos_sin, nang, hist);
+    PP_LAUNCH_CHECK("pp_angle_hist_kernel");
+    return TA_OK;
+}
+
+// mo = {m00, m01, m10, m11, offset0, offset1} of scipy.ndimage.rotate's affine map (output -> input)
+extern "C" int ta_pp_rotate(const uint8_t* ink, int32_t h, int32_t w, uint8_t* out, int32_t oh, int32_t ow,
+                            const double* mo, void* stream) {
+    if (h < 0 || w < 0 || oh < 0 || ow < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (!ink || !out || !mo) return ta_fail(TA_EINVAL, "null pointer argument");
+    const int64_t n = (int64_t)oh * ow;
+    if (n) hipLaunchKernelGGL(pp_rotate_kernel, dim3(pp_blocks(n)), dim3(kPpThreads), 0,
+                              reinterpret_cast<hipStream_t>(stream), ink, h, w, out, oh, ow, mo);
+    PP_LAUNCH_CHECK("pp_rotate_kernel");
+    return TA_OK;
+}
+
+extern "C" int ta_pp_open_runs(const uint8_t* in, uint8_t* out, int32_t h, int32_t w, int32_t len,
+                               int32_t axis, void* stream) {
+    if (h < 0 || w < 0 || len < 1 || (axis != 0 && axis != 1)) return ta_fail(TA_EINVAL, "bad argument");
+    if (!in || !out) return ta_fail(TA_EINVAL, "null pointer argument");
+    const int64_t n = (int64_t)h * w;
+    if (n) hipLaunchKernelGGL(pp_open_runs_kernel, dim3(pp_blocks(n)), dim3(kPpThreads), 0,
+                              reinterpret_cast<hipStream_t>(stream), in, out, h, w, len, axis);
+    PP_LAUNCH_CHECK("pp_open_runs_kernel");
+    return TA_OK;
+}
+
+extern "C" int ta_pp_row_sums(const uint8_t* ink, int32_t h, int32_t w, int32_t* sums, void* stream) {
+    if (h < 0 || w < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (!ink || !sums) return ta_fail(TA_EINVAL, "null pointer argument");
+    if (h) hipLaunchKernelGGL(pp_row_sums_kernel, dim3(h), dim3(kPpThreads), 0,
+                              reinterpret_cast<hipStream_t>(stream), ink, h, w, sums);
+    PP_LAUNCH_CHECK("pp_row_sums_kernel");
+    return TA_OK;
+}
+
+extern "C" int ta_pp_clear_rows(uint8_t* ink, int32_t w, const int32_t* rows, int32_t nrows, void* stream) {
+    if (w < 0 || nrows < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (nrows == 0) return TA_OK;
+    if (!ink || !rows) return ta_fail(TA_EINVAL, "null pointer argument");
+    hipLaunchKernelGGL(pp_clear_rows_kernel, dim3(nrows), dim3(kPpThreads), 0,
+                       reinterpret_cast<hipStream_t>(stream), ink, w, rows, nrows);
+    PP_LAUNCH_CHECK("pp_clear_rows_kernel");
+    return TA_OK;
+}
