@@ -76,17 +76,44 @@ __global__ __launch_bounds__(kPpThreads) void pp_label_flatten_kernel(int32_t* l
     }
 }
 
-// per-root statistics: area and bounding box (arrays indexed by the root's linear index)
+// per-root statistics: area and bounding box (arrays indexed by the root's linear index).  The 64
+// pixels of a wave are neighbours in a row and mostly share a root (the page background is one
+// component of millions of pixels), so each wave first combines its lanes per distinct root and
+// only the first lane of each root goes to memory.
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
 __global__ __launch_bounds__(kPpThreads) void pp_stats_kernel(const int32_t* lab, int h, int w, int32_t* area,
                                                               int32_t* x0, int32_t* y0, int32_t* x1, int32_t* y1) {
     const int64_t n = (int64_t)h * w;
-    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
-        const int32_t r = lab[e];
-        if (r < 0) continue;
-        const int y = (int)(e / w), x = (int)(e % w);
-        atomicAdd(&area[r], 1);
-        atomicMin(&x0[r], x); atomicMin(&y0[r], y);
-        atomicMax(&x1[r], x); atomicMax(&y1[r], y);
+    const int64_t span = (int64_t)gridDim.x * kPpThreads;
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = (int64_t)blockIdx.x * kPpThreads; base < n; base += span) {     // uniform trip count per wave
+        const int64_t e = base + threadIdx.x;
+        int32_t r = (e < n) ? lab[e] : -1;
+        const int y = (e < n) ? (int)(e / w) : 0, x = (e < n) ? (int)(e % w) : 0;
+        unsigned long long todo = __ballot(r >= 0);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const int32_t root = __shfl(r, leader, 64);
+            const bool same = (r == root);
+            const unsigned long long grp = __ballot(same);
+            const int mnx = wave_min(same ? x : 0x7fffffff), mny = wave_min(same ? y : 0x7fffffff);
+            const int mxx = wave_max(same ? x : -1), mxy = wave_max(same ? y : -1);
+            if (lane == leader) {
+                atomicAdd(&area[root], (int)__popcll(grp));
+                atomicMin(&x0[root], mnx); atomicMin(&y0[root], mny);
+                atomicMax(&x1[root], mxx); atomicMax(&y1[root], mxy);
+            }
+            todo &= ~grp;
+        }
     }
 }
 

@@ -15,6 +15,22 @@ from . import page as page_mod
 from . import textAlignPreprocessing as host
 
 
+class DeviceBinImage(page_mod.Image):
+    """A binarised page that lives on the device: `dim` / `ncols` / `nrows` as `process` and its
+    callers read them; `.ink` (bool array, True = ink) is downloaded on first use."""
+
+    def __init__(self, plane):
+        page_mod.Image.__init__(self, int(plane.shape[1]), int(plane.shape[0]))
+        self.plane = plane
+        self._ink = None
+
+    @property
+    def ink(self):
+        if self._ink is None:
+            self._ink = self.plane.cpu().numpy().astype(bool)
+        return self._ink
+
+
 class _Dev(object):
     def __init__(self, device="cuda"):
         self.dev = torch.device(device)
@@ -186,8 +202,7 @@ def find_lines(input_image, device="cuda"):
                       "ta_pp_clear_rows")
     lab, stats = d.label(work)
     recs = d.components(lab, stats)
-    ink_host = ink.cpu().numpy().astype(bool)
-    image_bin, image_eroded = host.BinImage(ink_host), host.BinImage(eroded.cpu().numpy().astype(bool))
+    image_bin, image_eroded = DeviceBinImage(ink), DeviceBinImage(eroded)
     comps = [(int(r[2]), int(r[3]), int(r[4]), int(r[5])) for r in recs if r[1] > host.noise_area_thresh]
     if not comps:
         return image_bin, image_eroded, angle, [], peaks
@@ -195,14 +210,20 @@ def find_lines(input_image, device="cuda"):
     med = np.median(heights)
     comps = [c for c, hgt in zip(comps, heights) if hgt < med * host.remove_capitals_scale]
     cc_median_height = np.median([c[3] - c[1] + 1 for c in comps])
-    strips = []
+    boxes = []
     for loc in peaks:
         hit = [c for c in comps if host.vertically_coincide(loc, c[1], c[3] - c[1] + 1, cc_median_height)]
         if not hit:
             continue
-        ulx, uly = min(c[0] for c in hit), min(c[1] for c in hit)
-        lrx, lry = max(c[2] for c in hit), max(c[3] for c in hit)
-        sub = ink_host[uly:lry + 1, ulx:lrx + 1]
-        pixels = np.where(sub, 0, 255).astype(np.uint8)
-        strips.append(page_mod.Strip(ulx, uly, lry - uly + 1, width=lrx - ulx + 1, pixels=pixels))
+        boxes.append((min(c[0] for c in hit), min(c[1] for c in hit), max(c[2] for c in hit), max(c[3] for c in hit)))
+    # cut the strips on the device (ink black on white, as the reference saves them) and bring
+    # only those over: the page itself stays where it is
+    flat = [((1 - ink[uly:lry + 1, ulx:lrx + 1]) * 255).reshape(-1) for ulx, uly, lrx, lry in boxes]
+    packed = torch.cat(flat).cpu().numpy() if flat else np.zeros(0, np.uint8)
+    strips, pos = [], 0
+    for ulx, uly, lrx, lry in boxes:
+        hh, ww = lry - uly + 1, lrx - ulx + 1
+        pixels = packed[pos:pos + hh * ww].reshape(hh, ww)
+        pos += hh * ww
+        strips.append(page_mod.Strip(ulx, uly, hh, width=ww, pixels=pixels))
     return image_bin, image_eroded, angle, strips, peaks
