@@ -38,6 +38,36 @@ def make_page(seed, nlines=30, raw=False):
     return page_mod.PreparedPage((2200, 3300), (2200, 3300), 0, strips, peaks), tr
 
 
+def make_page_image(seed, nlines=30):
+    """a whole text-layer page as a uint8 image (white, rows of word-like ink blobs, slightly
+    skewed): the input of the complete pipeline -- preprocessing, line finding, normaliser,
+    recogniser, aligner -- all on the device"""
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    h, w = 200 + 140 * nlines, 1400
+    ink = np.zeros((h, w), dtype=bool)
+    yy = np.arange(h)[:, None]
+    for k in range(nlines):
+        cy = 150 + 140 * k
+        dens = 0.55 * np.exp(-0.5 * ((yy - cy) / 8.0) ** 2)
+        x = 80
+        while x < w - 160:
+            ww = int(rng.integers(50, 120))
+            ink[:, x:x + ww] |= rng.random((h, ww)) < dens
+            x += ww + int(rng.integers(24, 40))
+    ink = ndimage.binary_closing(ink, structure=np.ones((3, 3), bool), iterations=2)
+    img = np.where(ink, 0, 255).astype(np.uint8)
+    img = ndimage.rotate(img, float(rng.uniform(-2, 2)), reshape=False, order=1, mode='constant', cval=255)
+    return img.astype(np.uint8)
+
+
+class RawPage(object):
+    def __init__(self, px):
+        from text_alignment_amd.page import Image
+        self.pixels = px
+        self.dim = Image(px.shape[1], px.shape[0]).dim
+
+
 def make_recognizer():
     from text_alignment_amd import ocr
     model = ocr.LineModel.random(7001, no=40)
@@ -71,8 +101,20 @@ def run(npages, seed0=100):
     atocr.process_batch(list(rpages), list(rtrs), rec, PARAMS)
     torch.cuda.synchronize()
     raw_dt = time.perf_counter() - t2
+    # and from whole page images: preprocessing and line finding on the device as well
+    nimg = min(npages, 16)
+    ipages = [RawPage(make_page_image(seed0 + 9000 + k)) for k in range(nimg)]
+    itrs = list(trs[:nimg])
+    atocr.process_batch(ipages[:2], itrs[:2], rec, PARAMS)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    atocr.process_batch(ipages, itrs, rec, PARAMS)
+    torch.cuda.synchronize()
+    img_dt = time.perf_counter() - t3
     return {"pages": npages, "seconds": dt, "pages_per_s": npages / dt, "lines_per_s": npages * 30 / dt,
             "single_page_ms": 1e3 * sorted(lat)[1],
+            "page_images": {"pages": nimg, "pages_per_s": nimg / img_dt, "seconds": img_dt,
+                            "note": "4400 x 1400 uint8 page images: csrc/ta_preproc.hip + ta_lineest.hip in front"},
             "raw_strips": {"pages_per_s": npages / raw_dt, "seconds": raw_dt,
                            "note": "strips as 60-row uint8 images, normalised by csrc/ta_lineest.hip"},
             "syllable_boxes": sum(len(r[0]) for r in res),
