@@ -92,8 +92,17 @@ def find_peak_locations(data, tol=prominence_tolerance, ranked=False):
 def moving_avg_filter(data, filter_size=filter_size):
     '''moving average over filter_size samples to either side; the ends stay zero (reference :147-157)'''
     smoothed = np.zeros(len(data))
-    for n in range(filter_size, len(data) - filter_size):
-        smoothed[n] = np.mean(data[n - filter_size: n + filter_size + 1])
+    data = np.asarray(data)
+    n = len(data)
+    if n > 2 * filter_size and data.dtype.kind in "iub":
+        # integer samples (a row projection): window sums are exact in any order, so a running
+        # sum gives bit for bit what np.mean gives per window
+        c = np.concatenate([[0], np.cumsum(data.astype(np.int64))])
+        win = c[2 * filter_size + 1:] - c[:n - 2 * filter_size]
+        smoothed[filter_size:n - filter_size] = win / float(2 * filter_size + 1)
+        return smoothed
+    for k in range(filter_size, n - filter_size):
+        smoothed[k] = np.mean(data[k - filter_size: k + filter_size + 1])
     return smoothed
 
 
