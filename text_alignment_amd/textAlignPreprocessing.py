@@ -51,29 +51,30 @@ def vertically_coincide(hline_position, comp_offset, comp_nrows, collision,
     return (not above and not below)
 
 
-def calculate_peak_prominence(data, index):
+def calculate_peak_prominence(data, index, data_max=None):
     '''log of the prominence of the peak at `index`: isolated peaks score high, peaks in the
-    foothills of larger ones low (reference :59-110).'''
+    foothills of larger ones low (reference :59-110).  `data_max` may carry max(data) when many
+    indices of the same array are scored.'''
     here = data[index]
     if (index == 0 or index == len(data) - 1 or data[index - 1] > here or data[index + 1] > here or
             (data[index - 1] == here and data[index + 1] == here)):
         return 0
-    if here == max(data):
+    if here == (max(data) if data_max is None else data_max):
         return np.log(here)
-    higher = [i for i, v in enumerate(data) if v > here]
-    right = [i for i in higher if i > index]
-    left = [i for i in higher if i < index]
-    nearest_right = min(right) if right else np.inf
-    nearest_left = max(left) if left else -np.inf
+    higher = np.nonzero(np.asarray(data) > here)[0]                 # indices of everything above this peak
+    cut = int(np.searchsorted(higher, index))
+    nearest_right = higher[cut] if cut < len(higher) else np.inf
+    nearest_left = higher[cut - 1] if cut > 0 else -np.inf
     nearest = nearest_left if (nearest_right - index) > (index - nearest_left) else nearest_right
     lo, hi = min(nearest, index), max(nearest, index)
-    key_col = min(data[lo:hi])
+    key_col = min(data[int(lo):int(hi)])
     return np.log(data[index] - key_col + 1)
 
 
 def find_peak_locations(data, tol=prominence_tolerance, ranked=False):
     '''indices of the prominent peaks of a row projection (reference :113-144)'''
-    proms = [(i, calculate_peak_prominence(data, i)) for i in range(len(data))]
+    data_max = max(data) if len(data) else None
+    proms = [(i, calculate_peak_prominence(data, i, data_max)) for i in range(len(data))]
     top = max([p[1] for p in proms])
     if top == 0 or len(proms) == 0:
         return []
