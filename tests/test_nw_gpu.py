@@ -351,3 +351,32 @@ def test_two_phase_with_16_bit_codes(tsc):
     batch.run()
     for (t, o), got in zip(probs, batch.results()):
         assert got.tolist() == nw_oracle.align_ids(t, o, SYSTEMS[1]).tolist()
+
+
+def test_adversarial_paths(tsc, two_phase):
+    """Paths that stress the windowed traceback and the tie rules: disjoint alphabets (the path
+    hugs the table edges), a 3000-token insertion in the middle (one horizontal / vertical run
+    crossing many windows and strips), constant strings (every cell ties), scoring systems that
+    reward gaps."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(123)
+    base = rng.integers(0, 27, size=1500).astype(np.int32)
+    ins = rng.integers(0, 27, size=3000).astype(np.int32)
+    cases = [
+        (rng.integers(0, 10, size=2500).astype(np.int32), rng.integers(20, 30, size=2700).astype(np.int32)),
+        (base, np.concatenate([base[:700], ins, base[700:]])),
+        (np.concatenate([base[:700], ins, base[700:]]), base),
+        (np.zeros(3000, np.int32), np.zeros(2600, np.int32)),
+        (np.tile(np.array([1, 2], np.int32), 1400), np.tile(np.array([2, 1], np.int32), 1300)),
+        (base, base[::-1].copy()),
+    ]
+    systems = [SYSTEMS[0], SYSTEMS[6], SYSTEMS[7], SYSTEMS[9], [3, -2, -1, -8, 0, -3]]
+    t_list, o_list, prm = [], [], []
+    for t, o in cases:
+        for s in systems:
+            t_list.append(t); o_list.append(o); prm.append(s)
+    batch = tsc.NWBatch(t_list, o_list, prm, two_phase=two_phase)
+    batch.run()
+    for k, got in enumerate(batch.results()):
+        want = nw_oracle.align_ids(t_list[k], o_list[k], prm[k])
+        assert got.tolist() == want.tolist(), (k // len(systems), prm[k])
