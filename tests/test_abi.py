@@ -60,6 +60,21 @@ def test_argument_errors_without_gpu(native):
         lambda: lib.ta_lstm_output(None, 16, None, 96, None, None, None, None),
         lambda: lib.ta_decode_summary(None, None, None, 1, 0.7, None, None, None, None, None),
         lambda: lib.ta_decode(None, None, None, 1, 96, 0.7, None, None, None, None, None),
+        lambda: lib.ta_linenorm_measure(None, None, None, None, 1, None, None, None, None, None, None, None,
+                                        None, None, None, None, None),
+        lambda: lib.ta_linenorm_resample(None, None, None, None, 1, None, None, None, None, None, None, None,
+                                         None, None, None, None),
+        lambda: lib.ta_pp_histogram(None, 10, None, None),
+        lambda: lib.ta_pp_threshold(None, 10, 128, 0, None, None),
+        lambda: lib.ta_pp_label(None, 4, 4, None, None, None, None),
+        lambda: lib.ta_pp_components(None, None, 4, 4, None, 8, None, None),
+        lambda: lib.ta_pp_filter_components(None, None, None, 4, 4, 1, 9, None),
+        lambda: lib.ta_pp_invert(None, 10, None),
+        lambda: lib.ta_pp_angle_histograms(None, 4, 4, 1, None, 2, None, None),
+        lambda: lib.ta_pp_rotate(None, 4, 4, None, 4, 4, None, None),
+        lambda: lib.ta_pp_open_runs(None, None, 4, 4, 2, 0, None),
+        lambda: lib.ta_pp_row_sums(None, 4, 4, None, None),
+        lambda: lib.ta_pp_clear_rows(None, 4, None, 1, None),
     ]
     for call in calls:
         assert call() == native.TA_EINVAL
