@@ -7,10 +7,12 @@ generator), inputs resident in HBM, plus -- with more than one GPU -- the single
 syllable-box records to rank 0 (the only collective on the path).  Pages/problems shard across
 ranks with no other communication, so scaling is "weak": every rank runs the same batch size.
 
-Also on the line: `roofline` for the dominant kernel (nw_fill_kernel, HIP events around its
-launches on the launch stream), `cpu_baseline` (the reference's algorithm on this host's cores,
-bounded sample, rank 0 only) and `ocr` (text-lines/s of the line recogniser on synthetic pages,
-timed separately, with its own MFMA roofline).
+Also on the line: `roofline` for the dominant kernel (nw_score_kernel of the two-phase aligner, or
+nw_fill_kernel with --one-pass; HIP events around its launches on the launch stream),
+`cpu_baseline` (the reference's algorithm on this host's cores, bounded sample, at N = 1 only),
+`ocr` (text-lines/s of the line recogniser on synthetic lines, timed separately, with its own MFMA
+roofline) and `pages_end_to_end` (process_batch from normalised strips, raw strips and whole page
+images).
 """
 import argparse
 import json
