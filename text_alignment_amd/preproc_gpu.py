@@ -211,11 +211,12 @@ def find_lines(input_image, device="cuda"):
     comps = [c for c, hgt in zip(comps, heights) if hgt < med * host.remove_capitals_scale]
     cc_median_height = np.median([c[3] - c[1] + 1 for c in comps])
     boxes = []
+    box = np.asarray(comps, dtype=np.int64)
     for loc in peaks:
-        hit = [c for c in comps if host.vertically_coincide(loc, c[1], c[3] - c[1] + 1, cc_median_height)]
-        if not hit:
+        hit = box[host.coincide_mask(loc, box[:, 1], box[:, 3] - box[:, 1] + 1, cc_median_height)]
+        if not len(hit):
             continue
-        boxes.append((min(c[0] for c in hit), min(c[1] for c in hit), max(c[2] for c in hit), max(c[3] for c in hit)))
+        boxes.append((int(hit[:, 0].min()), int(hit[:, 1].min()), int(hit[:, 2].max()), int(hit[:, 3].max())))
     # cut the strips on the device (ink black on white, as the reference saves them) and bring
     # only those over: the page itself stays where it is
     flat = [((1 - ink[uly:lry + 1, ulx:lrx + 1]) * 255).reshape(-1) for ulx, uly, lrx, lry in boxes]

@@ -51,6 +51,18 @@ def vertically_coincide(hline_position, comp_offset, comp_nrows, collision,
     return (not above and not below)
 
 
+def coincide_mask(hline_position, comp_offsets, comp_nrows, collision):
+    """vertically_coincide for many components at once (arrays of offsets and heights)"""
+    collision = collision * collision_strip_scale
+    top = np.asarray(comp_offsets)
+    bottom = top + np.asarray(comp_nrows)
+    strip_top = hline_position - int(collision / 2)
+    strip_bottom = hline_position + int(collision / 2)
+    above = (top < strip_top) & (bottom < strip_top)
+    below = (top > strip_bottom) & (bottom > strip_bottom)
+    return ~above & ~below
+
+
 def calculate_peak_prominence(data, index, data_max=None):
     '''log of the prominence of the peak at `index`: isolated peaks score high, peaks in the
     foothills of larger ones low (reference :59-110).  `data_max` may carry max(data) when many
@@ -282,12 +294,13 @@ def identify_text_lines(image_bin, image_eroded):
     comps = [c for c, h in zip(comps, heights) if h < med * remove_capitals_scale]
     cc_median_height = np.median([c[3] - c[1] + 1 for c in comps])
     strips = []
+    box = np.asarray(comps, dtype=np.int64)
     for loc in peaks:
-        hit = [c for c in comps if vertically_coincide(loc, c[1], c[3] - c[1] + 1, cc_median_height)]
-        if not hit:
+        hit = box[coincide_mask(loc, box[:, 1], box[:, 3] - box[:, 1] + 1, cc_median_height)]
+        if not len(hit):
             continue
-        ulx, uly = min(c[0] for c in hit), min(c[1] for c in hit)
-        lrx, lry = max(c[2] for c in hit), max(c[3] for c in hit)
+        ulx, uly = int(hit[:, 0].min()), int(hit[:, 1].min())
+        lrx, lry = int(hit[:, 2].max()), int(hit[:, 3].max())
         sub = image_bin.ink[uly:lry + 1, ulx:lrx + 1]
         pixels = np.where(sub, 0, 255).astype(np.uint8)        # as the saved PNG: ink black on white
         strips.append(page_mod.Strip(ulx, uly, lry - uly + 1, width=lrx - ulx + 1, pixels=pixels))
