@@ -286,11 +286,16 @@ extern "C" int ta_pp_label(const uint8_t* ink, int32_t h, int32_t w, int32_t* la
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nb = pp_blocks(n);
     hipLaunchKernelGGL(pp_label_init_kernel, dim3(nb), dim3(kPpThreads), 0, st, ink, n, lab);
-    for (int it = 0; it < 100000; ++it) {
+    // the iteration count is data-dependent: rounds of four scan / flatten pairs between looks at
+    // the flag (a pass over a converged labelling changes nothing, so overshooting is harmless and
+    // the host waits for the stream a quarter as often)
+    for (int round = 0; round < 100000; ++round) {
         hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), st);
         if (e != hipSuccess) return ta_fail_hip(e, "label flag memset");
-        hipLaunchKernelGGL(pp_label_scan_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, h, w, flag);
-        hipLaunchKernelGGL(pp_label_flatten_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, n);
+        for (int k = 0; k < 4; ++k) {
+            hipLaunchKernelGGL(pp_label_scan_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, h, w, flag);
+            hipLaunchKernelGGL(pp_label_flatten_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, n);
+        }
         int32_t changed = 0;
         e = hipMemcpyAsync(&changed, flag, sizeof(int32_t), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
