@@ -99,10 +99,10 @@ class NWBatch(object):
         # two-phase aligner (score-only fill + windowed pointer re-derivation, csrc/ta_nw2.hip):
         # its fill is ~30 % cheaper per cell, its traceback costs ~60 us more per 256-row strip of
         # the tallest problem (one wave walks the strips one after the other), and its workspace
-        # is 8x smaller.  Measured break-even on MI355X: total cells ~ 4.5e8 x strips.
+        # is 8x smaller.  Measured break-even on MI355X: total cells ~ 3.5e8 x strips.
         if two_phase is None:
             nstrips = (self.max_n + 255) // 256
-            two_phase = (self.cells > 4.5e8 * nstrips) or (self.cells > 64e9)
+            two_phase = (self.cells > 3.5e8 * nstrips) or (self.cells > 64e9)
         self.two_phase = bool(two_phase)
         # one-pass launch shape: None = library default (a problem is spread over several
         # workgroups when the batch has fewer problems than the GPU has CUs), True / False force it
