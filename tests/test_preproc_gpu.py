@@ -70,3 +70,19 @@ def test_preprocess_and_lines_match_host(seed, angle):
     for x, y in zip(s0, s1):
         assert (x.offset_x, x.offset_y, x.height, x.width) == (y.offset_x, y.offset_y, y.height, y.width)
         assert np.array_equal(x.pixels, y.pixels)
+
+
+def test_colour_and_float_pages_take_the_device_path():
+    """find_lines_all reduces colour / float pages to uint8 greyscale as to_onebit does and sends
+    them through the device kernels: same strips as the host restatement on the original array"""
+    from text_alignment_amd import alignToOCR as atocr
+    from text_alignment_amd import textAlignPreprocessing as H
+    grey = _noisy_page(7)
+    rgb = np.stack([grey, grey, grey], axis=2)
+    flt = grey.astype(np.float32) / 255.0
+    for page in (rgb, flt):
+        want = H.find_lines(page)
+        got = atocr.find_lines_all([page])[0]
+        assert want[2] == got[2] and np.array_equal(want[0].ink, got[0].ink)
+        assert [s.pixels.shape for s in want[3]] == [s.pixels.shape for s in got[3]]
+        assert all(np.array_equal(a.pixels, b.pixels) for a, b in zip(want[3], got[3]))

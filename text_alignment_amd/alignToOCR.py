@@ -273,17 +273,18 @@ def align_page(transcript, all_chars, angle, image_dim, raw_dim, seq_align_param
 
 def find_lines_all(pages, workers=1):
     """preprocessing + text-line finding of every page: (image_bin, image_eroded, angle, strips,
-    peak locations) per page.  Raw uint8 greyscale pages go through the device kernels
-    (preproc_gpu, csrc/ta_preproc.hip); PreparedPages pass through; anything else (colour, float,
-    bool) takes the host restatement, in `workers` processes when there are several."""
+    peak locations) per page.  Page images (greyscale or colour, any numeric type: reduced to uint8
+    greyscale exactly as the host's to_onebit does) go through the device kernels (preproc_gpu,
+    csrc/ta_preproc.hip); PreparedPages pass through; already-binarised (bool) pages take the host
+    restatement, in `workers` processes when there are several."""
     out = [None] * len(pages)
     rest = []
     for k, pg in enumerate(pages):
         px = getattr(pg, "pixels", pg)
         if not isinstance(pg, page_mod.PreparedPage) and isinstance(px, np.ndarray) and \
-                px.dtype == np.uint8 and px.ndim == 2:
+                px.dtype != bool and px.ndim in (2, 3):
             from . import preproc_gpu
-            out[k] = preproc_gpu.find_lines(px)
+            out[k] = preproc_gpu.find_lines(preproc.to_grey_u8(px))
         else:
             rest.append(k)
     if rest:

@@ -133,15 +133,22 @@ def otsu_threshold(grey):
     return int(np.argmax(between))
 
 
+def to_grey_u8(image):
+    """RGB / greyscale of any numeric type -> 2-D uint8 greyscale (what the threshold works on)"""
+    a = np.asarray(image)
+    if a.ndim == 3:
+        a = a[..., :3].mean(axis=2)
+    if a.dtype != np.uint8:
+        a = np.clip(a * (255.0 if a.max() <= 1.0 else 1.0), 0, 255).astype(np.uint8)
+    return a
+
+
 def to_onebit(image):
     """RGB / greyscale / bool array -> bool array, True = ink."""
     a = np.asarray(image)
     if a.dtype == bool:
         return a.copy()
-    if a.ndim == 3:
-        a = a[..., :3].mean(axis=2)
-    if a.dtype != np.uint8:
-        a = np.clip(a * (255.0 if a.max() <= 1.0 else 1.0), 0, 255).astype(np.uint8)
+    a = to_grey_u8(a)
     return a <= otsu_threshold(a)
 
 
