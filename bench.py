@@ -164,6 +164,47 @@ def ocr_cpu_baseline(model_seed, no, seconds=8.0):
             "sample": "%d lines of width 1000 (T = 1032) through oracle/ocr_ref_f64.py, %.1f s" % (done, dt)}
 
 
+def bench_pipelined(tsc, args, first):
+    """The same steps with two batches in flight on two streams: the traceback of one batch runs
+    beside the fill of the next (phase 2 keeps one wave per problem and leaves issue slots free).
+    Reported next to the headline, which times each kernel alone; per-kernel durations are not
+    meaningful here, so only the step rate is."""
+    second, _ = make_nw_batch(tsc, args.batch, args.n, args.m, 77, two_phase=True)
+    pair = [first, second]
+    s_fill, s_tb = torch.cuda.Stream(), torch.cuda.Stream()
+    fill_done = [torch.cuda.Event(), torch.cuda.Event()]
+    tb_done = [torch.cuda.Event(), torch.cuda.Event()]
+
+    def run(nsteps):
+        for k in range(nsteps):
+            b = k % 2
+            with torch.cuda.stream(s_fill):
+                if k >= 2:
+                    s_fill.wait_event(tb_done[b])          # the workspace of batch b is free again
+                pair[b].run(fill=True, traceback=False)
+                fill_done[b].record(s_fill)
+            with torch.cuda.stream(s_tb):
+                s_tb.wait_event(fill_done[b])
+                pair[b].run(fill=False, traceback=True)
+                tb_done[b].record(s_tb)
+        s_fill.synchronize()
+        s_tb.synchronize()
+    torch.cuda.synchronize()
+    run(2)
+    t0 = time.perf_counter()
+    run(args.steps)
+    dt = time.perf_counter() - t0
+    from oracle import nw_oracle
+    from oracle.synth import synth_pair_ids
+    t, o = synth_pair_ids(args.n, args.m, 77)
+    ok = second.results()[0].tolist() == nw_oracle.align_ids(t, o, DEFAULT_SYS).tolist()
+    del second
+    torch.cuda.empty_cache()
+    return {"value": first.cells * args.steps / dt, "unit": "cells/s", "ms_per_step": dt / args.steps * 1e3,
+            "bit_exact_vs_oracle": ok,
+            "note": "two batches in flight, fill and traceback on separate streams"}
+
+
 def bench_ocr(args, rank, precision="f32", nlines=None):
     from text_alignment_amd import ocr
     no = 96
@@ -211,6 +252,8 @@ def main():
     ap.add_argument("--ocr-lines", type=int, default=1920, help="text lines per GPU (64 pages x 30)")
     ap.add_argument("--ocr-lines-large", type=int, default=5760,
                     help="second OCR measurement with more lines than CUs x 16 (0 = skip)")
+    ap.add_argument("--no-pipelined", dest="pipelined", action="store_false",
+                    help="skip the extra two-stream measurement (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ocr", action="store_true")
     ap.add_argument("--pages", type=int, default=64,
@@ -278,6 +321,10 @@ def main():
     fill_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     tb_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
 
+    pipelined = None
+    if world == 1 and args.pipelined and batch.two_phase:
+        pipelined = bench_pipelined(tsc, args, batch)
+
     ocr_res = None
     if not args.no_ocr:
         ocr_res = bench_ocr(args, rank)
@@ -336,6 +383,8 @@ def main():
                          "traceback_kernel": "nw_trace2_kernel" if batch.two_phase else "nw_traceback_kernel",
                          "algorithmic_bytes_per_cell": 1},
         }
+        if pipelined is not None:
+            out["pipelined_two_streams"] = pipelined
         if ocr_res is not None:
             out["ocr"] = ocr_res
         if pages_res is not None:
