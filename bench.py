@@ -346,6 +346,12 @@ def main():
     if args.pages > 0 and not args.no_ocr:
         from tools import pages_bench
         pages_res = pages_bench.run(args.pages, seed0=100 + 1000 * rank)
+        if dist is not None:               # every rank ran its own share of pages: whole-job rates
+            agg = torch.tensor([pages_res["pages_per_s"], pages_res["raw_strips"]["pages_per_s"],
+                                pages_res["page_images"]["pages_per_s"]], dtype=torch.float64, device="cuda")
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+            pages_res["all_gpus"] = {"pages_per_s": float(agg[0]), "raw_strips_pages_per_s": float(agg[1]),
+                                     "page_images_pages_per_s": float(agg[2])}
 
     if rank == 0:
         # bit-exact spot check of the timed output against the oracle (checker only)
