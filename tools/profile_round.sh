@@ -12,12 +12,12 @@ OUT=$REPO/gpurun_out/prof_$ROUND
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/kt.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-pipelined > "$OUT/kt.log" 2>&1
 echo "kernel trace done"
 for mode in two one; do
   flag=""; [ $mode = one ] && flag="--one-pass"
   for ctr in WRITE_SIZE FETCH_SIZE; do
-    rocprofv3 --pmc $ctr --output-format csv -d "$OUT/${mode}_$ctr" -o nw -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-ocr $flag > "$OUT/${mode}_$ctr.log" 2>&1
+    rocprofv3 --pmc $ctr --output-format csv -d "$OUT/${mode}_$ctr" -o nw -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-ocr --no-pipelined $flag > "$OUT/${mode}_$ctr.log" 2>&1
     echo "$mode $ctr done"
   done
 done
