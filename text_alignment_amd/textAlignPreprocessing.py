@@ -86,7 +86,14 @@ def calculate_peak_prominence(data, index, data_max=None):
 def find_peak_locations(data, tol=prominence_tolerance, ranked=False):
     '''indices of the prominent peaks of a row projection (reference :113-144)'''
     data_max = max(data) if len(data) else None
-    proms = [(i, calculate_peak_prominence(data, i, data_max)) for i in range(len(data))]
+    # only local maxima can score: find them in one array pass (the same test
+    # calculate_peak_prominence starts with), everything else has prominence 0
+    d = np.asarray(data)
+    cand = np.zeros(len(d), dtype=bool)
+    if len(d) > 2:
+        mid, left, right = d[1:-1], d[:-2], d[2:]
+        cand[1:-1] = ~((left > mid) | (right > mid) | ((left == mid) & (right == mid)))
+    proms = [(i, calculate_peak_prominence(data, i, data_max) if cand[i] else 0) for i in range(len(data))]
     top = max([p[1] for p in proms])
     if top == 0 or len(proms) == 0:
         return []
