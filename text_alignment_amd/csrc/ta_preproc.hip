@@ -10,7 +10,9 @@
 // (HBM-bound, a few MB per page); connected components use label equivalence: every ink pixel
 // starts as its own label (its linear index), a scan pass lowers the root of a pixel's label to the
 // smallest label among its 8 neighbours, an analysis pass flattens the label trees, until nothing
-// changes.  The final label of a component is the linear index of its first pixel in raster order.
+// changes (tiles of 16 x 64 pixels are labelled in LDS first, the global passes only stitch across
+// tile borders).  The final label of a component is the linear index of its first pixel in raster
+// order.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -39,9 +41,52 @@ __global__ __launch_bounds__(kPpThreads) void pp_threshold_kernel(const uint8_t*
     }
 }
 
-__global__ __launch_bounds__(kPpThreads) void pp_label_init_kernel(const uint8_t* ink, int64_t n, int32_t* lab) {
-    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads)
-        lab[e] = ink[e] ? (int32_t)e : -1;
+// First stage of the labelling: every 16 x 64 tile is labelled on its own in LDS (the same scan /
+// flatten rounds, on tile-local indices, until the tile is stable), so the global rounds only have
+// to stitch components across tile borders -- a couple of rounds instead of one per pixel of
+// distance.  Output: lab[p] = global index of the tile-local root of p (roots point to themselves).
+constexpr int kTileH = 16, kTileW = 64;
+__global__ __launch_bounds__(kTileH * kTileW) void pp_label_tile_kernel(const uint8_t* ink, int h, int w, int32_t* lab) {
+    __shared__ int loc[kTileH * kTileW];
+    const int tx = threadIdx.x % kTileW, ty = threadIdx.x / kTileW;
+    const int x = blockIdx.x * kTileW + tx, y = blockIdx.y * kTileH + ty;
+    const bool inside = x < w && y < h;
+    const int me = threadIdx.x;
+    const bool on = inside && ink[(int64_t)y * w + x];
+    loc[me] = on ? me : -1;
+    __syncthreads();
+    while (true) {
+        int changed = 0;
+        if (on) {
+            const int mine = loc[me];
+            int m = mine;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = ty + dy, xx = tx + dx;
+                    if ((dy | dx) == 0 || yy < 0 || yy >= kTileH || xx < 0 || xx >= kTileW) continue;
+                    const int q = loc[yy * kTileW + xx];
+                    if (q >= 0 && q < m) m = q;
+                }
+            if (m < mine) { atomicMin(&loc[mine], m); changed = 1; }
+        }
+        if (!__syncthreads_or(changed)) break;
+        if (on) {
+            int r = loc[me];
+            while (loc[r] != r) r = loc[r];
+            loc[me] = r;
+        }
+        __syncthreads();
+    }
+    if (inside) {
+        int32_t out = -1;
+        if (on) {
+            const int r = loc[me];
+            out = (int32_t)((int64_t)(blockIdx.y * kTileH + r / kTileW) * w + blockIdx.x * kTileW + r % kTileW);
+        }
+        lab[(int64_t)y * w + x] = out;
+    }
 }
 
 __global__ __launch_bounds__(kPpThreads) void pp_label_scan_kernel(int32_t* lab, int h, int w, int32_t* changed) {
@@ -285,14 +330,15 @@ extern "C" int ta_pp_label(const uint8_t* ink, int32_t h, int32_t w, int32_t* la
     if (n >= (1ll << 31)) return ta_fail(TA_ELIMIT, "page too large for 32-bit labels");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nb = pp_blocks(n);
-    hipLaunchKernelGGL(pp_label_init_kernel, dim3(nb), dim3(kPpThreads), 0, st, ink, n, lab);
-    // the iteration count is data-dependent: rounds of four scan / flatten pairs between looks at
-    // the flag (a pass over a converged labelling changes nothing, so overshooting is harmless and
-    // the host waits for the stream a quarter as often)
+    hipLaunchKernelGGL(pp_label_tile_kernel, dim3((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH),
+                       dim3(kTileH * kTileW), 0, st, ink, h, w, lab);
+    // stitching across tiles.  The iteration count is data-dependent: rounds of two scan / flatten
+    // pairs between looks at the flag (a pass over a converged labelling changes nothing, so overshooting is harmless and
+    // the host waits for the stream half as often)
     for (int round = 0; round < 100000; ++round) {
         hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), st);
         if (e != hipSuccess) return ta_fail_hip(e, "label flag memset");
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 2; ++k) {
             hipLaunchKernelGGL(pp_label_scan_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, h, w, flag);
             hipLaunchKernelGGL(pp_label_flatten_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, n);
         }
