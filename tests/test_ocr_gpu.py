@@ -143,3 +143,12 @@ def test_decode_kernel_on_crafted_probabilities():
     k = int(dn.item())
     got = list(zip(dt.cpu().numpy()[:k].tolist(), dc.cpu().numpy()[:k].tolist()))
     assert got == want == [(3, 5), (7, 0), (11, 66)]
+
+
+@pytest.mark.parametrize("no", [5, 16, 17, 33, 80, 112, 128])
+def test_class_counts_cover_every_output_tile_variant(no):
+    """The output layer is compiled once per number of 16-class tiles (1..8): class counts on both
+    sides of the tile boundaries, up to the maximum of 128."""
+    from oracle import ocr_ref_f64 as R
+    from text_alignment_amd import ocr
+    _check_lines(R, ocr, _tame(R.synthetic_model(7100 + no, no=no)), [40, 129, 300], TOL)
