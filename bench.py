@@ -7,7 +7,13 @@ generator), inputs resident in HBM, plus -- with more than one GPU -- the single
 syllable-box records to rank 0 (the only collective on the path).  Pages/problems shard across
 ranks with no other communication, so scaling is "weak": every rank runs the same batch size.
 
-Also on the line: `roofline` for the dominant kernel (nw_score_kernel of the two-phase aligner, or
+`--gpus N` without a launcher (no RANK in the environment) starts N ranks itself -- a fresh
+`python -m torch.distributed.run` child, before this process has touched the GPU -- and exits with
+the child's code; under the driver's own torchrun the ranks are already there.
+
+Also on the line: `pages_sharded` (BASELINE configs[4]: 64 synthetic pages per GPU, Salzinnes- and
+St-Gall-shaped models, sharding.process_shard with its single gather of syllable-box records),
+`configs` (SURVEY.md 8(d)'s named NW shapes, N = 1 only), `roofline` for the dominant kernel (nw_score_kernel of the two-phase aligner, or
 nw_fill_kernel with --one-pass; HIP events around its launches on the launch stream),
 `cpu_baseline` (the reference's algorithm on this host's cores, bounded sample, at N = 1 only),
 `ocr` (text-lines/s of the line recogniser on synthetic lines, timed separately, with its own MFMA
@@ -31,38 +37,48 @@ F32_MFMA_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA peak (spec)
 DEFAULT_SYS = [8, -4, -7, -7, -3, 0]
 
 
+def _profile_file(*names):
+    for name in names:
+        path = os.path.join(REPO, "profiles", name)
+        if os.path.exists(path):
+            return name, path
+    return None, None
+
+
 def measured_traffic(batch, n, m, kernel):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes kept under
-    profiles/ (WRITE_SIZE + 2 x FETCH_SIZE, MI355X_MICROARCH.md HBM section); None for configs
-    that were not profiled."""
-    name = "r01_nw2_hbm_traffic.json" if kernel == "nw_score_kernel" else "r01_nw_hbm_traffic.json"
+    profiles/ (WRITE_SIZE + 2 x FETCH_SIZE, MI355X_MICROARCH.md HBM section) -- a number read from
+    that file, not measured in this run; (None, None) for configs that were not profiled."""
+    stem = "nw2_hbm_traffic.json" if kernel == "nw_score_kernel" else "nw_hbm_traffic.json"
+    name, path = _profile_file("r02_" + stem, "r01_" + stem)
     try:
-        with open(os.path.join(REPO, "profiles", name)) as f:
+        with open(path) as f:
             d = json.load(f)
         if d["config"] == {"batch": batch, "n": n, "m": m}:
             for k, v in d["kernels"].items():
                 if kernel in k:
-                    return v["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+                    return v["hbm_bytes_per_launch"], "profiles/" + name
+    except (OSError, KeyError, ValueError, TypeError):
         pass
-    return None
+    return None, None
 
 
 def measured_mfma_busy(kernel):
     """MFMA pipe utilisation of a recogniser kernel from the counter pass kept under profiles/
-    (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD-cycles, 1920-line workload); None if absent."""
+    (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD-cycles, 1920-line workload); (None, None) if absent."""
+    name, path = _profile_file("r02_ocr_pmc_mfma.json", "r01_ocr_pmc_mfma.json")
     try:
-        with open(os.path.join(REPO, "profiles", "r01_ocr_pmc_mfma.json")) as f:
+        with open(path) as f:
             for k, v in json.load(f)["kernels"].items():
                 if kernel in k:
-                    return v["mfma_pipe_utilisation"]
-    except (OSError, KeyError, ValueError):
+                    return v["mfma_pipe_utilisation"], "profiles/" + name
+    except (OSError, KeyError, ValueError, TypeError):
         pass
-    return None
+    return None, None
 
 
 def make_nw_batch(tsc, nprob, n, m, seed0, distinct=32, two_phase=False):
-    from oracle.synth import synth_pair_ids      # seeded input generator shared with the tests
+    from tools.synth import synth_pair_ids      # seeded input generator shared with the tests
     uniq = [synth_pair_ids(n, m, seed0 + k) for k in range(min(nprob, distinct))]
     probs = [uniq[k % len(uniq)] for k in range(nprob)]
     return tsc.NWBatch([p[0] for p in probs], [p[1] for p in probs], DEFAULT_SYS, two_phase=two_phase), uniq
@@ -84,7 +100,7 @@ def cpu_baseline(seconds=12.0):
     """oracle/nw_ref_py.py -- behavioural port of textSeqCompare.py:13-177 (per-cell Python loop
     over float64 numpy matrices) -- on one host core, config-1-shaped problems."""
     from oracle import nw_ref_py, nw_oracle
-    from oracle.synth import synth_pair
+    from tools.synth import synth_pair, synth_pair_ids
     n = m = 500
     done, t0 = 0, time.perf_counter()
     while True:
@@ -97,7 +113,7 @@ def cpu_baseline(seconds=12.0):
     out = {"value": done * n * m / dt, "unit": "cells/s", "cores": 1, "kind": "port",
            "sample": "%d problems of %dx%d (BASELINE configs[0] shape) through oracle/nw_ref_py.py, "
                      "%.1f s" % (done, n, m, dt),
-           "c_restatement_cells_per_s": nw_oracle.fill_only_rate(2048, 2048),
+           "c_restatement_cells_per_s": nw_oracle.fill_only_rate(*synth_pair_ids(2048, 2048, 1234)),
            "cpu_model": _cpu_model()}
     # the same port on every host core this process may use: one plain child interpreter per core
     # (the reference itself is single-threaded; SURVEY.md 8d asks for both figures)
@@ -105,7 +121,7 @@ def cpu_baseline(seconds=12.0):
     cores = _usable_cores()
     per = 4
     code = ("import sys; sys.path.insert(0, %r); from oracle import nw_ref_py; "
-            "from oracle.synth import synth_pair; s0 = int(sys.argv[1]); "
+            "from tools.synth import synth_pair; s0 = int(sys.argv[1]); "
             "[nw_ref_py.perform_alignment(*synth_pair(%d, %d, s0 + k)) for k in range(%d)]" % (REPO, n, m, per))
     t0 = time.perf_counter()
     procs = [subprocess.Popen([sys.executable, "-c", code, str(5000 + per * k)]) for k in range(cores)]
@@ -195,7 +211,7 @@ def bench_pipelined(tsc, args, first):
     run(args.steps)
     dt = time.perf_counter() - t0
     from oracle import nw_oracle
-    from oracle.synth import synth_pair_ids
+    from tools.synth import synth_pair_ids
     t, o = synth_pair_ids(args.n, args.m, 77)
     ok = second.results()[0].tolist() == nw_oracle.align_ids(t, o, DEFAULT_SYS).tolist()
     del second
@@ -231,14 +247,72 @@ def bench_ocr(args, rank, precision="f32", nlines=None):
     dec_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
     flops_lstm = tsteps * 238400.0                    # 2 dirs x 4 gates x 100 x 149 x 2
     tf = flops_lstm / (lstm_ms * 1e-3) / 1e12
+    busy, busy_src = measured_mfma_busy("lstm_seq_kernel") if nlines == 1920 and precision == "f32" else (None, None)
     return {"lines_per_s": nlines / dt, "timesteps_per_s": tsteps / dt, "lines": nlines,
             "timesteps": tsteps, "classes": no,
             "dtype": "f32" if precision == "f32" else "bf16x3 (split operands, f32 accumulate)",
             "ms": {"lstm": lstm_ms, "output_softmax": out_ms, "decode": dec_ms},
             "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                          "frac": tf / F32_MFMA_PEAK_TF, "traffic": None, "kernel": "lstm_seq_kernel",
-                         "mfma_pipe_busy_rocprof": measured_mfma_busy("lstm_seq_kernel") if nlines == 1920 and precision == "f32" else None,
+                         "mfma_pipe_busy_rocprof": busy, "mfma_pipe_busy_source": busy_src,
                          "algorithmic_flops_per_timestep": 238400}}
+
+
+def nw_configs(tsc, torch):
+    """SURVEY.md 8(d)'s named NW shapes beside the headline batch: device time of fill + traceback
+    (median of 5 after 2 warm-ups, events on the launch stream), every DISTINCT problem of each
+    batch checked bit-exact against the C oracle."""
+    from oracle import nw_oracle
+    from tools.synth import synth_pair_ids
+    rows = []
+    for name, nprob, n, m, distinct in [("headline 1x4096^2", 1, 4096, 4096, 1),
+                                        ("headline 64x4096^2", 64, 4096, 4096, 4),
+                                        ("C2 1024x2048^2", 1024, 2048, 2048, 8),
+                                        ("C4 1x8192^2", 1, 8192, 8192, 1)]:
+        uniq = [synth_pair_ids(n, m, 4321 + k) for k in range(distinct)]
+        batch = tsc.NWBatch([uniq[k % distinct][0] for k in range(nprob)],
+                            [uniq[k % distinct][1] for k in range(nprob)], DEFAULT_SYS)
+        for _ in range(2):
+            batch.run()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record(); batch.run(fill=True, traceback=False)
+            e[1].record(); batch.run(fill=False, traceback=True)
+            e[2].record()
+            torch.cuda.synchronize()
+            ts.append((e[0].elapsed_time(e[2]), e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])))
+        total, fill, tb = sorted(ts)[len(ts) // 2]
+        res = batch.results()
+        want = [nw_oracle.align_ids(t, o, DEFAULT_SYS).tolist() for t, o in uniq]
+        ok = all(res[k].tolist() == want[k % distinct] for k in range(nprob))
+        rows.append({"config": name, "problems": nprob, "n": n, "m": m,
+                     "mode": "two-phase" if batch.two_phase else "one-pass",
+                     "ms": total, "fill_ms": fill, "traceback_ms": tb,
+                     "cells_per_s": batch.cells / (total * 1e-3),
+                     "frac": batch.cells / (total * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "fill_frac": batch.cells / (fill * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "bit_exact": bool(ok), "problems_checked": nprob})
+        del batch
+        torch.cuda.empty_cache()
+    return rows
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks as a fresh child (one process
+    per GPU over RCCL) BEFORE this process has made any GPU call, and hand back its exit code."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -256,32 +330,38 @@ def main():
                     help="skip the extra two-stream measurement (N = 1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ocr", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the SURVEY 8(d) NW shapes (N = 1 only)")
     ap.add_argument("--pages", type=int, default=64,
-                    help="synthetic pages per GPU for the end-to-end process_batch timing (0 = skip)")
+                    help="synthetic pages per GPU for the sharded page pipeline and the end-to-end "
+                         "process_batch timings (0 = skip)")
     ap.add_argument("--one-pass", action="store_true",
                     help="use the single-pass fill (1 B/cell pointer matrix) instead of the two-phase aligner")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group even at world size 1 (rehearses the RCCL path)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for rehearsals)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    # ranks may outnumber the box's GPUs only in rehearsals (gloo): they then share device 0
+    ndev = torch.cuda.device_count()
+    dev_index = local if local < ndev else local % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1 or (args.force_dist and "RANK" in os.environ):
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
 
     from text_alignment_amd import sharding, textSeqCompare as tsc
     batch, uniq = make_nw_batch(tsc, args.batch, args.n, args.m, 1234 + rank * 100000,
                                two_phase=False if args.one_pass else None)
-    # the records a page driver would gather: ~150 syllable boxes per page/problem, packed at a
-    # fixed capacity so the gather is one collective with no size exchange (sharding.py)
-    recs = np.zeros((150 * args.batch, sharding.RECORD_FIELDS), dtype=np.int32)
-    recs[:, 0] = np.repeat(np.arange(args.batch) + rank * args.batch, 150)
-    packed = sharding.pack_records_device(recs, 150 * args.batch, torch.device("cuda", local))
-    pending = []
 
     def barrier():
         if dist is not None:
@@ -297,29 +377,59 @@ def main():
         batch.run(fill=False, traceback=True)
         if timed is not None:
             timed[2].record()
-        if dist is not None:           # asynchronous: overlaps the next step's fill
-            pending.append(sharding.gather_to_root(packed, async_op=True))
 
     for _ in range(args.warmup):
         step()
-    for work, _ in pending:
-        work.wait()
-    del pending[:]
     barrier()
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(ev[k])
-    for work, _ in pending:
-        work.wait()
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    red_dev = torch.device("cuda", dev_index) if args.backend == "nccl" else torch.device("cpu")
+
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def reduce_sum(xs):
+        t = torch.tensor(xs, dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(v) for v in t]
+
+    dt = reduce_max(dt)
     fill_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     tb_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+
+    # ---- BASELINE configs[4]: pages sharded over the ranks, one gather of syllable-box records ----
+    sharded = None
+    if args.pages > 0 and not args.no_ocr:
+        from tools import pages_bench
+        job = pages_bench.setup_sharded(args.pages, rank, world, seed0=100)
+        barrier()
+        t1 = time.perf_counter()
+        allrec = pages_bench.run_sharded(job)
+        barrier()
+        sh_dt = reduce_max(time.perf_counter() - t1)
+        if rank == 0:
+            heads = allrec[allrec[:, 1] == sharding.HEADER]
+            boxes = int((allrec[:, 1] != sharding.HEADER).sum())
+            sharded = {"pages": job["total_pages"], "pages_per_gpu": args.pages, "rccl_ranks": world,
+                       "backend": (args.backend if dist is not None else "none (single process)"),
+                       "seconds": sh_dt, "pages_per_s": job["total_pages"] / sh_dt,
+                       "lines_per_s": job["total_pages"] * 30 / sh_dt,
+                       "models": "half the pages 96 classes (Salzinnes-shaped), half 64 (St-Gall-shaped)",
+                       "gathered_records": int(allrec.shape[0]), "syllable_boxes": boxes,
+                       "gather_capacity_records_per_rank": job["capacity"],
+                       "gather_ok": bool(sorted(int(v) for v in heads[:, 0]) == list(range(job["total_pages"]))
+                                         and int(heads[:, 4].sum()) == boxes),
+                       "note": "sharding.process_shard: process_batch per model on this rank's pages + ONE "
+                               "gather of [page, syllable, ulx, uly, lrx, lry] records to rank 0"}
+        del job
 
     pipelined = None
     if world == 1 and args.pipelined and batch.two_phase:
@@ -338,57 +448,52 @@ def main():
             ocr_res["large_batch"] = {"lines": big["lines"], "lines_per_s": big["lines_per_s"], "ms": big["ms"],
                                       "mfma_frac": big["roofline"]["frac"]}
         if dist is not None:
-            agg = torch.tensor([ocr_res["lines_per_s"]], dtype=torch.float64, device="cuda")
-            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-            ocr_res["lines_per_s_all_gpus"] = float(agg.item())
+            ocr_res["lines_per_s_all_gpus"] = reduce_sum([ocr_res["lines_per_s"]])[0]
 
     pages_res = None
-    if args.pages > 0 and not args.no_ocr:
+    if args.pages > 0 and not args.no_ocr and world == 1:
         from tools import pages_bench
-        pages_res = pages_bench.run(args.pages, seed0=100 + 1000 * rank)
-        if dist is not None:               # every rank ran its own share of pages: whole-job rates
-            agg = torch.tensor([pages_res["pages_per_s"], pages_res["raw_strips"]["pages_per_s"],
-                                pages_res["page_images"]["pages_per_s"]], dtype=torch.float64, device="cuda")
-            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-            pages_res["all_gpus"] = {"pages_per_s": float(agg[0]), "raw_strips_pages_per_s": float(agg[1]),
-                                     "page_images_pages_per_s": float(agg[2])}
+        pages_res = pages_bench.run(args.pages, seed0=100)
+
+    configs = None
+    if world == 1 and not args.no_configs and not args.one_pass:
+        configs = nw_configs(tsc, torch)
 
     if rank == 0:
-        # bit-exact spot check of the timed output against the oracle (checker only)
+        # bit-exact check of the timed output against the oracle (checker only): every distinct
+        # problem of the batch, and every replica against its original
         from oracle import nw_oracle
         res = batch.results()
-        ok = True
-        for k in (0, len(uniq) - 1):
-            want = nw_oracle.align_ids(uniq[k][0], uniq[k][1], DEFAULT_SYS)
-            ok = ok and res[k].tolist() == want.tolist()
-        gathered_ok = True
-        if pending:
-            got = sharding.unpack_gathered(pending[-1][1])
-            gathered_ok = got.shape[0] == 150 * args.batch * world
+        want = [nw_oracle.align_ids(t, o, DEFAULT_SYS).tolist() for t, o in uniq]
+        ok = all(res[k].tolist() == want[k % len(uniq)] for k in range(len(res)))
         kname = "nw_score_kernel" if batch.two_phase else "nw_fill_kernel"
         cells_step = batch.cells * world
         fill_rate = batch.cells / (fill_ms * 1e-3)
+        traffic, traffic_src = measured_traffic(args.batch, args.n, args.m, kname)
         out = {
             "metric": "nw_dp_cells_per_s", "value": cells_step * args.steps / dt, "unit": "cells/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "affine-gap NW, %d problems of %dx%d per GPU per step, default "
-                                   "scoring [8,-4,-7,-7,-3,0], %s%s"
+                                   "scoring [8,-4,-7,-7,-3,0], %s"
                                    % (args.batch, args.n, args.m,
                                       "two-phase (score fill + windowed traceback)" if batch.two_phase
-                                      else "one-pass fill + traceback",
-                                      " + gather of syllable-box records" if world > 1 else ""),
-                       "cells_per_step": cells_step, "parallelism": "pages sharded x%d" % world,
-                       "bit_exact_vs_oracle": ok,
-                       "gather_ok": gathered_ok},
+                                      else "one-pass fill + traceback"),
+                       "cells_per_step": cells_step, "parallelism": "problems sharded x%d, no data-path collective" % world,
+                       "bit_exact_vs_oracle": ok, "problems_checked": len(res),
+                       "distinct_problems": len(uniq)},
             "roofline": {"bound": "hbm", "achieved": fill_rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": fill_rate / 1e9 / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.batch, args.n, args.m, kname),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kname, "kernel_ms": fill_ms, "traceback_ms": tb_ms,
                          "traceback_kernel": "nw_trace2_kernel" if batch.two_phase else "nw_traceback_kernel",
                          "algorithmic_bytes_per_cell": 1},
         }
+        if sharded is not None:
+            out["pages_sharded"] = sharded
+        if configs is not None:
+            out["configs"] = configs
         if pipelined is not None:
             out["pipelined_two_streams"] = pipelined
         if ocr_res is not None:

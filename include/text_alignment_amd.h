@@ -34,6 +34,13 @@ extern "C" {
 #define TA_NW_CODES8 4u      /* caller asserts every token id < 255: 1-byte codes in LDS (ta_nw2_batch) */
 #define TA_NW_WIDE 8u        /* ta_nw_batch: force one problem over several workgroups (HBM hand-off rows) */
 #define TA_NW_NARROW 16u     /* ta_nw_batch: force one workgroup per problem; default: wide iff nprob < 256 */
+#define TA_NW_OPENS_SAME 32u /* ta_nw2_batch hint: gap_open_x == gap_open_y in every scoring system of the batch */
+/* ta_nw2_batch hint: every token id of the batch is < a (1 <= a <= 254), every gap open is <= 0 and
+ * match/mismatch minus both gap extends fit a signed byte: phase 1 then keeps a score profile in LDS
+ * instead of comparing token ids per cell.  Hints change speed only: a problem that does not meet
+ * them is still aligned correctly, through a slower path. */
+#define TA_NW_ALPHABET_SHIFT 8
+#define TA_NW_ALPHABET(a) (((uint32_t)(a) & 0xFFu) << TA_NW_ALPHABET_SHIFT)
 
 int ta_version(void);
 const char* ta_last_error(void);
@@ -99,6 +106,12 @@ int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
                  uint8_t* ops_out, const int64_t* ops_off, int32_t* ops_len,
                  int32_t max_n, int32_t max_m, int64_t score_bound,
                  uint32_t flags, void* stream);
+
+/* What phase 1 of ta_nw2_batch would launch for a batch whose tallest / widest problem is
+ * max_n x max_m under `flags` (the hints above): out[0] = 1 compare-select cell, 2 score profile
+ * in LDS; out[1] = waves per workgroup; out[2] = dynamic LDS bytes per workgroup; out[3] = 1 if the
+ * single-gap-open form of the cell is used.  Pure host function (no GPU call). */
+int ta_nw2_phase1_plan(int32_t max_n, int32_t max_m, uint32_t flags, int32_t* out);
 
 /*
  * ta_nw_general: the same aligner for scoring systems the integer kernel does not take --

@@ -132,11 +132,12 @@ def perform_alignment(transcript, ocr, scoring_system=None, verbose=False):
     return ops_to_alignment(ops, transcript, ocr)
 
 
-def fill_only_rate(n, m, seed=1234, params=None):
-    """Time the C restatement's fill on a synth pair; returns cells/s (single thread)."""
+def fill_only_rate(t_ids, o_ids, params=None):
+    """Time the C restatement's fill on one problem; returns cells/s (single thread)."""
     import time
-    from .synth import synth_pair_ids
-    t_ids, o_ids = synth_pair_ids(n, m, seed)
+    t_ids = np.ascontiguousarray(t_ids, dtype=np.int32)
+    o_ids = np.ascontiguousarray(o_ids, dtype=np.int32)
+    n, m = len(t_ids), len(o_ids)
     p = np.asarray(params or DEFAULT_SYS, dtype=np.float64)
     t0 = time.perf_counter()
     lib().nw_oracle_fill_only(t_ids.ctypes.data, n, o_ids.ctypes.data, m, p.ctypes.data)

@@ -131,16 +131,21 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
     // row planes of lane 63: index [strip][j], j = 0..m
     std::vector<int> RV2((size_t)std::max(nstrips, 1) * (m + 2)), RD2(RV2.size()), RH3(RV2.size());
 
+    // phase 1 keeps V~ + gox / H~ + goy (the carried cell of nw_cell.h) when no gap open is
+    // positive, exactly as nw_score_kernel does; phase 2 undoes the offsets where it reads them
+    const bool carried = opens_nonpositive(c.gox, c.goy);
+    const int xadj = carried ? c.gox : 0, yadj = carried ? c.goy : 0;
+
     // ---------------- phase 1: raw fill ----------------
     {
         std::vector<int> hv(m + 2), hd(m + 2);
-        for (int j = 0; j <= m; ++j) { hv[j] = raw_of(bnd_V_row0(c, j)); hd[j] = raw_of(bnd_D_row0(c, j)); }
+        for (int j = 0; j <= m; ++j) { hv[j] = raw_of(bnd_V_row0(c, j)) + xadj; hd[j] = raw_of(bnd_D_row0(c, j)); }
         for (int s = 0; s < nstrips; ++s) {
             int D[kLanes][R], V[kLanes][R], H[kLanes][R], tcode[kLanes][R], dsave[kLanes];
             for (int l = 0; l < kLanes; ++l) {
                 for (int r = 0; r < R; ++r) {
                     const int i = s * L::SR + l * R + r + 1;
-                    D[l][r] = raw_of(bnd_D_col0(c, i)); H[l][r] = raw_of(bnd_H_col0(c, i)); V[l][r] = 0;
+                    D[l][r] = raw_of(bnd_D_col0(c, i)); H[l][r] = raw_of(bnd_H_col0(c, i)) + yadj; V[l][r] = 0;
                     tcode[l][r] = (i <= n) ? t[i - 1] : -1;
                 }
                 dsave[l] = raw_of(bnd_D_col0(c, s * L::SR + l * R));
@@ -171,7 +176,8 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
                         for (int r = 0; r < R; ++r) {
                             const int cs = (tcode[l][r] == o[j - 1]) ? cmat_raw : cmis_raw;
                             int d, v, h;
-                            cell_update_raw(d_ul, v_u, H[l][r], cs, c.gox, c.goy, d, v, h);
+                            if (carried) cell_update_carried(d_ul, v_u, H[l][r], cs, c.gox, c.goy, d, v, h);
+                            else cell_update_raw(d_ul, v_u, H[l][r], cs, c.gox, c.goy, d, v, h);
                             d_ul = D[l][r]; v_u = v;
                             nD[l][r] = d; nV[l][r] = v; nH[l][r] = h;
                         }
@@ -214,8 +220,8 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
             if (j == 0) { hdt[0] = bnd_D_col0(c, i_h); continue; }
             const size_t b = (size_t)(s - 1) * (m + 2);
             const int d_ul = (j - 1 >= 1) ? RD2[b + j - 1] : raw_of(bnd_D_col0(c, i_h - 1));
-            const int v_u = RV2[b + j];
-            const int h_l = (j - 1 >= 1) ? RH3[b + j - 1] : raw_of(bnd_H_col0(c, i_h));
+            const int v_u = RV2[b + j] - xadj;
+            const int h_l = (j - 1 >= 1) ? RH3[b + j - 1] - yadj : raw_of(bnd_H_col0(c, i_h));
             const int cs = (t[i_h - 1] == o[j - 1]) ? c.cmatch : c.cmismatch;
             int d, v, h;
             cell_update(enc_of(d_ul), enc_of(v_u), enc_of(h_l), cs, c.gox6, c.goy6, d, v, h);
@@ -235,8 +241,8 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
         if (g0 > 0) {
             const State& cs0 = ck[(size_t)s * nck + g0 / KCG];
             for (int ll = 0; ll < kLanes; ++ll) {
-                for (int rr = 0; rr < R; ++rr) { D[ll][rr] = enc_of(cs0.D[ll][rr]); H[ll][rr] = enc_of(cs0.H[ll][rr]); }
-                V[ll][R - 1] = enc_of(cs0.Vlast[ll]); dsave[ll] = enc_of(cs0.dsave[ll]);
+                for (int rr = 0; rr < R; ++rr) { D[ll][rr] = enc_of(cs0.D[ll][rr]); H[ll][rr] = enc_of(cs0.H[ll][rr] - yadj); }
+                V[ll][R - 1] = enc_of(cs0.Vlast[ll] - xadj); dsave[ll] = enc_of(cs0.dsave[ll]);
             }
         }
         // tagged fill of groups g0..g_in into a window buffer

@@ -130,3 +130,23 @@ def test_process_golden_end_to_end():
         js["median_line_spacing"] = float(js["median_line_spacing"])
         assert js == c["json"], c["name"]
         assert ''.join(x.char for x in all_chars) == c["expanded_ocr"]
+
+
+def test_llocs_parser_matches_reference():
+    """tests/golden/llocs.json: the reference's own perform_ocr_with_ocropus (alignToOCR.py:128-184)
+    run on canned .llocs files (tools/gen_golden.py: gen_llocs) -- reject / blank classes that still
+    advance the position, x.5 positions on odd and even strip offsets (np.round is half-to-even),
+    utf-8 characters, an empty line strip."""
+    from conftest import load_golden
+    from text_alignment_amd import alignToOCR as atocr
+    g = load_golden("llocs.json")
+    assert len(g["cases"]) >= 6
+    ties = 0
+    for c in g["cases"]:
+        got = []
+        for s in c["strips"]:
+            llocs = atocr.parse_llocs_text("".join(line + "\n" for line in s["llocs"]))
+            ties += sum(1 for _, x in llocs if abs(x * 2 - round(x * 2)) < 1e-9 and abs(x - round(x)) > 0.25)
+            atocr.chars_from_llocs(llocs, s["offset_x"], s["offset_y"], s["offset_y"] + s["height"], got)
+        assert [[b.char, [int(b.ul[0]), int(b.ul[1])], [int(b.lr[0]), int(b.lr[1])]] for b in got] == c["chars"]
+    assert ties >= 20            # the fixture does exercise the half-to-even cases

@@ -10,7 +10,7 @@ import pytest
 
 from conftest import REPO
 from oracle import nw_oracle
-from oracle.synth import synth_pair_ids
+from tools.synth import synth_pair_ids
 
 _SRC = os.path.join(REPO, "tests", "native", "sim_nw.cpp")
 _SO = os.path.join(REPO, "tests", "native", "libsim_nw.so")

@@ -61,7 +61,7 @@ def test_golden_random_small_one_launch(tsc):
 
 
 def test_golden_synth(tsc):
-    from oracle.synth import synth_pair
+    from tools.synth import synth_pair
     g = load_golden("nw_synth.json")
     for c in g["cases"]:
         t, o = synth_pair(c["n"], c["m"], c["seed"])
@@ -170,7 +170,7 @@ def test_waves_per_problem_variants(tsc, two_phase):
 
 def test_long_rows_and_long_columns(tsc, two_phase):
     from oracle import nw_oracle
-    from oracle.synth import synth_pair_ids
+    from tools.synth import synth_pair_ids
     for n, m, seed in [(8192, 8192, 5), (3000, 12000, 6), (12000, 900, 7)]:
         t, o = synth_pair_ids(n, m, seed)
         batch = tsc.NWBatch([t], [o], SYSTEMS[0], two_phase=two_phase)
@@ -184,7 +184,7 @@ def test_config2_batch_properties(tsc, two_phase):
     """BASELINE.json configs[1] shape (2048 x 2048, default scoring) at reduced batch for the
     oracle comparison, plus size-independent properties on every problem of the batch."""
     from oracle import nw_oracle
-    from oracle.synth import synth_pair_ids
+    from tools.synth import synth_pair_ids
     nprob = 256
     probs = [synth_pair_ids(2048, 2048, 1234 + k) for k in range(nprob)]
     batch = tsc.NWBatch([p[0] for p in probs], [p[1] for p in probs], SYSTEMS[0], two_phase=two_phase)
@@ -222,7 +222,7 @@ def test_random_scoring_systems_one_launch(tsc):
     """The parameter grid of evaluate_text_alignment.py:181-198 in one launch: 243 scoring systems
     drawn from the reference's 3^6 grid against one page-sized pair."""
     from oracle import nw_oracle
-    from oracle.synth import synth_pair
+    from tools.synth import synth_pair
     grid = [(m1, m2, gx, gy, ex, ey) for m1 in (5, 8, 11) for m2 in (-10, -7, -4)
             for gx in (-7, -5, -2) for gy in (-7, -5, -2) for ex in (-5, -3, 0) for ey in (0,)]
     t, o = synth_pair(420, 390, 77)
@@ -265,7 +265,7 @@ def test_overflow_guard_routes_to_general_kernel(tsc):
 def test_ocr_longer_than_lds_row_routes_to_general_kernel(tsc):
     """m beyond ta_nw_max_m() (the LDS hand-off row) still aligns, through the float64 kernel."""
     from oracle import nw_oracle
-    from oracle.synth import synth_pair
+    from tools.synth import synth_pair
     from text_alignment_amd import _native
     m = _native.lib.ta_nw_max_m() + 500
     t, o = synth_pair(700, m, 77)
@@ -299,7 +299,7 @@ def test_bench_default_shape_properties(tsc):
     size-independent properties: every token of both strings appears exactly once, no alignment
     column is a double gap, replicas of a problem give identical bytes, and the seed-1234 problem
     reproduces the alignment captured from the reference (tests/golden/nw_synth.json)."""
-    from oracle.synth import synth_pair_ids
+    from tools.synth import synth_pair_ids
     nprob, distinct = 4096, 16
     uniq = [synth_pair_ids(4096, 4096, 1234 + k) for k in range(distinct)]
     probs = [uniq[k % distinct] for k in range(nprob)]
@@ -323,7 +323,7 @@ def test_wide_launch_oversubscribed(tsc):
     more workgroups (255 x 4 chunks, 41 KB of LDS each) than the GPU holds at once: later chunks
     wait on earlier ones that must already be resident or done (in-order dispatch)."""
     from oracle import nw_oracle
-    from oracle.synth import synth_pair_ids
+    from tools.synth import synth_pair_ids
     distinct = 5
     uniq = [synth_pair_ids(4096, 4096, 4321 + k) for k in range(distinct)]
     probs = [uniq[k % distinct] for k in range(255)]
@@ -380,3 +380,57 @@ def test_adversarial_paths(tsc, two_phase):
     for k, got in enumerate(batch.results()):
         want = nw_oracle.align_ids(t_list[k], o_list[k], prm[k])
         assert got.tolist() == want.tolist(), (k // len(systems), prm[k])
+
+
+def _phase1_plan(batch):
+    import ctypes
+    from text_alignment_amd import _native
+    out = (ctypes.c_int32 * 4)()
+    flags = (_native.TA_NW_CODES8 if batch.codes8 else 0) | batch.hints
+    assert _native.lib.ta_nw2_phase1_plan(batch.max_n, batch.max_m, flags, out) == 0
+    return {"mode": out[0], "waves": out[1], "lds": out[2], "samego": out[3]}
+
+
+@pytest.mark.parametrize("variant", ["profile", "compare"])
+@pytest.mark.parametrize("waves", [None, 1, 2, 4, 8])
+def test_phase1_variants_and_forced_hints(tsc, variant, waves, monkeypatch):
+    """Phase 1 of the two-phase aligner in both forms (score profile in LDS / compare-select) and
+    with every workgroup width, on a launch whose hints are FORCED on although some problems do not
+    meet them (positive gap opens, gap_open_x != gap_open_y, substitution scores beyond a byte):
+    those problems must still come out right, through the kernel's general path."""
+    from oracle import nw_oracle
+    from text_alignment_amd import _native
+    monkeypatch.setenv("TA_NW2_PHASE1", variant)
+    if waves is not None:
+        monkeypatch.setenv("TA_NW2_W", str(waves))
+    rng = np.random.default_rng(41)
+    systems = SYSTEMS + [[120, -100, -7, -7, -3, 0], [8, -4, -7, -7, -3, 0], [6, -3, -5, -5, 0, -2],
+                         [127, -128, -3, -3, 0, 0], [200, -4, -7, -7, -3, 0]]
+    sizes = [(2300, 900), (1030, 2100), (300, 300), (64, 700), (513, 129), (1, 1), (0, 4), (2049, 257),
+             (257, 4100), (700, 64), (1200, 1200), (90, 90), (2600, 70), (255, 256), (1024, 1024)]
+    t_list, o_list, prm = [], [], []
+    for k, (n, m) in enumerate(sizes):
+        t, o = _random_problem(rng, n, m, [2, 4, 27, 31][k % 4], k % 2 == 0)
+        t_list.append(t); o_list.append(o); prm.append(systems[k % len(systems)])
+    batch = tsc.NWBatch(t_list, o_list, prm, two_phase=True)
+    assert batch.hints == 0                       # mixed systems: nothing may be assumed
+    batch.hints = (31 << _native.TA_NW_ALPHABET_SHIFT) | _native.TA_NW_OPENS_SAME
+    plan = _phase1_plan(batch)
+    assert plan["mode"] == (2 if variant == "profile" else 1)
+    assert waves is None or plan["waves"] == waves
+    for _ in range(2):
+        batch.run()
+    for k, got in enumerate(batch.results()):
+        want = nw_oracle.align_ids(t_list[k], o_list[k], prm[k])
+        assert got.tolist() == want.tolist(), (k, sizes[k], prm[k])
+    # launches that qualify as a whole (what the hints are for): one gap open, and two different ones
+    for system in ([8, -4, -7, -7, -3, 0], [9, -5, -6, -2, -1, -3]):
+        same = tsc.NWBatch(t_list, o_list, system, two_phase=True)
+        assert same.hints == (31 << _native.TA_NW_ALPHABET_SHIFT) | \
+            (_native.TA_NW_OPENS_SAME if system[2] == system[3] else 0)
+        plan = _phase1_plan(same)
+        assert plan["mode"] == (2 if variant == "profile" else 1) and plan["samego"] == int(system[2] == system[3])
+        same.run()
+        for k, got in enumerate(same.results()):
+            want = nw_oracle.align_ids(t_list[k], o_list[k], system)
+            assert got.tolist() == want.tolist(), (k, sizes[k], system)

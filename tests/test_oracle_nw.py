@@ -7,7 +7,7 @@ import pytest
 
 from conftest import kat_scoring, load_golden, unrle
 from oracle import nw_oracle, nw_ref_py
-from oracle.synth import synth_pair, synth_pair_ids
+from tools.synth import synth_pair, synth_pair_ids
 
 
 def _sha16(tra, ocr):

@@ -25,17 +25,24 @@ def _page(seed, nlines, R, page_mod):
     return page_mod.PreparedPage((2200, 3300), (2200, 3300), 0, strips, peaks), transcript
 
 
-def _expected(page, transcript, om, R, atocr, nw_oracle, params=None):
+def _expected(page, transcript, om, R, nw_oracle, params=None):
+    """The page's JSON from CHECKERS only: float64 recogniser restatement -> .llocs text ->
+    oracle/glue_ref.py (pinned to the reference's own outputs, tests/test_oracle_glue.py) with the
+    C aligner restatement; no product glue on this side."""
+    from oracle import glue_ref
+    from text_alignment_amd import latinSyllabification as latsyl          # pinned by tests/test_glue.py
     chars = []
     for s in page.strips:
         ref = R.recognise(om, s.prepared, raw_width=s.width)
-        atocr.chars_from_llocs(ref["llocs"], s.offset_x, s.offset_y, s.offset_y + s.height, chars)
-    expanded = atocr.expand_abbreviations(list(chars))
-    ocr = [c.char for c in expanded]
-    alignment = nw_oracle.perform_alignment(list(transcript), ocr, params)
-    boxes, _ = atocr.align_page(transcript, chars, page.angle, page.image.dim, page.dim, params,
-                                alignment=alignment)
-    return atocr.to_JSON_dict(boxes, page.lines_peak_locs), "".join(ocr)
+        lines = R.llocs_text(ref["llocs"]).split("\n")[:-1]
+        chars += glue_ref.chars_from_llocs(lines, s.offset_x, s.offset_y, s.offset_y + s.height)
+    expanded = glue_ref.expand(chars, latsyl.abbreviations)
+    ocr = "".join(b[0] for b in expanded)
+    tra_align, ocr_align = nw_oracle.perform_alignment(list(transcript), list(ocr), params)
+    js = glue_ref.syllable_json(latsyl.syllabify_text(transcript), expanded, tra_align, ocr_align, page.angle,
+                                (page.image.dim.ncols, page.image.dim.nrows), (page.dim.ncols, page.dim.nrows),
+                                page.lines_peak_locs)
+    return js, ocr
 
 
 def test_single_page_process_matches_oracle_pipeline():
@@ -50,7 +57,7 @@ def test_single_page_process_matches_oracle_pipeline():
     assert res is not None
     syl_boxes, image, peaks, all_chars = res
     got = atocr.to_JSON_dict(syl_boxes, peaks)
-    want, want_ocr = _expected(pg, transcript, om, R, atocr, nw_oracle, params)
+    want, want_ocr = _expected(pg, transcript, om, R, nw_oracle, params)
     assert "".join(c.char for c in all_chars) == want_ocr
     assert got == want
     assert len(got["syl_boxes"]) > 50
@@ -70,6 +77,34 @@ def test_process_batch_equals_process_and_sharded_driver():
     assert [atocr.to_JSON_dict(b[0], b[2]) for b in batch] == single
     out = sharding.process_pages(list(pages), list(trs), rec, seq_align_params=params)   # world size 1
     assert [out[k] for k in range(4)] == single
+
+
+def test_config5_shape_64_pages_two_models_sharded_driver():
+    """BASELINE configs[4] at one rank: 64 pages, half read with a 96-class (Salzinnes-shaped) model
+    and half with a 64-class (St-Gall-shaped) one, through sharding.process_pages (process_batch per
+    model + the single fixed-capacity gather); every page's JSON equals process() of that page
+    alone, and three pages are rebuilt from the checkers (float64 recogniser + C aligner + glue)."""
+    from oracle import nw_oracle, ocr_ref_f64 as R
+    from text_alignment_amd import alignToOCR as atocr, ocr, page as page_mod, sharding
+    oms, recs = [], []
+    for seed, no in ((7001, 96), (7002, 64)):
+        om = R.synthetic_model(seed, no=no)
+        om.W2[0, 0] += 4.0
+        om.W2[30:, :] *= 0.25                       # mostly the first classes come out: text-like strings
+        oms.append(om)
+        recs.append(ocr.LineRecognizer(ocr.LineModel(om.fwd, om.rev, om.W2, om.codec)))
+    pages, trs = zip(*[_page(200 + k, 3 + k % 5, R, page_mod) for k in range(64)])
+    models = [recs[k % 2] for k in range(64)]
+    params = [8, -1, -9, -9, -4, -4]
+    out = sharding.process_pages(list(pages), list(trs), models, seq_align_params=params)
+    assert sorted(out) == list(range(64))
+    for k in range(64):
+        res = atocr.process(pages[k], trs[k], models[k], seq_align_params=params)
+        assert out[k] == atocr.to_JSON_dict(res[0], res[2]), k
+    assert sum(len(out[k]["syl_boxes"]) for k in range(64)) > 300
+    for k in (0, 1, 37):
+        want, _ = _expected(pages[k], trs[k], oms[k % 2], R, nw_oracle, params)
+        assert out[k] == want, k
 
 
 def test_ocr_failure_returns_none(capsys):

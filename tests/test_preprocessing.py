@@ -69,11 +69,31 @@ def test_lines_found_on_synthetic_page():
         assert (s.pixels == 0).mean() > 0.3             # mostly ink inside a line strip
 
 
-def test_deskew_recovers_rotation():
-    from text_alignment_amd import textAlignPreprocessing as pp
-    img, _ = _synthetic_page(5, angle=2.0, seed=3)
-    _, _, angle = pp.preprocess_images(img)
-    assert abs(abs(angle) - 2.0) <= 0.4
+@pytest.mark.parametrize("skew", [2.0, -3.3, 4.0])
+def test_deskew_sign_and_box_unrotation(skew):
+    """A page skewed by a known signed angle: the reported angle has the sign that makes
+    rotate_bbox(box, -angle, image.dim, raw.dim) -- what process() applies to every syllable box
+    (reference alignToOCR.py:327-328) -- land boxes of the deskewed page back on the raw page's ink.
+    (With the opposite sign a point 400 px from the centre misses by ~60 px.)"""
+    from text_alignment_amd import alignToOCR as atocr, textAlignPreprocessing as pp
+    from text_alignment_amd.page import Image
+    img, _ = _synthetic_page(5, angle=skew, seed=3)
+    image_bin, _, angle = pp.preprocess_images(img)
+    assert abs(angle - skew) <= 0.4               # same sense as the scipy rotation that skewed the page
+    raw_ink = pp.to_onebit(img)
+    raw_dim = Image(img.shape[1], img.shape[0]).dim
+    ys, xs = np.nonzero(image_bin.ink)
+    pick = np.random.default_rng(1).choice(len(ys), size=300, replace=False)
+    boxes = [atocr.CharBox('x', (int(xs[k]), int(ys[k])), (int(xs[k]), int(ys[k]))) for k in pick]
+    back = atocr.rotate_bboxes(boxes, -1 * angle, image_bin.dim, raw_dim)
+    hits = 0
+    for b in back:
+        x, y = int(b.ulx), int(b.uly)
+        hits += bool(raw_ink[max(y - 2, 0):y + 3, max(x - 2, 0):x + 3].any())
+    assert hits >= 0.95 * len(back), hits
+    # the single-box form agrees with the vectorised one
+    one = atocr.rotate_bbox(boxes[0], -1 * angle, image_bin.dim, raw_dim)
+    assert (one.ulx, one.uly) == (back[0].ulx, back[0].uly)
 
 
 def test_prepared_page_passes_through():

@@ -79,3 +79,84 @@ def test_single_process_passthrough_and_cost():
     assert np.array_equal(sharding.gather_records(local), local)
     assert sharding.shard_indices([1, 5, 3], 1, 0) == [1, 2, 0]
     assert sharding.page_cost([100, 200], 800) > sharding.page_cost([100], 800)
+
+
+def _fake_process_batch(pages, transcripts, model, seq_align_params=None, indices_out=None, parallel=2):
+    """stands in for alignToOCR.process_batch on a CPU-only box: boxes are a function of the page
+    and the transcript only (every second non-empty syllable gets one), so any rank computes the
+    same boxes for the same page"""
+    from text_alignment_amd import alignToOCR as atocr, latinSyllabification as latsyl
+    out = []
+    for pg, tr in zip(pages, transcripts):
+        syls = [s for s in latsyl.syllabify_text(tr) if len(s) >= 1]
+        boxes, idx = [], []
+        for k, s in enumerate(syls):
+            if (k + pg["seed"]) % 2 == 0 and not pg["empty"]:
+                boxes.append(atocr.CharBox(s, (10 * k + pg["seed"], 100 + model["shift"]),
+                                           (10 * k + 8 + pg["seed"], 140 + model["shift"])))
+                idx.append(k)
+        if indices_out is not None:
+            indices_out.append(idx)
+        out.append((boxes, None, pg["peaks"], []))
+    return out
+
+
+_TEXTS = ["dominus dixit ad me", "filius meus es tu alleluia", "gloria patri et filio", "amen",
+          "laudate eum omnes gentes", "quoniam confirmata est super nos misericordia eius", "et"]
+
+
+def _pages_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from text_alignment_amd import alignToOCR as atocr, sharding
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    atocr.process_batch = _fake_process_batch
+    sharding.estimate_cost = lambda pg, tr: float(len(tr))
+    pages = [{"seed": k, "empty": k == 3, "peaks": [100, 220 + k, 340, 470 + 3 * k]} for k in range(len(_TEXTS))]
+    models = [{"shift": 0} if k % 2 == 0 else {"shift": 1000} for k in range(len(_TEXTS))]
+    models = [models[0] if k % 2 == 0 else models[1] for k in range(len(_TEXTS))]     # two distinct model objects
+    out = sharding.process_pages(pages, _TEXTS, models, None)
+    q.put((rank, out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_process_pages_world2_equals_single_process():
+    """sharding.process_pages -- the driver BASELINE configs[4] runs -- with two gloo ranks: rank 0
+    receives every page's JSON through the one fixed-capacity gather (two models, a page without
+    boxes, uneven shards), identical to what a single process computes; rank 1 gets None."""
+    ctx = mp.get_context("spawn")
+    results = {}
+    for world in (1, 2):
+        port = _free_port()
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_pages_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = dict(q.get(timeout=120) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        results[world] = got
+    single = results[1][0]
+    assert sorted(single) == list(range(len(_TEXTS)))
+    assert single[3]["syl_boxes"] == [] and single[3]["median_line_spacing"] == np.quantile(np.diff([100, 223, 340, 479]), 0.75)
+    assert sum(len(v["syl_boxes"]) for v in single.values()) > 15
+    assert single[1]["syl_boxes"][0]["ul"][1] == 1100 and single[0]["syl_boxes"][0]["ul"][1] == 100
+    assert results[2][1] is None
+    assert results[2][0] == single
+
+
+def test_capacity_is_an_upper_bound_and_plan_is_deterministic():
+    from text_alignment_amd import sharding, latinSyllabification as latsyl
+    for tr in _TEXTS + ["", "  ", "a e i o u"]:
+        nsyl = len([s for s in latsyl.syllabify_text(tr) if len(s) >= 1])
+        assert sharding.record_capacity(tr) >= 1 + nsyl
+    costs = [float(len(t)) for t in _TEXTS]
+    shards, cap = sharding.shard_plan(costs, _TEXTS, 3)
+    assert sorted(k for sh in shards for k in sh) == list(range(len(_TEXTS)))
+    assert cap == max(sum(sharding.record_capacity(_TEXTS[k]) for k in sh) for sh in shards)
+    with pytest.raises(ValueError):
+        sharding.pack_records_device(np.zeros((5, 6), np.int32), 4, torch.device("cpu"))

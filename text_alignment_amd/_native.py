@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libta_hip.so")
 TA_OK = 0
 TA_EINVAL, TA_ERANGE, TA_EHIP, TA_ELIMIT = -1, -2, -3, -4
 TA_NW_FILL, TA_NW_TRACEBACK, TA_NW_CODES8, TA_NW_WIDE, TA_NW_NARROW = 1, 2, 4, 8, 16
+TA_NW_OPENS_SAME, TA_NW_ALPHABET_SHIFT = 32, 8
 
 
 class NativeLibraryError(RuntimeError):
@@ -48,6 +49,8 @@ def _load():
     lib.ta_nw2_workspace_bytes.argtypes = [i32, i32]
     lib.ta_nw2_batch.restype = ctypes.c_int
     lib.ta_nw2_batch.argtypes = lib.ta_nw_batch.argtypes
+    lib.ta_nw2_phase1_plan.restype = ctypes.c_int
+    lib.ta_nw2_phase1_plan.argtypes = [i32, i32, ctypes.c_uint32, ctypes.c_void_p]
     lib.ta_nw_general_score_bytes.restype = i64
     lib.ta_nw_general_score_bytes.argtypes = [i32]
     lib.ta_nw_general_ptr_bytes.restype = i64
@@ -83,7 +86,7 @@ def _load():
 
 lib = _load()
 
-EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_batch",
+EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_batch", "ta_nw2_phase1_plan",
            "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general",
            "ta_lstm_packed_weight_floats", "ta_lstm_forward", "ta_lstm_output", "ta_decode",
            "ta_decode_summary", "ta_linenorm_measure", "ta_linenorm_resample",

@@ -154,6 +154,19 @@ def _edge_positions(xs, x_min):
     return np.rint(one_dec + x_min).astype(np.int64).tolist()
 
 
+def parse_llocs_text(text):
+    """The `.llocs` wire format ocropus-rpred writes and the reference reads back
+    (alignToOCR.py:157-170): one "char<TAB>x" line per decoded character, x with one decimal ->
+    [(char, x)] as chars_from_llocs takes it."""
+    out = []
+    for line in text.split('\n'):
+        if line == '':
+            continue
+        lsp = line.split('\t')
+        out.append((lsp[0], float(lsp[1])))
+    return out
+
+
 def chars_from_llocs(llocs, x_min, y_min, y_max, all_chars):
     """One strip's (char, x) list -> CharBoxes appended to all_chars (alignToOCR.py:160-182).
     ocropus reports the RIGHT edge of each character, so a character's box runs from the
@@ -293,6 +306,19 @@ def find_lines_all(pages, workers=1):
     return out
 
 
+def _raw_dim(pg):
+    """`raw_image.dim` of the reference (alignToOCR.py:328) for whatever stands for the raw page
+    here: an object with .dim (PreparedPage, a Gamera-like image), or a bare pixel array /
+    an object with .pixels, whose size is its shape."""
+    dim = getattr(pg, "dim", None)
+    if dim is not None and hasattr(dim, "ncols"):
+        return dim
+    px = np.asarray(getattr(pg, "pixels", pg))
+    if px.ndim < 2:
+        raise TypeError("a page is a PreparedPage, an image object with .dim, or a 2-D / 3-D pixel array")
+    return page_mod.Dim(px.shape[1], px.shape[0])
+
+
 def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indices_out=None,
                   parallel=parallel):
     """`process` for many pages at once: the strips of ALL pages go through the line recogniser
@@ -301,6 +327,7 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     seq_align_params).  Returns a list of (syl_boxes, image, lines_peak_locs, all_chars)."""
     from . import ocr
     rec = _recognizer_for(ocropus_model)
+    raw_dims = [_raw_dim(pg) for pg in pages]            # bad page types fail before any GPU work
     found = find_lines_all(list(pages), workers=parallel)
     prep = [((image, eroded, angle), ) for (image, eroded, angle, _, _) in found]
     strips_per_page = [f[3] for f in found]
@@ -320,10 +347,10 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     pairs = [(list(tr), [c.char for c in chars]) for tr, chars in zip(transcripts, chars_per_page)]
     alignments = tsc.perform_alignment_batch(pairs, seq_align_params)
     results = []
-    for pg, ((image, eroded, angle), ), tr, chars, lp, al in zip(pages, prep, transcripts,
-                                                                chars_per_page, peaks, alignments):
+    for raw_dim, ((image, eroded, angle), ), tr, chars, lp, al in zip(raw_dims, prep, transcripts,
+                                                                     chars_per_page, peaks, alignments):
         idx = [] if indices_out is not None else None
-        syl_boxes, all_chars_copy = align_page(tr, chars, angle, image.dim, pg.dim,
+        syl_boxes, all_chars_copy = align_page(tr, chars, angle, image.dim, raw_dim,
                                                seq_align_params, alignment=al, indices=idx, expanded=True)
         if indices_out is not None:
             indices_out.append(idx)
@@ -346,6 +373,7 @@ def process(raw_image,
     lines and aligns the results to the transcript text (reference alignToOCR.py:187-330).
     Returns (syl_boxes, image, lines_peak_locs, all_chars), or None when OCR fails.
     '''
+    raw_dim = _raw_dim(raw_image)
     image, eroded, angle, cc_strips, lines_peak_locs = find_lines_all([raw_image], workers=1)[0]
 
     all_chars = []
@@ -368,7 +396,7 @@ def process(raw_image,
             print('OCRopus failed! Skipping current file.')
             return None
 
-    syl_boxes, all_chars_copy = align_page(transcript, all_chars, angle, image.dim, raw_image.dim,
+    syl_boxes, all_chars_copy = align_page(transcript, all_chars, angle, image.dim, raw_dim,
                                            seq_align_params)
     return syl_boxes, image, lines_peak_locs, all_chars_copy
 

@@ -121,6 +121,21 @@ TA_HD void cell_update_raw(int d_ul, int v_u, int h_l, int cs, int gox, int goy,
     v = max3i(mr, v_u, yg);
     h = max3i(mr, xg, h_l);
 }
+// ---- score-only cell in CARRIED form, for non-positive gap opens (the reference's grid and its
+// default system never open a gap for free, evaluate_text_alignment.py:181-188) ----
+// State is XG = V~ + gox and YG = H~ + goy, i.e. what the max3 of the receiving cell consumes.
+// With gox <= 0:  V~(c) + gox = max3(M^, X~, Y~+goy) + gox = max(D(c) + gox, XG_in)  because
+// XG_in = X~ + gox >= X~ + 2 gox; likewise YG.  Same three scores as cell_update_raw, one add and
+// one max3 fewer per cell:  D = max3(M^, XG, YG);  XG' = max(D + gox, XG);  YG' = max(D + goy, YG).
+TA_HD bool opens_nonpositive(int gox, int goy) { return gox <= 0 && goy <= 0; }
+TA_HD void cell_update_carried(int d_ul, int xg_u, int yg_l, int cs, int gox, int goy,
+                               int& d, int& xg, int& yg) {
+    const int mr = d_ul + cs;
+    d = max3i(mr, xg_u, yg_l);
+    const int dx = d + gox, dy = d + goy;
+    xg = dx > xg_u ? dx : xg_u;
+    yg = dy > yg_l ? dy : yg_l;
+}
 TA_HD int raw_of(int enc) { return enc >> kShift; }            // arithmetic shift: floor
 TA_HD int enc_of(int raw) { return raw * 64; }                 // tag field zero
 

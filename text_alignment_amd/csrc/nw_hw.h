@@ -16,6 +16,7 @@ struct NwArgs {
     uint8_t* ops_out; const int64_t* ops_off; int32_t* ops_len;
     int32_t nprob;
     int32_t wide_stride;          // wide one-pass launch only: block index = chunk * wide_stride + p
+    int32_t apad;                 // phase 1 with a score profile in LDS: alphabet size + 1 (pad row)
 };
 
 // ---- single-instruction helpers.  Inline asm pins the instruction selection: left to
@@ -53,6 +54,15 @@ __device__ __forceinline__ int v_score(int t, int o, int miss, int hit) {
     asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d) : "v"(miss), "v"(hit), "s"(mask));
     return d;
 }
+// The carried score-only cell of phase 1 is written in plain C: hipcc selects v_max3_i32 for the
+// nested max and folds the byte unpack into v_add_u32_sdwa (sext, BYTE_b) by itself, and -- unlike
+// an asm statement -- needs no wait state between these instructions and their consumers.
+// a + (signed byte b of `packed`): unpack of the LDS score profile's entry (slow-class issue like
+// max3, but no v_cmp / v_cndmask per cell).  `b` is a constant after unrolling.
+__device__ __forceinline__ int c_add_sbyte(int a, int packed, int b) {
+    return a + (int)(int8_t)((unsigned)packed >> (8 * b));
+}
+__device__ __forceinline__ int c_max3(int a, int b, int c) { return max(max(a, b), c); }
 // lane l receives lane l-1's value; lane 0 keeps what the destination held (DPP wave_shr:1,
 // bound_ctrl off).  The leading s_nop covers the VALU-write -> DPP-read wait states (2) that
 // hipcc cannot see across asm statements; NOPS = 4 also covers an EXEC write before a DPP.
@@ -68,14 +78,16 @@ constexpr int kOPad = 64;     // o-code padding in front (lanes that have not st
 constexpr int kOTail = 80;    // steps run to m + 62 (+ group round-up) past the last code
 constexpr int kCheck = 16;    // hand-off progress is checked / published every kCheck groups
 
-// LDS carve (dynamic): int2 hvd[m+2] | int2 dummy[64*4] | uint16 ocode[kOPad+m+kOTail] | int prog[16]
+// LDS carve (dynamic): int2 hvd[m+2] | int2 dummy[64*4] | code ocode[kOPad+m+kOTail] | int prog[16]
+//                      | uint32 profile[waves][apad][64]   (phase 1 with a score profile only)
 struct NwLds {
-    size_t hvd_bytes, dummy_bytes, oc_bytes, total;
-    __host__ __device__ explicit NwLds(int m, int code_bytes = 2) {
+    size_t hvd_bytes, dummy_bytes, oc_bytes, tbl_off, total;
+    __host__ __device__ explicit NwLds(int m, int code_bytes = 2, int tbl_bytes = 0) {
         hvd_bytes = ((size_t)(m + 2) * 8 + 15) & ~(size_t)15;
         dummy_bytes = 64 * 4 * 8;
         oc_bytes = ((size_t)(kOPad + m + kOTail) * code_bytes + 15) & ~(size_t)15;
-        total = hvd_bytes + dummy_bytes + oc_bytes + 64;
+        tbl_off = hvd_bytes + dummy_bytes + oc_bytes + 64;
+        total = tbl_off + (size_t)tbl_bytes;
     }
 };
 

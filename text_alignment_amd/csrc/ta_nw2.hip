@@ -18,6 +18,8 @@
 // Data flow and the halo argument are replayed on the CPU by tests/native/sim_nw.cpp (run2).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 
 #include "nw_cell.h"
 #include "nw_hw.h"
@@ -66,16 +68,40 @@ __device__ __forceinline__ void cell_raw_hw(const RawRegs& k, int d_ul, int v_u,
     h = v_max3(mr, xg, h_l);
 }
 
+// carried form (nw_cell.h: cell_update_carried), compare-select score
+__device__ __forceinline__ void cell_carried_hw(const RawRegs& k, int d_ul, int xg_u, int yg_l, int t, int o,
+                                                int& d, int& xg, int& yg) {
+    const int mr = d_ul + v_score(t, o, k.cmis, k.cmat);
+    d = v_max3(mr, xg_u, yg_l);
+    xg = max(d + k.gox, xg_u);
+    yg = max(d + k.goy, yg_l);
+}
+
+__host__ __device__ inline bool fits_i8(int v) { return v >= -128 && v <= 127; }
+
 // ---------------------------------------------------------------------------------------------
 // phase 1
-// OC = uint8_t when every token id of the batch is below 255 (alphabets like the reference's 27
-// symbols): the OCR codes then take 1 byte each in LDS and a 4096-column problem fits four
-// workgroups per CU instead of three.
-template <int W, typename OC>
-__global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
+//
+// MODE 1: the substitution score of a cell is a compare + select on the two token ids.
+// MODE 2: score PROFILE in LDS.  Each wave keeps, for the 256 rows of the strip it is in, a table
+//   profile[o][lane] = the four substitution scores (signed bytes) of the lane's four rows against
+//   OCR token o; a step costs one conflict-free ds_read_b32 (bank = lane) for four cells and the
+//   byte is unpacked by the SDWA add that forms M^.  The table never needs rebuilding: it holds
+//   "mismatch" everywhere and a strip patches the <= 4 entries per lane where its transcript tokens
+//   match (and restores them when it leaves).  OCR codes sit in LDS pre-multiplied by the row pitch
+//   (256 B).  Needs a small alphabet (apad x 256 B per wave) and scores that fit a signed byte.
+// Both modes use the carried cell (non-positive gap opens).  A problem that does not qualify
+// (a positive gap open; in MODE 2 a score outside a byte; gox != goy under SAMEGO) runs every group
+// through the predicated edge body with the general cell: correct, slower, and rare.
+// OC (MODE 1) = uint8_t when every token id of the batch is below 255: the OCR codes then take 1 byte
+// each in LDS and a 4096-column problem fits four workgroups per CU instead of three.
+template <int W, int MODE, bool SAMEGO, typename OC>
+__global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwArgs a) {
     constexpr int R = 4;
     using L = PtrLayout<R>;
     constexpr int SPG = L::SPG;
+    constexpr bool PROFILE = (MODE == 2);
+    using LC = typename std::conditional<PROFILE, uint16_t, OC>::type;      // code type in LDS
 #ifndef TA_P1_CHK
 #define TA_P1_CHK 4
 #endif
@@ -96,45 +122,62 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
     RawRegs kr;
     kr.cmis = prm[1] - prm[4] - prm[5]; kr.cmat = prm[0] - prm[4] - prm[5];
     kr.gox = prm[2]; kr.goy = prm[3];
+    // state of a problem is kept in carried form (XG, YG) iff its gap opens are non-positive; phase 2
+    // applies the same predicate when it reads checkpoints and planes
+    const bool carried = opens_nonpositive(kr.gox, kr.goy);
+    const int xadj = carried ? kr.gox : 0, yadj = carried ? kr.goy : 0;
+    const int apad = PROFILE ? a.apad : 0;
+    const bool steady_ok = carried && (!PROFILE || (fits_i8(kr.cmis) && fits_i8(kr.cmat) && apad >= 2)) &&
+                           (!SAMEGO || kr.gox == kr.goy);
     // keep the two select constants resident in VGPRs (hipcc otherwise re-materialises them with
     // two v_mov per step, 8 % of the loop's VALU instructions)
-    asm volatile("" : "+v"(kr.cmis), "+v"(kr.cmat));
+    if (!PROFILE) asm volatile("" : "+v"(kr.cmis), "+v"(kr.cmat));
 
-    const NwLds lds(m, (int)sizeof(OC));
+    const NwLds lds(m, (int)sizeof(LC));
     int2* hvd = reinterpret_cast<int2*>(smem);
     int2* dummy = reinterpret_cast<int2*>(smem + lds.hvd_bytes);
-    OC* ocode = reinterpret_cast<OC*>(smem + lds.hvd_bytes + lds.dummy_bytes);
+    LC* ocode = reinterpret_cast<LC*>(smem + lds.hvd_bytes + lds.dummy_bytes);
     int* prog = reinterpret_cast<int*>(smem + lds.hvd_bytes + lds.dummy_bytes + lds.oc_bytes);
+    uint32_t* tbl = reinterpret_cast<uint32_t*>(smem + lds.tbl_off);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    // codes as the cells compare them: MODE 2 keeps them multiplied by the profile's row pitch
+    const int code_shift = PROFILE ? 8 : 0;
+    const LC pad_code = PROFILE ? (LC)((apad - 1) << 8) : (LC)~(LC)0;        // never a valid id
     for (int j = tid; j < kOPad + m + kOTail; j += W * 64) {
         const int src = j - kOPad;
-        ocode[j] = (src >= 0 && src < m) ? (OC)a.o_codes[o0 + src] : (OC)~(OC)0;   // pad: never a valid id
+        ocode[j] = (src >= 0 && src < m) ? (LC)(a.o_codes[o0 + src] << code_shift) : pad_code;
     }
     for (int j = tid; j <= m; j += W * 64)
-        hvd[j] = make_int2(raw_of(bnd_V_row0(c, j)), raw_of(bnd_D_row0(c, j)));
+        hvd[j] = make_int2(raw_of(bnd_V_row0(c, j)) + xadj, raw_of(bnd_D_row0(c, j)));
     if (tid < 16) prog[tid] = 0;
+    const uint32_t mis4 = (uint32_t)(kr.cmis & 0xFF) * 0x01010101u;
+    if (PROFILE)
+        for (int k = tid; k < W * apad * 64; k += W * 64) tbl[k] = mis4;
     __syncthreads();
+
+    uint32_t* const tblw = tbl + (size_t)wave * apad * 64;                   // this wave's profile
+    const unsigned char* const tbl_lane = reinterpret_cast<const unsigned char*>(tblw) + lane * 4;
 
     const Ws2 ws(n, m);
     uint8_t* const ws_p = a.ws + a.ws_off[p];
     const int nstrips = ws.nstrips, ngroups = ws.ngroups;
     const int prev_wave = (wave + W - 1) % W;
     const int g_lo = (63 + SPG - 1) / SPG;
-    const int g_hi = m / SPG;
+    const int g_hi = steady_ok ? m / SPG : 0;
     int pass = 0;
 
     for (int s = wave; s < nstrips; s += W, ++pass) {
-        int D[R], V[R], H[R], tc[R];
+        int D[R], V[R], H[R], tc[R];            // V, H hold XG, YG when the problem is carried
         const int row0 = s * L::SR + lane * R;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = row0 + r + 1;
             D[r] = raw_of(bnd_D_col0(c, i));
-            H[r] = raw_of(bnd_H_col0(c, i));
+            H[r] = raw_of(bnd_H_col0(c, i)) + yadj;
             V[r] = 0;
             tc[r] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
         }
@@ -144,6 +187,26 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
         // of the previous group
 #pragma unroll
         for (int r = 0; r < R; ++r) asm volatile("" :: "v"(tc[r]));
+        // MODE 2: patch the profile with this strip's matches
+        auto patch = [&](bool set) {
+            if (!PROFILE || !steady_ok) return;
+            const uint32_t matb = (uint32_t)(kr.cmat & 0xFF);
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (tc[r] < 0 || tc[r] >= apad - 1) continue;
+                uint32_t w = mis4;
+                if (set) {
+#pragma unroll
+                    for (int q = 0; q < R; ++q)
+                        if (tc[q] == tc[r]) w = (w & ~(0xFFu << (8 * q))) | (matb << (8 * q));
+                }
+                tblw[tc[r] * 64 + lane] = w;
+            }
+        };
+        patch(true);
+        int tcmp[R];                             // transcript codes in the form the LDS codes have
+#pragma unroll
+        for (int r = 0; r < R; ++r) tcmp[r] = tc[r] << code_shift;           // -1 stays negative
         const bool lane_has_rows = row0 < n;
         const int prod_pass = (wave == 0) ? pass - 1 : pass;
         int* const plane_v = reinterpret_cast<int*>(ws_p + ws.row_plane(s, 0));
@@ -226,7 +289,8 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int d_old = D[r];
-                        cell_raw_hw(kr, d_ul, v_u, H[r], tc[r], oc[q], D[r], V[r], H[r]);
+                        if (carried) cell_carried_hw(kr, d_ul, v_u, H[r], tcmp[r], oc[q], D[r], V[r], H[r]);
+                        else cell_raw_hw(kr, d_ul, v_u, H[r], tcmp[r], oc[q], D[r], V[r], H[r]);
                         d_ul = d_old;
                         v_u = V[r];
                     }
@@ -248,38 +312,53 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
         if (g < g_hi) {
             // ---- steady state: every lane is inside 1 <= j <= m, no EXEC changes.  Two groups per
             // iteration with two input buffers (A / B), so the LDS prefetch of the next group lands
-            // in the other buffer and no register copies are needed at the loop back-edge. ----
+            // in the other buffer and no register copies are needed at the loop back-edge.  MODE 2
+            // reads the OCR codes one group further ahead (X / Y) and turns them into profile
+            // entries when the group's other inputs are fetched. ----
             int2* wptr = (lane == 63) ? (hvd + (g * SPG - 62)) : (dummy + lane);
             const int winc = (lane == 63) ? SPG : 0;
-            int ocA[SPG], ocB[SPG];
+            int inA[SPG], inB[SPG];              // MODE 1: OCR codes; MODE 2: packed scores of the 4 rows
             int2 hdA[SPG], hdB[SPG];
+            int ocX[SPG], ocY[SPG];
+            auto codes = [&](int gn, int (&oc)[SPG]) {
+                const int idx = kOPad + gn * SPG - lane;    // stays inside ocode[]: gn <= m / SPG + 2
 #pragma unroll
-            for (int q = 0; q < SPG; ++q) { ocA[q] = oc_next[q]; hdA[q] = hd_next[q]; }
-            auto fetch = [&](int gn, int (&oc)[SPG], int2 (&hd)[SPG]) {       // inputs of group gn
+                for (int q = 0; q < SPG; ++q) oc[q] = ocode[idx + q];
+            };
+            auto fetch = [&](int gn, const int (&oc)[SPG], int (&in)[SPG], int2 (&hd)[SPG]) {   // inputs of group gn
                 if (gn < ngroups) {
                     if ((gn % CHK) == 0) wait_span(gn);
                     const int idx = kOPad + gn * SPG - lane;
 #pragma unroll
                     for (int q = 0; q < SPG; ++q) {
-                        oc[q] = ocode[idx + q];
+                        if constexpr (PROFILE) in[q] = *reinterpret_cast<const int*>(tbl_lane + oc[q]);
+                        else in[q] = ocode[idx + q];
                         hd[q] = hvd[min(gn * SPG + q + 1, m)];
                     }
                 }
             };
-            auto steady = [&](int gg, const int (&oc)[SPG], const int2 (&hd)[SPG]) {
+            auto steady = [&](int gg, const int (&in)[SPG], const int2 (&hd)[SPG]) {
                 checkpoint(gg);
                 int rv[SPG], rd[SPG], rh[SPG];
 #pragma unroll
                 for (int q = 0; q < SPG; ++q) {
-                    int v_up = hd[q].x, d_next = hd[q].y;
-                    wave_shr1_pair<1>(v_up, V[R - 1], d_next, D[R - 1]);
-                    int d_ul = dsave, v_u = v_up;
+                    int x_up = hd[q].x, d_next = hd[q].y;
+                    wave_shr1_pair<1>(x_up, V[R - 1], d_next, D[R - 1]);
+                    int d_ul = dsave, x_u = x_up;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int d_old = D[r];
-                        cell_raw_hw(kr, d_ul, v_u, H[r], tc[r], oc[q], D[r], V[r], H[r]);
+                        int mr;
+                        if constexpr (PROFILE) mr = c_add_sbyte(d_ul, in[q], r);
+                        else mr = d_ul + v_score(tc[r], in[q], kr.cmis, kr.cmat);
+                        const int d = c_max3(mr, x_u, H[r]);
+                        const int dgx = d + kr.gox;
+                        const int dgy = SAMEGO ? dgx : d + kr.goy;
+                        x_u = max(dgx, x_u);
+                        H[r] = max(dgy, H[r]);
+                        V[r] = x_u;
+                        D[r] = d;
                         d_ul = d_old;
-                        v_u = V[r];
                     }
                     dsave = d_next;
                     wptr[q] = make_int2(V[R - 1], D[R - 1]);
@@ -289,25 +368,28 @@ __global__ __launch_bounds__(W * 64) void nw_score_kernel(NwArgs a) {
                 store_planes(gg, rv, rd, rh);
                 publish(gg);
             };
+            if constexpr (PROFILE) { codes(g, ocX); codes(g + 1, ocY); }
+            fetch(g, ocX, inA, hdA);             // (hvd of group g was waited for by the edge's prefetch)
             while (g + 1 < g_hi) {
-                fetch(g + 1, ocB, hdB);
-                steady(g, ocA, hdA);
-                fetch(g + 2, ocA, hdA);
-                steady(g + 1, ocB, hdB);
+                fetch(g + 1, ocY, inB, hdB);
+                if constexpr (PROFILE) codes(g + 2, ocX);
+                steady(g, inA, hdA);
+                fetch(g + 2, ocX, inA, hdA);
+                if constexpr (PROFILE) codes(g + 3, ocY);
+                steady(g + 1, inB, hdB);
                 g += 2;
             }
             if (g < g_hi) {
-                fetch(g + 1, ocB, hdB);
-                steady(g, ocA, hdA);
+                steady(g, inA, hdA);
                 ++g;
-#pragma unroll
-                for (int q = 0; q < SPG; ++q) { oc_next[q] = ocB[q]; hd_next[q] = hdB[q]; }
-            } else {
-#pragma unroll
-                for (int q = 0; q < SPG; ++q) { oc_next[q] = ocA[q]; hd_next[q] = hdA[q]; }
+            }
+            if (g < ngroups) {
+                if ((g % CHK) == 0) wait_span(g);
+                load_group(g);
             }
         }
         for (; g < ngroups; ++g) group_edge(g);
+        patch(false);
     }
 }
 
@@ -346,6 +428,10 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
     CellRegs kr;
     kr.cmis = c.cmismatch; kr.cmat = c.cmatch; kr.gox6 = c.gox6; kr.goy6 = c.goy6;
     kr.clean = ~kTagMask;
+    // phase 1 leaves V~ + gox / H~ + goy in its checkpoints and planes when the gap opens are
+    // non-positive (carried cell); the tagged cell here wants V~ / H~
+    const bool carried = opens_nonpositive(c.gox, c.goy);
+    const int xadj = carried ? c.gox : 0, yadj = carried ? c.goy : 0;
     const Ws2 ws(max(n, 1), max(m, 1));
     uint8_t* const ws_p = a.ws + a.ws_off[p];
     uint8_t* const scratch = ws_p + ws.scratch;
@@ -400,10 +486,10 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
                         e = make_int2(0, bnd_D_col0(c, i_h));
                     } else {
                         const int d_ul = (j - 1 >= 1) ? rd_[it] : raw_of(bnd_D_col0(c, i_h - 1));
-                        const int h_l = (j - 1 >= 1) ? rh_[it] : raw_of(bnd_H_col0(c, i_h));
+                        const int h_l = (j - 1 >= 1) ? rh_[it] - yadj : raw_of(bnd_H_col0(c, i_h));
                         const int cs = (t_h == ro_[it]) ? c.cmatch : c.cmismatch;
                         int d, v, h;
-                        cell_update(enc_of(d_ul), enc_of(rv_[it]), enc_of(h_l), cs, c.gox6, c.goy6, d, v, h);
+                        cell_update(enc_of(d_ul), enc_of(rv_[it] - xadj), enc_of(h_l), cs, c.gox6, c.goy6, d, v, h);
                         e = make_int2(v, d);
                     }
                     hvt[j - k0] = e;
@@ -426,8 +512,8 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
         if (g0 > 0) {
             const int* stp = reinterpret_cast<const int*>(ws_p + ws.state(s, g0 / kCkGroups)) + lane;
 #pragma unroll
-            for (int rr = 0; rr < R; ++rr) { D[rr] = enc_of(stp[rr * 64]); H[rr] = enc_of(stp[(R + rr) * 64]); }
-            V[R - 1] = enc_of(stp[8 * 64]);
+            for (int rr = 0; rr < R; ++rr) { D[rr] = enc_of(stp[rr * 64]); H[rr] = enc_of(stp[(R + rr) * 64] - yadj); }
+            V[R - 1] = enc_of(stp[8 * 64] - xadj);
             dsave = enc_of(stp[9 * 64]);
         }
         const bool lane_has_rows = row0 < n;
@@ -547,23 +633,88 @@ extern "C" int64_t ta_nw2_workspace_bytes(int32_t n, int32_t m) {
     return (Ws2(n, m).total + 15) & ~(int64_t)15;
 }
 
-template <int W, typename OC>
-static hipError_t launch_score_oc(const NwArgs& a, int max_m, hipStream_t st) {
-    const size_t lds = NwLds(max_m, (int)sizeof(OC)).total;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nw_score_kernel<W, OC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
-    hipLaunchKernelGGL((nw_score_kernel<W, OC>), dim3(a.nprob), dim3(W * 64), lds, st, a);
+// one-time raise of a kernel's dynamic LDS limit (thread-safe function-local static per instantiation)
+template <typename K>
+static hipError_t allow_full_lds(K kernel) {
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return once;
+}
+
+template <int W, int MODE, bool SAMEGO, typename OC>
+static hipError_t launch_score_k(const NwArgs& a, size_t lds, hipStream_t st) {
+    hipError_t e = allow_full_lds(&nw_score_kernel<W, MODE, SAMEGO, OC>);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((nw_score_kernel<W, MODE, SAMEGO, OC>), dim3(a.nprob), dim3(W * 64), lds, st, a);
     return hipGetLastError();
 }
 
 template <int W>
-static hipError_t launch_score(const NwArgs& a, int max_m, bool codes8, hipStream_t st) {
-    return codes8 ? launch_score_oc<W, uint8_t>(a, max_m, st) : launch_score_oc<W, uint16_t>(a, max_m, st);
+static hipError_t launch_score_w(const NwArgs& a, size_t lds, bool profile, bool samego, bool codes8, hipStream_t st) {
+    if (profile) return samego ? launch_score_k<W, 2, true, uint16_t>(a, lds, st)
+                               : launch_score_k<W, 2, false, uint16_t>(a, lds, st);
+    return codes8 ? launch_score_k<W, 1, false, uint8_t>(a, lds, st)
+                  : launch_score_k<W, 1, false, uint16_t>(a, lds, st);
+}
+
+// Phase-1 launch shape.  Waves per workgroup W <= strips of the tallest problem; with the score
+// profile the LDS per workgroup grows by W x apad x 256 B, so W is the one that keeps the most
+// waves resident per CU (ties: fewer waves per workgroup = shorter pipeline ramps).
+struct P1Plan { int mode, w, apad; size_t lds; bool samego, codes8; };
+
+static P1Plan plan_phase1(int max_n, int max_m, uint32_t flags) {
+    P1Plan pl{};
+    const int nstrips = PtrLayout<4>::nstrips(max_n);
+    const int wmax = nstrips >= 8 ? 8 : nstrips >= 4 ? 4 : nstrips >= 2 ? 2 : 1;
+    pl.codes8 = (flags & TA_NW_CODES8) != 0;
+    pl.samego = (flags & TA_NW_OPENS_SAME) != 0;
+    const int alphabet = (int)((flags >> TA_NW_ALPHABET_SHIFT) & 0xFFu);
+    bool profile = alphabet > 0 && alphabet < 255;
+    const char* env = getenv("TA_NW2_PHASE1");                  // "compare": A/B timing and tests only
+    if (env && env[0] == 'c') profile = false;
+    pl.w = wmax;
+    if (profile) {
+        pl.apad = alphabet + 1;
+        int best_w = 0, best_res = 0;
+        for (int cand = wmax; cand >= 1; cand >>= 1) {
+            const size_t need = NwLds(max_m, 2, cand * pl.apad * 256).total;
+            if (need > 160 * 1024) continue;
+            const int res = (int)std::min<size_t>(32, (160 * 1024 / need) * cand);     // resident waves per CU
+            if (res >= best_res) { best_res = res; best_w = cand; }
+        }
+        // a profile that leaves fewer than 8 waves on a CU is not worth its LDS
+        if (best_w == 0 || best_res < 8) profile = false;
+        else pl.w = best_w;
+    }
+    if (const char* ew = getenv("TA_NW2_W")) {                  // tests / tuning only
+        const int v = atoi(ew);
+        if ((v == 1 || v == 2 || v == 4 || v == 8) && v <= wmax &&
+            (!profile || NwLds(max_m, 2, v * pl.apad * 256).total <= 160 * 1024))
+            pl.w = v;
+    }
+    pl.mode = profile ? 2 : 1;
+    if (!profile) pl.apad = 0;
+    pl.lds = profile ? NwLds(max_m, 2, pl.w * pl.apad * 256).total : NwLds(max_m, pl.codes8 ? 1 : 2).total;
+    return pl;
+}
+
+extern "C" int ta_nw2_phase1_plan(int32_t max_n, int32_t max_m, uint32_t flags, int32_t* out) {
+    if (!out || max_n < 0 || max_m < 0) return ta_fail(TA_EINVAL, "bad argument");
+    const P1Plan pl = plan_phase1(max_n, max_m, flags);
+    out[0] = pl.mode; out[1] = pl.w; out[2] = (int32_t)pl.lds; out[3] = pl.samego ? 1 : 0;
+    return TA_OK;
+}
+
+static hipError_t launch_score(NwArgs a, int max_n, int max_m, uint32_t flags, hipStream_t st) {
+    const P1Plan pl = plan_phase1(max_n, max_m, flags);
+    if (pl.lds > 160 * 1024) return hipErrorInvalidValue;
+    a.apad = pl.apad;
+    switch (pl.w) {
+    case 8: return launch_score_w<8>(a, pl.lds, pl.mode == 2, pl.samego, pl.codes8, st);
+    case 4: return launch_score_w<4>(a, pl.lds, pl.mode == 2, pl.samego, pl.codes8, st);
+    case 2: return launch_score_w<2>(a, pl.lds, pl.mode == 2, pl.samego, pl.codes8, st);
+    default: return launch_score_w<1>(a, pl.lds, pl.mode == 2, pl.samego, pl.codes8, st);
+    }
 }
 
 extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
@@ -586,13 +737,7 @@ extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
              ops_out, ops_off, ops_len, nprob};
     if ((flags & TA_NW_FILL) && max_n > 0 && max_m > 0) {
         if (!t_codes || !o_codes || !ws) return ta_fail(TA_EINVAL, "null code/workspace pointer");
-        const int nstrips = PtrLayout<4>::nstrips(max_n);
-        hipError_t e;
-        const bool codes8 = (flags & TA_NW_CODES8) != 0;
-        if (nstrips >= 8) e = launch_score<8>(a, max_m, codes8, st);
-        else if (nstrips >= 4) e = launch_score<4>(a, max_m, codes8, st);
-        else if (nstrips >= 2) e = launch_score<2>(a, max_m, codes8, st);
-        else e = launch_score<1>(a, max_m, codes8, st);
+        const hipError_t e = launch_score(a, max_n, max_m, flags, st);
         if (e != hipSuccess) return ta_fail_hip(e, "nw_score_kernel launch");
     }
     if (flags & TA_NW_TRACEBACK) {

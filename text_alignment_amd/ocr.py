@@ -25,6 +25,9 @@ class RecognitionError(Exception):
     pass
 
 
+MAX_CLASSES = 128        # csrc/ta_lstm.hip: kMaxCT = 8 class tiles of 16
+
+
 class LineModel(object):
     """Weights of one line-recognition model.
 
@@ -42,6 +45,10 @@ class LineModel(object):
             raise ValueError("the HIP kernels are built for ni=48, ns=100 line models")
         if self.W2.shape[1] != 1 + 2 * ns or len(self.codec) != self.no:
             raise ValueError("inconsistent output layer / codec sizes")
+        if not 2 <= self.no <= MAX_CLASSES:
+            raise ValueError("a line model needs 2..%d output classes (lstm_output_kernel holds the whole "
+                             "softmax row of a timestep in one accumulator tile); this one has %d"
+                             % (MAX_CLASSES, self.no))
 
     @classmethod
     def random(cls, seed, no=96):

@@ -169,16 +169,16 @@ def preprocess_images(input_image, despeckle_amt=host.despeckle_amt, filter_runs
     d.invert(ink)
     lab, stats = d.label(ink)                                # drop components taller than the threshold
     d.filter(ink, lab, stats, max_height=host.sat_area_thresh)
-    angle = rotation_angle_device(d, ink, -6, 6)
+    skew = rotation_angle_device(d, ink, -6, 6)
     if correct_rotation:
-        ink = rotate_device(d, ink, angle)
+        ink = rotate_device(d, ink, skew)
     eroded = ink
     for _ in range(filter_runs):
         eroded = open_runs_device(d, eroded, filter_runs_amt, 0)
         eroded = open_runs_device(d, eroded, filter_runs_amt, 1)
     if eroded is ink:
         eroded = ink.clone()
-    return d, ink, eroded, angle
+    return d, ink, eroded, host.reported_angle(skew)     # sign: see host.reported_angle
 
 
 def find_lines(input_image, device="cuda"):

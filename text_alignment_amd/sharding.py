@@ -3,10 +3,12 @@
 The reference processes pages in a plain serial loop (reference alignToOCR.py:407-438) and pages
 share nothing, so ranks never exchange data while computing: rank r takes its share of the pages
 (sorted by estimated cost, dealt round-robin), and the only collective is one variable-length
-gather of syllable-box records to rank 0 at the end -- an all-gather of the per-rank record
-counts followed by one all-gather of the padded int32 records (RCCL over xGMI when the backend
-is "nccl"; the same code runs on "gloo" for the CPU tests).  The payload is ~150 records x 24 B
-per page, i.e. latency-bound; there is deliberately no bucketing or overlap machinery.
+gather of syllable-box records to rank 0 at the end: every rank packs its int32 records into a
+tensor of a capacity all ranks derive from the transcripts alone (no size exchange, no host
+synchronisation), and one `gather` moves them (RCCL over xGMI when the backend is "nccl"; the same
+code runs on "gloo" for the CPU tests).  The payload is ~150 records x 24 B per page, i.e.
+latency-bound; there is deliberately no bucketing or overlap machinery.  (`gather_records`, the
+two-step all-gather for callers that cannot bound their record count, is kept for tools.)
 """
 import numpy as np
 import torch
@@ -103,43 +105,125 @@ def unpack_gathered(out):
     return np.concatenate([h[r, 1:1 + int(h[r, 0, 0])] for r in range(h.shape[0])], axis=0)
 
 
-def records_to_json(records, transcripts, lines_peak_locs):
+HEADER = -1              # syl_index of a page's header record
+
+
+def page_header(page_id, lines_peak_locs, nboxes):
+    """One record per processed page: the float64 `median_line_spacing` of alignToOCR.to_JSON_dict
+    (reference alignToOCR.py:338: the 75th percentile of the line gaps) as two int32 words, and the
+    page's box count -- so that rank 0 can rebuild every page's JSON from the gathered records and
+    the transcripts alone, pages without boxes included."""
+    q = np.float64(np.quantile(np.diff(lines_peak_locs), 0.75))
+    lo, hi = np.frombuffer(q.tobytes(), dtype=np.int32)
+    return np.array([[page_id, HEADER, int(lo), int(hi), int(nboxes), 0]], dtype=np.int32)
+
+
+def record_capacity(transcript):
+    """Upper bound of the records one page can emit, computable on every rank without talking:
+    the header plus one box per syllable, and a syllable has at least one non-blank character."""
+    return 1 + sum(1 for ch in transcript if not ch.isspace())
+
+
+def records_to_json(records, transcripts, lines_peak_locs=None):
     """Rank-0 side: the gathered records -> {page_id: dict laid out as alignToOCR.to_JSON_dict}.
-    transcripts[page_id] is the page's transcript string; syllable texts are recomputed here."""
+    transcripts[page_id] is the page's transcript string; syllable texts are recomputed here.
+    The line spacing comes from the page's header record (or, for records without headers, from
+    lines_peak_locs[page_id])."""
     from . import latinSyllabification as latsyl
     out = {}
     records = np.asarray(records).reshape(-1, RECORD_FIELDS)
-    for pid in sorted(set(int(r[0]) for r in records)):
-        rows = records[records[:, 0] == pid]
+    order = np.argsort(records[:, 0], kind="stable")
+    records = records[order]
+    bounds = np.flatnonzero(np.diff(records[:, 0])) + 1
+    for rows in np.split(records, bounds) if len(records) else []:
+        pid = int(rows[0, 0])
+        head = rows[rows[:, 1] == HEADER]
+        rows = rows[rows[:, 1] != HEADER]
         rows = rows[np.argsort(rows[:, 1], kind="stable")]
+        if len(head):
+            spacing = np.frombuffer(np.array(head[0, 2:4], dtype=np.int32).tobytes(), dtype=np.float64)[0]
+            assert int(head[0, 4]) == len(rows), \
+                "page %d: %d boxes announced, %d gathered" % (pid, head[0, 4], len(rows))
+        else:
+            spacing = np.quantile(np.diff(lines_peak_locs[pid]), 0.75)
         texts = [s for s in latsyl.syllabify_text(transcripts[pid]) if len(s) >= 1]
         out[pid] = {
-            "median_line_spacing": np.quantile(np.diff(lines_peak_locs[pid]), 0.75),
+            "median_line_spacing": spacing,
             "syl_boxes": [{"syl": texts[int(r[1])], "ul": [int(r[2]), int(r[3])],
                            "lr": [int(r[4]), int(r[5])]} for r in rows]}
     return out
 
 
-def process_pages(pages, transcripts, ocropus_model, seq_align_params=None, group=None):
-    """Shard `pages` over the ranks of the process group, run alignToOCR.process_batch on this
-    rank's share, gather the syllable boxes.  Returns {page index: JSON dict} on every rank
-    (rank 0 is the consumer); page indices with no boxes map to an empty syl_boxes list."""
+def estimate_cost(pg, transcript):
+    """page_cost from whatever the page object offers: strip widths of a PreparedPage, or the
+    pixel count of a raw page image (about one text line per 140 rows in the reference's scans)."""
+    strips = getattr(pg, "strips", None)
+    if strips is not None:
+        return page_cost([getattr(s, "width", 1000) for s in strips], len(transcript))
+    px = np.asarray(getattr(pg, "pixels", pg))
+    return page_cost([px.shape[1]] * max(1, px.shape[0] // 140), len(transcript))
+
+
+def _world(group):
     import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def shard_plan(costs, transcripts, world):
+    """(shards, capacity): the page indices of every rank and the record capacity of the gather,
+    both functions of the inputs alone, so every rank computes the same plan without talking."""
+    shards = [shard_indices(costs, world, r) for r in range(world)]
+    capacity = max([sum(record_capacity(transcripts[k]) for k in sh) for sh in shards] + [1])
+    return shards, capacity
+
+
+def process_shard(my_pages, my_transcripts, my_ids, my_models, capacity, seq_align_params=None,
+                  group=None, dst=0, device=None):
+    """This rank's pages (global indices `my_ids`) through alignToOCR.process_batch, one batch per
+    distinct recogniser model, then THE collective of the path: one fixed-capacity gather of the
+    box records to rank `dst`.  `capacity` must be the same on every rank (shard_plan).  Returns
+    the concatenated records on `dst`, None elsewhere."""
     from . import alignToOCR as atocr
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    rank = dist.get_rank(group) if world > 1 else 0
-    costs = [page_cost([getattr(s, "width", 1000) for s in pg.strips], len(tr))
-             for pg, tr in zip(pages, transcripts)]
-    mine = shard_indices(costs, world, rank)
-    idx = []
-    res = atocr.process_batch([pages[k] for k in mine], [transcripts[k] for k in mine],
-                              ocropus_model, seq_align_params, indices_out=idx)
-    recs = [boxes_to_records(pid, r[0], ix) for pid, r, ix in zip(mine, res, idx)]
+    import torch.distributed as dist
+    recs = []
+    by_model = {}
+    for k, mdl in enumerate(my_models):
+        by_model.setdefault(id(mdl), (mdl, []))[1].append(k)
+    for mdl, ks in by_model.values():
+        idx = []
+        res = atocr.process_batch([my_pages[k] for k in ks], [my_transcripts[k] for k in ks], mdl,
+                                  seq_align_params, indices_out=idx)
+        for k, r, ix in zip(ks, res, idx):
+            recs.append(page_header(my_ids[k], r[2], len(r[0])))
+            recs.append(boxes_to_records(my_ids[k], r[0], ix))
     local = np.concatenate(recs, axis=0) if recs else np.zeros((0, RECORD_FIELDS), np.int32)
-    allrec = gather_records(local, group)
-    peaks = {k: pages[k].lines_peak_locs for k in range(len(pages))}
-    out = records_to_json(allrec, {k: transcripts[k] for k in range(len(pages))}, peaks)
-    for k in range(len(pages)):
-        if k not in out:
-            out[k] = {"median_line_spacing": np.quantile(np.diff(peaks[k]), 0.75), "syl_boxes": []}
+    if device is None:
+        nccl = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
+        device = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    work, out = gather_to_root(pack_records_device(local, capacity, device), group=group, dst=dst)
+    return None if out is None else unpack_gathered(out)
+
+
+def process_pages(pages, transcripts, ocropus_model, seq_align_params=None, group=None, dst=0):
+    """The reference's page loop (alignToOCR.py:407-438) sharded over the ranks of the process
+    group: rank r runs alignToOCR.process_batch on its share of `pages` (heaviest first, dealt
+    round-robin), then one gather of syllable-box records to rank `dst`.  `ocropus_model` is one
+    model for all pages or a list with one per page (the reference's two manuscripts have one
+    each, alignToOCR.py:390-405).  Returns {page index: JSON dict as alignToOCR.to_JSON_dict} on
+    rank `dst` (every page present, pages without boxes with an empty list), None on other ranks."""
+    world, rank = _world(group)
+    models = list(ocropus_model) if isinstance(ocropus_model, (list, tuple)) else [ocropus_model] * len(pages)
+    if len(models) != len(pages) or len(transcripts) != len(pages):
+        raise ValueError("need one transcript (and, if a list is given, one model) per page")
+    costs = [estimate_cost(pg, tr) for pg, tr in zip(pages, transcripts)]
+    shards, capacity = shard_plan(costs, transcripts, world)
+    mine = shards[rank]
+    allrec = process_shard([pages[k] for k in mine], [transcripts[k] for k in mine], mine,
+                           [models[k] for k in mine], capacity, seq_align_params, group, dst)
+    if allrec is None:
+        return None
+    out = records_to_json(allrec, {k: transcripts[k] for k in range(len(pages))})
+    assert sorted(out) == list(range(len(pages))), "a page's header record is missing from the gather"
     return out

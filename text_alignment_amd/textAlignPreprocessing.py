@@ -203,6 +203,16 @@ def rotation_angle_projections(onebit, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
     return float(np.round(best, 3))
 
 
+def reported_angle(skew):
+    """The angle `preprocess_images` hands to `process`.  `process` maps syllable boxes back onto the
+    raw page with rotate_bbox(box, -angle, ...) (reference alignToOCR.py:327-328), whose rotation
+    x' = x cos a - y sin a, y' = x sin a + y cos a (image coordinates, y down; alignToOCR.py:104-112)
+    turns the opposite way from scipy.ndimage.rotate(img, a).  `rotate` below (and the device
+    kernel) deskew with scipy's sense, so the angle that makes rotate_bbox(-angle) the exact inverse
+    of the deskewing is minus the scipy angle that was applied."""
+    return -skew if skew != 0 else 0.0
+
+
 def rotate(onebit, angle):
     """rotate about the centre, growing the canvas to hold the whole page (as Gamera's rotate;
     alignToOCR.rotate_bbox undoes exactly this padding, reference alignToOCR.py:93-96)"""
@@ -260,14 +270,14 @@ def preprocess_images(input_image, despeckle_amt=despeckle_amt, filter_runs=1, f
     for k, sl in enumerate(objs):                              # drop components taller than the threshold
         if sl is not None and sat_area_thresh < (sl[0].stop - sl[0].start):
             ink[sl][lab[sl] == k + 1] = False
-    angle = rotation_angle_projections(ink, -6, 6)
+    skew = rotation_angle_projections(ink, -6, 6)
     if correct_rotation:
-        ink = rotate(ink, angle)
+        ink = rotate(ink, skew)
     eroded = ink.copy()
     for _ in range(filter_runs):
         eroded = filter_short_runs(eroded, filter_runs_amt)
         eroded = filter_narrow_runs(eroded, filter_runs_amt)
-    return BinImage(ink), BinImage(eroded), angle
+    return BinImage(ink), BinImage(eroded), reported_angle(skew)
 
 
 def find_lines(input_image):

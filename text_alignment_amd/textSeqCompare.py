@@ -140,7 +140,18 @@ class NWBatch(object):
         cat_o = np.concatenate(o_list) if self.nprob and o_off[-1] else np.zeros(1, np.int32)
         if (cat_t.max(initial=0) >= 65535) or (cat_o.max(initial=0) >= 65535):
             raise OverflowError("more than 65534 distinct tokens in one batch")
-        self.codes8 = bool(max(cat_t.max(initial=0), cat_o.max(initial=0)) < 255)
+        max_code = int(max(cat_t.max(initial=0), cat_o.max(initial=0)))
+        self.codes8 = bool(max_code < 255)
+        # hints for phase 1 of the two-phase aligner (include/text_alignment_amd.h): with a small
+        # alphabet, byte-sized substitution scores and no free gap opens it keeps a score profile
+        # in LDS instead of comparing token ids per cell
+        self.hints = 0
+        if p.size:
+            sub = p[:, :2] - p[:, 4:5] - p[:, 5:6]
+            if max_code < 254 and (p[:, 2:4] <= 0).all() and (np.abs(sub) <= 127).all():
+                self.hints |= (max_code + 1) << _native.TA_NW_ALPHABET_SHIFT
+            if (p[:, 2] == p[:, 3]).all():
+                self.hints |= _native.TA_NW_OPENS_SAME
         self.t_codes = dev(cat_t.astype(np.int32))
         self.o_codes = dev(cat_o.astype(np.int32))
         self.t_off = dev(t_off)
@@ -158,6 +169,8 @@ class NWBatch(object):
         flags = (_native.TA_NW_FILL if fill else 0) | (_native.TA_NW_TRACEBACK if traceback else 0)
         if self.codes8:
             flags |= _native.TA_NW_CODES8
+        if self.two_phase:
+            flags |= self.hints
         if self.wide is not None and not self.two_phase:
             flags |= _native.TA_NW_WIDE if self.wide else _native.TA_NW_NARROW
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -199,7 +212,8 @@ def perform_alignment_batch(pairs, scoring_systems=None):
     _require_gpu()
     pairs = [(list(t), list(o)) for t, o in pairs]
     if scoring_systems is None or not isinstance(scoring_systems, (list, tuple)) or \
-            (len(scoring_systems) in (4, 6) and not isinstance(scoring_systems[0], (list, tuple, np.ndarray))):
+            (len(scoring_systems) in (4, 6) and not isinstance(scoring_systems[0], (list, tuple, np.ndarray))) or \
+            (len(scoring_systems) == 5 and callable(scoring_systems[0])):
         systems = [scoring_systems] * len(pairs)
     else:
         systems = list(scoring_systems)

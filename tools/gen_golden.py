@@ -31,7 +31,7 @@ GOLD = os.path.join(REPO, "tests", "golden")
 sys.path.insert(0, REPO)
 sys.dont_write_bytecode = True          # never drop __pycache__ into the reference tree
 
-from oracle.synth import ALPHA, synth_pair  # noqa: E402
+from tools.synth import ALPHA, synth_pair  # noqa: E402
 
 
 # ----------------------------------------------------------------------------- harness
@@ -446,6 +446,57 @@ def gen_mei():
                            ((0, 0), (4, 9), (1, 2), (3, 5)), ((5, 5), (6, 6), (0, 0), (1, 1))]]}
 
 
+def gen_llocs(atocr):
+    """perform_ocr_with_ocropus (alignToOCR.py:128-184) itself, with the shell-out to ocropus-rpred
+    (:147) replaced by a stub that drops canned `_i.llocs` files (the tool's output format,
+    "%s\\t%.1f\\n" per character) where the reference then reads them: pins the .llocs -> CharBox
+    parser -- right-edge to left-edge shift, `~` / empty classes that still advance the position,
+    np.round half-to-even on x + offset_x, utf-8 -- to the reference."""
+    rng = np.random.default_rng(77)
+    alphabet = list("abcdefghilmnopqrstuv") + [" ", " ", "~", "", "\u016b", "\u0113", "^", "9", "_"]
+
+    class Strip(object):
+        def __init__(self, ox, oy, h):
+            self.offset_x, self.offset_y, self.height = ox, oy, h
+            self.saved = None
+
+        def save_image(self, path):
+            self.saved = path
+
+    cases = []
+    for c in range(6):
+        nstrips = [3, 1, 5, 2, 4, 1][c]
+        strips, files = [], []
+        for k in range(nstrips):
+            strips.append(Strip(int(rng.integers(0, 90)), 100 + 120 * k + int(rng.integers(0, 7)),
+                                int(rng.integers(30, 70))))
+            x, lines = 0.0, []
+            nchar = 0 if (c == 3 and k == 1) else int(rng.integers(1, 25))
+            for _ in range(nchar):
+                x += float(rng.integers(1, 60)) / 2.0 if rng.random() < 0.6 else float(rng.integers(1, 400)) / 10.0
+                lines.append("%s\t%.1f" % (alphabet[int(rng.integers(0, len(alphabet)))], x))
+            files.append(lines)
+        wk = "wk_llocs_%d" % c
+
+        def fake_check_call(cmd, shell=False, _files=files, _wk=wk):
+            assert shell and "ocropus-rpred" in cmd and "--llocs" in cmd and _wk in cmd
+            for k, lines in enumerate(_files):
+                with open("./%s/_%d.llocs" % (_wk, k), "w", encoding="utf-8") as f:
+                    f.write("".join(line + "\n" for line in lines))
+        os.makedirs(wk)
+        real = atocr.subprocess.check_call
+        atocr.subprocess.check_call = fake_check_call
+        try:
+            chars = atocr.perform_ocr_with_ocropus(strips, "some_model.pyrnn.gz", wk, parallel=2)
+        finally:
+            atocr.subprocess.check_call = real
+        assert [s.saved for s in strips] == ["./%s/_%d.png" % (wk, k) for k in range(nstrips)]
+        cases.append({"strips": [{"offset_x": s.offset_x, "offset_y": s.offset_y, "height": s.height,
+                                  "llocs": lines} for s, lines in zip(strips, files)],
+                      "chars": [[b.char, [int(b.ul[0]), int(b.ul[1])], [int(b.lr[0]), int(b.lr[1])]] for b in chars]})
+    return {"cases": cases}
+
+
 def speed_check(tsc):
     from oracle import nw_ref_py
     for n, m in [(500, 500), (1000, 1000)]:
@@ -487,6 +538,15 @@ def main():
         dump("preproc.json", gen_preproc())
     if not only or "mei" in only:
         dump("mei.json", gen_mei())
+    if not only or "llocs" in only:
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as scratch:
+            os.chdir(scratch)
+            try:
+                out = gen_llocs(atocr)
+            finally:
+                os.chdir(cwd)
+        dump("llocs.json", out)
     if not only or "synth" in only:
         dump("nw_synth.json", gen_nw_synth(tsc, big=args.big))
 

@@ -53,7 +53,7 @@ def main():
     import torch
     from text_alignment_amd import textSeqCompare as tsc
     from oracle import nw_oracle
-    from oracle.synth import synth_pair_ids
+    from tools.synth import synth_pair_ids
 
     rows = []
 

@@ -16,14 +16,23 @@ VOCAB = ("dominus deus meus alleluia gloria patri et filio spiritui sancto sicut
 PARAMS = [8, -1, -9, -9, -4, -4]     # cheap mismatches: a random-weight model's text still pairs up
 
 
+def page_meta(seed, nlines=30):
+    """(strip widths, transcript) of synthetic page `seed` -- all a rank needs to cost a page and to
+    size the gather, without building its pixels (sharding.shard_plan)."""
+    rng = np.random.default_rng([seed, 0])
+    widths = [int(w) for w in rng.integers(800, 2001, size=nlines)]
+    tr = " ".join(VOCAB[int(i)] for i in rng.integers(0, len(VOCAB), size=180))
+    return widths, tr
+
+
 def make_page(seed, nlines=30, raw=False):
     """raw = False: strips carry already-normalised (T, 48) rows (SURVEY 8d's OCR input);
     raw = True: strips are 60-row uint8 images as the page cutter saves them (device normaliser)."""
     from text_alignment_amd import page as page_mod
-    rng = np.random.default_rng(seed)
+    widths, tr = page_meta(seed, nlines)
+    rng = np.random.default_rng([seed, 1])
     strips = []
-    for k in range(nlines):
-        w = int(rng.integers(800, 2001))
+    for k, w in enumerate(widths):
         if raw:
             yy = np.arange(60)[:, None]
             dens = 0.6 * np.exp(-0.5 * ((yy - 30.0) / 8.0) ** 2)
@@ -31,10 +40,9 @@ def make_page(seed, nlines=30, raw=False):
             strips.append(page_mod.Strip(40, 100 + 120 * k, 60, width=w, pixels=px))
             continue
         xs = np.zeros((w + 32, 48), dtype=np.float32)
-        xs[16:16 + w] = (rng.random((w, 48)) < 0.15) * rng.random((w, 48))
+        xs[16:16 + w] = (rng.random((w, 48), dtype=np.float32) < 0.15) * rng.random((w, 48), dtype=np.float32)
         strips.append(page_mod.Strip(40, 100 + 120 * k, 60, width=2 * w, prepared=xs))
     peaks = [130 + 120 * k for k in range(nlines + 1)]
-    tr = " ".join(VOCAB[int(i)] for i in rng.integers(0, len(VOCAB), size=180))
     return page_mod.PreparedPage((2200, 3300), (2200, 3300), 0, strips, peaks), tr
 
 
@@ -68,11 +76,42 @@ class RawPage(object):
         self.dim = Image(px.shape[1], px.shape[0]).dim
 
 
-def make_recognizer():
+def make_recognizer(seed=7001, no=40):
     from text_alignment_amd import ocr
-    model = ocr.LineModel.random(7001, no=40)
+    model = ocr.LineModel.random(seed, no=no)
     model.W2[0, 0] += 4.0            # favour blanks: many short runs -> many characters
     return ocr.LineRecognizer(model)
+
+
+def setup_sharded(pages_per_rank, rank, world, seed0=100):
+    """BASELINE configs[4]: `pages_per_rank` x world synthetic pages, half read with a
+    Salzinnes-shaped model (96 classes), half with a St-Gall-shaped one (64), sharded over the
+    ranks by sharding.shard_plan.  Every rank builds only its own pages (the plan needs strip
+    widths and transcripts only).  Returns the arguments of sharding.process_shard + the transcripts."""
+    import torch
+    from text_alignment_amd import sharding
+    total = pages_per_rank * world
+    metas = [page_meta(seed0 + k) for k in range(total)]
+    transcripts = [m[1] for m in metas]
+    costs = [sharding.page_cost(m[0], len(m[1])) for m in metas]
+    shards, capacity = sharding.shard_plan(costs, transcripts, world)
+    mine = shards[rank]
+    recs = [make_recognizer(7001, 96), make_recognizer(7002, 64)]
+    job = {"pages": [make_page(seed0 + k)[0] for k in mine], "transcripts": [transcripts[k] for k in mine],
+           "ids": mine, "models": [recs[k % 2] for k in mine], "capacity": capacity,
+           "all_transcripts": transcripts, "total_pages": total}
+    sharding.process_shard(job["pages"][:2], job["transcripts"][:2], mine[:2], job["models"][:2],
+                           capacity, PARAMS)                       # warm-up (collective: every rank)
+    torch.cuda.synchronize()
+    return job
+
+
+def run_sharded(job):
+    """one timed pass: this rank's share through process_batch (one batch per model) and the single
+    gather; returns the gathered records on rank 0, None elsewhere"""
+    from text_alignment_amd import sharding
+    return sharding.process_shard(job["pages"], job["transcripts"], job["ids"], job["models"],
+                                  job["capacity"], PARAMS)
 
 
 def run(npages, seed0=100):

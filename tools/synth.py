@@ -1,4 +1,5 @@
-"""Seeded synthetic inputs shared by tests, tools/gen_golden.py and bench.py.
+"""Seeded synthetic inputs shared by tests, tools/gen_golden.py and bench.py (an input generator,
+not part of the oracle: it lives outside oracle/ so that only checkers import that package).
 
 `synth_pair` is the generator of SURVEY.md Appendix D (the recipe the golden sha256 values
 were captured with); it models an OCR read of a chant transcript with ~80 % character
