@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libta_hip.so")
+# TA_HIP_LIB: an alternative build of the same library (kernel timing experiments, tools/p1_ablate.sh)
+LIB_PATH = os.environ.get("TA_HIP_LIB") or os.path.join(_HERE, "libta_hip.so")
 
 TA_OK = 0
 TA_EINVAL, TA_ERANGE, TA_EHIP, TA_ELIMIT = -1, -2, -3, -4

@@ -105,6 +105,10 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
 #ifndef TA_P1_CHK
 #define TA_P1_CHK 4
 #endif
+#ifndef TA_P1_ABLATE
+#define TA_P1_ABLATE 0      // timing experiments only (tools/p1_ablate.sh): any bit set breaks the results
+#endif
+    constexpr int ABL = TA_P1_ABLATE;
     // groups between two looks at the progress word of the strip above: a strip follows the one
     // above at CHK + 17 groups, and the ramp of a workgroup (wave w idles w x that lag at the start,
     // the waves above idle as long at the end) is what a finer grain buys back
@@ -309,41 +313,62 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
         const int e1 = min(g_lo, ngroups);
         for (; g < e1; ++g) group_edge(g);
 
-        if (g < g_hi) {
-            // ---- steady state: every lane is inside 1 <= j <= m, no EXEC changes.  Two groups per
-            // iteration with two input buffers (A / B), so the LDS prefetch of the next group lands
-            // in the other buffer and no register copies are needed at the loop back-edge.  MODE 2
-            // reads the OCR codes one group further ahead (X / Y) and turns them into profile
-            // entries when the group's other inputs are fetched. ----
+        const int g_end = g_hi & ~3;                  // steady groups run in blocks of CHK = 4 (g_lo = 16)
+        if (g < g_end) {
+            // ---- steady state: every lane is inside 1 <= j <= m, no EXEC changes.  Blocks of four
+            // groups with two input buffers (A / B): the LDS prefetch of the next group lands in the
+            // other buffer, no register copies at the back-edge, and everything that depends on the
+            // group index -- progress wait and publish (once per block), checkpoint (every fourth
+            // block), row / code / plane addresses (running pointers) -- stays out of the groups.
+            // MODE 2 reads the OCR codes one group further ahead (X / Y) and turns them into
+            // profile entries when the group's other inputs are fetched. ----
+            static_assert(CHK == 4 && SPG == 4, "the block loop is written for 4 groups of 4 steps");
             int2* wptr = (lane == 63) ? (hvd + (g * SPG - 62)) : (dummy + lane);
             const int winc = (lane == 63) ? SPG : 0;
+            int hrd = (g * SPG + 1) * 8;                          // byte offset of the next group's hvd entries
+            int crd = (kOPad + g * SPG - lane) * (int)sizeof(LC); // byte offset of the next group's codes (per lane)
+            asm volatile("" : "+v"(hrd), "+v"(crd));              // running VGPR pointers, immediate offsets below
+            const unsigned char* const hvd_b = reinterpret_cast<const unsigned char*>(hvd);
+            const unsigned char* const oc_b = reinterpret_cast<const unsigned char*>(ocode);
+            int* pv = plane_v + 4 * (g - 15);
+            int* pd = plane_d + 4 * (g - 15);
+            int* ph = plane_h + 4 * (g - 15);
+            const int need_cap = min(ngroups, (m + 62) / SPG + 1);
+            const int need_base = prod_pass * ngroups;
             int inA[SPG], inB[SPG];              // MODE 1: OCR codes; MODE 2: packed scores of the 4 rows
             int2 hdA[SPG], hdB[SPG];
             int ocX[SPG], ocY[SPG];
-            auto codes = [&](int gn, int (&oc)[SPG]) {
-                const int idx = kOPad + gn * SPG - lane;    // stays inside ocode[]: gn <= m / SPG + 2
+            auto codes = [&](int (&oc)[SPG]) {                    // codes of the next group not yet read
 #pragma unroll
-                for (int q = 0; q < SPG; ++q) oc[q] = ocode[idx + q];
+                for (int q = 0; q < SPG; ++q) oc[q] = *reinterpret_cast<const LC*>(oc_b + crd + q * (int)sizeof(LC));
+                crd += SPG * (int)sizeof(LC);
             };
-            auto fetch = [&](int gn, const int (&oc)[SPG], int (&in)[SPG], int2 (&hd)[SPG]) {   // inputs of group gn
-                if (gn < ngroups) {
-                    if ((gn % CHK) == 0) wait_span(gn);
-                    const int idx = kOPad + gn * SPG - lane;
+            auto fetch = [&](const int (&oc)[SPG], int (&in)[SPG], int2 (&hd)[SPG]) {   // inputs of the next group
 #pragma unroll
-                    for (int q = 0; q < SPG; ++q) {
-                        if constexpr (PROFILE) in[q] = *reinterpret_cast<const int*>(tbl_lane + oc[q]);
-                        else in[q] = ocode[idx + q];
-                        hd[q] = hvd[min(gn * SPG + q + 1, m)];
-                    }
+                for (int q = 0; q < SPG; ++q) {
+                    if constexpr (PROFILE) in[q] = (ABL & 2) ? oc[q] : *reinterpret_cast<const int*>(tbl_lane + oc[q]);
+                    else in[q] = oc[q];
+                    hd[q] = *reinterpret_cast<const int2*>(hvd_b + hrd + q * 8);
+                }
+                hrd += SPG * 8;
+            };
+            auto wait_block = [&](int g_first) {                  // wait_span without the edge clamps
+                if (W == 1 || s == 0 || (ABL & 8)) return;
+                const int need = need_base + min(need_cap, g_first + CHK + 17);
+                while (true) {
+                    const int have = __hip_atomic_load(&prog[prev_wave], __ATOMIC_ACQUIRE,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (__builtin_amdgcn_readfirstlane(have) >= need) break;
+                    __builtin_amdgcn_s_sleep(2);
                 }
             };
-            auto steady = [&](int gg, const int (&in)[SPG], const int2 (&hd)[SPG]) {
-                checkpoint(gg);
+            auto steady = [&](const int (&in)[SPG], const int2 (&hd)[SPG]) {
                 int rv[SPG], rd[SPG], rh[SPG];
 #pragma unroll
                 for (int q = 0; q < SPG; ++q) {
                     int x_up = hd[q].x, d_next = hd[q].y;
-                    wave_shr1_pair<1>(x_up, V[R - 1], d_next, D[R - 1]);
+                    if (!(ABL & 16)) wave_shr1_pair<1>(x_up, V[R - 1], d_next, D[R - 1]);
+                    else { x_up += V[R - 1]; d_next += D[R - 1]; }
                     int d_ul = dsave, x_u = x_up;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
@@ -361,27 +386,37 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
                         d_ul = d_old;
                     }
                     dsave = d_next;
-                    wptr[q] = make_int2(V[R - 1], D[R - 1]);
+                    if (!(ABL & 1)) wptr[q] = make_int2(V[R - 1], D[R - 1]);
                     rv[q] = V[R - 2]; rd[q] = D[R - 2]; rh[q] = H[R - 1];
                 }
                 wptr += winc;
-                store_planes(gg, rv, rd, rh);
-                publish(gg);
+                if (!(ABL & 4) && lane == 63) {
+                    *reinterpret_cast<int4*>(pv) = make_int4(rv[0], rv[1], rv[2], rv[3]);
+                    *reinterpret_cast<int4*>(pd) = make_int4(rd[0], rd[1], rd[2], rd[3]);
+                    *reinterpret_cast<int4*>(ph) = make_int4(rh[0], rh[1], rh[2], rh[3]);
+                }
+                pv += 4; pd += 4; ph += 4;
             };
-            if constexpr (PROFILE) { codes(g, ocX); codes(g + 1, ocY); }
-            fetch(g, ocX, inA, hdA);             // (hvd of group g was waited for by the edge's prefetch)
-            while (g + 1 < g_hi) {
-                fetch(g + 1, ocY, inB, hdB);
-                if constexpr (PROFILE) codes(g + 2, ocX);
-                steady(g, inA, hdA);
-                fetch(g + 2, ocX, inA, hdA);
-                if constexpr (PROFILE) codes(g + 3, ocY);
-                steady(g + 1, inB, hdB);
-                g += 2;
-            }
-            if (g < g_hi) {
-                steady(g, inA, hdA);
-                ++g;
+            // (hvd of group g was waited for by the last edge group's prefetch)
+            if constexpr (PROFILE) { codes(ocX); codes(ocY); fetch(ocX, inA, hdA); }
+            else { codes(ocX); fetch(ocX, inA, hdA); }
+            for (; g < g_end; g += CHK) {
+                if (!(ABL & 4) && (g & (kCkGroups - 1)) == 0) checkpoint(g);
+                if constexpr (PROFILE) {
+                    fetch(ocY, inB, hdB); codes(ocX); steady(inA, hdA);
+                    if (!(ABL & 8)) publish(g);
+                    fetch(ocX, inA, hdA); codes(ocY); steady(inB, hdB);
+                    fetch(ocY, inB, hdB); codes(ocX); steady(inA, hdA);
+                    wait_block(g + CHK);
+                    fetch(ocX, inA, hdA); codes(ocY); steady(inB, hdB);
+                } else {
+                    codes(ocY); fetch(ocY, inB, hdB); steady(inA, hdA);
+                    if (!(ABL & 8)) publish(g);
+                    codes(ocX); fetch(ocX, inA, hdA); steady(inB, hdB);
+                    codes(ocY); fetch(ocY, inB, hdB); steady(inA, hdA);
+                    wait_block(g + CHK);
+                    codes(ocX); fetch(ocX, inA, hdA); steady(inB, hdB);
+                }
             }
             if (g < ngroups) {
                 if ((g % CHK) == 0) wait_span(g);
