@@ -99,6 +99,9 @@ int ta_nw_batch(const int32_t* t_codes, const int64_t* t_off,
  * 1 B/cell pointer matrix).  TA_NW_FILL = phase 1, TA_NW_TRACEBACK = phase 2.
  */
 int64_t ta_nw2_workspace_bytes(int32_t n, int32_t m);
+/* widest OCR string ta_nw2_batch takes (its LDS holds the OCR codes only; the hand-off rows between
+ * strips live in the workspace) */
+int32_t ta_nw2_max_m(void);
 int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
                  const int32_t* o_codes, const int64_t* o_off, int32_t nprob,
                  const int32_t* params, int32_t params_stride,

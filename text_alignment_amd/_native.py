@@ -46,6 +46,8 @@ def _load():
     lib.ta_nw_batch.restype = ctypes.c_int
     lib.ta_nw_batch.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp,
                                 i32, i32, i64, u32, vp]
+    lib.ta_nw2_max_m.restype = i32
+    lib.ta_nw2_max_m.argtypes = []
     lib.ta_nw2_workspace_bytes.restype = i64
     lib.ta_nw2_workspace_bytes.argtypes = [i32, i32]
     lib.ta_nw2_batch.restype = ctypes.c_int
@@ -87,7 +89,7 @@ def _load():
 
 lib = _load()
 
-EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_batch", "ta_nw2_phase1_plan",
+EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_max_m", "ta_nw2_batch", "ta_nw2_phase1_plan",
            "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general",
            "ta_lstm_packed_weight_floats", "ta_lstm_forward", "ta_lstm_output", "ta_decode",
            "ta_decode_summary", "ta_linenorm_measure", "ta_linenorm_resample",

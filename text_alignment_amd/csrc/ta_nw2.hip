@@ -35,7 +35,7 @@ constexpr int kStateInts = 10;                // D[4], H[4], V[3], dsave
 // per-problem layout of the phase-1/2 workspace (all offsets in bytes, 16-byte aligned)
 struct Ws2 {
     int nstrips, ngroups, nck, mrow;
-    int64_t rowck, stck, scratch, total;
+    int64_t rowck, stck, scratch, hrow, total;
     __host__ __device__ Ws2(int n, int m) {
         using L = PtrLayout<4>;
         nstrips = L::nstrips(n);
@@ -45,7 +45,10 @@ struct Ws2 {
         rowck = 0;
         stck = rowck + (int64_t)nstrips * 3 * mrow * 4;
         scratch = stck + (int64_t)nstrips * nck * kStateInts * 64 * 4;
-        total = scratch + (int64_t)kWinGroups * 1024;
+        // phase 1's hand-off row: (XG, D) of the row above the strip a wave is in, entry j at
+        // index j + 1 (so that the four entries a group reads start on a 16-byte boundary)
+        hrow = scratch + (int64_t)kWinGroups * 1024;
+        total = hrow + (((int64_t)(m + 8) * 8 + 15) & ~(int64_t)15);
     }
     __host__ __device__ int64_t row_plane(int s, int plane) const {       // int index base, entry j at +j+2
         return rowck + ((int64_t)(s * 3 + plane) * mrow) * 4;
@@ -78,6 +81,17 @@ __device__ __forceinline__ void cell_carried_hw(const RawRegs& k, int d_ul, int 
 }
 
 __host__ __device__ inline bool fits_i8(int v) { return v >= -128 && v <= 127; }
+
+// LDS carve of phase 1 (dynamic): code ocode[kOPad+m+kOTail] | int prog[16] | uint32 profile[waves][apad][64]
+// (the hand-off row between strips lives in the workspace -- L2 -- not in LDS: Ws2::hrow)
+struct P1Lds {
+    size_t oc_bytes, tbl_off, total;
+    __host__ __device__ explicit P1Lds(int m, int code_bytes, int tbl_bytes = 0) {
+        oc_bytes = ((size_t)(kOPad + m + kOTail) * code_bytes + 15) & ~(size_t)15;
+        tbl_off = oc_bytes + 64;
+        total = tbl_off + (size_t)tbl_bytes;
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // phase 1
@@ -137,12 +151,17 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
     // two v_mov per step, 8 % of the loop's VALU instructions)
     if (!PROFILE) asm volatile("" : "+v"(kr.cmis), "+v"(kr.cmat));
 
-    const NwLds lds(m, (int)sizeof(LC));
-    int2* hvd = reinterpret_cast<int2*>(smem);
-    int2* dummy = reinterpret_cast<int2*>(smem + lds.hvd_bytes);
-    LC* ocode = reinterpret_cast<LC*>(smem + lds.hvd_bytes + lds.dummy_bytes);
-    int* prog = reinterpret_cast<int*>(smem + lds.hvd_bytes + lds.dummy_bytes + lds.oc_bytes);
+    const P1Lds lds(m, (int)sizeof(LC));
+    LC* ocode = reinterpret_cast<LC*>(smem);
+    int* prog = reinterpret_cast<int*>(smem + lds.oc_bytes);
     uint32_t* tbl = reinterpret_cast<uint32_t*>(smem + lds.tbl_off);
+    const Ws2 ws(n, m);
+    uint8_t* const ws_p = a.ws + a.ws_off[p];
+    // Hand-off row between consecutive strips, in place, in the workspace (it stays in L2): a wave
+    // reads entry j (what the strip above left) long before its own lane 63 overwrites it.  All waves
+    // of a workgroup share one CU and its L1, so the workgroup-scope release / acquire on the
+    // progress words (LDS) is all the ordering these plain loads and stores need.
+    int2* const hvd = reinterpret_cast<int2*>(ws_p + ws.hrow) + 1;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -166,8 +185,6 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
     uint32_t* const tblw = tbl + (size_t)wave * apad * 64;                   // this wave's profile
     const unsigned char* const tbl_lane = reinterpret_cast<const unsigned char*>(tblw) + lane * 4;
 
-    const Ws2 ws(n, m);
-    uint8_t* const ws_p = a.ws + a.ws_off[p];
     const int nstrips = ws.nstrips, ngroups = ws.ngroups;
     const int prev_wave = (wave + W - 1) % W;
     const int g_lo = (63 + SPG - 1) / SPG;
@@ -323,12 +340,10 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
             // MODE 2 reads the OCR codes one group further ahead (X / Y) and turns them into
             // profile entries when the group's other inputs are fetched. ----
             static_assert(CHK == 4 && SPG == 4, "the block loop is written for 4 groups of 4 steps");
-            int2* wptr = (lane == 63) ? (hvd + (g * SPG - 62)) : (dummy + lane);
-            const int winc = (lane == 63) ? SPG : 0;
-            int hrd = (g * SPG + 1) * 8;                          // byte offset of the next group's hvd entries
+            const int4* hrp = reinterpret_cast<const int4*>(hvd + (g * SPG + 1));   // next group's 4 entries (16-B aligned)
+            int2* hwp = hvd + (g * SPG - 62);                      // lane 63's columns of the group being computed
             int crd = (kOPad + g * SPG - lane) * (int)sizeof(LC); // byte offset of the next group's codes (per lane)
-            asm volatile("" : "+v"(hrd), "+v"(crd));              // running VGPR pointers, immediate offsets below
-            const unsigned char* const hvd_b = reinterpret_cast<const unsigned char*>(hvd);
+            asm volatile("" : "+v"(crd));                         // a running VGPR pointer, immediate offsets below
             const unsigned char* const oc_b = reinterpret_cast<const unsigned char*>(ocode);
             int* pv = plane_v + 4 * (g - 15);
             int* pd = plane_d + 4 * (g - 15);
@@ -348,9 +363,11 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
                 for (int q = 0; q < SPG; ++q) {
                     if constexpr (PROFILE) in[q] = (ABL & 2) ? oc[q] : *reinterpret_cast<const int*>(tbl_lane + oc[q]);
                     else in[q] = oc[q];
-                    hd[q] = *reinterpret_cast<const int2*>(hvd_b + hrd + q * 8);
                 }
-                hrd += SPG * 8;
+                const int4 e01 = hrp[0], e23 = hrp[1];
+                hd[0] = make_int2(e01.x, e01.y); hd[1] = make_int2(e01.z, e01.w);
+                hd[2] = make_int2(e23.x, e23.y); hd[3] = make_int2(e23.z, e23.w);
+                hrp += 2;
             };
             auto wait_block = [&](int g_first) {                  // wait_span without the edge clamps
                 if (W == 1 || s == 0 || (ABL & 8)) return;
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
                 }
             };
             auto steady = [&](const int (&in)[SPG], const int2 (&hd)[SPG]) {
-                int rv[SPG], rd[SPG], rh[SPG];
+                int rv[SPG], rd[SPG], rh[SPG], bv[SPG], bd[SPG];
 #pragma unroll
                 for (int q = 0; q < SPG; ++q) {
                     int x_up = hd[q].x, d_next = hd[q].y;
@@ -386,16 +403,21 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
                         d_ul = d_old;
                     }
                     dsave = d_next;
-                    if (!(ABL & 1)) wptr[q] = make_int2(V[R - 1], D[R - 1]);
+                    bv[q] = V[R - 1]; bd[q] = D[R - 1];
                     rv[q] = V[R - 2]; rd[q] = D[R - 2]; rh[q] = H[R - 1];
                 }
-                wptr += winc;
-                if (!(ABL & 4) && lane == 63) {
-                    *reinterpret_cast<int4*>(pv) = make_int4(rv[0], rv[1], rv[2], rv[3]);
-                    *reinterpret_cast<int4*>(pd) = make_int4(rd[0], rd[1], rd[2], rd[3]);
-                    *reinterpret_cast<int4*>(ph) = make_int4(rh[0], rh[1], rh[2], rh[3]);
+                if (lane == 63) {                                  // the strip's bottom rows, by their owner
+                    if (!(ABL & 1)) {
+#pragma unroll
+                        for (int q = 0; q < SPG; ++q) hwp[q] = make_int2(bv[q], bd[q]);
+                    }
+                    if (!(ABL & 4)) {
+                        *reinterpret_cast<int4*>(pv) = make_int4(rv[0], rv[1], rv[2], rv[3]);
+                        *reinterpret_cast<int4*>(pd) = make_int4(rd[0], rd[1], rd[2], rd[3]);
+                        *reinterpret_cast<int4*>(ph) = make_int4(rh[0], rh[1], rh[2], rh[3]);
+                    }
                 }
-                pv += 4; pd += 4; ph += 4;
+                hwp += SPG; pv += 4; pd += 4; ph += 4;
             };
             // (hvd of group g was waited for by the last edge group's prefetch)
             if constexpr (PROFILE) { codes(ocX); codes(ocY); fetch(ocX, inA, hdA); }
@@ -663,6 +685,9 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
 
 using namespace ta;
 
+// widest problem of the two-phase aligner: its LDS holds the OCR codes (2 B each) only
+extern "C" int32_t ta_nw2_max_m(void) { return 65000; }
+
 extern "C" int64_t ta_nw2_workspace_bytes(int32_t n, int32_t m) {
     if (n <= 0 || m <= 0) return 16;
     return (Ws2(n, m).total + 15) & ~(int64_t)15;
@@ -693,8 +718,8 @@ static hipError_t launch_score_w(const NwArgs& a, size_t lds, bool profile, bool
 }
 
 // Phase-1 launch shape.  Waves per workgroup W <= strips of the tallest problem; with the score
-// profile the LDS per workgroup grows by W x apad x 256 B, so W is the one that keeps the most
-// waves resident per CU (ties: fewer waves per workgroup = shorter pipeline ramps).
+// profile the LDS per workgroup is W x apad x 256 B + the codes, so W is the one that keeps the most
+// waves resident per CU.
 struct P1Plan { int mode, w, apad; size_t lds; bool samego, codes8; };
 
 static P1Plan plan_phase1(int max_n, int max_m, uint32_t flags) {
@@ -711,11 +736,13 @@ static P1Plan plan_phase1(int max_n, int max_m, uint32_t flags) {
     if (profile) {
         pl.apad = alphabet + 1;
         int best_w = 0, best_res = 0;
-        for (int cand = wmax; cand >= 1; cand >>= 1) {
-            const size_t need = NwLds(max_m, 2, cand * pl.apad * 256).total;
+        for (int cand : {4, 8, 2, 1}) {            // order of preference among equals (measured: 4 >= 8 > 2)
+            if (cand > wmax) continue;
+            const size_t need = P1Lds(max_m, 2, cand * pl.apad * 256).total;
             if (need > 160 * 1024) continue;
-            const int res = (int)std::min<size_t>(32, (160 * 1024 / need) * cand);     // resident waves per CU
-            if (res >= best_res) { best_res = res; best_w = cand; }
+            // resident waves per CU: whole workgroups, within the LDS and within 5 waves per SIMD (VGPRs)
+            const int res = (int)std::min<size_t>(160 * 1024 / need, 20 / cand) * cand;
+            if (res > best_res) { best_res = res; best_w = cand; }
         }
         // a profile that leaves fewer than 8 waves on a CU is not worth its LDS
         if (best_w == 0 || best_res < 8) profile = false;
@@ -724,12 +751,12 @@ static P1Plan plan_phase1(int max_n, int max_m, uint32_t flags) {
     if (const char* ew = getenv("TA_NW2_W")) {                  // tests / tuning only
         const int v = atoi(ew);
         if ((v == 1 || v == 2 || v == 4 || v == 8) && v <= wmax &&
-            (!profile || NwLds(max_m, 2, v * pl.apad * 256).total <= 160 * 1024))
+            (!profile || P1Lds(max_m, 2, v * pl.apad * 256).total <= 160 * 1024))
             pl.w = v;
     }
     pl.mode = profile ? 2 : 1;
     if (!profile) pl.apad = 0;
-    pl.lds = profile ? NwLds(max_m, 2, pl.w * pl.apad * 256).total : NwLds(max_m, pl.codes8 ? 1 : 2).total;
+    pl.lds = profile ? P1Lds(max_m, 2, pl.w * pl.apad * 256).total : P1Lds(max_m, pl.codes8 ? 1 : 2).total;
     return pl;
 }
 
@@ -766,7 +793,7 @@ extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
     if (params_stride != 0 && params_stride != 6) return ta_fail(TA_EINVAL, "params_stride must be 0 or 6");
     if (score_bound < 0 || score_bound >= (1ll << 23))
         return ta_fail(TA_ERANGE, "(n+m+2)*max|param| does not fit the 32-bit encoded scores");
-    if (max_m > ta_nw_max_m()) return ta_fail(TA_ELIMIT, "m exceeds the LDS hand-off row capacity");
+    if (max_m > ta_nw2_max_m()) return ta_fail(TA_ELIMIT, "m exceeds the LDS capacity for the OCR codes");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     NwArgs a{t_codes, t_off, o_codes, o_off, params, params_stride, ws, ws_off,
              ops_out, ops_off, ops_len, nprob};

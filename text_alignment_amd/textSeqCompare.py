@@ -102,7 +102,8 @@ class NWBatch(object):
         # is 8x smaller.  Measured break-even on MI355X: total cells ~ 3.5e8 x strips.
         if two_phase is None:
             nstrips = (self.max_n + 255) // 256
-            two_phase = (self.cells > 3.5e8 * nstrips) or (self.cells > 64e9)
+            two_phase = (self.cells > 3.5e8 * nstrips) or (self.cells > 64e9) or \
+                (self.max_m > _native.lib.ta_nw_max_m())       # wider than the one-pass kernel's LDS row
         self.two_phase = bool(two_phase)
         # one-pass launch shape: None = library default (a problem is spread over several
         # workgroups when the batch has fewer problems than the GPU has CUs), True / False force it
@@ -119,8 +120,8 @@ class NWBatch(object):
             raise OverflowError("scoring parameters too large for the integer kernels")
         if self.score_bound >= 2 ** 23:
             raise OverflowError("(n+m+2)*max|param| does not fit the 32-bit encoded scores")
-        if self.max_m > _native.lib.ta_nw_max_m():
-            raise OverflowError("OCR string longer than the LDS hand-off row of the integer kernels")
+        if self.max_m > (_native.lib.ta_nw2_max_m() if self.two_phase else _native.lib.ta_nw_max_m()):
+            raise OverflowError("OCR string longer than the integer kernels take")
 
         lib = _native.lib
         t_off = np.zeros(self.nprob + 1, dtype=np.int64); np.cumsum(self.n, out=t_off[1:])
