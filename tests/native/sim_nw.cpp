@@ -127,7 +127,7 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
     const int nstrips = L::nstrips(n), ngroups = L::ngroups(m);
     const int nck = ngroups / KCG + 1;
     struct State { int D[kLanes][R], H[kLanes][R], Vlast[kLanes], dsave[kLanes]; };
-    std::vector<State> ck((size_t)std::max(nstrips, 1) * nck);
+    std::vector<State> ck_((size_t)std::max(nstrips, 1) * nck);
     // row planes of lane 63: index [strip][j], j = 0..m
     std::vector<int> RV2((size_t)std::max(nstrips, 1) * (m + 2)), RD2(RV2.size()), RH3(RV2.size());
 
@@ -152,7 +152,7 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
             }
             for (int g = 0; g < ngroups; ++g) {
                 if (g > 0 && g % KCG == 0) {
-                    State& st = ck[(size_t)s * nck + g / KCG];
+                    State& st = ck_[(size_t)s * nck + g / KCG];
                     for (int l = 0; l < kLanes; ++l) {
                         for (int r = 0; r < R; ++r) { st.D[l][r] = D[l][r]; st.H[l][r] = H[l][r]; }
                         st.Vlast[l] = V[l][R - 1]; st.dsave[l] = dsave[l];
@@ -198,107 +198,127 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
         }
     }
 
-    // ---------------- phase 2: windowed tagged re-fill + walk ----------------
+    // ---------------- phase 2: chunked tagged re-fill + walk (nw_trace2_kernel's data flow) ----------------
+    // A chunk = the KCG groups between two state checkpoints.  The chunk the walk is in is re-filled
+    // with the tagged cell from its checkpoint (in carried form when phase 1 used it); its first two
+    // steps carry no valid tags, so when the walk gets there the chunk before is re-filled one group
+    // further (g_top = the first group of the chunk just left).  (GSPAN is unused by this data flow.)
+    (void)GSPAN;
+    const int xadj6 = xadj * 64, yadj6 = yadj * 64;
     std::vector<uint8_t> rev;
     int x = n, y = m, st = 0;
     bool first = true;
     int guard = 0;
     while (x > 0 && y > 0) {
-        if (++guard > 4 * (n + m) + 16) return -9;
         const int s = (x - 1) / L::SR;
         int l = ((x - 1) % L::SR) / R, r = (x - 1) % R, k = (y - 1) + l;
-        const int g_in = k / SPG;
-        const int g0 = KCG * (std::max(0, g_in - GSPAN) / KCG);
-        const int k0 = g0 * SPG;
-        const int kvalid = g0 > 0 ? k0 + 2 : 0;
         const int i_h = s * L::SR;                        // row above the strip (1-based index)
-        // tagged hand-off row for columns k0 .. min(m, (g_in+1)*SPG)
-        const int jhi = std::min(m, (g_in + 1) * SPG);
-        std::vector<int> hvt(m + 2, 0), hdt(m + 2, 0);
-        for (int j = std::max(0, k0); j <= jhi; ++j) {
-            if (s == 0) { hvt[j] = bnd_V_row0(c, j); hdt[j] = bnd_D_row0(c, j); continue; }
-            if (j == 0) { hdt[0] = bnd_D_col0(c, i_h); continue; }
-            const size_t b = (size_t)(s - 1) * (m + 2);
-            const int d_ul = (j - 1 >= 1) ? RD2[b + j - 1] : raw_of(bnd_D_col0(c, i_h - 1));
-            const int v_u = RV2[b + j] - xadj;
-            const int h_l = (j - 1 >= 1) ? RH3[b + j - 1] - yadj : raw_of(bnd_H_col0(c, i_h));
-            const int cs = (t[i_h - 1] == o[j - 1]) ? c.cmatch : c.cmismatch;
-            int d, v, h;
-            cell_update(enc_of(d_ul), enc_of(v_u), enc_of(h_l), cs, c.gox6, c.goy6, d, v, h);
-            hvt[j] = v; hdt[j] = d;
-        }
-        // lane state at the start of group g0
-        int D[kLanes][R], V[kLanes][R], H[kLanes][R], tcode[kLanes][R], dsave[kLanes];
-        for (int ll = 0; ll < kLanes; ++ll) {
-            for (int rr = 0; rr < R; ++rr) {
-                const int i = s * L::SR + ll * R + rr + 1;
-                tcode[ll][rr] = (i <= n) ? t[i - 1] : -1;
-                V[ll][rr] = 0;
-                if (g0 == 0) { D[ll][rr] = bnd_D_col0(c, i); H[ll][rr] = bnd_H_col0(c, i); }
+        int ck = (k / SPG) / KCG;
+        int g_top = k / SPG;
+        bool in_strip = true;
+        while (in_strip) {
+            if (++guard > 8 * (n + m) + 64) return -9;
+            const int g0 = ck * KCG, k0 = g0 * SPG;
+            const int kvalid = ck > 0 ? k0 + 2 : 0;
+            // tagged hand-off row for columns k0 .. min(m, (g_top+1)*SPG), x-input in the re-fill's form
+            const int jhi = std::min(m, (g_top + 1) * SPG);
+            std::vector<int> hvt(m + 2, 0), hdt(m + 2, 0);
+            for (int j = std::max(0, k0); j <= jhi; ++j) {
+                if (s == 0) { hvt[j] = bnd_V_row0(c, j) + xadj6; hdt[j] = bnd_D_row0(c, j); continue; }
+                if (j == 0) { hdt[0] = bnd_D_col0(c, i_h); continue; }
+                const size_t b = (size_t)(s - 1) * (m + 2);
+                const int d_ul = (j - 1 >= 1) ? RD2[b + j - 1] : raw_of(bnd_D_col0(c, i_h - 1));
+                const int v_u = RV2[b + j] - xadj;
+                const int h_l = (j - 1 >= 1) ? RH3[b + j - 1] - yadj : raw_of(bnd_H_col0(c, i_h));
+                const int cs = (t[i_h - 1] == o[j - 1]) ? c.cmatch : c.cmismatch;
+                int d, v, h;
+                cell_update(enc_of(d_ul), enc_of(v_u), enc_of(h_l), cs, c.gox6, c.goy6, d, v, h);
+                hvt[j] = v + xadj6; hdt[j] = d;
             }
-            if (g0 == 0) dsave[ll] = bnd_D_col0(c, s * L::SR + ll * R);
-        }
-        if (g0 > 0) {
-            const State& cs0 = ck[(size_t)s * nck + g0 / KCG];
+            // lane state at the start of group g0
+            int D[kLanes][R], V[kLanes][R], H[kLanes][R], tcode[kLanes][R], dsave[kLanes];
             for (int ll = 0; ll < kLanes; ++ll) {
-                for (int rr = 0; rr < R; ++rr) { D[ll][rr] = enc_of(cs0.D[ll][rr]); H[ll][rr] = enc_of(cs0.H[ll][rr] - yadj); }
-                V[ll][R - 1] = enc_of(cs0.Vlast[ll] - xadj); dsave[ll] = enc_of(cs0.dsave[ll]);
-            }
-        }
-        // tagged fill of groups g0..g_in into a window buffer
-        std::vector<uint8_t> wbuf((size_t)(g_in - g0 + 1) * 1024, 0xEE);
-        for (int g = g0; g <= g_in; ++g) {
-            uint8_t acc[kLanes][16];
-            memset(acc, 0xEE, sizeof(acc));
-            for (int q = 0; q < SPG; ++q) {
-                const int kk = g * SPG + q;
-                int vup[kLanes], dnext[kLanes];
-                for (int ll = 0; ll < kLanes; ++ll) {
-                    const int j = kk - ll + 1;
-                    if (ll == 0) { const int jj = std::min(std::max(j, 0), m); vup[ll] = hvt[jj]; dnext[ll] = hdt[jj]; }
-                    else { vup[ll] = V[ll - 1][R - 1]; dnext[ll] = D[ll - 1][R - 1]; }
+                for (int rr = 0; rr < R; ++rr) {
+                    const int i = s * L::SR + ll * R + rr + 1;
+                    tcode[ll][rr] = (i <= n) ? t[i - 1] : -1;
+                    V[ll][rr] = 0;
+                    D[ll][rr] = bnd_D_col0(c, i); H[ll][rr] = bnd_H_col0(c, i) + yadj6;
                 }
-                int nD[kLanes][R], nV[kLanes][R], nH[kLanes][R];
-                bool act[kLanes];
-                for (int ll = 0; ll < kLanes; ++ll) {
-                    const int j = kk - ll + 1;
-                    act[ll] = (j >= 1 && j <= m);
-                    if (!act[ll]) continue;
-                    int d_ul = dsave[ll], v_u = vup[ll];
-                    for (int rr = 0; rr < R; ++rr) {
-                        const int cs = (tcode[ll][rr] == o[j - 1]) ? c.cmatch : c.cmismatch;
-                        int d, v, h;
-                        const unsigned b = cell_update(d_ul, v_u, H[ll][rr], cs, c.gox6, c.goy6, d, v, h);
-                        acc[ll][q * R + rr] = (uint8_t)(b & 0x3F);
-                        d_ul = D[ll][rr]; v_u = v;
-                        nD[ll][rr] = d; nV[ll][rr] = v; nH[ll][rr] = h;
+                dsave[ll] = bnd_D_col0(c, s * L::SR + ll * R);
+            }
+            if (g0 > 0) {
+                // lanes that have not started by step k0 (lane >= k0: only with checkpoint periods
+                // shorter than 64 steps) keep the TAGGED boundary values: the scores are the same
+                // and their column-0 tags are pointers of the column-1 cells
+                const State& cs0 = ck_[(size_t)s * nck + g0 / KCG];
+                for (int ll = 0; ll < std::min(kLanes, k0); ++ll) {
+                    for (int rr = 0; rr < R; ++rr) { D[ll][rr] = enc_of(cs0.D[ll][rr]); H[ll][rr] = enc_of(cs0.H[ll][rr]); }
+                    V[ll][R - 1] = enc_of(cs0.Vlast[ll]); dsave[ll] = enc_of(cs0.dsave[ll]);
+                }
+            }
+            // tagged fill of groups g0..g_top into the chunk buffer
+            std::vector<uint8_t> wbuf((size_t)(g_top - g0 + 1) * 1024, 0xEE);
+            for (int g = g0; g <= g_top; ++g) {
+                uint8_t acc[kLanes][16];
+                memset(acc, 0xEE, sizeof(acc));
+                for (int q = 0; q < SPG; ++q) {
+                    const int kk = g * SPG + q;
+                    int vup[kLanes], dnext[kLanes];
+                    for (int ll = 0; ll < kLanes; ++ll) {
+                        const int j = kk - ll + 1;
+                        if (ll == 0) { const int jj = std::min(std::max(j, 0), m); vup[ll] = hvt[jj]; dnext[ll] = hdt[jj]; }
+                        else { vup[ll] = V[ll - 1][R - 1]; dnext[ll] = D[ll - 1][R - 1]; }
+                    }
+                    int nD[kLanes][R], nV[kLanes][R], nH[kLanes][R];
+                    bool act[kLanes];
+                    for (int ll = 0; ll < kLanes; ++ll) {
+                        const int j = kk - ll + 1;
+                        act[ll] = (j >= 1 && j <= m);
+                        if (!act[ll]) continue;
+                        int d_ul = dsave[ll], v_u = vup[ll];
+                        for (int rr = 0; rr < R; ++rr) {
+                            const int cs = (tcode[ll][rr] == o[j - 1]) ? c.cmatch : c.cmismatch;
+                            int d, v, h;
+                            const unsigned b = carried
+                                ? cell_update_carried_tagged(d_ul, v_u, H[ll][rr], cs, c.gox6, c.goy6, d, v, h)
+                                : cell_update(d_ul, v_u, H[ll][rr], cs, c.gox6, c.goy6, d, v, h);
+                            acc[ll][q * R + rr] = (uint8_t)(b & 0x3F);
+                            d_ul = D[ll][rr]; v_u = v;
+                            nD[ll][rr] = d; nV[ll][rr] = v; nH[ll][rr] = h;
+                        }
+                    }
+                    for (int ll = 0; ll < kLanes; ++ll) {
+                        if (!act[ll]) continue;
+                        for (int rr = 0; rr < R; ++rr) { D[ll][rr] = nD[ll][rr]; V[ll][rr] = nV[ll][rr]; H[ll][rr] = nH[ll][rr]; }
+                        dsave[ll] = dnext[ll];
                     }
                 }
-                for (int ll = 0; ll < kLanes; ++ll) {
-                    if (!act[ll]) continue;
-                    for (int rr = 0; rr < R; ++rr) { D[ll][rr] = nD[ll][rr]; V[ll][rr] = nV[ll][rr]; H[ll][rr] = nH[ll][rr]; }
-                    dsave[ll] = dnext[ll];
-                }
+                for (int ll = 0; ll < kLanes; ++ll) memcpy(&wbuf[((size_t)(g - g0) * 64 + ll) * 16], acc[ll], 16);
             }
-            for (int ll = 0; ll < kLanes; ++ll) memcpy(&wbuf[((size_t)(g - g0) * 64 + ll) * 16], acc[ll], 16);
+            auto byte_at = [&](int ll, int rr, int kk) -> unsigned {
+                return wbuf[((size_t)(kk / SPG - g0) * 64 + ll) * 16 + (kk % SPG) * R + rr];
+            };
+            if (first && k >= kvalid) { st = ptr_pm(byte_at(l, r, k)); first = false; }   // start state, textSeqCompare.py:102
+            int steps = 0;
+            while (x > 0 && y > 0 && l >= 0 && k >= kvalid) {
+                if (k / SPG > g_top) return -6;               // would read past what this chunk re-filled
+                const unsigned b = byte_at(l, r, k);
+                if (b == 0xEE) return -7;
+                const int up = (st != 2), left = (st != 1);
+                rev.push_back((uint8_t)st);
+                st = 2 - (int)((b >> (2 * st)) & 3u);
+                const int wrap = up & (r == 0);
+                r = (r - up) & (R - 1);
+                x -= up; y -= left; k -= left + wrap; l -= wrap;
+                ++steps;
+            }
+            if (x <= 0 || y <= 0 || l < 0) in_strip = false;
+            else {
+                g_top = g0;
+                ck -= 1;
+                if (ck < 0) return -5;
+            }
         }
-        auto byte_at = [&](int ll, int rr, int kk) -> unsigned {
-            return wbuf[((size_t)(kk / SPG - g0) * 64 + ll) * 16 + (kk % SPG) * R + rr];
-        };
-        if (first) { st = ptr_pm(byte_at(l, r, k)); first = false; }
-        int steps = 0;
-        while (x > 0 && y > 0 && l >= 0 && k >= kvalid) {
-            const unsigned b = byte_at(l, r, k);
-            if (b == 0xEE) return -7;
-            const int up = (st != 2), left = (st != 1);
-            rev.push_back((uint8_t)st);
-            st = 2 - (int)((b >> (2 * st)) & 3u);
-            const int wrap = up & (r == 0);
-            r = (r - up) & (R - 1);
-            x -= up; y -= left; k -= left + wrap; l -= wrap;
-            ++steps;
-        }
-        if (steps == 0) return -8;
     }
     while (y > 0) { rev.push_back(2); --y; }
     while (x > 0) { rev.push_back(1); --x; }

@@ -136,6 +136,27 @@ TA_HD void cell_update_carried(int d_ul, int xg_u, int yg_l, int cs, int gox, in
     xg = dx > xg_u ? dx : xg_u;
     yg = dy > yg_l ? dy : yg_l;
 }
+// ---- the carried cell on ENCODED values (score << 6 | tag): scores as cell_update_carried, and the
+// winner tags of its three outputs are the pointers of the reference, like cell_update's.  Why the
+// two 2-operand maxima pick the same winners as cell_update's max3 (a = M^, b = X~, c = Y~ + goy):
+//   tag(D) = M: D = a;  XG' = max(a + gox [M], b + gox [X]) -> M iff a >= b            (= max3(a, b, c), a >= c)
+//   tag(D) = X: D = b + gox <= b;  XG' = max(b + 2 gox [X], b + gox [X]) -> X            (a < b + gox <= b, b >= c)
+//   tag(D) = Y: D = c;  XG' = max(c + gox [Y], b + gox [X]) -> X iff b >= c, else Y     (a < c)
+// and symmetrically for YG'.  Needs gox, goy <= 0 (opens_nonpositive).
+// in : d_ul = D(i-1,j-1), xg_u = XG(i-1,j), yg_l = YG(i,j-1) (any tags), cs = cmatch / cmismatch
+// out: d, xg, yg of (i,j); returns the pointer byte of (i,j) (bits 6-7 don't-care)
+TA_HD unsigned cell_update_carried_tagged(int d_ul, int xg_u, int yg_l, int cs, int gox6, int goy6,
+                                          int& d, int& xg, int& yg) {
+    const int mr = (d_ul & ~kTagMask) + cs;            // M^ tagged M
+    const int xr = (xg_u & ~kTagMask) | kTagX;         // X~ + gox tagged X
+    const int yr = (yg_l & ~kTagMask);                 // Y~ + goy tagged Y (= 0)
+    d = max3i(mr, xr, yr);
+    const int dx = d + gox6, dy = d + goy6;            // keep D's tag
+    xg = dx > xr ? dx : xr;
+    yg = dy > yr ? dy : yr;
+    const unsigned inner = ((unsigned)xg_u & 0x0Cu) | ((unsigned)yg_l & ~0x0Cu);
+    return ((unsigned)d_ul & 0x03u) | (inner & ~0x03u);
+}
 TA_HD int raw_of(int enc) { return enc >> kShift; }            // arithmetic shift: floor
 TA_HD int enc_of(int raw) { return raw * 64; }                 // tag field zero
 

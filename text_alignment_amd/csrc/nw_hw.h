@@ -110,6 +110,19 @@ __device__ __forceinline__ unsigned cell_hw(const CellRegs& k, int d_ul, int v_u
     return v_bfi3((unsigned)d_ul, v_bfi12((unsigned)v_u, (unsigned)h_l));
 }
 
+// the carried cell on encoded values (ta::cell_update_carried_tagged), one VALU instruction per line
+__device__ __forceinline__ unsigned cell_carried_tagged_hw(const CellRegs& k, int d_ul, int xg_u, int yg_l,
+                                                           int t, int o, int& d, int& xg, int& yg) {
+    const int cs = v_score(t, o, k.cmis, k.cmat);        // v_cmp_eq + v_cndmask
+    const int mr = (d_ul & k.clean) + cs;                 // v_and, v_add
+    const int xr = v_and_or_x(xg_u, k.clean);             // v_and_or
+    const int yr = yg_l & k.clean;                        // v_and
+    d = v_max3(mr, xr, yr);
+    xg = max(d + k.gox6, xr);                             // v_add, v_max
+    yg = max(d + k.goy6, yr);                             // v_add, v_max
+    return v_bfi3((unsigned)d_ul, v_bfi12((unsigned)xg_u, (unsigned)yg_l));
+}
+
 // pack the low bytes of four values into one dword (3 v_perm_b32)
 __device__ __forceinline__ unsigned pack4(unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
     const unsigned lo = __builtin_amdgcn_perm(b1, b0, 0x0C0C0400u);

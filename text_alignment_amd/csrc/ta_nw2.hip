@@ -8,12 +8,12 @@
 //           v_cmp + v_cndmask, 3 v_add, 3 v_max3_i32 and nothing else; no pointer byte is formed
 //           or stored.  It leaves checkpoints in HBM (0.13 B per cell): every kCkGroups groups the
 //           wave's whole lane state, and per strip three planes of lane 63's last two rows.
-//  phase 2  nw_trace2_kernel  one wave per problem walks back strip by strip.  For the strip the
-//           walk is in, it re-runs the TAGGED fill (ta_nw.hip's cell) over a window of skewed steps
-//           restarted from the nearest state checkpoint (two halo steps make the missing winner
-//           tags of the restart state irrelevant; the row above the strip is re-derived with tags
-//           from the three planes), writes that window's pointer bytes to a small scratch and
-//           walks them.  About 10 % of the cells are recomputed.
+//  phase 2  nw_trace2_kernel  one wave per problem walks back strip by strip and, inside a strip,
+//           checkpoint interval by checkpoint interval: it re-runs the TAGGED cell over the
+//           interval the walk is in, restarted from that interval's state checkpoint (two halo
+//           steps make the missing winner tags of the restart state irrelevant; the row above the
+//           strip is re-derived with tags from the three planes), keeps the interval's pointer
+//           bytes in LDS and walks them.  About 10 % of the cells are recomputed.
 //
 // Data flow and the halo argument are replayed on the CPU by tests/native/sim_nw.cpp (run2).
 #include <hip/hip_runtime.h>
@@ -28,14 +28,12 @@
 namespace ta {
 
 constexpr int kCkGroups = 16;                 // state checkpoint every 16 groups (64 skewed steps)
-constexpr int kSpanGroups = 84;               // phase 2 restarts >= this many groups before the entry
-constexpr int kWinGroups = kCkGroups + kSpanGroups;     // upper bound of a window, in groups
 constexpr int kStateInts = 10;                // D[4], H[4], V[3], dsave
 
 // per-problem layout of the phase-1/2 workspace (all offsets in bytes, 16-byte aligned)
 struct Ws2 {
     int nstrips, ngroups, nck, mrow;
-    int64_t rowck, stck, scratch, hrow, total;
+    int64_t rowck, stck, hrow, total;
     __host__ __device__ Ws2(int n, int m) {
         using L = PtrLayout<4>;
         nstrips = L::nstrips(n);
@@ -44,10 +42,9 @@ struct Ws2 {
         mrow = (m + 8 + 3) & ~3;
         rowck = 0;
         stck = rowck + (int64_t)nstrips * 3 * mrow * 4;
-        scratch = stck + (int64_t)nstrips * nck * kStateInts * 64 * 4;
         // phase 1's hand-off row: (XG, D) of the row above the strip a wave is in, entry j at
         // index j + 1 (so that the four entries a group reads start on a 16-byte boundary)
-        hrow = scratch + (int64_t)kWinGroups * 1024;
+        hrow = stck + (int64_t)nstrips * nck * kStateInts * 64 * 4;
         total = hrow + (((int64_t)(m + 8) * 8 + 15) & ~(int64_t)15);
     }
     __host__ __device__ int64_t row_plane(int s, int plane) const {       // int index base, entry j at +j+2
@@ -452,23 +449,103 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
 
 // ---------------------------------------------------------------------------------------------
 // phase 2
-// Walk sub-window staged in LDS, in groups (1 KiB each).  The sub-window is what limits how many
-// problems a CU holds at once (32 groups: 38 KB per workgroup -> one wave per SIMD).  A lone wave
-// issues only every ~8 cycles, so batches with more problems than the GPU has SIMDs use a small
-// sub-window: more loads and barriers per strip, but several walkers per SIMD.
-constexpr int kTb2GroupsFew = 32, kTb2GroupsMany = 8;
-constexpr int kTb2ManyProblems = 2048;
+// One wave per problem walks back strip by strip, and inside a strip CHUNK by chunk (a chunk =
+// the kCkGroups groups between two state checkpoints).  For the chunk the walk is in, the wave
+// re-runs the TAGGED cell from the chunk's checkpoint -- straight into LDS: the chunk's pointer
+// bytes (16 KiB) never go to memory -- walks them, and steps to the chunk before when the walk
+// reaches the chunk's first two steps (the restart state carries no winner tags; two steps later
+// every input of a cell has been produced with tags).  Those two steps belong to the chunk before,
+// whose re-fill therefore runs one group further (17 groups).
+constexpr int kChunk = kCkGroups;                 // groups per chunk
+constexpr int kChunkGroups = kChunk + 1;          // + the group holding the next chunk's two halo steps
+constexpr int kChunkSteps = kChunkGroups * 4;
 constexpr int kTb2Ops = 512;
 
-template <int kTb2Groups>
+#ifndef TA_P2_ABLATE
+#define TA_P2_ABLATE 0      // timing experiments only: 2 re-fill one group only, 4 no walk
+#endif
+
+template <bool CARRIED>
+__device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], int (&V)[4], int (&H)[4], int& dsave,
+                                             const int (&tc)[4], const int2* hvt, const uint16_t* ow,
+                                             uint4* win, int g0, int g_top, int m, int lane, bool lane_has_rows) {
+    constexpr int R = 4, SPG = 4;
+    const int k0 = g0 * SPG;
+    int oc_next[SPG];
+    int2 hd_next[SPG];
+    auto load_group = [&](int g) {
+#pragma unroll
+        for (int q = 0; q < SPG; ++q) {
+            const int kk = g * SPG + q;
+            oc_next[q] = ow[kk - k0 + 63 - lane];
+            hd_next[q] = hvt[min(kk + 1, m) - k0];
+        }
+    };
+    auto cell = [&](int d_ul, int x_u, int y_l, int t, int o, int& d, int& x, int& y) -> unsigned {
+        if constexpr (CARRIED) return cell_carried_tagged_hw(kr, d_ul, x_u, y_l, t, o, d, x, y);
+        else return cell_hw(kr, d_ul, x_u, y_l, t, o, d, x, y);
+    };
+    load_group(g0);
+    const int gs_lo = (63 + SPG - 1) / SPG, gs_hi = m / SPG;     // steady groups [gs_lo, gs_hi)
+    for (int g = g0; g <= g_top; ++g) {
+        int oc[SPG];
+        int2 hd[SPG];
+#pragma unroll
+        for (int q = 0; q < SPG; ++q) { oc[q] = oc_next[q]; hd[q] = hd_next[q]; }
+        if (g < g_top) load_group(g + 1);
+        unsigned acc[4] = {0u, 0u, 0u, 0u};
+        if (g >= gs_lo && g < gs_hi) {
+#pragma unroll
+            for (int q = 0; q < SPG; ++q) {
+                int v_up = hd[q].x, d_next = hd[q].y;
+                wave_shr1_pair<1>(v_up, V[R - 1], d_next, D[R - 1]);
+                int d_ul = dsave, v_u = v_up;
+                unsigned b[R];
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    const int d_old = D[rr];
+                    b[rr] = cell(d_ul, v_u, H[rr], tc[rr], oc[q], D[rr], V[rr], H[rr]);
+                    d_ul = d_old;
+                    v_u = V[rr];
+                }
+                acc[q] = pack4(b[0], b[1], b[2], b[3]);
+                dsave = d_next;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < SPG; ++q) {
+                const int kk = g * SPG + q;
+                const int j = kk - lane + 1;
+                const bool active = (j >= 1) && (j <= m) && lane_has_rows;
+                int v_up = hd[q].x, d_next = hd[q].y;
+                wave_shr1_pair<4>(v_up, V[R - 1], d_next, D[R - 1]);
+                if (active) {
+                    int d_ul = dsave, v_u = v_up;
+                    unsigned b[R];
+#pragma unroll
+                    for (int rr = 0; rr < R; ++rr) {
+                        const int d_old = D[rr];
+                        b[rr] = cell(d_ul, v_u, H[rr], tc[rr], oc[q], D[rr], V[rr], H[rr]);
+                        d_ul = d_old;
+                        v_u = V[rr];
+                    }
+                    acc[q] = pack4(b[0], b[1], b[2], b[3]);
+                    dsave = d_next;
+                }
+            }
+        }
+        win[(g - g0) * 64 + lane] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
 __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
+    constexpr int ABL2 = TA_P2_ABLATE;
     constexpr int R = 4;
     using L = PtrLayout<R>;
     constexpr int SPG = L::SPG;
-    constexpr int kSteps = kWinGroups * SPG;                    // 512 skewed steps per window at most
-    __shared__ int2 hvt[kSteps + 8];                            // tagged (V~, D) of the row above, columns k0..
-    __shared__ uint16_t ow[kSteps + 64 + 8];                    // OCR codes, o index (k0 - 63) + i
-    __shared__ uint4 win[kTb2Groups * 64];
+    __shared__ uint4 win[kChunkGroups * 64];                    // pointer bytes of the chunk, strip layout
+    __shared__ int2 hvt[kChunkSteps + 8];                       // tagged (V~ or XG, D) of the row above, columns k0..
+    __shared__ uint16_t ow[kChunkSteps + 64 + 8];               // OCR codes, o index (k0 - 63) + i
     __shared__ uint8_t opsbuf[kTb2Ops];
 
     const int p = blockIdx.x, lane = threadIdx.x;
@@ -486,194 +563,141 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
     kr.cmis = c.cmismatch; kr.cmat = c.cmatch; kr.gox6 = c.gox6; kr.goy6 = c.goy6;
     kr.clean = ~kTagMask;
     // phase 1 leaves V~ + gox / H~ + goy in its checkpoints and planes when the gap opens are
-    // non-positive (carried cell); the tagged cell here wants V~ / H~
+    // non-positive (carried cell), and the chunks are then re-filled in that form too
     const bool carried = opens_nonpositive(c.gox, c.goy);
     const int xadj = carried ? c.gox : 0, yadj = carried ? c.goy : 0;
+    const int xadj6 = xadj * 64, yadj6 = yadj * 64;
     const Ws2 ws(max(n, 1), max(m, 1));
     uint8_t* const ws_p = a.ws + a.ws_off[p];
-    uint8_t* const scratch = ws_p + ws.scratch;
 
     while (x > 0 && y > 0) {
         const int s = (x - 1) / L::SR;
         int l = ((x - 1) % L::SR) / R;
         int r = (x - 1) % R;
         int k = (y - 1) + l;
-        const int g_in = k >> 2;
-        const int g0 = kCkGroups * (max(0, g_in - kSpanGroups) / kCkGroups);
-        const int k0 = g0 * SPG;
-        const int kvalid = g0 > 0 ? k0 + 2 : 0;
         const int i_h = s * L::SR;                              // 1-based index of the row above the strip
-        const int nsteps_w = (g_in - g0 + 1) * SPG;
-
-        // (a) OCR codes of the window: ow[i] = o[(k0 - 63) + i]
-        // (fixed trip counts, fully unrolled: all loads of a stage are in flight together)
-#pragma unroll
-        for (int it = 0; it < (kSteps + 64 + 63) / 64; ++it) {
-            const int i = it * 64 + lane;
-            const int src = k0 - 63 + i;
-            if (i < nsteps_w + 64)
-                ow[i] = (src >= 0 && src < m) ? (uint16_t)a.o_codes[o0 + src] : (uint16_t)0xFFFF;
-        }
-        // (b) the row above the strip with winner tags, columns k0 .. min(m, k0 + nsteps_w)
-        {
-            const int jhi = min(m, k0 + nsteps_w);
-            const int* pv = reinterpret_cast<const int*>(ws_p + ws.row_plane(max(s - 1, 0), 0)) + 2;
-            const int* pd = reinterpret_cast<const int*>(ws_p + ws.row_plane(max(s - 1, 0), 1)) + 2;
-            const int* ph = reinterpret_cast<const int*>(ws_p + ws.row_plane(max(s - 1, 0), 2)) + 2;
-            const int t_h = (s > 0) ? a.t_codes[t0 + i_h - 1] : -1;
-            if (s == 0) {
-                for (int j = k0 + lane; j <= jhi; j += 64)
-                    hvt[j - k0] = make_int2(bnd_V_row0(c, j), bnd_D_row0(c, j));
-            } else {
-                constexpr int kIt = (kSteps + 1 + 63) / 64;
-                int rd_[kIt], rv_[kIt], rh_[kIt], ro_[kIt];
-#pragma unroll
-                for (int it = 0; it < kIt; ++it) {                 // issue every load first
-                    const int j = min(k0 + it * 64 + lane, jhi);
-                    const int jm = max(j - 1, 0);
-                    rd_[it] = pd[jm]; rv_[it] = pv[j]; rh_[it] = ph[jm];
-                    ro_[it] = a.o_codes[o0 + jm];
-                }
-#pragma unroll
-                for (int it = 0; it < kIt; ++it) {
-                    const int j = k0 + it * 64 + lane;
-                    if (j > jhi) continue;
-                    int2 e;
-                    if (j == 0) {
-                        e = make_int2(0, bnd_D_col0(c, i_h));
-                    } else {
-                        const int d_ul = (j - 1 >= 1) ? rd_[it] : raw_of(bnd_D_col0(c, i_h - 1));
-                        const int h_l = (j - 1 >= 1) ? rh_[it] - yadj : raw_of(bnd_H_col0(c, i_h));
-                        const int cs = (t_h == ro_[it]) ? c.cmatch : c.cmismatch;
-                        int d, v, h;
-                        cell_update(enc_of(d_ul), enc_of(rv_[it] - xadj), enc_of(h_l), cs, c.gox6, c.goy6, d, v, h);
-                        e = make_int2(v, d);
-                    }
-                    hvt[j - k0] = e;
-                }
-            }
-        }
-        // (c) lane state at the start of group g0
-        int D[R], V[R], H[R], tc[R];
-        int dsave;
         const int row0 = s * L::SR + lane * R;
+        const bool lane_has_rows = row0 < n;
+        int tc[R];
 #pragma unroll
         for (int rr = 0; rr < R; ++rr) {
             const int i = row0 + rr + 1;
             tc[rr] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
-            V[rr] = 0;
-            D[rr] = bnd_D_col0(c, i);
-            H[rr] = bnd_H_col0(c, i);
         }
-        dsave = bnd_D_col0(c, row0);
-        if (g0 > 0) {
-            const int* stp = reinterpret_cast<const int*>(ws_p + ws.state(s, g0 / kCkGroups)) + lane;
-#pragma unroll
-            for (int rr = 0; rr < R; ++rr) { D[rr] = enc_of(stp[rr * 64]); H[rr] = enc_of(stp[(R + rr) * 64] - yadj); }
-            V[R - 1] = enc_of(stp[8 * 64] - xadj);
-            dsave = enc_of(stp[9 * 64]);
-        }
-        const bool lane_has_rows = row0 < n;
-        __syncthreads();
+        const int t_h = (s > 0) ? a.t_codes[t0 + i_h - 1] : -1;
+        const int* const pv = reinterpret_cast<const int*>(ws_p + ws.row_plane(max(s - 1, 0), 0)) + 2;
+        const int* const pd = reinterpret_cast<const int*>(ws_p + ws.row_plane(max(s - 1, 0), 1)) + 2;
+        const int* const ph = reinterpret_cast<const int*>(ws_p + ws.row_plane(max(s - 1, 0), 2)) + 2;
 
-        // (d) tagged fill of groups g0 .. g_in into the scratch (strip layout, group index g - g0);
-        // inputs of group g+1 are fetched from LDS while group g computes, and groups in which
-        // every lane is inside 1 <= j <= m run without EXEC changes (as in ta_nw.hip)
-        {
-            int oc_next[SPG];
-            int2 hd_next[SPG];
-            auto load_group = [&](int g) {
+        int ck = (k >> 2) / kChunk;                             // chunk the walk is in
+        int g_top = k >> 2;                                     // last group to re-fill
+        bool in_strip = true;
+        while (in_strip) {
+            const int g0 = ck * kChunk;
+            const int k0 = g0 * SPG;
+            const int kvalid = ck > 0 ? k0 + 2 : 0;
+            const int nsteps_w = (g_top - g0 + 1) * SPG;
+
+            // (a) OCR codes of the chunk: ow[i] = o[(k0 - 63) + i]
 #pragma unroll
-                for (int q = 0; q < SPG; ++q) {
-                    const int kk = g * SPG + q;
-                    oc_next[q] = ow[kk - k0 + 63 - lane];
-                    hd_next[q] = hvt[min(kk + 1, m) - k0];
-                }
-            };
-            load_group(g0);
-            const int gs_lo = (63 + SPG - 1) / SPG, gs_hi = m / SPG;     // steady groups [gs_lo, gs_hi)
-            for (int g = g0; g <= g_in; ++g) {
-                int oc[SPG];
-                int2 hd[SPG];
-#pragma unroll
-                for (int q = 0; q < SPG; ++q) { oc[q] = oc_next[q]; hd[q] = hd_next[q]; }
-                if (g < g_in) load_group(g + 1);
-                unsigned acc[4] = {0u, 0u, 0u, 0u};
-                if (g >= gs_lo && g < gs_hi) {
-#pragma unroll
-                    for (int q = 0; q < SPG; ++q) {
-                        int v_up = hd[q].x, d_next = hd[q].y;
-                        wave_shr1_pair<1>(v_up, V[R - 1], d_next, D[R - 1]);
-                        int d_ul = dsave, v_u = v_up;
-                        unsigned b[R];
-#pragma unroll
-                        for (int rr = 0; rr < R; ++rr) {
-                            const int d_old = D[rr];
-                            b[rr] = cell_hw(kr, d_ul, v_u, H[rr], tc[rr], oc[q], D[rr], V[rr], H[rr]);
-                            d_ul = d_old;
-                            v_u = V[rr];
-                        }
-                        acc[q] = pack4(b[0], b[1], b[2], b[3]);
-                        dsave = d_next;
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < SPG; ++q) {
-                        const int kk = g * SPG + q;
-                        const int j = kk - lane + 1;
-                        const bool active = (j >= 1) && (j <= m) && lane_has_rows;
-                        int v_up = hd[q].x, d_next = hd[q].y;
-                        wave_shr1_pair<4>(v_up, V[R - 1], d_next, D[R - 1]);
-                        if (active) {
-                            int d_ul = dsave, v_u = v_up;
-                            unsigned b[R];
-#pragma unroll
-                            for (int rr = 0; rr < R; ++rr) {
-                                const int d_old = D[rr];
-                                b[rr] = cell_hw(kr, d_ul, v_u, H[rr], tc[rr], oc[q], D[rr], V[rr], H[rr]);
-                                d_ul = d_old;
-                                v_u = V[rr];
-                            }
-                            acc[q] = pack4(b[0], b[1], b[2], b[3]);
-                            dsave = d_next;
-                        }
-                    }
-                }
-                *reinterpret_cast<uint4*>(scratch + ((int64_t)(g - g0) * 64 + lane) * 16) =
-                    make_uint4(acc[0], acc[1], acc[2], acc[3]);
+            for (int it = 0; it < (kChunkSteps + 64 + 63) / 64; ++it) {
+                const int i = it * 64 + lane;
+                const int src = k0 - 63 + i;
+                if (i < nsteps_w + 64)
+                    ow[i] = (src >= 0 && src < m) ? (uint16_t)a.o_codes[o0 + src] : (uint16_t)0xFFFF;
             }
-        }
-        // the walk below re-reads these bytes: same wave, same CU -- workgroup-scope ordering (the
-        // barrier's vmcnt wait) is enough; an agent-scope fence would write back the XCD's L2 per window
-        __syncthreads();
-
-        // (e) walk the window (LDS-staged sub-windows of kTb2Groups groups)
-        bool leave = false;
-        while (!leave) {
-            const int gw_hi = k >> 2;
-            const int gw_lo = max(g0, gw_hi - (kTb2Groups - 1));
-            const int klow = max(kvalid, gw_lo * SPG);
-#pragma unroll 8
-            for (int it = 0; it <= gw_hi - gw_lo; ++it)
-                win[it * 64 + lane] = *reinterpret_cast<const uint4*>(
-                    scratch + ((int64_t)(gw_lo + it - g0) * 64 + lane) * 16);
+            // (b) the row above the strip with winner tags, columns k0 .. min(m, k0 + nsteps_w)
+            {
+                const int jhi = min(m, k0 + nsteps_w);
+                if (s == 0) {
+                    for (int j = k0 + lane; j <= jhi; j += 64)
+                        hvt[j - k0] = make_int2(bnd_V_row0(c, j) + xadj6, bnd_D_row0(c, j));
+                } else {
+                    constexpr int kIt = (kChunkSteps + 1 + 63) / 64;
+                    int rd_[kIt], rv_[kIt], rh_[kIt], ro_[kIt];
+#pragma unroll
+                    for (int it = 0; it < kIt; ++it) {                 // issue every load first
+                        const int j = min(k0 + it * 64 + lane, jhi);
+                        const int jm = max(j - 1, 0);
+                        rd_[it] = pd[jm]; rv_[it] = pv[j]; rh_[it] = ph[jm];
+                        ro_[it] = a.o_codes[o0 + jm];
+                    }
+#pragma unroll
+                    for (int it = 0; it < kIt; ++it) {
+                        const int j = k0 + it * 64 + lane;
+                        if (j > jhi) continue;
+                        int2 e;
+                        if (j == 0) {
+                            e = make_int2(0, bnd_D_col0(c, i_h));
+                        } else {
+                            const int d_ul = (j - 1 >= 1) ? rd_[it] : raw_of(bnd_D_col0(c, i_h - 1));
+                            const int h_l = (j - 1 >= 1) ? rh_[it] - yadj : raw_of(bnd_H_col0(c, i_h));
+                            const int cs = (t_h == ro_[it]) ? c.cmatch : c.cmismatch;
+                            int d, v, h;
+                            cell_update(enc_of(d_ul), enc_of(rv_[it] - xadj), enc_of(h_l), cs, c.gox6, c.goy6, d, v, h);
+                            e = make_int2(v + xadj6, d);                // adding gox << 6 keeps the tag
+                        }
+                        hvt[j - k0] = e;
+                    }
+                }
+            }
+            // (c) lane state at the start of group g0 (in the form the re-fill keeps: carried or not)
+            int D[R], V[R], H[R];
+            int dsave;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int i = row0 + rr + 1;
+                V[rr] = 0;
+                D[rr] = bnd_D_col0(c, i);
+                H[rr] = bnd_H_col0(c, i) + yadj6;
+            }
+            dsave = bnd_D_col0(c, row0);
+            static_assert(kChunk * SPG >= 64, "a lane must have started before the first checkpoint: its "
+                                               "column-0 values carry tags only in the boundary form");
+            if (g0 > 0) {
+                const int* stp = reinterpret_cast<const int*>(ws_p + ws.state(s, g0 / kCkGroups)) + lane;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) { D[rr] = enc_of(stp[rr * 64]); H[rr] = enc_of(stp[(R + rr) * 64]); }
+                V[R - 1] = enc_of(stp[8 * 64]);
+                dsave = enc_of(stp[9 * 64]);
+            }
             __syncthreads();
+
+            // (d) tagged re-fill of groups g0 .. g_top into LDS
+            {
+                if (carried) refill_chunk<true>(kr, D, V, H, dsave, tc, hvt, ow, win, g0, g_top, m, lane, lane_has_rows);
+                else refill_chunk<false>(kr, D, V, H, dsave, tc, hvt, ow, win, g0, g_top, m, lane, lane_has_rows);
+            }
+            __syncthreads();
+
+            // (e) walk the chunk
             const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
-            if (first) {                                       // start state, textSeqCompare.py:102
-                st = ptr_pm(wb[(((k >> 2) - gw_lo) * 64 + l) * 16 + (k & 3) * R + r]);
+            if (first && k >= kvalid) {                        // start state, textSeqCompare.py:102
+                st = ptr_pm(wb[(((k >> 2) - g0) * 64 + l) * 16 + (k & 3) * R + r]);
                 first = false;
             }
-            const int cnt = walk_window_vec(win, gw_lo, klow, s * L::SR, x, y, st, opsbuf, kTb2Ops, lane);
-            __syncthreads();
-            for (int i = lane; i < cnt; i += 64) ops[cap - 1 - (len + i)] = opsbuf[i];
-            len += cnt;
-            __syncthreads();
+            if (ABL2 & 4) { x = s * L::SR; y = max(y - 300, 1); }
+            bool again = !(ABL2 & 4);
+            while (again) {
+                const int cnt = walk_window_vec(win, g0, kvalid, s * L::SR, x, y, st, opsbuf, kTb2Ops, lane);
+                __syncthreads();
+                for (int i = lane; i < cnt; i += 64) ops[cap - 1 - (len + i)] = opsbuf[i];
+                len += cnt;
+                __syncthreads();
+                again = (cnt == kTb2Ops);                       // the ops buffer was full: keep walking this chunk
+            }
             // position in layout coordinates after the walk
             l = (x > s * L::SR) ? ((x - 1) % L::SR) / R : -1;
             r = (x - 1) & (R - 1);
             k = (y - 1) + l;
-            // leave this fill window when the walk left the strip, finished, or ran below the valid steps
-            leave = (x <= 0) | (y <= 0) | (l < 0) | (k < kvalid) | (cnt == 0);
+            if ((x <= 0) | (y <= 0) | (l < 0)) {
+                in_strip = false;                              // the walk left the strip or finished
+            } else {
+                // it ran into the chunk's two halo steps (k < kvalid): the chunk before, extended by
+                // the group that holds them
+                g_top = g0;
+                ck -= 1;
+            }
         }
     }
     while (y > 0) { if (lane == 0) ops[cap - 1 - len] = 2; ++len; --y; }
@@ -804,10 +828,7 @@ extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
     }
     if (flags & TA_NW_TRACEBACK) {
         if (!ops_out && (max_n + max_m) > 0) return ta_fail(TA_EINVAL, "null ops_out");
-        if (nprob >= kTb2ManyProblems)
-            hipLaunchKernelGGL(nw_trace2_kernel<kTb2GroupsMany>, dim3(nprob), dim3(64), 0, st, a);
-        else
-            hipLaunchKernelGGL(nw_trace2_kernel<kTb2GroupsFew>, dim3(nprob), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(nw_trace2_kernel, dim3(nprob), dim3(64), 0, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return ta_fail_hip(e, "nw_trace2_kernel launch");
     }

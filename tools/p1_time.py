@@ -27,5 +27,12 @@ for _ in range(5):
     torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))
 ms = sorted(ts)[2]
+tb = []
+for _ in range(5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); batch.run(fill=False, traceback=True); e1.record()
+    torch.cuda.synchronize()
+    tb.append(e0.elapsed_time(e1))
+print("traceback %.3f ms" % sorted(tb)[2])
 print("%s W=%s fill %.3f ms  %.3e cells/s  frac %.3f" % (sys.argv[1] if len(sys.argv) > 1 else "profile",
       os.environ.get("TA_NW2_W", "auto"), ms, batch.cells / ms * 1e3, batch.cells / ms * 1e3 / 8e12))
