@@ -158,6 +158,11 @@ int ta_nw_general(const int32_t* t, int32_t n, const int32_t* o, int32_t m,
  *          plane of W_gate[unit 16*wave + lane%16][kp 32*kstep + 8*(lane/16) + j], kp as above
  *          padded with zeros to 160.
  *   peep = float[2][3][112]: WIP, WFP, WOP per direction, units >= 100 zero.
+ *   h0, c0, tstart (all NULL for fresh lines, or all given): a "line" may be the continuation of a
+ *          sequence run elsewhere -- float h0[lines][2][100] / c0[lines][2][100] are the LSTM output
+ *          and cell state before its first step, per direction (index 1 = the reversed LSTM, whose
+ *          first step is the line's LAST row), and int32 tstart[lines][2] the number of steps of the
+ *          sequence already done (> 0: the peepholes that ocropy skips at t = 0 apply from the start).
  * ta_lstm_output: w2p = float[201][16*ceil(no/16)] (classes beyond `no` zero): row 0 = bias
  *   column W2[:, 0]; row 1 + 4*kk + kq = W2[:, 1 + 50*kq + kk] (kk < 50, kq < 4) -- the k order
  *   in which the kernel consumes a row of hout.  no <= 128.  probs / logits / summary are each
@@ -170,7 +175,8 @@ int ta_nw_general(const int32_t* t, int32_t n, const int32_t* o, int32_t m,
 int32_t ta_lstm_packed_weight_floats(int32_t mode);
 int ta_lstm_forward(const float* x, const int64_t* row_off, const int32_t* T,
                     const int32_t* group_lines, int32_t ngroups,
-                    const float* wp, const float* peep, float* hout, int32_t mode, void* stream);
+                    const float* wp, const float* peep, float* hout, int32_t mode,
+                    const float* h0, const float* c0, const int32_t* tstart, void* stream);
 int ta_lstm_output(const float* y, int64_t rows, const float* w2p, int32_t no,
                    float* probs, float* logits, float* summary, void* stream);
 int ta_decode_summary(const float* summary, const int64_t* row_off, const int32_t* T,

@@ -68,36 +68,46 @@ def synthetic_line(seed, width=None, ni=48):
 
 
 def _sigmoid(x):
-    return 1.0 / (1.0 + np.exp(np.clip(-x, -20, 20)))
+    return (1.0 / (1.0 + np.exp(np.clip(-x, -20, 20)))).astype(x.dtype)
 
 
-def lstm_forward(w, xs):
-    """One direction, Appendix B.3 (`forward_py`): returns (T, ns) outputs."""
+def lstm_forward(w, xs, h0=None, c0=None, t0=0, return_cell=False, dtype=np.float64):
+    """One direction, Appendix B.3 (`forward_py`): returns (T, ns) outputs.
+
+    h0, c0, t0: continue a sequence whose first t0 steps were run elsewhere (the peephole rules
+    "[t > 0]" refer to the position in the whole sequence).  return_cell: also the (T, ns) cell
+    states.  dtype=np.float32 runs the same loop in single precision (tests use it to show how fast
+    two float32 implementations of THIS model drift apart; the oracle of record is float64)."""
     T = xs.shape[0]
     ns = w["WGI"].shape[0]
-    h = np.zeros(ns)
-    c = np.zeros(ns)
-    out = np.zeros((T, ns))
+    W = {k: np.asarray(v, dtype=dtype) for k, v in w.items()}
+    xs = np.asarray(xs, dtype=dtype)
+    h = np.zeros(ns, dtype=dtype) if h0 is None else np.asarray(h0, dtype=dtype)
+    c = np.zeros(ns, dtype=dtype) if c0 is None else np.asarray(c0, dtype=dtype)
+    out = np.zeros((T, ns), dtype=dtype)
+    cells = np.zeros((T, ns), dtype=dtype)
+    one = np.ones(1, dtype=dtype)
     for t in range(T):
-        src = np.concatenate(([1.0], xs[t], h))
-        gi = w["WGI"].dot(src)
-        gf = w["WGF"].dot(src)
-        go = w["WGO"].dot(src)
-        ci = np.tanh(w["WCI"].dot(src))
-        if t > 0:
-            gi = gi + w["WIP"] * c
-            gf = gf + w["WFP"] * c
+        src = np.concatenate((one, xs[t], h))
+        gi = W["WGI"].dot(src)
+        gf = W["WGF"].dot(src)
+        go = W["WGO"].dot(src)
+        ci = np.tanh(W["WCI"].dot(src))
+        if t + t0 > 0:
+            gi = gi + W["WIP"] * c
+            gf = gf + W["WFP"] * c
         gi = _sigmoid(gi)
         gf = _sigmoid(gf)
         c_new = ci * gi
-        if t > 0:
+        if t + t0 > 0:
             c_new = c_new + gf * c
-            go = go + w["WOP"] * c_new          # output peephole skipped at t = 0
+            go = go + W["WOP"] * c_new          # output peephole skipped at t = 0
         go = _sigmoid(go)
         c = c_new
         h = np.tanh(c) * go
         out[t] = h
-    return out
+        cells[t] = c
+    return (out, cells) if return_cell else out
 
 
 def bilstm_states(model, xs):

@@ -48,3 +48,31 @@ def test_llocs_wire_format():
     for line, (t, c) in zip(txt.splitlines(), out["decoded"]):
         ch, x = line.split("\t") if "\t" in line else ("", line)
         assert abs(float(x) - (t - 16) * 2.0) <= 0.05 + 1e-9
+
+
+def test_spec_model_amplifies_float32_rounding_and_segments_bound_it():
+    """Why long-line parity of the SURVEY 8(d) model is stated per segment (tests/test_ocr_gpu.py).
+    The oracle's own loop run in float32 -- same operations, same order, numpy -- drifts from the
+    float64 run by up to ~1.4e-4 in the logits on lines of the benchmark's widths: the random weights
+    amplify a 1e-7 rounding difference about a thousandfold, by an amount that differs from line to
+    line.  Restarted from the float64 state every 128 steps the same float32 loop stays at ~1e-5,
+    so a bound per segment measures the arithmetic of an implementation and not the model's
+    sensitivity.  (The HIP kernel's per-segment error is 5e-5, its free-running error up to 7e-4.)"""
+    m = R.synthetic_model(7001, no=96)
+    W2f = m.W2[:, 1:101]                                      # the forward half's share of the logits
+    worst_free, worst_seg = 0.0, 0.0
+    for seed, width in [(8003, 900), (8004, 1000)]:
+        xs = R.synthetic_line(seed, width=width)
+        h64, c64 = R.lstm_forward(m.fwd, xs, return_cell=True)
+        h32 = R.lstm_forward(m.fwd, xs, dtype=np.float32)
+        worst_free = max(worst_free, float(np.abs((h32 - h64).dot(W2f.T)).max()))
+        for a in range(128, xs.shape[0], 128):
+            seg = R.lstm_forward(m.fwd, xs[a:a + 128], h0=h64[a - 1], c0=c64[a - 1], t0=a, dtype=np.float32)
+            worst_seg = max(worst_seg, float(np.abs((seg - h64[a:a + 128]).dot(W2f.T)).max()))
+        # continuation in float64 is exact: the restart inputs mean what the GPU test assumes
+        a = 640
+        again = R.lstm_forward(m.fwd, xs[a:], h0=h64[a - 1], c0=c64[a - 1], t0=a)
+        assert np.array_equal(again, h64[a:])
+    print("float32 numpy loop vs float64: free run %.3g, per 128-step segment %.3g" % (worst_free, worst_seg))
+    assert worst_seg < 3e-5
+    assert worst_free > 5 * worst_seg

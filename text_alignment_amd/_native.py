@@ -64,7 +64,7 @@ def _load():
     lib.ta_lstm_packed_weight_floats.restype = i32
     lib.ta_lstm_packed_weight_floats.argtypes = [i32]
     lib.ta_lstm_forward.restype = ctypes.c_int
-    lib.ta_lstm_forward.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, i32, vp]
+    lib.ta_lstm_forward.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.ta_lstm_output.restype = ctypes.c_int
     lib.ta_lstm_output.argtypes = [vp, i64, vp, i32, vp, vp, vp, vp]
     lib.ta_decode_summary.restype = ctypes.c_int

@@ -43,6 +43,10 @@ struct LstmArgs {
     const float* wp;           // packed B fragments [2][7][4][38][64]
     const float* peep;         // [2][3][112]
     float* hout;               // [rows][200]
+    // optional continuation of sequences that were started elsewhere (all three null: fresh lines)
+    const float* h0;           // [lines][2][100] outputs before the first step, per direction
+    const float* c0;           // [lines][2][100] cell states before the first step
+    const int32_t* tstart;     // [lines][2] steps of the sequence already done (> 0: the "[t > 0]" rules apply from step 0)
 };
 
 // exp(z) for |z| <= 40 on the hardware exp2 unit (v_exp_f32, ~1 ulp) with a compensated
@@ -142,6 +146,22 @@ __global__ __launch_bounds__(kSeqWaves * 64) void lstm_seq_kernel(LstmArgs a) {
         myrow[r] = s_row[slot];
     }
     float c[4] = {0.f, 0.f, 0.f, 0.f};
+    int ts[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int id = s_line[(lane >> 4) * 4 + r];
+        if (id >= 0 && !helper) {
+            if (a.c0 && unit < kNs) c[r] = a.c0[((size_t)id * 2 + dir) * kNs + unit];
+            if (a.tstart) ts[r] = a.tstart[(size_t)id * 2 + dir];
+        }
+    }
+    if (a.h0) {                                            // h_{-1} of continued sequences into the first A tile
+        for (int e = tid; e < kLines * kNs; e += kSeqWaves * 64) {
+            const int slot = e / kNs, u = e % kNs, kp = kXK + u;
+            const int id = s_line[slot];
+            if (id >= 0) src[0][kp & 3][slot][kp >> 2] = a.h0[((size_t)id * 2 + dir) * kNs + u];
+        }
+    }
 
     // loader role: element e -> (slot, kp) of the x part [16][52]
     constexpr int kXE = kLines * kXK;                      // 832
@@ -224,11 +244,12 @@ __global__ __launch_bounds__(kSeqWaves * 64) void lstm_seq_kernel(LstmArgs a) {
         for (int r = 0; r < 4; ++r) {
             float gi = acc[0][r], gf = acc[1][r], go = acc[2][r];
             const float ci = tanh_fast(acc[3][r]);
-            if (t > 0) { gi += wip * c[r]; gf += wfp * c[r]; }
+            const bool past0 = (t > 0) | (ts[r] > 0);             // not the first step of the whole sequence
+            if (past0) { gi += wip * c[r]; gf += wfp * c[r]; }
             gi = sigmoid_clip(gi);
             gf = sigmoid_clip(gf);
             float cn = ci * gi;
-            if (t > 0) { cn += gf * c[r]; go += wop * cn; }      // output peephole skipped at t = 0
+            if (past0) { cn += gf * c[r]; go += wop * cn; }      // output peephole skipped at t = 0
             go = sigmoid_clip(go);
             const float h = tanh_fast(cn) * go;
             c[r] = cn;
@@ -274,6 +295,7 @@ __device__ __forceinline__ void split3(float v, unsigned short& hi, unsigned sho
 
 __global__ __launch_bounds__(kWaves * 64) void lstm_seq_bf16x3_kernel(LstmArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short srcp[2][3][kLines][kRS2];
+    __shared__ int s_line[kLines];
     __shared__ int s_T[kLines];
     __shared__ long long s_row[kLines];
 
@@ -285,6 +307,7 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_bf16x3_kernel(LstmArgs a
 
     if (tid < kLines) {
         const int id = a.group_lines[grp * kLines + tid];
+        s_line[tid] = id;
         s_T[tid] = id >= 0 ? a.T[id] : 0;
         s_row[tid] = id >= 0 ? a.row_off[id] : 0;
     }
@@ -323,6 +346,28 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_bf16x3_kernel(LstmArgs a
         myrow[r] = s_row[slot];
     }
     float c[4] = {0.f, 0.f, 0.f, 0.f};
+    int ts[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int id = s_line[(lane >> 4) * 4 + r];
+        if (id >= 0) {
+            if (a.c0 && unit < kNs) c[r] = a.c0[((size_t)id * 2 + dir) * kNs + unit];
+            if (a.tstart) ts[r] = a.tstart[(size_t)id * 2 + dir];
+        }
+    }
+    if (a.h0) {
+        for (int e = tid; e < kLines * kNs; e += kWaves * 64) {
+            const int slot = e / kNs, u = e % kNs;
+            const int id = s_line[slot];
+            if (id >= 0) {
+                unsigned short hi, mid, lo;
+                split3(a.h0[((size_t)id * 2 + dir) * kNs + u], hi, mid, lo);
+                srcp[0][0][slot][kXK + u] = hi;
+                srcp[0][1][slot][kXK + u] = mid;
+                srcp[0][2][slot][kXK + u] = lo;
+            }
+        }
+    }
 
     constexpr int kXE = kLines * kXK;                      // 832 elements of [16][52]
     auto x_value = [&](int e, int t) -> float {
@@ -382,11 +427,12 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_bf16x3_kernel(LstmArgs a
         for (int r = 0; r < 4; ++r) {
             float gi = acc[0][r], gf = acc[1][r], go = acc[2][r];
             const float ci = tanh_fast<false>(acc[3][r]);
-            if (t > 0) { gi += wip * c[r]; gf += wfp * c[r]; }
+            const bool past0 = (t > 0) | (ts[r] > 0);
+            if (past0) { gi += wip * c[r]; gf += wfp * c[r]; }
             gi = sigmoid_clip<false>(gi);
             gf = sigmoid_clip<false>(gf);
             float cn = ci * gi;
-            if (t > 0) { cn += gf * c[r]; go += wop * cn; }
+            if (past0) { cn += gf * c[r]; go += wop * cn; }
             go = sigmoid_clip<false>(go);
             const float h = tanh_fast<false>(cn) * go;
             c[r] = cn;
@@ -672,13 +718,16 @@ extern "C" int32_t ta_lstm_packed_weight_floats(int32_t mode) {
 extern "C" int ta_lstm_forward(const float* x, const int64_t* row_off, const int32_t* T,
                                const int32_t* group_lines, int32_t ngroups,
                                const float* wp, const float* peep, float* hout, int32_t mode,
+                               const float* h0, const float* c0, const int32_t* tstart,
                                void* stream) {
     if (ngroups < 0) return ta_fail(TA_EINVAL, "negative group count");
     if (ngroups == 0) return TA_OK;
     if (!x || !row_off || !T || !group_lines || !wp || !peep || !hout)
         return ta_fail(TA_EINVAL, "null pointer argument");
     if (mode != 0 && mode != 1) return ta_fail(TA_EINVAL, "mode must be 0 (f32 MFMA) or 1 (bf16 x 3)");
-    LstmArgs a{x, row_off, T, group_lines, wp, peep, hout};
+    if ((h0 != nullptr) != (c0 != nullptr) || (h0 != nullptr) != (tstart != nullptr))
+        return ta_fail(TA_EINVAL, "h0, c0 and tstart go together (all null, or all given)");
+    LstmArgs a{x, row_off, T, group_lines, wp, peep, hout, h0, c0, tstart};
     if (mode == 1)
         hipLaunchKernelGGL(lstm_seq_bf16x3_kernel, dim3(2 * ngroups), dim3(kWaves * 64), 0,
                            reinterpret_cast<hipStream_t>(stream), a);

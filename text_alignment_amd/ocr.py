@@ -219,10 +219,13 @@ class LineRecognizer(object):
         lib = _native.lib
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if lstm:
+            cont = st.get("continuation")          # (h0, c0, tstart) device tensors, or None: fresh lines
             _native.check(lib.ta_lstm_forward(
                 st["x"].data_ptr(), st["row_off"].data_ptr(), st["T"].data_ptr(),
                 st["group_lines"].data_ptr(), st["ngroups"], self.wp.data_ptr(),
-                self.peep.data_ptr(), st["hout"].data_ptr(), self.mode, stream), "ta_lstm_forward")
+                self.peep.data_ptr(), st["hout"].data_ptr(), self.mode,
+                cont[0].data_ptr() if cont else None, cont[1].data_ptr() if cont else None,
+                cont[2].data_ptr() if cont else None, stream), "ta_lstm_forward")
         full = want_logits or from_probs
         if full and st["probs"] is None:
             shape = (max(st["rows"], 1), self.model.no)
