@@ -11,7 +11,8 @@
  * (HBM) address owned by the caller; [host] is host memory.  `stream` is a hipStream_t
  * passed as void* (NULL = default stream).  Calls enqueue work and return without
  * synchronising.  Return value: 0 = ok, negative = TA_E*; ta_last_error() describes the
- * most recent failure on the calling thread.  The library keeps no global state.
+ * most recent failure on the calling thread.  The library keeps no mutable global state besides the
+ * lazily loaded code object and one-time, thread-safe raises of kernels' dynamic-LDS limits.
  */
 #ifndef TEXT_ALIGNMENT_AMD_H
 #define TEXT_ALIGNMENT_AMD_H
@@ -135,6 +136,16 @@ int ta_nw_general(const int32_t* t, int32_t n, const int32_t* o, int32_t m,
                   const double* params, const double* table, int32_t tm,
                   double* score_ws, uint8_t* ptr_ws,
                   uint8_t* ops_out, int32_t* ops_len, void* stream);
+/* The same for many problems in one launch (one workgroup each), match/mismatch scoring only:
+ * concatenated codes with offsets as in ta_nw_batch; params = double[nprob or 1][6] with
+ * params_stride 6 or 0; score_off (in doubles) / ptr_off / ops_off (in bytes) = per-problem offsets
+ * into the workspaces (sizes as above) and into ops_out (capacity n + m, right-aligned). */
+int ta_nw_general_batch(const int32_t* t_codes, const int64_t* t_off,
+                        const int32_t* o_codes, const int64_t* o_off, int32_t nprob,
+                        const double* params, int32_t params_stride,
+                        double* score_ws, const int64_t* score_off,
+                        uint8_t* ptr_ws, const int64_t* ptr_off,
+                        uint8_t* ops_out, const int64_t* ops_off, int32_t* ops_len, void* stream);
 
 /*
  * Line recogniser: replaces the `ocropus-rpred` subprocess of

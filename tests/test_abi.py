@@ -56,7 +56,8 @@ def test_argument_errors_without_gpu(native):
     calls = [
         lambda: lib.ta_nw2_batch(None, None, None, None, 1, None, 0, None, None, None, None, None, 10, 10, 100, 3, None),
         lambda: lib.ta_nw_general(None, 3, None, 3, None, None, 0, None, None, None, None, None),
-        lambda: lib.ta_lstm_forward(None, None, None, None, 1, None, None, None, 0, None),
+        lambda: lib.ta_lstm_forward(None, None, None, None, 1, None, None, None, 0, None, None, None, None),
+        lambda: lib.ta_nw_general_batch(None, None, None, None, 2, None, 0, None, None, None, None, None, None, None, None),
         lambda: lib.ta_lstm_output(None, 16, None, 96, None, None, None, None),
         lambda: lib.ta_decode_summary(None, None, None, 1, 0.7, None, None, None, None, None),
         lambda: lib.ta_decode(None, None, None, 1, 96, 0.7, None, None, None, None, None),

@@ -181,11 +181,11 @@ def test_long_rows_and_long_columns(tsc, two_phase):
 
 
 def test_config2_batch_properties(tsc, two_phase):
-    """BASELINE.json configs[1] shape (2048 x 2048, default scoring) at reduced batch for the
-    oracle comparison, plus size-independent properties on every problem of the batch."""
+    """BASELINE.json configs[1] (1024 problems of 2048 x 2048, default scoring): oracle comparison on
+    a sample, size-independent properties on every problem of the batch."""
     from oracle import nw_oracle
     from tools.synth import synth_pair_ids
-    nprob = 256
+    nprob = 1024
     probs = [synth_pair_ids(2048, 2048, 1234 + k) for k in range(nprob)]
     batch = tsc.NWBatch([p[0] for p in probs], [p[1] for p in probs], SYSTEMS[0], two_phase=two_phase)
     batch.run()
@@ -194,7 +194,7 @@ def test_config2_batch_properties(tsc, two_phase):
         c = np.bincount(ops, minlength=3)
         assert c[0] + c[1] == 2048 and c[0] + c[2] == 2048, k      # every token exactly once
         assert len(c) == 3
-    for k in (0, 1, 17, 100, 255):
+    for k in (0, 1, 17, 100, 255, 600, 1023):
         want = nw_oracle.align_ids(probs[k][0], probs[k][1], SYSTEMS[0])
         assert res[k].tolist() == want.tolist(), k
     g = load_golden("nw_synth.json")
@@ -262,17 +262,57 @@ def test_overflow_guard_routes_to_general_kernel(tsc):
     assert tsc.perform_alignment(t, o, big) == nw_oracle.perform_alignment(t, o, big)
 
 
-def test_ocr_longer_than_lds_row_routes_to_general_kernel(tsc):
-    """m beyond ta_nw_max_m() (the LDS hand-off row) still aligns, through the float64 kernel."""
+def test_ocr_longer_than_the_one_pass_lds_row_stays_on_the_integer_path(tsc):
+    """m beyond ta_nw_max_m() (the one-pass kernel's LDS hand-off row): the two-phase aligner keeps
+    its hand-off rows in the workspace and takes OCR strings up to ta_nw2_max_m() tokens -- the
+    reference has no such limit (textSeqCompare.py:45-50).  Beyond that, the float64 kernel."""
+    from oracle import nw_oracle
+    from tools.synth import synth_pair, synth_pair_ids
+    from text_alignment_amd import _native
+    assert _native.lib.ta_nw2_max_m() >= 40000 > _native.lib.ta_nw_max_m()
+    t, o = synth_pair_ids(700, 40000, 77)
+    batch = tsc.NWBatch([t, t[:300]], [o, o[:17000]], SYSTEMS[0])
+    assert batch.two_phase                                   # chosen automatically: too wide for one pass
+    batch.run()
+    res = batch.results()
+    assert res[0].tolist() == nw_oracle.align_ids(t, o, SYSTEMS[0]).tolist()
+    assert res[1].tolist() == nw_oracle.align_ids(t[:300], o[:17000], SYSTEMS[0]).tolist()
+    with pytest.raises(OverflowError):
+        tsc.NWBatch([t], [o], SYSTEMS[0], two_phase=False)
+    tt, oo = synth_pair(700, 40000, 77)
+    res = tsc.perform_alignment_batch([(tt, oo), (list("abc"), list("abd"))])
+    assert res[0] == nw_oracle.perform_alignment(tt, oo)
+    assert res[1] == nw_oracle.perform_alignment(list("abc"), list("abd"))
+    m = _native.lib.ta_nw2_max_m() + 300                     # even wider: float64 kernel, same answer
+    tt, oo = synth_pair(150, m, 78)
+    assert tsc.perform_alignment(tt, oo) == nw_oracle.perform_alignment(tt, oo)
+
+
+def test_float_scoring_grid_is_one_launch(tsc, monkeypatch):
+    """A grid of NON-integral scoring systems (the float case of textSeqCompare.py:30-40 under the
+    loop of evaluate_text_alignment.py:178-198) goes through ta_nw_general_batch: one launch, one
+    workgroup per system, results as the float64 oracle's."""
     from oracle import nw_oracle
     from tools.synth import synth_pair
-    from text_alignment_amd import _native
-    m = _native.lib.ta_nw_max_m() + 500
-    t, o = synth_pair(700, m, 77)
-    assert tsc.perform_alignment(t, o) == nw_oracle.perform_alignment(t, o)
-    res = tsc.perform_alignment_batch([(t, o), (list("abc"), list("abd"))])
-    assert res[0] == nw_oracle.perform_alignment(t, o)
-    assert res[1] == nw_oracle.perform_alignment(list("abc"), list("abd"))
+    from text_alignment_amd import _native, nw_general
+    grid = [[m1 + 0.5, m2 - 0.25, gx, gy - 0.5, ex, 0.0] for m1 in (5, 8, 11) for m2 in (-10, -7, -4)
+            for gx in (-7, -5, -2) for gy in (-7, -5, -2) for ex in (-5, -3, 0.5)]
+    assert len(grid) == 243
+    t, o = synth_pair(140, 130, 5)
+    calls = []
+    real = nw_general.align_batch
+    monkeypatch.setattr(nw_general, "align_batch", lambda *a: (calls.append(len(a[0])), real(*a))[1])
+    res = tsc.perform_alignment_batch([(t, o)] * len(grid), grid)
+    assert calls == [243]
+    for g, got in list(zip(grid, res))[::7]:
+        assert got == nw_oracle.perform_alignment(t, o, g), g
+    ragged = [(list("abcd"), list("xbcy")), ([], list("ab")), (t, o[:40]), (list("a"), [])]
+    for (a, b), got in zip(ragged, tsc.perform_alignment_batch(ragged, [8.5, -4.25, -7, -7, -3, 0])):
+        assert got == nw_oracle.perform_alignment(a, b, [8.5, -4.25, -7, -7, -3, 0])
+    fn = lambda a, b: 3.5 if a == b else -2.0                                      # noqa: E731
+    sys5 = [fn, -7, -7, -3, 0]                                  # the 5-element callable form, as ONE system
+    got = tsc.perform_alignment_batch(ragged[:3], sys5)
+    assert got == [nw_oracle.perform_alignment(a, b, sys5) for a, b in ragged[:3]]
 
 
 def test_two_phase_many_problems_small_walk_window(tsc):

@@ -60,6 +60,8 @@ def _load():
     lib.ta_nw_general_ptr_bytes.argtypes = [i32, i32]
     lib.ta_nw_general.restype = ctypes.c_int
     lib.ta_nw_general.argtypes = [vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    lib.ta_nw_general_batch.restype = ctypes.c_int
+    lib.ta_nw_general_batch.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     f32 = ctypes.c_float
     lib.ta_lstm_packed_weight_floats.restype = i32
     lib.ta_lstm_packed_weight_floats.argtypes = [i32]
@@ -90,7 +92,7 @@ def _load():
 lib = _load()
 
 EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_max_m", "ta_nw2_batch", "ta_nw2_phase1_plan",
-           "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general",
+           "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general", "ta_nw_general_batch",
            "ta_lstm_packed_weight_floats", "ta_lstm_forward", "ta_lstm_output", "ta_decode",
            "ta_decode_summary", "ta_linenorm_measure", "ta_linenorm_resample",
            "ta_pp_histogram", "ta_pp_threshold", "ta_pp_label", "ta_pp_components", "ta_pp_filter_components",

@@ -741,14 +741,10 @@ extern "C" int ta_lstm_forward(const float* x, const int64_t* row_off, const int
 
 template <int NCT>
 static hipError_t launch_output(const OutArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    if (lds > 64 * 1024) {          // above the default dynamic-LDS limit
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_output_kernel<NCT>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            raised = true;
-        }
+    if (lds > 64 * 1024) {          // above the default dynamic-LDS limit: raise it once (thread-safe)
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_output_kernel<NCT>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (once != hipSuccess) return once;
     }
     hipLaunchKernelGGL(lstm_output_kernel<NCT>, grid, dim3(kOWaves * 64), lds, st, a);
     return hipSuccess;

@@ -409,13 +409,10 @@ extern "C" int32_t ta_nw_max_m(void) {
 template <int W>
 static hipError_t launch_fill(const NwArgs& a, int max_m, hipStream_t st) {
     const size_t lds = NwLds(max_m).total;
-    static bool raised = false;         // allow > 64 KiB of dynamic LDS, once per process
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nw_fill_kernel<kR, W, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    // allow > 64 KiB of dynamic LDS: once per process, thread-safe (function-local static initialiser)
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&nw_fill_kernel<kR, W, false>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (once != hipSuccess) return once;
     hipLaunchKernelGGL((nw_fill_kernel<kR, W, false>), dim3(a.nprob), dim3(W * 64), lds, st, a);
     return hipGetLastError();
 }
@@ -425,13 +422,9 @@ static hipError_t launch_fill(const NwArgs& a, int max_m, hipStream_t st) {
 // dealt round-robin to the 8 XCDs, so all chunks of a problem share one L2 for the HBM hand-off rows.
 static hipError_t launch_fill_wide(NwArgs a, int nstrips, int max_m, hipStream_t st) {
     const size_t lds = NwLds(max_m).total;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nw_fill_kernel<kR, kWideW, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&nw_fill_kernel<kR, kWideW, true>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (once != hipSuccess) return once;
     a.wide_stride = (a.nprob + 7) & ~7;
     const int chunks = (nstrips + kWideW - 1) / kWideW;
     hipLaunchKernelGGL((nw_wide_init_kernel<kR>), dim3(a.nprob), dim3(64), 0, st, a);

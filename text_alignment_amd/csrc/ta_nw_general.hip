@@ -6,7 +6,8 @@
 // literally -- IEEE float64 scores, -1e100 boundary sentinels (textSeqCompare.py:55,60),
 // left-to-right additions (textSeqCompare.py:75-85), first maximum wins -- so results are
 // bit-identical to the reference for any inputs.  It is a correctness path, not a fast one:
-// one workgroup sweeps anti-diagonals with a barrier per diagonal.
+// one workgroup per problem sweeps anti-diagonals with a barrier per diagonal
+// (ta_nw_general_batch: many problems in one launch).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -36,7 +37,7 @@ __device__ __forceinline__ void boundary(int i, int j, double& M, double& X, dou
     else        { M = -1.0 * i; X = -1e100;   Y = -1.0 * i; }
 }
 
-__global__ __launch_bounds__(1024) void nw_general_kernel(GenArgs a) {
+__device__ __forceinline__ void general_one(const GenArgs& a) {
     const int n = a.n, m = a.m, tid = threadIdx.x;
     const double match = a.params[0], mismatch = a.params[1];
     const double gox = a.params[2], goy = a.params[3], gex = a.params[4], gey = a.params[5];
@@ -87,6 +88,35 @@ __global__ __launch_bounds__(1024) void nw_general_kernel(GenArgs a) {
     *a.ops_len = len;
 }
 
+__global__ __launch_bounds__(1024) void nw_general_kernel(GenArgs a) { general_one(a); }
+
+// many problems, one workgroup each (a parameter grid with non-integral numbers: the reference's
+// evaluate_text_alignment.py:178-198 loop, one launch instead of one per scoring system)
+struct GenBatchArgs {
+    const int32_t* t_codes; const int64_t* t_off;
+    const int32_t* o_codes; const int64_t* o_off;
+    const double* params; int params_stride;          // 0: one system for all, 6: one per problem
+    double* sc; const int64_t* sc_off;                 // in doubles
+    uint8_t* ptr; const int64_t* ptr_off;              // in bytes
+    uint8_t* ops; const int64_t* ops_off; int32_t* ops_len;
+};
+
+__global__ __launch_bounds__(1024) void nw_general_batch_kernel(GenBatchArgs b) {
+    const int p = blockIdx.x;
+    GenArgs a;
+    a.t = b.t_codes + b.t_off[p];
+    a.o = b.o_codes + b.o_off[p];
+    a.n = (int)(b.t_off[p + 1] - b.t_off[p]);
+    a.m = (int)(b.o_off[p + 1] - b.o_off[p]);
+    a.params = b.params + (size_t)p * b.params_stride;
+    a.table = nullptr; a.tm = 0;
+    a.sc = b.sc + b.sc_off[p];
+    a.ptr = b.ptr + b.ptr_off[p];
+    a.ops = b.ops + b.ops_off[p];
+    a.ops_len = b.ops_len + p;
+    general_one(a);
+}
+
 }  // namespace ta
 
 extern "C" int64_t ta_nw_general_score_bytes(int32_t n) { return (int64_t)9 * ((int64_t)n + 1) * 8; }
@@ -107,5 +137,26 @@ extern "C" int ta_nw_general(const int32_t* t, int32_t n, const int32_t* o, int3
                        reinterpret_cast<hipStream_t>(stream), a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ta_fail_hip(e, "nw_general_kernel launch");
+    return TA_OK;
+}
+
+extern "C" int ta_nw_general_batch(const int32_t* t_codes, const int64_t* t_off,
+                                   const int32_t* o_codes, const int64_t* o_off, int32_t nprob,
+                                   const double* params, int32_t params_stride,
+                                   double* score_ws, const int64_t* score_off,
+                                   uint8_t* ptr_ws, const int64_t* ptr_off,
+                                   uint8_t* ops_out, const int64_t* ops_off, int32_t* ops_len, void* stream) {
+    if (nprob < 0) return ta_fail(TA_EINVAL, "negative problem count");
+    if (nprob == 0) return TA_OK;
+    if (params_stride != 0 && params_stride != 6) return ta_fail(TA_EINVAL, "params_stride must be 0 or 6");
+    if (!t_codes || !t_off || !o_codes || !o_off || !params || !score_ws || !score_off || !ptr_ws || !ptr_off ||
+        !ops_out || !ops_off || !ops_len)
+        return ta_fail(TA_EINVAL, "null pointer argument");
+    ta::GenBatchArgs b{t_codes, t_off, o_codes, o_off, params, params_stride, score_ws, score_off,
+                       ptr_ws, ptr_off, ops_out, ops_off, ops_len};
+    hipLaunchKernelGGL(ta::nw_general_batch_kernel, dim3(nprob), dim3(1024), 0,
+                       reinterpret_cast<hipStream_t>(stream), b);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ta_fail_hip(e, "nw_general_batch_kernel launch");
     return TA_OK;
 }

@@ -221,21 +221,27 @@ def perform_alignment_batch(pairs, scoring_systems=None):
         if len(systems) != len(pairs):
             raise ValueError("need one scoring system per pair")
     parsed = [parse_scoring_system(s) for s in systems]
-    if any(fn is not None for _, fn in parsed) or not all(_is_integral(p) for p, _ in parsed):
+    if any(fn is not None for _, fn in parsed):      # a scoring callable: its table is per pair
         return [perform_alignment(t, o, s) for (t, o), s in zip(pairs, systems)]
     t_list, o_list = [], []
     for t, o in pairs:
         (ti, oi), _ = encode_tokens(t, o)
         t_list.append(ti); o_list.append(oi)
-    params = np.array([[int(v) for v in p] for p, _ in parsed], dtype=np.int64)
-    if len(pairs) and (params == params[0]).all():
-        params = params[:1]
-    try:
-        batch = NWBatch(t_list, o_list, params)
-    except OverflowError:           # some problem exceeds the integer kernels' limits: one by one
-        return [perform_alignment(t, o, s) for (t, o), s in zip(pairs, systems)]
-    batch.run()
-    return [ops_to_alignment(ops, t, o) for ops, (t, o) in zip(batch.results(), pairs)]
+    all_ops = None
+    if all(_is_integral(p) for p, _ in parsed):
+        params = np.array([[int(v) for v in p] for p, _ in parsed], dtype=np.int64)
+        if len(pairs) and (params == params[0]).all():
+            params = params[:1]
+        try:
+            batch = NWBatch(t_list, o_list, params)
+            batch.run()
+            all_ops = batch.results()
+        except OverflowError:       # beyond the 32-bit kernels' limits: the float64 kernel below
+            pass
+    if all_ops is None:             # non-integral numbers (or too large): float64 kernel, still one launch
+        from . import nw_general
+        all_ops = nw_general.align_batch(t_list, o_list, [[float(v) for v in p] for p, _ in parsed])
+    return [ops_to_alignment(ops, t, o) for ops, (t, o) in zip(all_ops, pairs)]
 
 
 def perform_alignment(transcript, ocr, scoring_system=None, verbose=False):
