@@ -1,0 +1,117 @@
+"""text_alignment_amd/page_batch.py (the array form of the page glue process_batch runs) against the
+reference's own outputs (tests/golden/glue.json, llocs.json) and against the object-by-object
+functions of alignToOCR.py.  CPU only: the aligner here is oracle/nw_oracle.py."""
+import numpy as np
+
+from conftest import load_golden
+
+
+def _ops(tra, ocr):
+    return np.array([1 if b == '_' and a != '_' else (2 if a == '_' else 0) for a, b in zip(tra, ocr)], dtype=np.uint8)
+
+
+def test_array_glue_reproduces_reference_pages():
+    from oracle import nw_oracle
+    from text_alignment_amd import alignToOCR as atocr, latinSyllabification as latsyl, page_batch as pb
+    from text_alignment_amd.page import Dim
+    g = load_golden("glue.json")
+    for c in g["process_cases"]:
+        chars = [ch for ch, _, _ in c["chars"]]
+        boxes = np.array([[ul[0], ul[1], lr[0], lr[1]] for _, ul, lr in c["chars"]], dtype=np.int64).reshape(-1, 4)
+        if any(len(ch) != 1 for ch in chars):
+            continue
+        text, idx = pb.expand_abbreviations(''.join(chars), np.arange(len(chars)), latsyl.abbreviations)
+        assert text == c["expanded_ocr"], c["name"]
+        tr = c["transcript"]
+        tra, ocr = nw_oracle.perform_alignment(list(tr), list(text), c["params"])
+        syls = latsyl.syllabify_text(tr)
+        assert pb.plain_page(tr, syls)
+        which, sb = pb.syllable_boxes_arrays(tr, syls, _ops(tra, ocr), boxes[idx])
+        sb = pb.rotate_boxes(sb, -1 * c["angle"], Dim(*c["img_dim"]), Dim(*c["raw_dim"]))
+        named = [s for s in syls if len(s) >= 1]
+        seq = pb.BoxSeq([named[w] for w in which], sb, atocr.CharBox)
+        js = atocr.to_JSON_dict(seq, c["peak_locs"])
+        js["median_line_spacing"] = float(js["median_line_spacing"])
+        assert js == c["json"], c["name"]
+
+
+def test_chars_of_batch_matches_reference_llocs():
+    """the decoder's (t, class) arrays -> boxes, on the reference's llocs fixture: positions are put
+    back into timestep form (scale 1: raw width == T - 32) so that x = t - 16 reproduces the file"""
+    from text_alignment_amd import page_batch as pb
+    g = load_golden("llocs.json")
+    for c in g["cases"]:
+        codec, dec_t, dec_c, dec_n, T, xmin, ymin, ymax = ["", "~"], [], [], [], [], [], [], []
+        for s in c["strips"]:
+            n = 0
+            for line in s["llocs"]:
+                ch, x = line.split("\t")
+                if ch not in codec:
+                    codec.append(ch)
+                # x has one decimal: carry it as t = 10 x + 16 on a line whose scale is 1/10
+                dec_t.append(int(round(float(x) * 10)) + 16)
+                dec_c.append(codec.index(ch))
+                n += 1
+            dec_n.append(n); T.append(100032)
+            xmin.append(s["offset_x"]); ymin.append(s["offset_y"]); ymax.append(s["offset_y"] + s["height"])
+        off = np.concatenate([[0], np.cumsum(dec_n)[:-1]]).astype(np.int64)
+        cps = pb.codec_code_points(codec)
+        line, cp, boxes = pb.chars_of_batch(np.array(dec_t), np.array(dec_c), np.array(dec_n, dtype=np.int64), off,
+                                            np.array(T), np.full(len(T), 10000), np.array(xmin), np.array(ymin),
+                                            np.array(ymax), cps, 16)
+        got = [[chr(int(a)), [int(b[0]), int(b[1])], [int(b[2]), int(b[3])]] for a, b in zip(cp, boxes)]
+        assert got == c["chars"]
+    assert pb.codec_code_points(["", " ", "~", "ab"]) is None
+
+
+def test_array_glue_equals_object_glue_on_random_pages():
+    """random OCR strings with gaps on both sides, two text lines, abbreviations: the array path and
+    alignToOCR.align_page give the same boxes and the same syllable indices"""
+    from oracle import nw_oracle
+    from text_alignment_amd import alignToOCR as atocr, latinSyllabification as latsyl, page_batch as pb
+    from text_alignment_amd.page import Dim
+    rng = np.random.default_rng(5)
+    words = "dominus deus meus alleluia gloria patri et filio cuius eius in excelsis laudate dns alla".split()
+    pages, all_boxes, nbox = [], [], 0
+    for trial in range(40):
+        tr = " ".join(words[int(i)] for i in rng.integers(0, len(words) - 2, size=int(rng.integers(3, 30))))
+        noisy = []
+        for ch in tr:
+            u = rng.random()
+            if u < 0.1:
+                continue
+            noisy.append(ch if u < 0.8 else "abcdeilmnostu^ "[int(rng.integers(0, 15))])
+            if rng.random() < 0.08:
+                noisy.append("xq"[int(rng.integers(0, 2))])
+        if trial % 5 == 0:
+            noisy[2:2] = list("dns")
+        boxes = np.array([[30 + 20 * k, 100 if k < len(noisy) // 2 else 220, 48 + 20 * k, 140 if k < len(noisy) // 2 else 262]
+                          for k in range(len(noisy))], dtype=np.int64).reshape(-1, 4)
+        objs = [atocr.CharBox(ch, b[0:2], b[2:4]) for ch, b in zip(noisy, boxes)]
+        angle = float(rng.uniform(-3, 3))
+        dims = (Dim(1000, 800), Dim(980, 790))
+        text, idx = pb.expand_abbreviations(''.join(noisy), np.arange(len(noisy)), latsyl.abbreviations)
+        expanded = atocr.expand_abbreviations(list(objs))
+        assert text == ''.join(o.char for o in expanded)
+        al = nw_oracle.perform_alignment(list(tr), list(text), None)
+        want_idx = []
+        want, _ = atocr.align_page(tr, expanded, angle, dims[0], dims[1], None, alignment=al, indices=want_idx,
+                                   expanded=True)
+        which, sb = pb.syllable_boxes_arrays(tr, latsyl.syllabify_text(tr), _ops(*al), boxes[idx])
+        sb = pb.rotate_boxes(sb, -1 * angle, dims[0], dims[1])
+        assert which.tolist() == want_idx
+        assert sb.tolist() == [[int(b.ulx), int(b.uly), int(b.lrx), int(b.lry)] for b in want]
+        pages.append((tr, latsyl.syllabify_text(tr), _ops(*al), idx + nbox, angle, want_idx, sb))
+        all_boxes.append(boxes)
+        nbox += len(boxes)
+    # the same pages through the many-pages form, three at a time and all at once
+    all_boxes = np.concatenate(all_boxes)
+    for chunk in (3, len(pages)):
+        for a in range(0, len(pages), chunk):
+            part = pages[a:a + chunk]
+            got = pb.syllable_boxes_batch([p[0] for p in part], [p[1] for p in part], [p[2] for p in part],
+                                          [p[3] for p in part], all_boxes, [p[4] for p in part],
+                                          [dims[0]] * len(part), [dims[1]] * len(part))
+            for p, (which, sb) in zip(part, got):
+                assert which.tolist() == p[5] and sb.tolist() == p[6].tolist()
+    assert pb.syllable_boxes_batch([], [], [], [], all_boxes, [], [], []) == []

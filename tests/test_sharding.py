@@ -81,7 +81,8 @@ def test_single_process_passthrough_and_cost():
     assert sharding.page_cost([100, 200], 800) > sharding.page_cost([100], 800)
 
 
-def _fake_process_batch(pages, transcripts, model, seq_align_params=None, indices_out=None, parallel=2):
+def _fake_process_batch(pages, transcripts, model, seq_align_params=None, indices_out=None, parallel=2,
+                        arrays_out=None):
     """stands in for alignToOCR.process_batch on a CPU-only box: boxes are a function of the page
     and the transcript only (every second non-empty syllable gets one), so any rank computes the
     same boxes for the same page"""

@@ -319,23 +319,11 @@ def _raw_dim(pg):
     return page_mod.Dim(px.shape[1], px.shape[0])
 
 
-def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indices_out=None,
-                  parallel=parallel):
-    """`process` for many pages at once: the strips of ALL pages go through the line recogniser
-    in one batch and the transcript/OCR alignments of all pages run in one NW launch -- the shape
-    in which a GPU is worth using.  Per page the result equals process(page, transcript, model,
-    seq_align_params).  Returns a list of (syl_boxes, image, lines_peak_locs, all_chars)."""
-    from . import ocr
-    rec = _recognizer_for(ocropus_model)
-    raw_dims = [_raw_dim(pg) for pg in pages]            # bad page types fail before any GPU work
-    found = find_lines_all(list(pages), workers=parallel)
-    prep = [((image, eroded, angle), ) for (image, eroded, angle, _, _) in found]
-    strips_per_page = [f[3] for f in found]
-    peaks = [f[4] for f in found]
-    prepared = page_mod.prepared_lines([st for strips in strips_per_page for st in strips], workers=parallel)
-    lines = [xs for xs, _ in prepared]
-    widths = [w for _, w in prepared]
-    decoded = rec.recognise(lines)
+def _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, widths, transcripts,
+                           seq_align_params, indices_out):
+    """process_batch, object by object (CharBox lists, alignToOCR.py:247-330 per page): the path for
+    scoring callables / non-integral numbers and for codecs with multi-character entries."""
+    decoded = rec.decoded(rec._last_state)
     chars_per_page, k = [], 0
     for strips in strips_per_page:
         all_chars = []
@@ -347,8 +335,8 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     pairs = [(list(tr), [c.char for c in chars]) for tr, chars in zip(transcripts, chars_per_page)]
     alignments = tsc.perform_alignment_batch(pairs, seq_align_params)
     results = []
-    for raw_dim, ((image, eroded, angle), ), tr, chars, lp, al in zip(raw_dims, prep, transcripts,
-                                                                     chars_per_page, peaks, alignments):
+    for raw_dim, f, tr, chars, al in zip(raw_dims, found, transcripts, chars_per_page, alignments):
+        image, angle, lp = f[0], f[2], f[4]
         idx = [] if indices_out is not None else None
         syl_boxes, all_chars_copy = align_page(tr, chars, angle, image.dim, raw_dim,
                                                seq_align_params, alignment=al, indices=idx, expanded=True)
@@ -356,6 +344,109 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
             indices_out.append(idx)
         results.append((syl_boxes, image, lp, all_chars_copy))
     return results
+
+
+def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indices_out=None,
+                  parallel=parallel, arrays_out=None):
+    """`process` for many pages at once: the strips of ALL pages go through the line recogniser
+    in one batch, the transcript/OCR alignments of all pages run in one NW launch, and the glue in
+    between runs on arrays (text_alignment_amd.page_batch) -- the shape in which a GPU is worth
+    using.  Per page the result equals process(page, transcript, model, seq_align_params).
+    Returns a list of (syl_boxes, image, lines_peak_locs, all_chars); the two box lists are
+    sequences that build their CharBox objects on access.  indices_out, if given, receives per page
+    the index of each box's syllable among the transcript's non-empty syllables; arrays_out the
+    boxes themselves as an int array [k, 4] (ulx, uly, lrx, lry)."""
+    from . import page_batch as pb
+    rec = _recognizer_for(ocropus_model)
+    raw_dims = [_raw_dim(pg) for pg in pages]            # bad page types fail before any GPU work
+    found = find_lines_all(list(pages), workers=parallel)
+    strips_per_page = [f[3] for f in found]
+    all_strips = [st for strips in strips_per_page for st in strips]
+    prepared = page_mod.prepared_lines(all_strips, workers=parallel)
+    lines = [xs for xs, _ in prepared]
+    widths = [w for _, w in prepared]
+    st = rec.prepare(lines)
+    rec.last_T = st["T_host"]
+    rec._last_state = st
+    rec.run(st)
+
+    params, fn = tsc.parse_scoring_system(seq_align_params)
+    cps = pb.codec_code_points(rec.model.codec)
+    if fn is not None or cps is None or not tsc._is_integral(params):
+        return _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, widths,
+                                      transcripts, seq_align_params, indices_out)
+
+    # host work that needs no OCR result runs while the recogniser kernels do
+    syls_all = [latsyl.syllabify_text(tr) for tr in transcripts]
+    t_cp = [np.frombuffer(tr.encode('utf-32-le'), dtype='<u4').astype(np.int64) for tr in transcripts]
+
+    # ---- every character of every line: code points + boxes (alignToOCR.py:160-182) ----
+    nlines = len(all_strips)
+    dec_t = st["dec_t"].cpu().numpy()
+    dec_c = st["dec_c"].cpu().numpy()
+    dec_n = st["dec_n"].cpu().numpy()[:nlines].astype(np.int64) if nlines else np.zeros(0, np.int64)
+    x_min = np.array([s.offset_x for s in all_strips], dtype=np.int64)
+    y_min = np.array([s.offset_y for s in all_strips], dtype=np.int64)
+    y_max = y_min + np.array([s.height for s in all_strips], dtype=np.int64)
+    line, cp, boxes = pb.chars_of_batch(dec_t, dec_c, dec_n, st["row_off_host"][:-1], st["T_host"],
+                                        np.asarray(widths, dtype=np.int64), x_min, y_min, y_max, cps, ocr_pad())
+    first_line = np.zeros(len(pages) + 1, dtype=np.int64)
+    np.cumsum([len(s) for s in strips_per_page], out=first_line[1:])
+    first_char = np.searchsorted(line, first_line)         # characters of page k: first_char[k] .. first_char[k+1]
+
+    # ---- abbreviations, then one NW launch for all pages (alignToOCR.py:251-276) ----
+    texts, idxs = [], []
+    for k in range(len(pages)):
+        a, b = int(first_char[k]), int(first_char[k + 1])
+        text = cp[a:b].astype('<u4').tobytes().decode('utf-32-le')
+        text, idx = pb.expand_abbreviations(text, np.arange(a, b), latsyl.abbreviations)
+        texts.append(text)
+        idxs.append(idx)
+    o_cp = [np.frombuffer(tx.encode('utf-32-le'), dtype='<u4').astype(np.int64) for tx in texts]
+    alphabet = np.unique(np.concatenate(t_cp + o_cp)) if (t_cp or o_cp) else np.zeros(0, np.int64)
+    try:
+        batch = tsc.NWBatch([np.searchsorted(alphabet, a).astype(np.int32) for a in t_cp],
+                            [np.searchsorted(alphabet, a).astype(np.int32) for a in o_cp],
+                            [int(v) for v in params])
+    except OverflowError:
+        return _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, widths,
+                                      transcripts, seq_align_params, indices_out)
+    batch.run()
+    all_ops = batch.results()
+
+    # ---- syllable boxes (alignToOCR.py:277-328): all plain pages in one set of array operations ----
+    plain = [k for k in range(len(pages)) if pb.plain_page(transcripts[k], syls_all[k])]
+    batched = dict(zip(plain, pb.syllable_boxes_batch(
+        [transcripts[k] for k in plain], [syls_all[k] for k in plain], [all_ops[k] for k in plain],
+        [idxs[k] for k in plain], boxes, [found[k][2] for k in plain], [found[k][0].dim for k in plain],
+        [raw_dims[k] for k in plain])))
+    results = []
+    for k, (raw_dim, f, tr) in enumerate(zip(raw_dims, found, transcripts)):
+        image, angle, lp = f[0], f[2], f[4]
+        chars_seq = pb.BoxSeq(list(texts[k]), boxes[idxs[k]], CharBox)
+        if k in batched:
+            which, sb = batched[k]
+            named = [s for s in syls_all[k] if len(s) >= 1]
+            syl_seq = pb.BoxSeq([named[w] for w in which], sb, CharBox)
+            which = which.tolist()
+        else:                                             # characters `re` would interpret: object path
+            which = []
+            al = tsc.ops_to_alignment(all_ops[k], list(tr), list(texts[k]))
+            syl_boxes, _ = align_page(tr, list(chars_seq), angle, image.dim, raw_dim, seq_align_params,
+                                      alignment=al, indices=which, expanded=True)
+            sb = np.array([[b.ulx, b.uly, b.lrx, b.lry] for b in syl_boxes], dtype=np.int64).reshape(-1, 4)
+            syl_seq = syl_boxes
+        if indices_out is not None:
+            indices_out.append(which)
+        if arrays_out is not None:
+            arrays_out.append(sb)
+        results.append((syl_seq, image, lp, chars_seq))
+    return results
+
+
+def ocr_pad():
+    from . import ocr
+    return ocr.PAD
 
 
 def process(raw_image,

@@ -129,6 +129,17 @@ def _pack_lstm(model):
     return wp, peep, w2p
 
 
+_pool = None
+
+
+def _copy_pool():
+    global _pool
+    if _pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(8)
+    return _pool
+
+
 class LineRecognizer(object):
     """precision: "f32" (default) runs the recurrence as an exact f32-input MFMA chain -- the mode
     the 1e-3 logit parity is stated for.  "bf16x3" runs it on the bf16 matrix cores with split
@@ -150,11 +161,44 @@ class LineRecognizer(object):
         self.peep = torch.from_numpy(peep).to(self.device)
         self.w2p = torch.from_numpy(w2p).to(self.device)
 
+    # ---- host -> device ------------------------------------------------------------------
+    def _upload_rows(self, lines, row_off, rows):
+        """All prepared lines as one [rows, 48] float32 device tensor.  The lines are copied (and, if
+        need be, converted) straight into a pinned staging buffer by a few threads -- numpy releases
+        the GIL for these copies, and at ~275 KB per line a page is 8 MB, so one thread's memcpy
+        rate would bound the whole pipeline -- and go over PCIe in one asynchronous transfer."""
+        if rows == 0:
+            return torch.zeros((1, NI), dtype=torch.float32, device=self.device)
+        stage = getattr(self, "_stage", None)
+        if stage is None or stage.shape[0] < rows:
+            stage = self._stage = torch.empty((int(rows * 1.25) + 1024, NI), dtype=torch.float32, pin_memory=True)
+        view = stage.numpy()
+
+        def copy(span):
+            for k in range(*span):
+                view[row_off[k]:row_off[k + 1]] = lines[k]
+        nthreads = min(8, max(1, len(lines) // 64))
+        if nthreads == 1:
+            copy((0, len(lines)))
+        else:
+            cuts = np.searchsorted(row_off, np.linspace(0, rows, nthreads + 1)).tolist()
+            cuts[0], cuts[-1] = 0, len(lines)
+            list(_copy_pool().map(copy, [(cuts[i], cuts[i + 1]) for i in range(nthreads)]))
+        x_dev = torch.empty((rows, NI), dtype=torch.float32, device=self.device)
+        x_dev.copy_(stage[:rows], non_blocking=True)
+        # the staging buffer is reused by the next batch: the transfer has to be over before then
+        self._stage_done = torch.cuda.Event()
+        self._stage_done.record()
+        return x_dev
+
     # ---- batched device pass -------------------------------------------------------------
     def prepare(self, lines):
         """Upload lines and allocate outputs.  A line is either a prepared (T, 48) float array
         (ink = 1, padded) or a raw 2-D uint8 strip (white background), which is normalised on the
         device (lineest_gpu, csrc/ta_lineest.hip) without a host round trip."""
+        done = getattr(self, "_stage_done", None)
+        if done is not None:
+            done.synchronize()
         raw = [k for k, ln in enumerate(lines) if getattr(ln, "dtype", None) == np.uint8]
         T = np.zeros(len(lines), dtype=np.int64)
         x_raw, T_raw = None, None
@@ -180,8 +224,7 @@ class LineRecognizer(object):
         raw_set = set(raw)
         host = [k for k in range(len(lines)) if k not in raw_set]
         if not raw:
-            x = np.concatenate(lines, axis=0).astype(np.float32) if rows else np.zeros((1, NI), np.float32)
-            x_dev = torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+            x_dev = self._upload_rows(lines, row_off, rows)
         elif not host:
             x_dev = x_raw
         else:                                   # mixed batch: stitch the two sources together in line order

@@ -192,12 +192,19 @@ def process_shard(my_pages, my_transcripts, my_ids, my_models, capacity, seq_ali
     for k, mdl in enumerate(my_models):
         by_model.setdefault(id(mdl), (mdl, []))[1].append(k)
     for mdl, ks in by_model.values():
-        idx = []
+        idx, arrs = [], []
         res = atocr.process_batch([my_pages[k] for k in ks], [my_transcripts[k] for k in ks], mdl,
-                                  seq_align_params, indices_out=idx)
-        for k, r, ix in zip(ks, res, idx):
+                                  seq_align_params, indices_out=idx, arrays_out=arrs)
+        for j, (k, r, ix) in enumerate(zip(ks, res, idx)):
             recs.append(page_header(my_ids[k], r[2], len(r[0])))
-            recs.append(boxes_to_records(my_ids[k], r[0], ix))
+            if j < len(arrs):                     # the array pipeline hands the boxes over as they are
+                rec = np.empty((len(ix), RECORD_FIELDS), dtype=np.int32)
+                rec[:, 0] = my_ids[k]
+                rec[:, 1] = ix
+                rec[:, 2:6] = arrs[j]
+                recs.append(rec)
+            else:
+                recs.append(boxes_to_records(my_ids[k], r[0], ix))
     local = np.concatenate(recs, axis=0) if recs else np.zeros((0, RECORD_FIELDS), np.int32)
     if device is None:
         nccl = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"

@@ -100,8 +100,8 @@ def setup_sharded(pages_per_rank, rank, world, seed0=100):
     job = {"pages": [make_page(seed0 + k)[0] for k in mine], "transcripts": [transcripts[k] for k in mine],
            "ids": mine, "models": [recs[k % 2] for k in mine], "capacity": capacity,
            "all_transcripts": transcripts, "total_pages": total}
-    sharding.process_shard(job["pages"][:2], job["transcripts"][:2], mine[:2], job["models"][:2],
-                           capacity, PARAMS)                       # warm-up (collective: every rank)
+    sharding.process_shard(job["pages"], job["transcripts"], mine, job["models"],
+                           capacity, PARAMS)                       # warm-up at full size (collective: every rank)
     torch.cuda.synchronize()
     return job
 
@@ -119,7 +119,7 @@ def run(npages, seed0=100):
     from text_alignment_amd import alignToOCR as atocr
     rec = make_recognizer()
     pages, trs = zip(*[make_page(seed0 + k) for k in range(npages)])
-    atocr.process_batch(list(pages[:2]), list(trs[:2]), rec, PARAMS)          # warm-up
+    atocr.process_batch(list(pages), list(trs), rec, PARAMS)                  # warm-up at full size (staging buffer)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     res = atocr.process_batch(list(pages), list(trs), rec, PARAMS)
@@ -136,7 +136,7 @@ def run(npages, seed0=100):
         lat.append(time.perf_counter() - t1)
     # the same from raw strips: line normaliser on the device in front of the recogniser
     rpages, rtrs = zip(*[make_page(seed0 + 5000 + k, raw=True) for k in range(npages)])
-    atocr.process_batch(list(rpages[:2]), list(rtrs[:2]), rec, PARAMS)
+    atocr.process_batch(list(rpages), list(rtrs), rec, PARAMS)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     atocr.process_batch(list(rpages), list(rtrs), rec, PARAMS)
@@ -159,7 +159,7 @@ def run(npages, seed0=100):
             "raw_strips": {"pages_per_s": npages / raw_dt, "seconds": raw_dt,
                            "note": "strips as 60-row uint8 images, normalised by csrc/ta_lineest.hip"},
             "syllable_boxes": sum(len(r[0]) for r in res),
-            "note": "process_batch end to end: host upload + K3/K4/K5 + NW + host glue (Python)"}
+            "note": "process_batch end to end: host upload + K3/K4/K5 + NW + host glue (numpy arrays, page_batch.py)"}
 
 
 if __name__ == "__main__":
