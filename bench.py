@@ -34,6 +34,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 F32_MFMA_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA peak (spec)
+BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (spec)
 DEFAULT_SYS = [8, -4, -7, -7, -3, 0]
 
 
@@ -221,7 +222,7 @@ def bench_pipelined(tsc, args, first):
             "note": "two batches in flight, fill and traceback on separate streams"}
 
 
-def bench_ocr(args, rank, precision="f32", nlines=None):
+def bench_ocr(args, rank, precision="split", nlines=None):
     from text_alignment_amd import ocr
     no = 96
     nlines = args.ocr_lines if nlines is None else nlines
@@ -247,15 +248,25 @@ def bench_ocr(args, rank, precision="f32", nlines=None):
     dec_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
     flops_lstm = tsteps * 238400.0                    # 2 dirs x 4 gates x 100 x 149 x 2
     tf = flops_lstm / (lstm_ms * 1e-3) / 1e12
-    busy, busy_src = measured_mfma_busy("lstm_seq_kernel") if nlines == 1920 and precision == "f32" else (None, None)
+    f32 = precision == "f32"
+    busy, busy_src = measured_mfma_busy("lstm_seq_kernel") if nlines == 1920 and f32 else (None, None)
+    roof = {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": tf / F32_MFMA_PEAK_TF, "traffic": None,
+            "kernel": "lstm_seq_kernel" if f32 else "lstm_seq_split_kernel",
+            "algorithmic_flops_per_timestep": 238400,
+            "peak_is": "f32-input MFMA, the rate exact-f32 arithmetic of this recurrence is bounded by"}
+    if f32:
+        roof["mfma_pipe_busy_rocprof"], roof["mfma_pipe_busy_source"] = busy, busy_src
+    else:
+        # what the matrix pipe executes in this mode: 4 products per k-step on 16x16x32 tiles over
+        # 160 padded inputs and 112 padded units, both directions: 2 x 7 x 80 MFMAs of 16384 flop per 16 lines
+        executed = tsteps / 16.0 * 2 * 7 * 80 * 16384.0
+        roof["executed_16bit_mfma"] = {"achieved": executed / (lstm_ms * 1e-3) / 1e12, "peak": BF16_MFMA_PEAK_TF,
+                                       "unit": "TFLOP/s", "frac": executed / (lstm_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF}
     return {"lines_per_s": nlines / dt, "timesteps_per_s": tsteps / dt, "lines": nlines,
             "timesteps": tsteps, "classes": no,
-            "dtype": "f32" if precision == "f32" else "bf16x3 (split operands, f32 accumulate)",
-            "ms": {"lstm": lstm_ms, "output_softmax": out_ms, "decode": dec_ms},
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": tf / F32_MFMA_PEAK_TF, "traffic": None, "kernel": "lstm_seq_kernel",
-                         "mfma_pipe_busy_rocprof": busy, "mfma_pipe_busy_source": busy_src,
-                         "algorithmic_flops_per_timestep": 238400}}
+            "dtype": "f32" if f32 else "split 16-bit operands (W: bf16 + fp16, a: 3 x bf16 + fp16), f32 accumulate",
+            "ms": {"lstm": lstm_ms, "output_softmax": out_ms, "decode": dec_ms}, "roofline": roof}
 
 
 def nw_configs(tsc, torch):
@@ -438,9 +449,9 @@ def main():
     ocr_res = None
     if not args.no_ocr:
         ocr_res = bench_ocr(args, rank)
-        fast = bench_ocr(args, rank, precision="bf16x3")
-        ocr_res["bf16x3_mode"] = {"lines_per_s": fast["lines_per_s"], "ms": fast["ms"],
-                                  "note": "optional fast mode, not the parity mode"}
+        exact = bench_ocr(args, rank, precision="f32")
+        ocr_res["f32_mode"] = {"lines_per_s": exact["lines_per_s"], "ms": exact["ms"], "roofline": exact["roofline"],
+                               "note": "the same recurrence as an exact f32-input MFMA chain (precision='f32')"}
         if args.ocr_lines_large > args.ocr_lines:
             # 240 workgroups on 256 CUs leave the longest line group in charge of the time; with
             # several workgroups per CU (longest first) the same kernels fill the chip

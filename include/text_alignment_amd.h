@@ -163,9 +163,10 @@ int ta_nw_general_batch(const int32_t* t_codes, const int64_t* t_off,
  *          [dir 2][wave 7][gate GI,GF,GO,CI][k-step 38][lane 64] =
  *          W_gate[unit 16*wave + lane%16][kp 4*kstep + lane/16], kp: 0 bias, 1..48 x,
  *          49..51 zero, 52..151 h; units >= 100 zero.
- *   mode 1: bf16 matrix cores on 3-way split operands (W = W_hi + W_mid in bf16, activations
- *          three bf16 terms, f32 accumulation).  wp = ta_lstm_packed_weight_floats(1) 4-byte
- *          units holding bf16 [dir 2][wave 7][plane hi,mid][gate 4][k-step 5][lane 64][8] =
+ *   mode 1: 16-bit matrix cores on split operands, f32 accumulation: W = W_hi (bf16) + W_r (fp16 of
+ *          W - W_hi), activations three bf16 terms + one fp16; W.a ~ W_hi.(a_lo + a_mid + a_hi) + W_r.a16.
+ *          wp = ta_lstm_packed_weight_floats(1) 4-byte units holding 16-bit patterns
+ *          [dir 2][wave 7][plane hi,r][gate 4][k-step 5][lane 64][8] =
  *          plane of W_gate[unit 16*wave + lane%16][kp 32*kstep + 8*(lane/16) + j], kp as above
  *          padded with zeros to 160.
  *   peep = float[2][3][112]: WIP, WFP, WOP per direction, units >= 100 zero.

@@ -50,7 +50,9 @@ def test_single_page_process_matches_oracle_pipeline():
     from text_alignment_amd import alignToOCR as atocr, ocr, page as page_mod
     om = R.synthetic_model(7001, no=40)             # small class count: mostly letters come out
     om.W2[0, 0] += 4.0                              # favour blanks -> many short runs -> many characters
-    pm = ocr.LineModel(om.fwd, om.rev, om.W2, om.codec)
+    # free-running lines of a random-weight model against the float64 restatement: the exact-f32 mode
+    # (a character whose blank probability sits at the 0.7 threshold flips on a 1e-4 difference)
+    pm = ocr.LineRecognizer(ocr.LineModel(om.fwd, om.rev, om.W2, om.codec), precision="f32")
     pg, transcript = _page(3, 30, R, page_mod)
     params = [8, -1, -9, -9, -4, -4]     # cheap mismatches: the random model's text pairs up with the transcript
     res = atocr.process(pg, transcript, pm, seq_align_params=params)
@@ -92,7 +94,7 @@ def test_config5_shape_64_pages_two_models_sharded_driver():
         om.W2[0, 0] += 4.0
         om.W2[30:, :] *= 0.25                       # mostly the first classes come out: text-like strings
         oms.append(om)
-        recs.append(ocr.LineRecognizer(ocr.LineModel(om.fwd, om.rev, om.W2, om.codec)))
+        recs.append(ocr.LineRecognizer(ocr.LineModel(om.fwd, om.rev, om.W2, om.codec), precision="f32"))
     pages, trs = zip(*[_page(200 + k, 3 + k % 5, R, page_mod) for k in range(64)])
     models = [recs[k % 2] for k in range(64)]
     params = [8, -1, -9, -9, -4, -4]

@@ -84,6 +84,18 @@ __device__ __forceinline__ float tanh_fast(float x) {
     return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
 }
 
+// The same two functions at minimum instruction count, for the split-operand kernel, where the gate
+// math (not the matrix pipe) sets the step time: no clip (exp2 saturates to 0 / inf and the
+// reciprocal to 1 / 0 exactly where the reference's clip(-x, -20, 20) has long stopped mattering
+// in float32: |sigma(20) - 1| = 2e-9), and tanh(x) = 2 sigma(2x) - 1 -- four and five instructions,
+// two of them transcendental.  Absolute error < 1.2e-7 (the cancellation near 0 is absolute, too).
+__device__ __forceinline__ float sigmoid_min(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269502162933349609375f));
+}
+__device__ __forceinline__ float tanh_min(float x) {
+    return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.8853900432586669921875f)), -1.0f);
+}
+
 // Seven waves own 16 units each (4 gates x 38 k-steps = 152 MFMAs per timestep); on four SIMDs that
 // is 2, 2, 2, 1 waves and the SIMDs with two waves set the pace.  An eighth wave takes the CI gate of
 // waves 4, 5 and 6 (3 x 38 = 114 MFMAs, the same operands in the same order, so the sums are
@@ -243,15 +255,15 @@ __global__ __launch_bounds__(kSeqWaves * 64) void lstm_seq_kernel(LstmArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float gi = acc[0][r], gf = acc[1][r], go = acc[2][r];
-            const float ci = tanh_fast(acc[3][r]);
+            const float ci = tanh_min(acc[3][r]);
             const bool past0 = (t > 0) | (ts[r] > 0);             // not the first step of the whole sequence
             if (past0) { gi += wip * c[r]; gf += wfp * c[r]; }
-            gi = sigmoid_clip(gi);
-            gf = sigmoid_clip(gf);
+            gi = sigmoid_min(gi);
+            gf = sigmoid_min(gf);
             float cn = ci * gi;
             if (past0) { cn += gf * c[r]; go += wop * cn; }      // output peephole skipped at t = 0
-            go = sigmoid_clip(go);
-            const float h = tanh_fast(cn) * go;
+            go = sigmoid_min(go);
+            const float h = tanh_min(cn) * go;
             c[r] = cn;
             if (unit < kNs) {
                 const int slot = (lane >> 4) * 4 + r;
@@ -268,33 +280,38 @@ __global__ __launch_bounds__(kSeqWaves * 64) void lstm_seq_kernel(LstmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3 (bf16 x 3): the same recurrence on the bf16 matrix cores.  v_mfma_f32_16x16x32_bf16 runs at
-// 16x the rate of the f32-input MFMA, so f32 operands are split into bf16 terms whose products
-// are accumulated in f32: activations a = a_hi + a_mid + a_lo (exact to 24 bits), weights
-// W = W_hi + W_mid (16 mantissa bits, relative error 2^-17), five products per k-step
-//   W_hi.(a_hi + a_mid + a_lo) + W_mid.(a_hi + a_mid)
-// i.e. 100 MFMAs of 16 cycles per wave and timestep instead of 152 of 32.  The split of h is done
-// once where it is produced (gate math) and stored as three bf16 planes in LDS, so consumers
-// load ready A fragments (one ds_read_b128 per plane and k-step).
+// K3 (split operands): the same recurrence on the 16-bit matrix cores.  v_mfma_f32_16x16x32_bf16 /
+// _f16 run at 16x the rate of the f32-input MFMA, so f32 operands are split into 16-bit terms whose
+// products are accumulated in f32:
+//   weights      W = W_hi (bf16, 8 significant bits) + W_r (fp16 of the rest, 11 more: |W - W_hi - W_r| <= 2^-20 |W|)
+//   activations  a = a_hi + a_mid + a_lo (bf16, exact to 24 bits);  a16 = fp16(a) (11 bits, only ever multiplied by W_r)
+//   W . a  ~  W_hi . (a_lo + a_mid + a_hi)  +  W_r . a16          4 MFMAs per k-step, relative error ~2^-19
+// i.e. 80 MFMAs of 16 cycles per wave and timestep instead of 152 of 32.  (The first version of this
+// mode kept W_r in bf16 too -- 16 weight bits, five products -- and was 1.25x slower and 8x less
+// exact.)  The split of h is done once where it is produced (gate math) and stored as four 16-bit
+// planes in LDS, so consumers load ready A fragments (one ds_read_b128 per plane and k-step).
 constexpr int kKP2 = 160;          // [1, x(48), 3 pads, h(100), 8 pads]
 constexpr int kKS2 = kKP2 / 32;    // 5 k-steps of 32
 constexpr int kRS2 = 168;          // LDS row stride in bf16 (336 B: conflict-free b128 reads)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int kPlanes = 4;         // activation planes in LDS: bf16 hi, mid, lo and fp16
 
-__device__ __forceinline__ void split3(float v, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+struct Split4 { unsigned short hi, mid, lo, h16; };
+__device__ __forceinline__ Split4 split4(float v) {
     const __bf16 h = (__bf16)v;
     const float r1 = v - (float)h;
     const __bf16 m = (__bf16)r1;
     const float r2 = r1 - (float)m;
     const __bf16 l = (__bf16)r2;
-    hi = __builtin_bit_cast(unsigned short, h);
-    mid = __builtin_bit_cast(unsigned short, m);
-    lo = __builtin_bit_cast(unsigned short, l);
+    const _Float16 f = (_Float16)v;
+    return {__builtin_bit_cast(unsigned short, h), __builtin_bit_cast(unsigned short, m),
+            __builtin_bit_cast(unsigned short, l), __builtin_bit_cast(unsigned short, f)};
 }
 
-__global__ __launch_bounds__(kWaves * 64) void lstm_seq_bf16x3_kernel(LstmArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short srcp[2][3][kLines][kRS2];
+__global__ __launch_bounds__(kWaves * 64) void lstm_seq_split_kernel(LstmArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short srcp[2][kPlanes][kLines][kRS2];
     __shared__ int s_line[kLines];
     __shared__ int s_T[kLines];
     __shared__ long long s_row[kLines];
@@ -311,13 +328,13 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_bf16x3_kernel(LstmArgs a
         s_T[tid] = id >= 0 ? a.T[id] : 0;
         s_row[tid] = id >= 0 ? a.row_off[id] : 0;
     }
-    for (int e = tid; e < 2 * 3 * kLines * kRS2; e += kWaves * 64) (&srcp[0][0][0][0])[e] = 0;
+    for (int e = tid; e < 2 * kPlanes * kLines * kRS2; e += kWaves * 64) (&srcp[0][0][0][0])[e] = 0;
     __syncthreads();
     int Tmax = 0;
 #pragma unroll
     for (int s = 0; s < kLines; ++s) Tmax = max(Tmax, s_T[s]);
 
-    // B fragments: [dir][wave][plane 2][gate 4][kstep 5][lane 64] x 8 bf16 (16 bytes)
+    // B fragments: [dir][wave][plane 2: W_hi bf16, W_r fp16][gate 4][kstep 5][lane 64] x 8 halves (16 bytes)
     bf16x8 Bf[2][4][kKS2];
     {
         const uint4* wp = reinterpret_cast<const uint4*>(a.wp) +
@@ -360,11 +377,11 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_bf16x3_kernel(LstmArgs a
             const int slot = e / kNs, u = e % kNs;
             const int id = s_line[slot];
             if (id >= 0) {
-                unsigned short hi, mid, lo;
-                split3(a.h0[((size_t)id * 2 + dir) * kNs + u], hi, mid, lo);
-                srcp[0][0][slot][kXK + u] = hi;
-                srcp[0][1][slot][kXK + u] = mid;
-                srcp[0][2][slot][kXK + u] = lo;
+                const Split4 sp = split4(a.h0[((size_t)id * 2 + dir) * kNs + u]);
+                srcp[0][0][slot][kXK + u] = sp.hi;
+                srcp[0][1][slot][kXK + u] = sp.mid;
+                srcp[0][2][slot][kXK + u] = sp.lo;
+                srcp[0][3][slot][kXK + u] = sp.h16;
             }
         }
     }
@@ -382,11 +399,11 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_bf16x3_kernel(LstmArgs a
     };
     auto x_store = [&](int e, int buf, float v) {
         const int slot = e / kXK, kp = e % kXK;
-        unsigned short hi, mid, lo;
-        split3(v, hi, mid, lo);
-        srcp[buf][0][slot][kp] = hi;
-        srcp[buf][1][slot][kp] = mid;
-        srcp[buf][2][slot][kp] = lo;
+        const Split4 sp = split4(v);
+        srcp[buf][0][slot][kp] = sp.hi;
+        srcp[buf][1][slot][kp] = sp.mid;
+        srcp[buf][2][slot][kp] = sp.lo;
+        srcp[buf][3][slot][kp] = sp.h16;
     };
     for (int e = tid; e < kXE; e += kWaves * 64) x_store(e, 0, x_value(e, 0));
     __syncthreads();
@@ -408,13 +425,13 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_bf16x3_kernel(LstmArgs a
             const bf16x8 ahi = *reinterpret_cast<const bf16x8*>(&srcp[cur][0][lane & 15][off]);
             const bf16x8 amid = *reinterpret_cast<const bf16x8*>(&srcp[cur][1][lane & 15][off]);
             const bf16x8 alo = *reinterpret_cast<const bf16x8*>(&srcp[cur][2][lane & 15][off]);
+            const f16x8 a16 = *reinterpret_cast<const f16x8*>(&srcp[cur][3][lane & 15][off]);
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                f32x4 v = acc[g4];
+                f32x4 v = acc[g4];                          // small terms first
                 v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, Bf[0][g4][ks], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(amid, Bf[1][g4][ks], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16, __builtin_bit_cast(f16x8, Bf[1][g4][ks]), v, 0, 0, 0);
                 v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(amid, Bf[0][g4][ks], v, 0, 0, 0);
-                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, Bf[1][g4][ks], v, 0, 0, 0);
                 v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, Bf[0][g4][ks], v, 0, 0, 0);
                 acc[g4] = v;
             }
@@ -426,23 +443,23 @@ __global__ __launch_bounds__(kWaves * 64) void lstm_seq_bf16x3_kernel(LstmArgs a
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float gi = acc[0][r], gf = acc[1][r], go = acc[2][r];
-            const float ci = tanh_fast<false>(acc[3][r]);
+            const float ci = tanh_min(acc[3][r]);
             const bool past0 = (t > 0) | (ts[r] > 0);
             if (past0) { gi += wip * c[r]; gf += wfp * c[r]; }
-            gi = sigmoid_clip<false>(gi);
-            gf = sigmoid_clip<false>(gf);
+            gi = sigmoid_min(gi);
+            gf = sigmoid_min(gf);
             float cn = ci * gi;
             if (past0) { cn += gf * c[r]; go += wop * cn; }
-            go = sigmoid_clip<false>(go);
-            const float h = tanh_fast<false>(cn) * go;
+            go = sigmoid_min(go);
+            const float h = tanh_min(cn) * go;
             c[r] = cn;
             if (unit < kNs) {
                 const int slot = (lane >> 4) * 4 + r;
-                unsigned short hi, mid, lo;
-                split3(h, hi, mid, lo);
-                srcp[nxt][0][slot][kXK + unit] = hi;
-                srcp[nxt][1][slot][kXK + unit] = mid;
-                srcp[nxt][2][slot][kXK + unit] = lo;
+                const Split4 sp = split4(h);
+                srcp[nxt][0][slot][kXK + unit] = sp.hi;
+                srcp[nxt][1][slot][kXK + unit] = sp.mid;
+                srcp[nxt][2][slot][kXK + unit] = sp.lo;
+                srcp[nxt][3][slot][kXK + unit] = sp.h16;
                 if (t < myT[r]) {
                     const int tt = dir ? myT[r] - 1 - t : t;
                     a.hout[(myrow[r] + tt) * (2 * kNs) + dir * kNs + unit] = h;
@@ -711,7 +728,7 @@ __global__ __launch_bounds__(64) void decode_summary_kernel(DecSumArgs a) {
 using namespace ta;
 
 extern "C" int32_t ta_lstm_packed_weight_floats(int32_t mode) {
-    // mode 0: f32 fragments [2][7][4][38][64]; mode 1: bf16 pairs [2][7][2][4][5][64][8] (as 4-byte units)
+    // mode 0: f32 fragments [2][7][4][38][64]; mode 1: 16-bit planes [2][7][2][4][5][64][8] (as 4-byte units)
     return mode == 0 ? 2 * kWaves * 4 * kKS * 64 : 2 * kWaves * 2 * 4 * kKS2 * 64 * 4;
 }
 
@@ -724,12 +741,12 @@ extern "C" int ta_lstm_forward(const float* x, const int64_t* row_off, const int
     if (ngroups == 0) return TA_OK;
     if (!x || !row_off || !T || !group_lines || !wp || !peep || !hout)
         return ta_fail(TA_EINVAL, "null pointer argument");
-    if (mode != 0 && mode != 1) return ta_fail(TA_EINVAL, "mode must be 0 (f32 MFMA) or 1 (bf16 x 3)");
+    if (mode != 0 && mode != 1) return ta_fail(TA_EINVAL, "mode must be 0 (f32 MFMA) or 1 (split 16-bit operands)");
     if ((h0 != nullptr) != (c0 != nullptr) || (h0 != nullptr) != (tstart != nullptr))
         return ta_fail(TA_EINVAL, "h0, c0 and tstart go together (all null, or all given)");
     LstmArgs a{x, row_off, T, group_lines, wp, peep, hout, h0, c0, tstart};
     if (mode == 1)
-        hipLaunchKernelGGL(lstm_seq_bf16x3_kernel, dim3(2 * ngroups), dim3(kWaves * 64), 0,
+        hipLaunchKernelGGL(lstm_seq_split_kernel, dim3(2 * ngroups), dim3(kWaves * 64), 0,
                            reinterpret_cast<hipStream_t>(stream), a);
     else
         hipLaunchKernelGGL(lstm_seq_kernel, dim3(2 * ngroups), dim3(kSeqWaves * 64), 0,

@@ -78,9 +78,9 @@ def _bf16_bits(x):
     return r.astype(np.uint16), back
 
 
-def _pack_lstm_bf16x3(model):
-    """B fragments of csrc/ta_lstm.hip's bf16 x 3 kernel: W = W_hi + W_mid in bf16,
-    [dir 2][wave 7][plane 2][gate 4][k-step 5][lane 64][8]."""
+def _pack_lstm_split(model):
+    """B fragments of csrc/ta_lstm.hip's split-operand kernel: W = W_hi (bf16) + W_r (fp16 of the
+    rest), [dir 2][wave 7][plane 2: hi, r][gate 4][k-step 5][lane 64][8] 16-bit patterns."""
     out = np.zeros((2, 7, 2, 4, 5, 64, 8), dtype=np.uint16)
     lane = np.arange(64)
     for d, w in enumerate((model.fwd, model.rev)):
@@ -90,14 +90,14 @@ def _pack_lstm_bf16x3(model):
             Wp[:NS, 0:1 + NI] = W[:, 0:1 + NI]
             Wp[:NS, 52:152] = W[:, 1 + NI:]
             hi_bits, hi_val = _bf16_bits(Wp)
-            mid_bits, _ = _bf16_bits(Wp - hi_val)
+            rest_bits = (Wp - hi_val).astype(np.float16).view(np.uint16)
             for wv in range(7):
                 rows = 16 * wv + (lane & 15)
                 for ks in range(5):
                     for j in range(8):
                         cols = 32 * ks + 8 * (lane >> 4) + j
                         out[d, wv, 0, g, ks, :, j] = hi_bits[rows, cols]
-                        out[d, wv, 1, g, ks, :, j] = mid_bits[rows, cols]
+                        out[d, wv, 1, g, ks, :, j] = rest_bits[rows, cols]
     assert out.size * 2 == _native.lib.ta_lstm_packed_weight_floats(1) * 4
     return out
 
@@ -141,22 +141,24 @@ def _copy_pool():
 
 
 class LineRecognizer(object):
-    """precision: "f32" (default) runs the recurrence as an exact f32-input MFMA chain -- the mode
-    the 1e-3 logit parity is stated for.  "bf16x3" runs it on the bf16 matrix cores with split
-    operands (activations 3 bf16 terms, weights 2 = 16 mantissa bits, f32 accumulation): 1.8x
-    faster, pre-activation error ~1e-5 instead of ~1e-6."""
+    """precision: "f32" runs the recurrence as an exact f32-input MFMA chain.  "split" runs it on
+    the 16-bit matrix cores with split operands (weights bf16 + fp16 = 19 significant bits,
+    activations three bf16 terms + one fp16, f32 accumulation, four products per k-step): twice as
+    fast, pre-activation error ~2e-6.  Both hold the 1e-3 logit parity of the spec model per
+    128-step segment (tests/test_ocr_gpu.py).  ("bf16x3", the name of this mode's first form, is
+    accepted.)"""
 
-    def __init__(self, model, device="cuda", precision="f32"):
+    def __init__(self, model, device="cuda", precision="split"):
         if not torch.cuda.is_available():
             raise RuntimeError("text_alignment_amd needs an AMD GPU (MI355X); there is no CPU fallback")
-        if precision not in ("bf16x3", "f32"):
-            raise ValueError("precision must be 'bf16x3' or 'f32'")
+        if precision not in ("split", "bf16x3", "f32"):
+            raise ValueError("precision must be 'f32' or 'split'")
         self.model = model
         self.device = torch.device(device)
-        self.mode = 1 if precision == "bf16x3" else 0
+        self.mode = 0 if precision == "f32" else 1
         wp, peep, w2p = _pack_lstm(model)
         if self.mode == 1:
-            wp = _pack_lstm_bf16x3(model)
+            wp = _pack_lstm_split(model)
         self.wp = torch.from_numpy(wp).to(self.device)
         self.peep = torch.from_numpy(peep).to(self.device)
         self.w2p = torch.from_numpy(w2p).to(self.device)
