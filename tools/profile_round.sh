@@ -1,24 +1,38 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence kept under profiles/ (run on the MI355X box from the repo root):
-#   tools/profile_round.sh r01
-# 1. kernel trace + stats of the default bench command        -> profiles/<round>_kernel_stats_bench_default.csv
-# 2. WRITE_SIZE and FETCH_SIZE counter passes (separate runs, counters only, no trace flags)
-#    of the two-phase and the one-pass aligner                -> profiles/<round>_nw2_hbm_traffic.json, <round>_nw_hbm_traffic.json
-# 3. kernel stats of the NW configuration sweep is not profiled (tools/nw_configs.py times it with events).
+#   tools/profile_round.sh r02
+# 1. kernel trace + stats of the headline NW step alone (4096 x 4096^2, two-phase), so that the
+#    per-kernel averages are not mixed with other shapes       -> <round>_kernel_stats_nw_headline.csv
+# 2. kernel trace + stats of the line recogniser alone, per workload and mode
+#                                                              -> <round>_kernel_stats_ocr_<lines>_<mode>.csv
+# 3. WRITE_SIZE and FETCH_SIZE counter passes (separate runs, counters only, no trace flags) of the
+#    two-phase and the one-pass aligner                        -> <round>_nw2_hbm_traffic.json, <round>_nw_hbm_traffic.json
+# 4. matrix-pipe counters of the recogniser kernels (1920 lines, both modes) -> <round>_ocr_pmc_mfma.json
+# then (where gpurun_out/ was merged back): python3 tools/profile_summarise.py <round> gpurun_out/prof_<round>
 set -eo pipefail
-ROUND=${1:-r01}
+ROUND=${1:-r02}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$ROUND
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o bench -- python3 "$REPO/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-pipelined > "$OUT/kt.log" 2>&1
-echo "kernel trace done"
+NW="--steps 5 --warmup 2 --no-cpu-baseline --no-pipelined --no-configs --no-ocr --pages 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_nw" -o nw -- python3 "$REPO/bench.py" $NW > "$OUT/kt_nw.log" 2>&1
+echo "nw kernel trace done"
+for w in "1920 split" "1920 f32" "5760 split"; do
+  set -- $w
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_$1_$2" -o ocr -- python3 "$REPO/tools/ocr_only.py" $1 $2 > "$OUT/kt_ocr_$1_$2.log" 2>&1
+  echo "ocr $1 $2 kernel trace done"
+done
 for mode in two one; do
   flag=""; [ $mode = one ] && flag="--one-pass"
   for ctr in WRITE_SIZE FETCH_SIZE; do
-    rocprofv3 --pmc $ctr --output-format csv -d "$OUT/${mode}_$ctr" -o nw -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-ocr --no-pipelined $flag > "$OUT/${mode}_$ctr.log" 2>&1
+    rocprofv3 --pmc $ctr --output-format csv -d "$OUT/${mode}_$ctr" -o nw -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined --no-configs --no-ocr --pages 0 $flag > "$OUT/${mode}_$ctr.log" 2>&1
     echo "$mode $ctr done"
   done
 done
-echo "now run (where gpurun_out/ was merged back): python3 tools/profile_summarise.py $ROUND gpurun_out/prof_$ROUND"
+for prec in split f32; do
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_$prec" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 $prec > "$OUT/ocr_pmc_$prec.log" 2>&1
+  echo "ocr pmc $prec done"
+done
+echo "now run: python3 tools/profile_summarise.py $ROUND gpurun_out/prof_$ROUND"

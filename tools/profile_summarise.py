@@ -10,7 +10,7 @@ import shutil
 import sys
 
 
-def counter_means(path, counter):
+def counter_means(path, counter, only="nw_"):
     acc = {}
     for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
         with open(f, newline="") as fh:
@@ -18,7 +18,7 @@ def counter_means(path, counter):
                 if row["Counter_Name"] != counter:
                     continue
                 name = row["Kernel_Name"]
-                if "nw_" not in name:
+                if only and only not in name:
                     continue
                 s = acc.setdefault(name, [0.0, 0])
                 s[0] += float(row["Counter_Value"])
@@ -30,9 +30,14 @@ def main():
     rnd, out = sys.argv[1], sys.argv[2]
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prof = os.path.join(repo, "profiles")
-    stats = glob.glob(os.path.join(out, "kt", "**", "*kernel_stats.csv"), recursive=True)
-    if stats:
-        shutil.copy(stats[0], os.path.join(prof, "%s_kernel_stats_bench_default.csv" % rnd))
+    for sub in sorted(glob.glob(os.path.join(out, "kt_*"))):
+        if not os.path.isdir(sub):
+            continue
+        stats = glob.glob(os.path.join(sub, "**", "*kernel_stats.csv"), recursive=True)
+        if stats:
+            tag = os.path.basename(sub)[3:]
+            name = "nw_headline" if tag == "nw" else tag
+            shutil.copy(stats[0], os.path.join(prof, "%s_kernel_stats_%s.csv" % (rnd, name)))
     for mode, fname, desc in (("two", "%s_nw2_hbm_traffic.json", "two-phase aligner"),
                               ("one", "%s_nw_hbm_traffic.json", "one-pass aligner (--one-pass)")):
         wr = counter_means(os.path.join(out, mode + "_WRITE_SIZE"), "WRITE_SIZE")
@@ -43,13 +48,36 @@ def main():
             kernels[k] = {"WRITE_SIZE_KiB_mean": w, "FETCH_SIZE_KiB_mean": r,
                           "hbm_bytes_per_launch": w * 1024 + 2 * r * 1024}
         doc = {"command": "rocprofv3 --pmc WRITE_SIZE (and, separately, FETCH_SIZE) --output-format csv -- python3 "
-                          "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ocr%s   [4096 problems of "
+                          "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined --no-configs --no-ocr --pages 0%s   [4096 problems of "
                           "4096x4096, %s]" % (" --one-pass" if mode == "one" else "", desc),
                "units": "counter values are KiB (x1024 -> bytes); FETCH_SIZE is doubled for wide coalesced reads "
                         "per MI355X_MICROARCH.md (HBM section); WRITE_SIZE is exact for 16-B-per-lane streaming stores",
                "config": {"batch": 4096, "n": 4096, "m": 4096}, "kernels": kernels}
         with open(os.path.join(prof, fname % rnd), "w") as fh:
             json.dump(doc, fh, indent=1)
+    # matrix-pipe counters of the recogniser kernels
+    kernels = {}
+    for prec in ("split", "f32"):
+        path = os.path.join(out, "ocr_pmc_" + prec)
+        names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES",
+                 "GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU"]
+        per = {}
+        for c in names:
+            for k, v in counter_means(path, c, only="lstm_").items():
+                per.setdefault(k, {})[c] = v
+        for k, d in per.items():
+            if d.get("GRBM_GUI_ACTIVE") and d.get("SQ_INSTS_MFMA"):
+                d["mfma_pipe_utilisation"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * d["GRBM_GUI_ACTIVE"] / 8.0)
+                d["busy_cycles_per_mfma"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["SQ_INSTS_MFMA"]
+            kernels["%s [precision=%s]" % (k, prec)] = d
+    if kernels:
+        with open(os.path.join(prof, "%s_ocr_pmc_mfma.json" % rnd), "w") as fh:
+            json.dump({"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU "
+                                  "SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -- python3 "
+                                  "tools/ocr_only.py 1920 <split|f32>   (counter pass only)",
+                       "reading": "GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES"
+                                  " / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
+                       "kernels": kernels}, fh, indent=1)
     print("profiles updated")
 
 
