@@ -61,34 +61,14 @@ __device__ __forceinline__ float exp_fast(float z) {
     return __builtin_amdgcn_exp2f(hi) * fmaf(lo, 0.693147182464599609375f, 1.0f);
 }
 // Gate non-linearities: outputs in (-1, 1) that are summed into pre-activations of order one, so
-// ABSOLUTE accuracy is what counts.  exp2(z log2 e) without the compensation has a relative error of
+// ABSOLUTE accuracy is what counts.  exp2(z log2 e) on the hardware unit has a relative error of
 // ~|z| 2^-24; through sigma (slope <= 1/4) and tanh (slope <= 1) that is < 3e-8 absolute at any z --
-// below the rounding of the accumulations.  COMP = false: two VALU + one transcendental per
-// exponential (used by the bf16x3 kernel, +3.5 %); the f32 kernel keeps the compensated form, with
-// which hipcc's schedule of that kernel happens to be 7 % faster (10.75 vs 11.5 ms, measured).
-template <bool COMP>
-__device__ __forceinline__ float exp_gate(float z) {
-    return COMP ? exp_fast(z) : __builtin_amdgcn_exp2f(z * 1.44269502162933349609375f);
-}
-template <bool COMP = true>
-__device__ __forceinline__ float sigmoid_clip(float x) {       // 1/(1+exp(clip(-x,-20,20)))
-    const float z = fminf(fmaxf(-x, -20.0f), 20.0f);
-    return __builtin_amdgcn_rcpf(1.0f + exp_gate<COMP>(z));
-}
-template <bool COMP = true>
-__device__ __forceinline__ float tanh_fast(float x) {
-    // (1 - e)/(1 + e), e = exp(-2|x|).  Near zero 1 - e cancels, but only relatively: the absolute
-    // error stays below 6e-8, so a separate small-|x| series buys nothing for the recurrence.
-    const float ax = fminf(fabsf(x), 20.0f);
-    const float e = exp_gate<COMP>(-2.0f * ax);
-    return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
-}
-
-// The same two functions at minimum instruction count, for the split-operand kernel, where the gate
-// math (not the matrix pipe) sets the step time: no clip (exp2 saturates to 0 / inf and the
-// reciprocal to 1 / 0 exactly where the reference's clip(-x, -20, 20) has long stopped mattering
-// in float32: |sigma(20) - 1| = 2e-9), and tanh(x) = 2 sigma(2x) - 1 -- four and five instructions,
-// two of them transcendental.  Absolute error < 1.2e-7 (the cancellation near 0 is absolute, too).
+// below the rounding of the accumulations.  Minimum instruction count, because the gate math
+// (not the matrix pipe) sets the step time of the split-operand kernel and adds to it in the f32
+// kernel: no clip (exp2 saturates to 0 / inf and the reciprocal to 1 / 0 exactly where the
+// reference's clip(-x, -20, 20) has long stopped mattering in float32: |sigma(20) - 1| = 2e-9), and
+// tanh(x) = 2 sigma(2x) - 1 -- four and five instructions, two of them transcendental.  Absolute
+// error < 1.2e-7 (the cancellation near 0 is absolute, too).
 __device__ __forceinline__ float sigmoid_min(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269502162933349609375f));
 }

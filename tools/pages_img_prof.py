@@ -1,0 +1,24 @@
+"""cProfile of process_batch on whole page images (device preprocessing + line finding in front)."""
+import cProfile
+import os
+import pstats
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from tools import pages_bench as pb
+from text_alignment_amd import alignToOCR as atocr
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+rec = pb.make_recognizer()
+pages = [pb.RawPage(pb.make_page_image(9100 + k)) for k in range(n)]
+trs = [pb.page_meta(100 + k)[1] for k in range(n)]
+atocr.process_batch(pages, trs, rec, pb.PARAMS)
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+atocr.process_batch(pages, trs, rec, pb.PARAMS)
+torch.cuda.synchronize()
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
