@@ -115,3 +115,15 @@ def test_normaliser_pool_matches_inline():
     for (a, wa), (b, wb) in zip(pooled, inline):
         assert wa == wb and a.shape == b.shape and np.array_equal(a, b)
     assert pooled[2][0] is ready and pooled[2][1] == 136
+
+
+def test_class_count_limit_is_refused_up_front():
+    """the output kernel holds a timestep's whole softmax row in one accumulator tile (128 classes):
+    a model with more is refused when it is built, not at the first recognise()"""
+    from text_alignment_amd import ocr
+    ok = ocr.LineModel.random(1, no=128)
+    assert ok.no == 128
+    with pytest.raises(ValueError, match="2..128 output classes"):
+        ocr.LineModel.random(1, no=129)
+    with pytest.raises(ValueError):
+        ocr.LineModel(ok.fwd, ok.rev, ok.W2[:1], ok.codec[:1])

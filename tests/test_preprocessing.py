@@ -171,3 +171,25 @@ def test_process_batch_from_raw_images_with_workers():
     for pg, tr, got in zip(pages, trs, batch):
         alone = atocr.process(pg, tr, rec, seq_align_params=params, verbose=False)
         assert atocr.to_JSON_dict(got[0], got[2]) == atocr.to_JSON_dict(alone[0], alone[2])
+
+
+@pytest.mark.gpu
+def test_bare_arrays_are_pages_too():
+    """process / process_batch / sharding.process_pages on PLAIN numpy arrays (no .pixels, no .dim):
+    the raw page's size is its shape.  A page of a type nobody can read fails before any GPU work."""
+    from text_alignment_amd import alignToOCR as atocr, ocr, sharding
+    model = ocr.LineModel.random(5, no=30)
+    model.W2[0, 0] += 4.0
+    rec = ocr.LineRecognizer(model)
+    params = [8, -1, -9, -9, -4, -4]
+    pages = [_synthetic_page(4, seed=k)[0] for k in range(2)]
+    trs = ["dominus dixit ad me filius meus es tu", "ego hodie genui te alleluia"]
+    alone = [atocr.process(pg, tr, rec, seq_align_params=params, verbose=False) for pg, tr in zip(pages, trs)]
+    want = [atocr.to_JSON_dict(a[0], a[2]) for a in alone]
+    assert all(len(w["syl_boxes"]) > 0 for w in want)
+    batch = atocr.process_batch(pages, trs, rec, params)
+    assert [atocr.to_JSON_dict(b[0], b[2]) for b in batch] == want
+    out = sharding.process_pages(pages, trs, rec, seq_align_params=params)
+    assert [out[k] for k in range(2)] == want
+    with pytest.raises(TypeError):
+        atocr.process_batch([np.zeros(7)], ["dominus"], rec, params)
