@@ -113,10 +113,14 @@ static int run(const int32_t* t, int n, const int32_t* o, int m, const int* p,
 
 // ---------------------------------------------------------------------------------------------
 // Two-phase aligner: phase 1 fills scores only (raw integers, no pointer bytes) and checkpoints
-// (a) every KCG groups the whole lane state of the strip's wave and (b) per strip three planes of
-// lane 63's last two rows; phase 2 walks back strip by strip, re-running the TAGGED fill only over
-// a window of skewed steps [g0*SPG, k_in] restarted from a checkpoint (two halo steps make the
-// winner tags of the restart state irrelevant) and walking the pointer bytes of that window.
+// (a) every KCG groups the whole lane state of the strip's wave and (b) per strip the bottom row
+// (XG or V~, D) that the strip below starts from; phase 2 walks back strip by strip, re-running the
+// TAGGED fill only over a window of skewed steps [g0*SPG, k_in] restarted from a checkpoint (two
+// halo steps make the winner tags of the restart state irrelevant) and walking the pointer bytes
+// of that window.  The stored bottom rows carry no winner tags, so the two pointers a strip's first
+// row takes from the row above (PM, PX) are not in the window: a step that leaves the strip upwards
+// is taken with its next state PENDING, and the state is read off the tagged outputs of the cell it
+// lands on when the strip above is re-filled.
 template <int R>
 static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, int KCG, int GSPAN,
                 uint8_t* ops_out, int* ops_len) {
@@ -128,8 +132,9 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
     const int nck = ngroups / KCG + 1;
     struct State { int D[kLanes][R], H[kLanes][R], Vlast[kLanes], dsave[kLanes]; };
     std::vector<State> ck_((size_t)std::max(nstrips, 1) * nck);
-    // row planes of lane 63: index [strip][j], j = 0..m
-    std::vector<int> RV2((size_t)std::max(nstrips, 1) * (m + 2)), RD2(RV2.size()), RH3(RV2.size());
+    // bottom rows: row s is what strip s starts from (row 0 = the table's boundary row), strip s
+    // leaves row s + 1; index [row][j], j = 0..m
+    std::vector<int> HV((size_t)(std::max(nstrips, 1) + 1) * (m + 2)), HD(HV.size());
 
     // phase 1 keeps V~ + gox / H~ + goy (the carried cell of nw_cell.h) when no gap open is
     // positive, exactly as nw_score_kernel does; phase 2 undoes the offsets where it reads them
@@ -138,9 +143,12 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
 
     // ---------------- phase 1: raw fill ----------------
     {
-        std::vector<int> hv(m + 2), hd(m + 2);
-        for (int j = 0; j <= m; ++j) { hv[j] = raw_of(bnd_V_row0(c, j)) + xadj; hd[j] = raw_of(bnd_D_row0(c, j)); }
+        for (int j = 0; j <= m; ++j) { HV[j] = raw_of(bnd_V_row0(c, j)) + xadj; HD[j] = raw_of(bnd_D_row0(c, j)); }
         for (int s = 0; s < nstrips; ++s) {
+            const int* hv = &HV[(size_t)s * (m + 2)];
+            const int* hd = &HD[(size_t)s * (m + 2)];
+            int* hv_out = &HV[(size_t)(s + 1) * (m + 2)];
+            int* hd_out = &HD[(size_t)(s + 1) * (m + 2)];
             int D[kLanes][R], V[kLanes][R], H[kLanes][R], tcode[kLanes][R], dsave[kLanes];
             for (int l = 0; l < kLanes; ++l) {
                 for (int r = 0; r < R; ++r) {
@@ -188,9 +196,7 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
                         dsave[l] = dnext[l];
                         if (l == kLanes - 1) {
                             const int j = k - l + 1;
-                            hv[j] = V[l][R - 1]; hd[j] = D[l][R - 1];
-                            const size_t b = (size_t)s * (m + 2) + j;
-                            RV2[b] = V[l][R - 2]; RD2[b] = D[l][R - 2]; RH3[b] = H[l][R - 1];
+                            hv_out[j] = V[l][R - 1]; hd_out[j] = D[l][R - 1];
                         }
                     }
                 }
@@ -208,11 +214,18 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
     std::vector<uint8_t> rev;
     int x = n, y = m, st = 0;
     bool first = true;
+    // pend: 0, or 3 + (state the strip was left in): the next state is the winner tag of D (3, left
+    // in state M) or of XG / V~ (4, left in state X) of the cell (x, y) the walk now stands on.
+    int pend = 0;
+    bool probe = false;                               // start state of a walk that begins in a strip's first row
+    if ((n - 1) % L::SR == 0 && n > 1) {              // textSeqCompare.py:102 reads PM(n, m) = tag of D(n-1, m-1)
+        if (m == 1) { st = 0; first = false; }        // D(n-1, 0): boundary column, M
+        else { x = n - 1; y = m - 1; pend = 3; probe = true; }
+    }
     int guard = 0;
     while (x > 0 && y > 0) {
         const int s = (x - 1) / L::SR;
         int l = ((x - 1) % L::SR) / R, r = (x - 1) % R, k = (y - 1) + l;
-        const int i_h = s * L::SR;                        // row above the strip (1-based index)
         int ck = (k / SPG) / KCG;
         int g_top = k / SPG;
         bool in_strip = true;
@@ -220,20 +233,14 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
             if (++guard > 8 * (n + m) + 64) return -9;
             const int g0 = ck * KCG, k0 = g0 * SPG;
             const int kvalid = ck > 0 ? k0 + 2 : 0;
-            // tagged hand-off row for columns k0 .. min(m, (g_top+1)*SPG), x-input in the re-fill's form
+            // the row above the strip for columns k0 .. min(m, (g_top+1)*SPG), x-input in the re-fill's
+            // form; tags only where they are known analytically (the table's boundary row)
             const int jhi = std::min(m, (g_top + 1) * SPG);
             std::vector<int> hvt(m + 2, 0), hdt(m + 2, 0);
             for (int j = std::max(0, k0); j <= jhi; ++j) {
                 if (s == 0) { hvt[j] = bnd_V_row0(c, j) + xadj6; hdt[j] = bnd_D_row0(c, j); continue; }
-                if (j == 0) { hdt[0] = bnd_D_col0(c, i_h); continue; }
-                const size_t b = (size_t)(s - 1) * (m + 2);
-                const int d_ul = (j - 1 >= 1) ? RD2[b + j - 1] : raw_of(bnd_D_col0(c, i_h - 1));
-                const int v_u = RV2[b + j] - xadj;
-                const int h_l = (j - 1 >= 1) ? RH3[b + j - 1] - yadj : raw_of(bnd_H_col0(c, i_h));
-                const int cs = (t[i_h - 1] == o[j - 1]) ? c.cmatch : c.cmismatch;
-                int d, v, h;
-                cell_update(enc_of(d_ul), enc_of(v_u), enc_of(h_l), cs, c.gox6, c.goy6, d, v, h);
-                hvt[j] = v + xadj6; hdt[j] = d;
+                const size_t b = (size_t)s * (m + 2);
+                hvt[j] = enc_of(HV[b + j]); hdt[j] = enc_of(HD[b + j]);
             }
             // lane state at the start of group g0
             int D[kLanes][R], V[kLanes][R], H[kLanes][R], tcode[kLanes][R], dsave[kLanes];
@@ -256,8 +263,11 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
                     V[ll][R - 1] = enc_of(cs0.Vlast[ll]); dsave[ll] = enc_of(cs0.dsave[ll]);
                 }
             }
-            // tagged fill of groups g0..g_top into the chunk buffer
+            // tagged fill of groups g0..g_top into the chunk buffer; the tagged outputs of the strip's
+            // bottom row are kept per step for a pending state
             std::vector<uint8_t> wbuf((size_t)(g_top - g0 + 1) * 1024, 0xEE);
+            std::vector<int> capV((size_t)(g_top - g0 + 1) * SPG, 0), capD(capV.size(), 0);
+            std::vector<char> capOk(capV.size(), 0);
             for (int g = g0; g <= g_top; ++g) {
                 uint8_t acc[kLanes][16];
                 memset(acc, 0xEE, sizeof(acc));
@@ -292,12 +302,27 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
                         for (int rr = 0; rr < R; ++rr) { D[ll][rr] = nD[ll][rr]; V[ll][rr] = nV[ll][rr]; H[ll][rr] = nH[ll][rr]; }
                         dsave[ll] = dnext[ll];
                     }
+                    if (act[kLanes - 1]) {
+                        capV[kk - k0] = V[kLanes - 1][R - 1]; capD[kk - k0] = D[kLanes - 1][R - 1]; capOk[kk - k0] = 1;
+                    }
                 }
                 for (int ll = 0; ll < kLanes; ++ll) memcpy(&wbuf[((size_t)(g - g0) * 64 + ll) * 16], acc[ll], 16);
             }
             auto byte_at = [&](int ll, int rr, int kk) -> unsigned {
                 return wbuf[((size_t)(kk / SPG - g0) * 64 + ll) * 16 + (kk % SPG) * R + rr];
             };
+            if (pend) {                                   // the cell the walk stands on: bottom row of this strip
+                if (l != kLanes - 1 || r != R - 1) return -10;
+                if (k < k0 || k / SPG > g_top || !capOk[k - k0]) return -11;
+                const int tagged = (pend == 3) ? capD[k - k0] : capV[k - k0];
+                st = 2 - (tagged & 3);
+                pend = 0;
+                if (probe) {                              // that was the start state: back to (n, m)
+                    probe = false; first = false;
+                    x = n; y = m;
+                    break;
+                }
+            }
             if (first && k >= kvalid) { st = ptr_pm(byte_at(l, r, k)); first = false; }   // start state, textSeqCompare.py:102
             int steps = 0;
             while (x > 0 && y > 0 && l >= 0 && k >= kvalid) {
@@ -306,7 +331,9 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
                 if (b == 0xEE) return -7;
                 const int up = (st != 2), left = (st != 1);
                 rev.push_back((uint8_t)st);
-                st = 2 - (int)((b >> (2 * st)) & 3u);
+                const bool leaves_up = up && l == 0 && r == 0 && s > 0;   // PM / PX of the strip's first row
+                if (leaves_up) pend = 3 + st;
+                else st = 2 - (int)((b >> (2 * st)) & 3u);
                 const int wrap = up & (r == 0);
                 r = (r - up) & (R - 1);
                 x -= up; y -= left; k -= left + wrap; l -= wrap;

@@ -109,3 +109,15 @@ def test_two_phase_sim_matches_oracle(sim, kcg, gspan):
         t, o = synth_pair_ids(n, m, seed)
         want = nw_oracle.align_ids(t, o, SYSTEMS[0])
         assert _sim2_ops(sim, t, o, SYSTEMS[0], 4, kcg, gspan).tolist() == want.tolist()
+    # walks that START in a strip's first row (n = 256 s + 1: the start state is a tag of the strip
+    # above) and that cross strip borders in every state, under every scoring system
+    for k, (n, m) in enumerate([(257, 300), (513, 1), (257, 1), (513, 2), (769, 640), (257, 64), (512, 300),
+                                (258, 257), (513, 513), (257, 5)]):
+        for sc in SYSTEMS[k % 3::3]:
+            t = rng.integers(0, 3, size=n)
+            o = rng.integers(0, 3, size=m)
+            if k % 2:
+                kk = min(n, m)
+                o[:kk] = np.where(rng.random(kk) < 0.7, t[:kk], o[:kk])
+            want = nw_oracle.align_ids(t, o, sc)
+            assert _sim2_ops(sim, t, o, sc, 4, kcg, gspan).tolist() == want.tolist(), (n, m, sc, kcg)

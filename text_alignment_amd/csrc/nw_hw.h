@@ -74,6 +74,13 @@ __device__ __forceinline__ void wave_shr1_pair(int& a_io, int a_src, int& b_io, 
                  : "+v"(a_io), "+v"(b_io) : "v"(a_src), "v"(b_src), "n"(NOPS));
 }
 
+// The same shift through the compiler's DPP builtin: hipcc then sees the VALU-write -> DPP-read wait
+// states itself and fills them with independent work of the next step where it has any.
+__device__ __forceinline__ void wave_shr1_pair_sched(int& a_io, int a_src, int& b_io, int b_src) {
+    a_io = __builtin_amdgcn_update_dpp(a_io, a_src, 0x138, 0xf, 0xf, false);      // 0x138 = wave_shr:1
+    b_io = __builtin_amdgcn_update_dpp(b_io, b_src, 0x138, 0xf, 0xf, false);
+}
+
 constexpr int kOPad = 64;     // o-code padding in front (lanes that have not started yet)
 constexpr int kOTail = 80;    // steps run to m + 62 (+ group round-up) past the last code
 constexpr int kCheck = 16;    // hand-off progress is checked / published every kCheck groups
@@ -143,6 +150,11 @@ __device__ __forceinline__ unsigned pack4(unsigned b0, unsigned b1, unsigned b2,
 // strip (cells with x > x_lo are in it); klow: smallest valid skewed step.  Returns the number
 // of ops appended to opsbuf; updates x, y, st.  The walk stops when it leaves the strip, the
 // valid steps, the table (x == 0 or y == 0) or after max_ops.
+//
+// TOP_PENDING (two-phase aligner): the window's first-row cells hold no PM / PX (the row above came
+// without winner tags).  A step that leaves a strip below the first one upwards is still taken,
+// and ends the walk with st = 3 + (the state it was taken in): the caller resolves it.
+template <bool TOP_PENDING = false>
 __device__ __forceinline__ int walk_window_vec(const uint4* win, int gw_lo, int klow, int x_lo,
                                                int& x, int& y, int& st, uint8_t* opsbuf, int max_ops,
                                                int lane) {
@@ -156,7 +168,8 @@ __device__ __forceinline__ int walk_window_vec(const uint4* win, int gw_lo, int 
         const bool valid = (xi > x_lo) & (yi > 0) & (ki >= klow);
         unsigned b = 0;
         if (valid) b = wb[((ki >> 2) - gw_lo) * 1024 + li * 16 + (ki & 3) * 4 + ((xi - 1) & 3)];
-        const int nxt = 2 - (int)((b >> (2 * st)) & 3u);
+        int nxt = 2 - (int)((b >> (2 * st)) & 3u);
+        if (TOP_PENDING && up && x_lo > 0 && xi == x_lo + 1) nxt = 3 + st;
         const unsigned long long vmask = __ballot(valid);
         if ((vmask & 1ull) == 0ull) break;                       // lane 0 (the current cell) is out
         const unsigned long long cmask = __ballot(valid && nxt == st);

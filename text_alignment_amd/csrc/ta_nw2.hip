@@ -6,14 +6,17 @@
 //
 //  phase 1  nw_score_kernel   the same strip / lane / skew wavefront on RAW integer scores: per cell
 //           v_cmp + v_cndmask, 3 v_add, 3 v_max3_i32 and nothing else; no pointer byte is formed
-//           or stored.  It leaves checkpoints in HBM (0.13 B per cell): every kCkGroups groups the
-//           wave's whole lane state, and per strip three planes of lane 63's last two rows.
+//           or stored.  It leaves checkpoints in HBM (0.07 B per cell): every kCkGroups groups the
+//           wave's whole lane state, and per strip its bottom row (XG, D) -- which is also what the
+//           next strip starts from.
 //  phase 2  nw_trace2_kernel  one wave per problem walks back strip by strip and, inside a strip,
 //           checkpoint interval by checkpoint interval: it re-runs the TAGGED cell over the
 //           interval the walk is in, restarted from that interval's state checkpoint (two halo
-//           steps make the missing winner tags of the restart state irrelevant; the row above the
-//           strip is re-derived with tags from the three planes), keeps the interval's pointer
-//           bytes in LDS and walks them.  About 10 % of the cells are recomputed.
+//           steps make the missing winner tags of the restart state irrelevant), keeps the
+//           interval's pointer bytes in LDS and walks them.  The bottom rows carry no tags either:
+//           a step that leaves a strip upwards gets its next state from the tagged outputs of the
+//           cell it lands on, once the strip above is re-filled.  About 10 % of the cells are
+//           recomputed.
 //
 // Data flow and the halo argument are replayed on the CPU by tests/native/sim_nw.cpp (run2).
 #include <hip/hip_runtime.h>
@@ -29,27 +32,28 @@ namespace ta {
 
 constexpr int kCkGroups = 16;                 // state checkpoint every 16 groups (64 skewed steps)
 constexpr int kStateInts = 10;                // D[4], H[4], V[3], dsave
+constexpr int kWsRange = 0x7ffff000;          // record count of a workspace buffer descriptor: every real offset is below
 
 // per-problem layout of the phase-1/2 workspace (all offsets in bytes, 16-byte aligned)
 struct Ws2 {
-    int nstrips, ngroups, nck, mrow;
-    int64_t rowck, stck, hrow, total;
+    int nstrips, ngroups, nck;
+    int64_t rows, row_pitch, stck, total;
     __host__ __device__ Ws2(int n, int m) {
         using L = PtrLayout<4>;
         nstrips = L::nstrips(n);
         ngroups = L::ngroups(m);
         nck = ngroups / kCkGroups + 1;
-        mrow = (m + 8 + 3) & ~3;
-        rowck = 0;
-        stck = rowck + (int64_t)nstrips * 3 * mrow * 4;
-        // phase 1's hand-off row: (XG, D) of the row above the strip a wave is in, entry j at
-        // index j + 1 (so that the four entries a group reads start on a 16-byte boundary)
-        hrow = stck + (int64_t)nstrips * nck * kStateInts * 64 * 4;
-        total = hrow + (((int64_t)(m + 8) * 8 + 15) & ~(int64_t)15);
+        // bottom rows: row s is the row above strip s -- (XG or V~, D) per column, what the strip's
+        // first lane consumes -- row 0 the table's boundary row; strip s leaves row s + 1.  Entry j
+        // sits at index j + 1, so that the four entries a group reads start on a 16-byte boundary.
+        // Phase 1 hands a strip's results to the next strip through them (they are in L2 when the
+        // next wave, ~25 groups behind, reads them) and phase 2 restarts from them.
+        rows = 0;
+        row_pitch = ((int64_t)(m + 8) * 8 + 15) & ~(int64_t)15;
+        stck = rows + (int64_t)(nstrips + 1) * row_pitch;
+        total = stck + (int64_t)nstrips * nck * kStateInts * 64 * 4;
     }
-    __host__ __device__ int64_t row_plane(int s, int plane) const {       // int index base, entry j at +j+2
-        return rowck + ((int64_t)(s * 3 + plane) * mrow) * 4;
-    }
+    __host__ __device__ int64_t row(int r) const { return rows + (int64_t)r * row_pitch; }
     __host__ __device__ int64_t state(int s, int ck) const {
         return stck + ((int64_t)(s * nck + ck) * kStateInts * 64) * 4;
     }
@@ -80,7 +84,7 @@ __device__ __forceinline__ void cell_carried_hw(const RawRegs& k, int d_ul, int 
 __host__ __device__ inline bool fits_i8(int v) { return v >= -128 && v <= 127; }
 
 // LDS carve of phase 1 (dynamic): code ocode[kOPad+m+kOTail] | int prog[16] | uint32 profile[waves][apad][64]
-// (the hand-off row between strips lives in the workspace -- L2 -- not in LDS: Ws2::hrow)
+// (the rows handed from strip to strip live in the workspace -- L2 -- not in LDS: Ws2::rows)
 struct P1Lds {
     size_t oc_bytes, tbl_off, total;
     __host__ __device__ explicit P1Lds(int m, int code_bytes, int tbl_bytes = 0) {
@@ -154,11 +158,10 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
     uint32_t* tbl = reinterpret_cast<uint32_t*>(smem + lds.tbl_off);
     const Ws2 ws(n, m);
     uint8_t* const ws_p = a.ws + a.ws_off[p];
-    // Hand-off row between consecutive strips, in place, in the workspace (it stays in L2): a wave
-    // reads entry j (what the strip above left) long before its own lane 63 overwrites it.  All waves
-    // of a workgroup share one CU and its L1, so the workgroup-scope release / acquire on the
-    // progress words (LDS) is all the ordering these plain loads and stores need.
-    int2* const hvd = reinterpret_cast<int2*>(ws_p + ws.hrow) + 1;
+    // Bottom rows (Ws2::rows): strip s reads row s and writes row s + 1.  All waves of a workgroup
+    // share one CU and its L1, so the workgroup-scope release / acquire on the progress words (LDS)
+    // is all the ordering these plain loads and stores need.
+    int2* const row0p = reinterpret_cast<int2*>(ws_p + ws.row(0)) + 1;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
         ocode[j] = (src >= 0 && src < m) ? (LC)(a.o_codes[o0 + src] << code_shift) : pad_code;
     }
     for (int j = tid; j <= m; j += W * 64)
-        hvd[j] = make_int2(raw_of(bnd_V_row0(c, j)) + xadj, raw_of(bnd_D_row0(c, j)));
+        row0p[j] = make_int2(raw_of(bnd_V_row0(c, j)) + xadj, raw_of(bnd_D_row0(c, j)));
     if (tid < 16) prog[tid] = 0;
     const uint32_t mis4 = (uint32_t)(kr.cmis & 0xFF) * 0x01010101u;
     if (PROFILE)
@@ -182,10 +185,18 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
     uint32_t* const tblw = tbl + (size_t)wave * apad * 64;                   // this wave's profile
     const unsigned char* const tbl_lane = reinterpret_cast<const unsigned char*>(tblw) + lane * 4;
 
+    // buffer descriptor of the problem's workspace, for the straight-line stores of the steady state
+    // (inputs through readfirstlane: hipcc must be able to PROVE them wave-uniform, or it wraps every
+    // buffer operation in a waterfall loop)
+    const uint64_t wsa = reinterpret_cast<uint64_t>(ws_p);
+    unsigned char* const ws_u = reinterpret_cast<unsigned char*>(
+        ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(wsa >> 32)) << 32) |
+        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wsa));
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(ws_u, 0, kWsRange, 0x00020000);
     const int nstrips = ws.nstrips, ngroups = ws.ngroups;
     const int prev_wave = (wave + W - 1) % W;
     const int g_lo = (63 + SPG - 1) / SPG;
-    const int g_hi = steady_ok ? m / SPG : 0;
+    const int g_hi = (steady_ok && ws.total < kWsRange) ? m / SPG : 0;
     int pass = 0;
 
     for (int s = wave; s < nstrips; s += W, ++pass) {
@@ -227,9 +238,8 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
         for (int r = 0; r < R; ++r) tcmp[r] = tc[r] << code_shift;           // -1 stays negative
         const bool lane_has_rows = row0 < n;
         const int prod_pass = (wave == 0) ? pass - 1 : pass;
-        int* const plane_v = reinterpret_cast<int*>(ws_p + ws.row_plane(s, 0));
-        int* const plane_d = reinterpret_cast<int*>(ws_p + ws.row_plane(s, 1));
-        int* const plane_h = reinterpret_cast<int*>(ws_p + ws.row_plane(s, 2));
+        const int2* const hvd = reinterpret_cast<const int2*>(ws_p + ws.row(s)) + 1;       // the row above: entry j
+        int2* const hvo = reinterpret_cast<int2*>(ws_p + ws.row(s + 1)) + 1;               // this strip's bottom row
 
         auto wait_span = [&](int g_first) {
             if (W == 1 || s == 0) return;
@@ -244,9 +254,13 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
                 __builtin_amdgcn_s_sleep(2);
             }
         };
+        // Progress words say "the hand-off entries of these groups are in L2": the stores must have
+        // COMPLETED, not merely been issued, before the word is written (a workgroup-scope release
+        // only orders the LDS side on this target: it emits no vmcnt wait).
         auto publish = [&](int g) {
             if (W == 1) return;
             if ((g % CHK) == 0 || g == ngroups - 1) {     // published values are 1 mod CHK, like the needs
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 63)
                     __hip_atomic_store(&prog[wave], pass * ngroups + g + 1, __ATOMIC_RELEASE,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -269,23 +283,15 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
             }
         };
         // whole lane state, taken BEFORE group g runs: what phase 2 restarts from
-        auto checkpoint = [&](int g) {
-            if (g > 0 && (g % kCkGroups) == 0) {
-                int* st = reinterpret_cast<int*>(ws_p + ws.state(s, g / kCkGroups)) + lane;
+        auto checkpoint_now = [&](int g) {
+            int* st = reinterpret_cast<int*>(ws_p + ws.state(s, g / kCkGroups)) + lane;
 #pragma unroll
-                for (int r = 0; r < R; ++r) { st[r * 64] = D[r]; st[(R + r) * 64] = H[r]; }
-                st[8 * 64] = V[R - 1];
-                st[9 * 64] = dsave;
-            }
+            for (int r = 0; r < R; ++r) { st[r * 64] = D[r]; st[(R + r) * 64] = H[r]; }
+            st[8 * 64] = V[R - 1];
+            st[9 * 64] = dsave;
         };
-        // lane 63's last two rows: V~ and D of row R-2, H~ of row R-1, per column (entry j at j+2)
-        auto store_planes = [&](int g, const int (&rv)[SPG], const int (&rd)[SPG], const int (&rh)[SPG]) {
-            if (lane == 63 && g >= 15) {
-                const int base = 4 * (g - 15);
-                *reinterpret_cast<int4*>(plane_v + base) = make_int4(rv[0], rv[1], rv[2], rv[3]);
-                *reinterpret_cast<int4*>(plane_d + base) = make_int4(rd[0], rd[1], rd[2], rd[3]);
-                *reinterpret_cast<int4*>(plane_h + base) = make_int4(rh[0], rh[1], rh[2], rh[3]);
-            }
+        auto checkpoint = [&](int g) {
+            if (g > 0 && (g % kCkGroups) == 0) checkpoint_now(g);
         };
         auto group_edge = [&](int g) {
             checkpoint(g);
@@ -294,7 +300,6 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
 #pragma unroll
             for (int q = 0; q < SPG; ++q) { oc[q] = oc_next[q]; hd[q] = hd_next[q]; }
             prefetch(g);
-            int rv[SPG], rd[SPG], rh[SPG];
 #pragma unroll
             for (int q = 0; q < SPG; ++q) {
                 const int k = g * SPG + q;
@@ -313,11 +318,9 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
                         v_u = V[r];
                     }
                     dsave = d_next;
-                    if (lane == 63) hvd[j] = make_int2(V[R - 1], D[R - 1]);
+                    if (lane == 63) hvo[j] = make_int2(V[R - 1], D[R - 1]);
                 }
-                rv[q] = V[R - 2]; rd[q] = D[R - 2]; rh[q] = H[R - 1];
             }
-            store_planes(g, rv, rd, rh);
             publish(g);
         };
 
@@ -338,13 +341,21 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
             // profile entries when the group's other inputs are fetched. ----
             static_assert(CHK == 4 && SPG == 4, "the block loop is written for 4 groups of 4 steps");
             const int4* hrp = reinterpret_cast<const int4*>(hvd + (g * SPG + 1));   // next group's 4 entries (16-B aligned)
-            int2* hwp = hvd + (g * SPG - 62);                      // lane 63's columns of the group being computed
+            // What lane 63 leaves behind per group -- four entries of the bottom row, two 16-byte
+            // stores -- goes through a raw buffer descriptor of the problem's workspace with a per-lane
+            // offset that is out of range for every other lane: the hardware drops those lanes'
+            // stores, and the code stays STRAIGHT-LINE.  Under `if (lane == 63)` (a branch) hipcc cannot
+            // count the stores, so its s_waitcnt for the next group's loads came out as vmcnt(2) and
+            // made every group wait for its stores to be acknowledged.
+            // The whole offset sits in the per-lane VGPR (+ an immediate per group of the block): with an
+            // SGPR offset hipcc does not cover the store-data hazard of 16-byte buffer stores on this
+            // chip (a VALU write to a data register in the two issue slots behind the store is what
+            // gets stored; seen as ~12 % wrong first words when a second workgroup shares the CU).
+            const int only63 = (lane == 63) ? 0 : kWsRange;       // in range for lane 63 only
+            int vo_w = only63 + (int)(ws.row(s + 1) + 8 + (int64_t)(g * SPG - 62) * 8);
             int crd = (kOPad + g * SPG - lane) * (int)sizeof(LC); // byte offset of the next group's codes (per lane)
             asm volatile("" : "+v"(crd));                         // a running VGPR pointer, immediate offsets below
             const unsigned char* const oc_b = reinterpret_cast<const unsigned char*>(ocode);
-            int* pv = plane_v + 4 * (g - 15);
-            int* pd = plane_d + 4 * (g - 15);
-            int* ph = plane_h + 4 * (g - 15);
             const int need_cap = min(ngroups, (m + 62) / SPG + 1);
             const int need_base = prod_pass * ngroups;
             int inA[SPG], inB[SPG];              // MODE 1: OCR codes; MODE 2: packed scores of the 4 rows
@@ -376,12 +387,13 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
                     __builtin_amdgcn_s_sleep(2);
                 }
             };
-            auto steady = [&](const int (&in)[SPG], const int2 (&hd)[SPG]) {
-                int rv[SPG], rd[SPG], rh[SPG], bv[SPG], bd[SPG];
+            auto steady = [&](auto blk, const int (&in)[SPG], const int2 (&hd)[SPG]) {
+                constexpr int B = decltype(blk)::value;           // group's place in the block: immediate offsets
+                int bv[SPG], bd[SPG];
 #pragma unroll
                 for (int q = 0; q < SPG; ++q) {
                     int x_up = hd[q].x, d_next = hd[q].y;
-                    if (!(ABL & 16)) wave_shr1_pair<1>(x_up, V[R - 1], d_next, D[R - 1]);
+                    if (!(ABL & 16)) wave_shr1_pair_sched(x_up, V[R - 1], d_next, D[R - 1]);
                     else { x_up += V[R - 1]; d_next += D[R - 1]; }
                     int d_ul = dsave, x_u = x_up;
 #pragma unroll
@@ -401,41 +413,59 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
                     }
                     dsave = d_next;
                     bv[q] = V[R - 1]; bd[q] = D[R - 1];
-                    rv[q] = V[R - 2]; rd[q] = D[R - 2]; rh[q] = H[R - 1];
                 }
-                if (lane == 63) {                                  // the strip's bottom rows, by their owner
-                    if (!(ABL & 1)) {
-#pragma unroll
-                        for (int q = 0; q < SPG; ++q) hwp[q] = make_int2(bv[q], bd[q]);
-                    }
-                    if (!(ABL & 4)) {
-                        *reinterpret_cast<int4*>(pv) = make_int4(rv[0], rv[1], rv[2], rv[3]);
-                        *reinterpret_cast<int4*>(pd) = make_int4(rd[0], rd[1], rd[2], rd[3]);
-                        *reinterpret_cast<int4*>(ph) = make_int4(rh[0], rh[1], rh[2], rh[3]);
-                    }
+                typedef int v4i __attribute__((ext_vector_type(4)));
+                if (!(ABL & 1)) {                                  // the strip's bottom row, by its owner
+                    __builtin_amdgcn_raw_buffer_store_b128((v4i){bv[0], bd[0], bv[1], bd[1]}, wsrc, vo_w + B * 32, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128((v4i){bv[2], bd[2], bv[3], bd[3]}, wsrc, vo_w + B * 32 + 16, 0, 0);
                 }
-                hwp += SPG; pv += 4; pd += 4; ph += 4;
             };
             // (hvd of group g was waited for by the last edge group's prefetch)
             if constexpr (PROFILE) { codes(ocX); codes(ocY); fetch(ocX, inA, hdA); }
             else { codes(ocX); fetch(ocX, inA, hdA); }
-            for (; g < g_end; g += CHK) {
-                if (!(ABL & 4) && (g & (kCkGroups - 1)) == 0) checkpoint(g);
+            constexpr std::integral_constant<int, 0> blk0{};
+            constexpr std::integral_constant<int, 1> blk1{};
+            constexpr std::integral_constant<int, 2> blk2{};
+            constexpr std::integral_constant<int, 3> blk3{};
+            auto block = [&]() {                                  // four groups, g .. g + 3
                 if constexpr (PROFILE) {
-                    fetch(ocY, inB, hdB); codes(ocX); steady(inA, hdA);
-                    if (!(ABL & 8)) publish(g);
-                    fetch(ocX, inA, hdA); codes(ocY); steady(inB, hdB);
-                    fetch(ocY, inB, hdB); codes(ocX); steady(inA, hdA);
+                    fetch(ocY, inB, hdB); codes(ocX); steady(blk0, inA, hdA);
+                    fetch(ocX, inA, hdA); codes(ocY); steady(blk1, inB, hdB);
+                    fetch(ocY, inB, hdB); codes(ocX); steady(blk2, inA, hdA);
                     wait_block(g + CHK);
-                    fetch(ocX, inA, hdA); codes(ocY); steady(inB, hdB);
+                    fetch(ocX, inA, hdA); codes(ocY); steady(blk3, inB, hdB);
                 } else {
-                    codes(ocY); fetch(ocY, inB, hdB); steady(inA, hdA);
-                    if (!(ABL & 8)) publish(g);
-                    codes(ocX); fetch(ocX, inA, hdA); steady(inB, hdB);
-                    codes(ocY); fetch(ocY, inB, hdB); steady(inA, hdA);
+                    codes(ocY); fetch(ocY, inB, hdB); steady(blk0, inA, hdA);
+                    codes(ocX); fetch(ocX, inA, hdA); steady(blk1, inB, hdB);
+                    codes(ocY); fetch(ocY, inB, hdB); steady(blk2, inA, hdA);
                     wait_block(g + CHK);
-                    codes(ocX); fetch(ocX, inA, hdA); steady(inB, hdB);
+                    codes(ocX); fetch(ocX, inA, hdA); steady(blk3, inB, hdB);
                 }
+                // progress, one block late: this block issued 8 stores and 8 loads (16 vector-memory
+                // operations, + 10 checkpoint stores in every fourth block), so once all but the 16
+                // youngest are done, every store of the blocks before this one has completed -- without
+                // waiting for the stores just issued.  Published: groups < g.
+                vo_w += CHK * SPG * 8;
+                if (W > 1 && !(ABL & 8)) {
+                    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    if (lane == 63)
+                        __hip_atomic_store(&prog[wave], pass * ngroups + g, __ATOMIC_RELEASE,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                g += CHK;
+            };
+            // Checkpoint intervals whole (g is a multiple of kCkGroups here: g_lo = 16), so that the ten
+            // checkpoint stores sit in straight-line code: behind a branch hipcc's s_waitcnt for the
+            // next loads can no longer count them and waits for all of them (a full store round trip
+            // every 16 groups).
+            static_assert(kCkGroups == 4 * CHK && ((63 + SPG - 1) / SPG) % kCkGroups == 0, "interval = 4 blocks, aligned");
+            while (g + kCkGroups <= g_end) {
+                if (!(ABL & 4)) checkpoint_now(g);
+                block(); block(); block(); block();
+            }
+            while (g < g_end) {
+                if (!(ABL & 4)) checkpoint(g);
+                block();
             }
             if (g < ngroups) {
                 if ((g % CHK) == 0) wait_span(g);
@@ -468,7 +498,8 @@ constexpr int kTb2Ops = 512;
 template <bool CARRIED>
 __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], int (&V)[4], int (&H)[4], int& dsave,
                                              const int (&tc)[4], const int2* hvt, const uint16_t* ow,
-                                             uint4* win, int g0, int g_top, int m, int lane, bool lane_has_rows) {
+                                             uint4* win, int2* hvb, int g0, int g_top, int m, int lane,
+                                             bool lane_has_rows) {
     constexpr int R = 4, SPG = 4;
     const int k0 = g0 * SPG;
     int oc_next[SPG];
@@ -510,6 +541,7 @@ __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], in
                 }
                 acc[q] = pack4(b[0], b[1], b[2], b[3]);
                 dsave = d_next;
+                if (lane == 63) hvb[g * SPG + q - k0] = make_int2(V[R - 1], D[R - 1]);
             }
         } else {
 #pragma unroll
@@ -531,6 +563,7 @@ __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], in
                     }
                     acc[q] = pack4(b[0], b[1], b[2], b[3]);
                     dsave = d_next;
+                    if (lane == 63) hvb[kk - k0] = make_int2(V[R - 1], D[R - 1]);
                 }
             }
         }
@@ -544,7 +577,8 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
     using L = PtrLayout<R>;
     constexpr int SPG = L::SPG;
     __shared__ uint4 win[kChunkGroups * 64];                    // pointer bytes of the chunk, strip layout
-    __shared__ int2 hvt[kChunkSteps + 8];                       // tagged (V~ or XG, D) of the row above, columns k0..
+    __shared__ int2 hvt[kChunkSteps + 8];                       // (V~ or XG, D) of the row above, columns k0..
+    __shared__ int2 hvb[kChunkSteps];                           // tagged (V~ or XG, D) the strip's bottom row puts out, per step
     __shared__ uint16_t ow[kChunkSteps + 64 + 8];               // OCR codes, o index (k0 - 63) + i
     __shared__ uint8_t opsbuf[kTb2Ops];
 
@@ -556,6 +590,17 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
     const int cap = n + m;
     int x = n, y = m, len = 0, st = 0;
     bool first = true;
+    // The bottom rows of phase 1 carry no winner tags, so the two pointers a strip's first row takes
+    // from the row above (PM, PX) are not in a re-filled window.  A step that leaves the strip
+    // upwards is taken with its next state PENDING (pend = 3: the tag of D, = 4: the tag of XG / V~,
+    // of the cell (x, y) the walk then stands on -- bottom row of the strip above), and the state is
+    // read off that cell's tagged outputs (hvb) when the strip above is re-filled.
+    int pend = 0;
+    bool probe = false;
+    if (n > 1 && (n - 1) % L::SR == 0) {                        // the start state PM(n, m) is such a tag: D(n-1, m-1)
+        if (m == 1) { st = 0; first = false; }                  // boundary column: M
+        else { x = n - 1; y = m - 1; pend = 3; probe = true; }
+    }
 
     const int32_t* prm = a.params + (size_t)p * a.params_stride;
     const CellConsts c = make_consts(prm[0], prm[1], prm[2], prm[3], prm[4], prm[5]);
@@ -584,10 +629,7 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
             const int i = row0 + rr + 1;
             tc[rr] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
         }
-        const int t_h = (s > 0) ? a.t_codes[t0 + i_h - 1] : -1;
-        const int* const pv = reinterpret_cast<const int*>(ws_p + ws.row_plane(max(s - 1, 0), 0)) + 2;
-        const int* const pd = reinterpret_cast<const int*>(ws_p + ws.row_plane(max(s - 1, 0), 1)) + 2;
-        const int* const ph = reinterpret_cast<const int*>(ws_p + ws.row_plane(max(s - 1, 0), 2)) + 2;
+        const int2* const hrow = reinterpret_cast<const int2*>(ws_p + ws.row(s)) + 1;     // the row above: entry j
 
         int ck = (k >> 2) / kChunk;                             // chunk the walk is in
         int g_top = k >> 2;                                     // last group to re-fill
@@ -606,38 +648,17 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
                 if (i < nsteps_w + 64)
                     ow[i] = (src >= 0 && src < m) ? (uint16_t)a.o_codes[o0 + src] : (uint16_t)0xFFFF;
             }
-            // (b) the row above the strip with winner tags, columns k0 .. min(m, k0 + nsteps_w)
+            // (b) the row above the strip, columns k0 .. min(m, k0 + nsteps_w): tagged only where the
+            // tags are known analytically (the table's boundary row)
             {
                 const int jhi = min(m, k0 + nsteps_w);
                 if (s == 0) {
                     for (int j = k0 + lane; j <= jhi; j += 64)
                         hvt[j - k0] = make_int2(bnd_V_row0(c, j) + xadj6, bnd_D_row0(c, j));
                 } else {
-                    constexpr int kIt = (kChunkSteps + 1 + 63) / 64;
-                    int rd_[kIt], rv_[kIt], rh_[kIt], ro_[kIt];
-#pragma unroll
-                    for (int it = 0; it < kIt; ++it) {                 // issue every load first
-                        const int j = min(k0 + it * 64 + lane, jhi);
-                        const int jm = max(j - 1, 0);
-                        rd_[it] = pd[jm]; rv_[it] = pv[j]; rh_[it] = ph[jm];
-                        ro_[it] = a.o_codes[o0 + jm];
-                    }
-#pragma unroll
-                    for (int it = 0; it < kIt; ++it) {
-                        const int j = k0 + it * 64 + lane;
-                        if (j > jhi) continue;
-                        int2 e;
-                        if (j == 0) {
-                            e = make_int2(0, bnd_D_col0(c, i_h));
-                        } else {
-                            const int d_ul = (j - 1 >= 1) ? rd_[it] : raw_of(bnd_D_col0(c, i_h - 1));
-                            const int h_l = (j - 1 >= 1) ? rh_[it] - yadj : raw_of(bnd_H_col0(c, i_h));
-                            const int cs = (t_h == ro_[it]) ? c.cmatch : c.cmismatch;
-                            int d, v, h;
-                            cell_update(enc_of(d_ul), enc_of(rv_[it] - xadj), enc_of(h_l), cs, c.gox6, c.goy6, d, v, h);
-                            e = make_int2(v + xadj6, d);                // adding gox << 6 keeps the tag
-                        }
-                        hvt[j - k0] = e;
+                    for (int j = k0 + lane; j <= jhi; j += 64) {
+                        const int2 e = hrow[max(j, 1)];
+                        hvt[j - k0] = (j == 0) ? make_int2(0, bnd_D_col0(c, i_h)) : make_int2(enc_of(e.x), enc_of(e.y));
                     }
                 }
             }
@@ -665,13 +686,24 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
 
             // (d) tagged re-fill of groups g0 .. g_top into LDS
             {
-                if (carried) refill_chunk<true>(kr, D, V, H, dsave, tc, hvt, ow, win, g0, g_top, m, lane, lane_has_rows);
-                else refill_chunk<false>(kr, D, V, H, dsave, tc, hvt, ow, win, g0, g_top, m, lane, lane_has_rows);
+                if (carried) refill_chunk<true>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows);
+                else refill_chunk<false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows);
             }
             __syncthreads();
 
             // (e) walk the chunk
             const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
+            if (pend) {                                        // (x, y): lane 63's last row, step k of this chunk
+                const int2 e = hvb[k - k0];
+                st = 2 - (((pend == 3) ? e.y : e.x) & 3);
+                pend = 0;
+                if (probe) {                                   // that was the start state: back to (n, m)
+                    probe = false; first = false;
+                    x = n; y = m;
+                    __syncthreads();
+                    break;
+                }
+            }
             if (first && k >= kvalid) {                        // start state, textSeqCompare.py:102
                 st = ptr_pm(wb[(((k >> 2) - g0) * 64 + l) * 16 + (k & 3) * R + r]);
                 first = false;
@@ -679,13 +711,14 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
             if (ABL2 & 4) { x = s * L::SR; y = max(y - 300, 1); }
             bool again = !(ABL2 & 4);
             while (again) {
-                const int cnt = walk_window_vec(win, g0, kvalid, s * L::SR, x, y, st, opsbuf, kTb2Ops, lane);
+                const int cnt = walk_window_vec<true>(win, g0, kvalid, s * L::SR, x, y, st, opsbuf, kTb2Ops, lane);
                 __syncthreads();
                 for (int i = lane; i < cnt; i += 64) ops[cap - 1 - (len + i)] = opsbuf[i];
                 len += cnt;
                 __syncthreads();
                 again = (cnt == kTb2Ops);                       // the ops buffer was full: keep walking this chunk
             }
+            if (st >= 3) { pend = st; st = 0; }                // left the strip upwards: state pending
             // position in layout coordinates after the walk
             l = (x > s * L::SR) ? ((x - 1) % L::SR) / R : -1;
             r = (x - 1) & (R - 1);
