@@ -491,6 +491,9 @@ constexpr int kChunkGroups = kChunk + 1;          // + the group holding the nex
 constexpr int kChunkSteps = kChunkGroups * 4;
 constexpr int kTb2Ops = 512;
 
+#ifndef TA_P2_PROFILE
+#define TA_P2_PROFILE 0     // cycle counters per problem into row 0 of its workspace (tools/p2_profile.py)
+#endif
 #ifndef TA_P2_ABLATE
 #define TA_P2_ABLATE 0      // timing experiments only: 2 re-fill one group only, 4 no walk
 #endif
@@ -614,6 +617,13 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
     const int xadj6 = xadj * 64, yadj6 = yadj * 64;
     const Ws2 ws(max(n, 1), max(m, 1));
     uint8_t* const ws_p = a.ws + a.ws_off[p];
+#if TA_P2_PROFILE
+    long long pc_setup = 0, pc_fill = 0, pc_walk = 0, pc_chunks = 0, pc_t = __builtin_readcyclecounter(), pc_groups = 0;
+    const long long pc_start = pc_t;
+#define PC_LAP(acc) { const long long now_ = __builtin_readcyclecounter(); acc += now_ - pc_t; pc_t = now_; }
+#else
+#define PC_LAP(acc)
+#endif
 
     while (x > 0 && y > 0) {
         const int s = (x - 1) / L::SR;
@@ -683,6 +693,7 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
                 dsave = enc_of(stp[9 * 64]);
             }
             __syncthreads();
+            PC_LAP(pc_setup)
 
             // (d) tagged re-fill of groups g0 .. g_top into LDS
             {
@@ -690,6 +701,10 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
                 else refill_chunk<false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows);
             }
             __syncthreads();
+            PC_LAP(pc_fill)
+#if TA_P2_PROFILE
+            pc_chunks += 1; pc_groups += g_top - g0 + 1;
+#endif
 
             // (e) walk the chunk
             const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
@@ -719,6 +734,7 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
                 again = (cnt == kTb2Ops);                       // the ops buffer was full: keep walking this chunk
             }
             if (st >= 3) { pend = st; st = 0; }                // left the strip upwards: state pending
+            PC_LAP(pc_walk)
             // position in layout coordinates after the walk
             l = (x > s * L::SR) ? ((x - 1) % L::SR) / R : -1;
             r = (x - 1) & (R - 1);
@@ -736,6 +752,13 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
     while (y > 0) { if (lane == 0) ops[cap - 1 - len] = 2; ++len; --y; }
     while (x > 0) { if (lane == 0) ops[cap - 1 - len] = 1; ++len; --x; }
     if (lane == 0) a.ops_len[p] = len;
+#if TA_P2_PROFILE
+    if (lane == 0) {                                   // row 0 of the workspace is phase 1's: free by now
+        long long* out = reinterpret_cast<long long*>(ws_p + ws.row(0));
+        out[0] = pc_setup; out[1] = pc_fill; out[2] = pc_walk; out[3] = pc_chunks; out[4] = pc_groups; out[5] = len;
+        out[6] = pc_start; out[7] = __builtin_readcyclecounter();
+    }
+#endif
 }
 
 }  // namespace ta
