@@ -180,6 +180,11 @@ int ta_nw_general_batch(const int32_t* t_codes, const int64_t* t_off,
  *   in which the kernel consumes a row of hout.  no <= 128.  probs / logits / summary are each
  *   optional (at least one of probs, summary): summary = float[rows][4] =
  *   {P(class 0), best P, best class (integer bits), 0}, all the decoder needs.
+ * ta_lstm_output_split: the same layer on the 16-bit matrix cores with split operands (the output
+ *   stage of mode 1 above; products exact to ~2^-19 relative): w2s = ta_lstm_output_split_weight_bytes(no)
+ *   bytes of 16-bit patterns [plane hi,r][class tile ceil(no/16)][k-step 7][lane 64][8] =
+ *   plane of W2[16*tile + lane%16][1 + 32*kstep + 4*(lane/16) + 16*(j/4) + j%4] (inputs >= 200 and classes >= no
+ *   zero), W2 = bf16 hi + fp16 rest as for the recurrence; bias = float[16*ceil(no/16)] = W2[:, 0].
  * ta_decode / ta_decode_summary: translate_back(outputs, threshold) per line, from the full
  *   probabilities or from the summaries; line b writes dec_n[b] (t, class) pairs at
  *   dec_t/dec_c + dec_off[b] (capacity (T[b] + 1) / 2 entries).
@@ -191,6 +196,9 @@ int ta_lstm_forward(const float* x, const int64_t* row_off, const int32_t* T,
                     const float* h0, const float* c0, const int32_t* tstart, void* stream);
 int ta_lstm_output(const float* y, int64_t rows, const float* w2p, int32_t no,
                    float* probs, float* logits, float* summary, void* stream);
+int64_t ta_lstm_output_split_weight_bytes(int32_t no);
+int ta_lstm_output_split(const float* y, int64_t rows, const void* w2s, const float* bias, int32_t no,
+                         float* probs, float* logits, float* summary, void* stream);
 int ta_decode_summary(const float* summary, const int64_t* row_off, const int32_t* T,
                       int32_t nlines, float threshold,
                       int32_t* dec_t, int32_t* dec_c, int32_t* dec_n, const int64_t* dec_off,

@@ -236,10 +236,46 @@ def test_decode_kernel_on_crafted_probabilities():
     assert got == want == [(3, 5), (7, 0), (11, 66)]
 
 
+@pytest.mark.parametrize("precision", ["f32", "split"])
 @pytest.mark.parametrize("no", [5, 16, 17, 33, 80, 112, 128])
-def test_class_counts_cover_every_output_tile_variant(no):
-    """The output layer is compiled once per number of 16-class tiles (1..8): class counts on both
-    sides of the tile boundaries, up to the maximum of 128."""
+def test_class_counts_cover_every_output_tile_variant(no, precision):
+    """The output layer is compiled once per number of 16-class tiles (1..8), in both forms (f32
+    MFMA; split 16-bit operands, which also take 4, 3 or 2 row tiles per wave depending on the
+    class count): class counts on both sides of the tile boundaries, up to the maximum of 128, and
+    row counts that leave the last row tiles of a wave partly or wholly empty."""
     from oracle import ocr_ref_f64 as R
     from text_alignment_amd import ocr
-    _check_lines(R, ocr, _tame(R.synthetic_model(7100 + no, no=no)), [40, 129, 300], TOL)
+    _check_lines(R, ocr, _tame(R.synthetic_model(7100 + no, no=no)), [40, 129, 300, 1, 7], TOL, precision=precision)
+
+
+def test_split_output_layer_matches_f32_output_layer():
+    """K4 alone: the split-operand output layer against the f32-input one on the same LSTM states
+    (random states in (-1, 1), the spec model's W2): logits within 2e-5, far inside the 1e-3 budget."""
+    import torch
+    from oracle import ocr_ref_f64 as R
+    from text_alignment_amd import _native, ocr
+    om = R.synthetic_model(7001, no=96)
+    rec = ocr.LineRecognizer(ocr.LineModel(om.fwd, om.rev, om.W2, om.codec), precision="split")
+    rng = np.random.default_rng(5)
+    for rows in (1, 47, 48, 49, 1000, 4099):
+        h = torch.from_numpy(rng.uniform(-1, 1, size=(rows, 200)).astype(np.float32)).cuda()
+        outs = []
+        for split in (False, True):
+            probs = torch.empty((rows, 96), dtype=torch.float32, device="cuda")
+            logits = torch.empty_like(probs)
+            summary = torch.empty((rows, 4), dtype=torch.float32, device="cuda")
+            if split:
+                rc = _native.lib.ta_lstm_output_split(h.data_ptr(), rows, rec.w2s.data_ptr(), rec.w2bias.data_ptr(), 96,
+                                                      probs.data_ptr(), logits.data_ptr(), summary.data_ptr(), None)
+            else:
+                rc = _native.lib.ta_lstm_output(h.data_ptr(), rows, rec.w2p.data_ptr(), 96,
+                                                probs.data_ptr(), logits.data_ptr(), summary.data_ptr(), None)
+            assert rc == 0
+            torch.cuda.synchronize()
+            outs.append((probs.cpu().numpy(), logits.cpu().numpy(), summary.cpu().numpy()))
+        want = h.cpu().numpy().astype(np.float64).dot(om.W2[:, 1:].T) + om.W2[:, 0]
+        assert np.abs(outs[0][1] - want).max() < 2e-5
+        assert np.abs(outs[1][1] - want).max() < 2e-5, np.abs(outs[1][1] - want).max()
+        assert np.abs(outs[1][0] - outs[0][0]).max() < 3e-5       # probabilities: |dp| <= p |dz|
+        assert np.array_equal(outs[1][2][:, 2].view(np.int32), outs[0][2][:, 2].view(np.int32)) or \
+            np.abs(outs[1][2][:, 1] - outs[0][2][:, 1]).max() < 3e-5

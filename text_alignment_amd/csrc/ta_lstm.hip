@@ -512,6 +512,63 @@ __device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long k
     return dpp_max_u64<kDppMirror>(k);
 }
 
+// clip + softmax (+ summary) of one 16-row accumulator tile: rows (lane>>4)*4 + r, classes
+// ct*16 + (lane&15).  Shared by the f32 and the split-operand output kernels.
+struct OutSinks { int64_t rows; int no; float* probs; float* logits; float4* summary; };
+template <int NCT>
+__device__ __forceinline__ void softmax_tile(f32x4 (&acc)[NCT], int64_t r0, const OutSinks& a, int lane) {
+    const int rr = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = r0 + (lane >> 4) * 4 + r;
+        float zmax = -3.0e38f;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int cls = ct * 16 + rr;
+            if (cls < a.no) {
+                if (a.logits && row < a.rows) a.logits[row * a.no + cls] = acc[ct][r];
+                const float z = fminf(fmaxf(acc[ct][r], -100.f), 100.f);
+                acc[ct][r] = z;
+                zmax = fmaxf(zmax, z);
+            }
+        }
+        zmax = row16_max(zmax);
+        float sum = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int cls = ct * 16 + rr;
+            if (cls < a.no) {
+                const float e = exp_fast(fmaxf(acc[ct][r] - zmax, -87.0f));
+                acc[ct][r] = e;
+                sum += e;
+            }
+        }
+        sum = row16_sum(sum);
+        const float inv = 1.0f / sum;
+        unsigned long long key = 0ull;           // larger P wins, then the smaller class
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int cls = ct * 16 + rr;
+            if (cls < a.no) {
+                const float pr = acc[ct][r] * inv;
+                if (a.probs && row < a.rows) a.probs[row * a.no + cls] = pr;
+                const unsigned long long k =
+                    ((unsigned long long)__float_as_uint(pr) << 32) | (unsigned)(0xFFFFFFFFu - cls);
+                key = k > key ? k : key;
+                if (ct == 0) acc[0][r] = pr;     // lane rr == 0 keeps P(class 0)
+            }
+        }
+        if (a.summary) {
+            key = row16_max_u64(key);
+            if (rr == 0 && row < a.rows) {
+                const unsigned cls = 0xFFFFFFFFu - (unsigned)key;
+                a.summary[row] = make_float4(acc[0][r], __uint_as_float((unsigned)(key >> 32)),
+                                             __uint_as_float(cls), 0.f);
+            }
+        }
+    }
+}
+
 template <int NCT>
 __global__ __launch_bounds__(kOWaves * 64) void lstm_output_kernel(OutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float osm[];
@@ -522,6 +579,7 @@ __global__ __launch_bounds__(kOWaves * 64) void lstm_output_kernel(OutArgs a) {
     for (int e = tid; e < 201 * nop; e += kOWaves * 64) w2[e] = a.w2p[e];
     __syncthreads();
     const int kq = lane >> 4, rr = lane & 15;
+    const OutSinks sinks{a.rows, a.no, a.probs, a.logits, a.summary};
 
     const int64_t ntiles = (a.rows + 15) / 16;
     const int64_t stride = (int64_t)gridDim.x * kOWaves;
@@ -550,58 +608,148 @@ __global__ __launch_bounds__(kOWaves * 64) void lstm_output_kernel(OutArgs a) {
             for (int ct = 0; ct < NCT; ++ct)
                 acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[kk], bp[ct * 16], acc[ct], 0, 0, 0);
         }
-        // accumulator rows (lane>>4)*4 + r, classes ct*16 + (lane&15)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = r0 + (lane >> 4) * 4 + r;
-            float zmax = -3.0e38f;
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const int cls = ct * 16 + rr;
-                if (cls < a.no) {
-                    if (a.logits && row < a.rows) a.logits[row * a.no + cls] = acc[ct][r];
-                    const float z = fminf(fmaxf(acc[ct][r], -100.f), 100.f);
-                    acc[ct][r] = z;
-                    zmax = fmaxf(zmax, z);
-                }
-            }
-            zmax = row16_max(zmax);
-            float sum = 0.f;
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const int cls = ct * 16 + rr;
-                if (cls < a.no) {
-                    const float e = exp_fast(fmaxf(acc[ct][r] - zmax, -87.0f));
-                    acc[ct][r] = e;
-                    sum += e;
-                }
-            }
-            sum = row16_sum(sum);
-            const float inv = 1.0f / sum;
-            unsigned long long key = 0ull;           // larger P wins, then the smaller class
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const int cls = ct * 16 + rr;
-                if (cls < a.no) {
-                    const float pr = acc[ct][r] * inv;
-                    if (a.probs && row < a.rows) a.probs[row * a.no + cls] = pr;
-                    const unsigned long long k =
-                        ((unsigned long long)__float_as_uint(pr) << 32) | (unsigned)(0xFFFFFFFFu - cls);
-                    key = k > key ? k : key;
-                    if (ct == 0) acc[0][r] = pr;     // lane rr == 0 keeps P(class 0)
-                }
-            }
-            if (a.summary) {
-                key = row16_max_u64(key);
-                if (rr == 0 && row < a.rows) {
-                    const unsigned cls = 0xFFFFFFFFu - (unsigned)key;
-                    a.summary[row] = make_float4(acc[0][r], __uint_as_float((unsigned)(key >> 32)),
-                                                 __uint_as_float(cls), 0.f);
-                }
-            }
-        }
+        softmax_tile<NCT>(acc, r0, sinks, lane);
 #pragma unroll
         for (int q = 0; q < kOKS; ++q) A[q] = An[q];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4 (split operands): the same product on the 16-bit matrix cores, operands split as in the
+// recurrence above -- W2 = W_hi (bf16) + W_r (fp16 of the rest), a row of hout = three bf16 terms +
+// one fp16 -- four v_mfma_f32_16x16x32 per k-step of 32 and class tile, f32 accumulation, relative
+// error of a product sum ~2^-19.  The f32-input kernel above needs 300 MFMAs of 32 cycles per
+// 16-row tile; this one 168 of 16 cycles, and the split of the hout rows (once per row tile, reused
+// by every class tile) is VALU work that runs beside them.  A wave takes two (four: up to 32
+// classes) row tiles at a time so that each B fragment it reads from LDS (W2 sits there as ready
+// fragments, 14 KiB per class tile) feeds eight MFMAs, and twelve waves per CU (168 VGPRs) keep
+// enough row loads in flight: with everything but the loads removed the kernel still takes 0.57 ms
+// per 2.76 M rows (3.9 TB/s), 0.76 ms complete (the f32-input form: 1.5 ms).
+constexpr int kO2KS = 7;           // k-steps of 32 over the 200 inputs (+ 24 zeros)
+// 16-row tiles per wave and pass: as many as the register file takes beside the accumulators
+#ifdef TA_O2T
+constexpr int o2_tiles(int) { return TA_O2T; }
+#else
+constexpr int o2_tiles(int nct) { return nct <= 2 ? 4 : 2; }
+#endif
+#ifndef TA_O2_ABL
+#define TA_O2_ABL 0     // timing experiments only: 1 no MFMAs, 2 no softmax, 4 no operand split
+#endif
+#ifndef TA_O2W
+#define TA_O2W 12
+#endif
+constexpr int kO2Waves = TA_O2W;
+
+struct Out2Args {
+    const float* y;        // [rows][200]
+    int64_t rows;
+    const uint4* w2s;      // [plane 2: hi, r][nct][k-step 7][lane 64]: 8 x 16 bit = W2[ct*16 + lane%16][1 + 32*ks + 4*(lane/16) + 16*(j/4) + j%4]
+    const float* bias;     // [nct * 16]: W2[:, 0]
+    int no, nct;
+    float* probs; float* logits; float4* summary;
+};
+
+__device__ __forceinline__ void split8(const float4& v0, const float4& v1, bf16x8& hi, bf16x8& mid, bf16x8& lo, f16x8& h16) {
+    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)v[i];
+        const float r1 = v[i] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        hi[i] = h; mid[i] = m; lo[i] = (__bf16)r2; h16[i] = (_Float16)v[i];
+    }
+}
+
+template <int NCT>
+__global__ __launch_bounds__(kO2Waves * 64) void lstm_output_split_kernel(Out2Args a) {
+    constexpr int kO2T = o2_tiles(NCT);
+    extern __shared__ __attribute__((aligned(16))) uint4 wsm[];       // [2][NCT][7][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < 2 * NCT * kO2KS * 64; e += kO2Waves * 64) wsm[e] = a.w2s[e];
+    __syncthreads();
+    const int kb = lane >> 4, rr = lane & 15;
+    const OutSinks sinks{a.rows, a.no, a.probs, a.logits, a.summary};
+    float bias[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) bias[ct] = a.bias[ct * 16 + rr];
+
+    const int64_t nsuper = (a.rows + 16 * kO2T - 1) / (16 * kO2T);
+    for (int64_t sup = (int64_t)blockIdx.x * kO2Waves + wave; sup < nsuper; sup += (int64_t)gridDim.x * kO2Waves) {
+        const int64_t r0 = sup * (16 * kO2T);
+        // this lane's 8 inputs of its row per k-step: 32*ks + 4*kb + {0..3} and + 16 (the order of the
+        // sum over k is free, and this one makes every load instruction read 64 contiguous bytes
+        // per row; the B fragments are packed in the same order); rows past the end are clamped
+        // (read, never stored); the last k-step holds inputs 192..199 only
+        const float* rowp[kO2T];
+#pragma unroll
+        for (int t = 0; t < kO2T; ++t)
+            rowp[t] = a.y + min(r0 + t * 16 + rr, a.rows - 1) * 200 + kb * 4;
+        f32x4 acc[kO2T][NCT];
+#pragma unroll
+        for (int t = 0; t < kO2T; ++t)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[t][ct] = (f32x4){bias[ct], bias[ct], bias[ct], bias[ct]};
+        float4 raw[kO2T][2], nxt[kO2T][2];
+#pragma unroll
+        for (int t = 0; t < kO2T; ++t) {
+            raw[t][0] = *reinterpret_cast<const float4*>(rowp[t]);
+            raw[t][1] = *reinterpret_cast<const float4*>(rowp[t] + 16);
+        }
+#pragma unroll 1
+        for (int ks = 0; ks < kO2KS; ++ks) {
+            if (ks + 1 < kO2KS) {
+                const bool have1 = (ks + 1 < kO2KS - 1);            // the last k-step: inputs 192..199 only
+                const bool have0 = have1 || kb < 2;
+#pragma unroll
+                for (int t = 0; t < kO2T; ++t) {
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    nxt[t][0] = have0 ? *reinterpret_cast<const float4*>(rowp[t] + 32 * (ks + 1)) : z;
+                    nxt[t][1] = have1 ? *reinterpret_cast<const float4*>(rowp[t] + 32 * (ks + 1) + 16) : z;
+                }
+            }
+            bf16x8 ahi[kO2T], amid[kO2T], alo[kO2T];
+            f16x8 a16[kO2T];
+#pragma unroll
+            for (int t = 0; t < kO2T; ++t) {
+                if (TA_O2_ABL & 4) {
+                    ahi[t] = __builtin_bit_cast(bf16x8, raw[t][0]); amid[t] = __builtin_bit_cast(bf16x8, raw[t][1]);
+                    alo[t] = ahi[t]; a16[t] = __builtin_bit_cast(f16x8, raw[t][1]);
+                } else split8(raw[t][0], raw[t][1], ahi[t], amid[t], alo[t], a16[t]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, wsm[((0 * NCT + ct) * kO2KS + ks) * 64 + lane]);
+                const f16x8 br = __builtin_bit_cast(f16x8, wsm[((1 * NCT + ct) * kO2KS + ks) * 64 + lane]);
+#pragma unroll
+                for (int t = 0; t < kO2T; ++t) {
+                    f32x4 v = acc[t][ct];
+                    if (TA_O2_ABL & 1) {
+                        v[0] += (float)alo[t][0] * (float)bh[0] + (float)a16[t][1] * (float)br[1] + (float)amid[t][2] + (float)ahi[t][3];
+                        acc[t][ct] = v;
+                        continue;
+                    }
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[t], bh, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_f16(a16[t], br, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(amid[t], bh, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[t], bh, v, 0, 0, 0);
+                    acc[t][ct] = v;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kO2T; ++t) { raw[t][0] = nxt[t][0]; raw[t][1] = nxt[t][1]; }
+        }
+#pragma unroll
+        for (int t = 0; t < kO2T; ++t) {
+            if (TA_O2_ABL & 2) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) sacc += acc[t][ct][0] + acc[t][ct][1] + acc[t][ct][2] + acc[t][ct][3];
+                const int64_t row = r0 + t * 16 + (lane >> 4) * 4;
+                if (rr == 0 && row < a.rows && a.summary) a.summary[row] = make_float4(sacc, 0.f, 0.f, 0.f);
+            } else softmax_tile<NCT>(acc[t], r0 + t * 16, sinks, lane);
+        }
     }
 }
 
@@ -773,6 +921,50 @@ extern "C" int ta_lstm_output(const float* y, int64_t rows, const float* w2p, in
     if (pre != hipSuccess) return ta_fail_hip(pre, "hipFuncSetAttribute(lstm_output_kernel)");
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ta_fail_hip(e, "lstm_output_kernel launch");
+    return TA_OK;
+}
+
+template <int NCT>
+static hipError_t launch_output_split(const Out2Args& a, dim3 grid, size_t lds, hipStream_t st) {
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_output_split_kernel<NCT>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (once != hipSuccess) return once;
+    hipLaunchKernelGGL(lstm_output_split_kernel<NCT>, grid, dim3(kO2Waves * 64), lds, st, a);
+    return hipSuccess;
+}
+
+extern "C" int64_t ta_lstm_output_split_weight_bytes(int32_t no) {
+    if (no <= 0 || no > 16 * kMaxCT) return 0;
+    return (int64_t)2 * ((no + 15) / 16) * kO2KS * 64 * 16;
+}
+
+extern "C" int ta_lstm_output_split(const float* y, int64_t rows, const void* w2s, const float* bias, int32_t no,
+                                    float* probs, float* logits, float* summary, void* stream) {
+    if (rows < 0 || no <= 0 || no > 16 * kMaxCT) return ta_fail(TA_EINVAL, "bad rows / class count");
+    if (rows == 0) return TA_OK;
+    if (!y || !w2s || !bias || !(probs || summary)) return ta_fail(TA_EINVAL, "null pointer argument");
+    const int nct = (no + 15) / 16;
+    Out2Args a{y, rows, reinterpret_cast<const uint4*>(w2s), bias, no, nct, probs, logits,
+               reinterpret_cast<float4*>(summary)};
+    const size_t lds = (size_t)ta_lstm_output_split_weight_bytes(no);
+    const int64_t nsuper = (rows + 16 * o2_tiles(nct) - 1) / (16 * o2_tiles(nct));
+    const int64_t want = (nsuper + kO2Waves - 1) / kO2Waves;
+    const dim3 grid((unsigned)(want < 256 ? want : 256));     // the fragments of W2 take most of a CU's LDS: one workgroup per CU
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t pre = hipSuccess;
+    switch (nct) {
+        case 1: pre = launch_output_split<1>(a, grid, lds, st); break;
+        case 2: pre = launch_output_split<2>(a, grid, lds, st); break;
+        case 3: pre = launch_output_split<3>(a, grid, lds, st); break;
+        case 4: pre = launch_output_split<4>(a, grid, lds, st); break;
+        case 5: pre = launch_output_split<5>(a, grid, lds, st); break;
+        case 6: pre = launch_output_split<6>(a, grid, lds, st); break;
+        case 7: pre = launch_output_split<7>(a, grid, lds, st); break;
+        default: pre = launch_output_split<8>(a, grid, lds, st); break;
+    }
+    if (pre != hipSuccess) return ta_fail_hip(pre, "hipFuncSetAttribute(lstm_output_split_kernel)");
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ta_fail_hip(e, "lstm_output_split_kernel launch");
     return TA_OK;
 }
 

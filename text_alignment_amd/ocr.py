@@ -7,7 +7,7 @@ translate_back(threshold 0.7).  `LineRecognizer` packs a model's weights into th
 layout of csrc/ta_lstm.hip once, then recognises any number of prepared text lines per call:
 lines are sorted by length, grouped 16 to a workgroup, and run through K3 (BiLSTM), K4
 (output layer + softmax) and K5 (decode) behind the C ABI (`ta_lstm_forward`,
-`ta_lstm_output`, `ta_decode`).
+`ta_lstm_output` / `ta_lstm_output_split`, `ta_decode`).
 """
 import numpy as np
 import torch
@@ -102,6 +102,33 @@ def _pack_lstm_split(model):
     return out
 
 
+def _pack_output_split(model):
+    """B fragments of the split-operand output layer: W2 = W_hi (bf16) + W_r (fp16 of the rest),
+    [plane 2: hi, r][class tile][k-step 7][lane 64][8] 16-bit patterns of
+    W2[16 tile + lane % 16][1 + 32 kstep + 4 (lane // 16) + 16 (j // 4) + j % 4] (inputs beyond 200
+    zero; the kernel reads a row of hout in this order), and the bias
+    column W2[:, 0] padded to whole class tiles."""
+    nct = (model.no + 15) // 16
+    W2 = np.asarray(model.W2, dtype=np.float64)
+    Wp = np.zeros((nct * 16, 7 * 32), dtype=np.float32)
+    Wp[:model.no, :2 * NS] = W2[:, 1:]
+    hi_bits, hi_val = _bf16_bits(Wp)
+    rest_bits = (Wp - hi_val).astype(np.float16).view(np.uint16)
+    out = np.zeros((2, nct, 7, 64, 8), dtype=np.uint16)
+    lane = np.arange(64)
+    for ct in range(nct):
+        rows = 16 * ct + (lane & 15)
+        for ks in range(7):
+            for j in range(8):
+                cols = 32 * ks + 4 * (lane >> 4) + 16 * (j // 4) + j % 4
+                out[0, ct, ks, :, j] = hi_bits[rows, cols]
+                out[1, ct, ks, :, j] = rest_bits[rows, cols]
+    assert out.size * 2 == _native.lib.ta_lstm_output_split_weight_bytes(model.no)
+    bias = np.zeros(nct * 16, dtype=np.float32)
+    bias[:model.no] = W2[:, 0]
+    return out, bias
+
+
 def _pack_lstm(model):
     nfl = _native.lib.ta_lstm_packed_weight_floats(0)
     wp = np.zeros((2, 7, 4, 38, 64), dtype=np.float32)
@@ -162,6 +189,10 @@ class LineRecognizer(object):
         self.wp = torch.from_numpy(wp).to(self.device)
         self.peep = torch.from_numpy(peep).to(self.device)
         self.w2p = torch.from_numpy(w2p).to(self.device)
+        if self.mode == 1:
+            w2s, bias = _pack_output_split(model)
+            self.w2s = torch.from_numpy(w2s).to(self.device)
+            self.w2bias = torch.from_numpy(bias).to(self.device)
 
     # ---- host -> device ------------------------------------------------------------------
     def _upload_rows(self, lines, row_off, rows):
@@ -276,7 +307,13 @@ class LineRecognizer(object):
             shape = (max(st["rows"], 1), self.model.no)
             st["probs"] = torch.empty(shape, dtype=torch.float32, device=self.device)
             st["logits"] = torch.empty(shape, dtype=torch.float32, device=self.device)
-        if output:
+        if output and self.mode == 1:
+            _native.check(lib.ta_lstm_output_split(
+                st["hout"].data_ptr(), st["rows"], self.w2s.data_ptr(), self.w2bias.data_ptr(), self.model.no,
+                st["probs"].data_ptr() if full else None,
+                st["logits"].data_ptr() if full else None,
+                st["summary"].data_ptr(), stream), "ta_lstm_output_split")
+        elif output:
             _native.check(lib.ta_lstm_output(
                 st["hout"].data_ptr(), st["rows"], self.w2p.data_ptr(), self.model.no,
                 st["probs"].data_ptr() if full else None,
