@@ -620,8 +620,8 @@ __global__ __launch_bounds__(kOWaves * 64) void lstm_output_kernel(OutArgs a) {
 // one fp16 -- four v_mfma_f32_16x16x32 per k-step of 32 and class tile, f32 accumulation, relative
 // error of a product sum ~2^-19.  The f32-input kernel above needs 300 MFMAs of 32 cycles per
 // 16-row tile; this one 168 of 16 cycles, and the split of the hout rows (once per row tile, reused
-// by every class tile) is VALU work that runs beside them.  A wave takes two (four: up to 32
-// classes) row tiles at a time so that each B fragment it reads from LDS (W2 sits there as ready
+// by every class tile) is VALU work that runs beside them.  A wave takes two row tiles at a time (four with up to 16
+// classes, one with more than 96) so that each B fragment it reads from LDS (W2 sits there as ready
 // fragments, 14 KiB per class tile) feeds eight MFMAs, and twelve waves per CU (168 VGPRs) keep
 // enough row loads in flight: with everything but the loads removed the kernel still takes 0.57 ms
 // per 2.76 M rows (3.9 TB/s), 0.76 ms complete (the f32-input form: 1.5 ms).
@@ -630,7 +630,7 @@ constexpr int kO2KS = 7;           // k-steps of 32 over the 200 inputs (+ 24 ze
 #ifdef TA_O2T
 constexpr int o2_tiles(int) { return TA_O2T; }
 #else
-constexpr int o2_tiles(int nct) { return nct <= 2 ? 4 : 2; }
+constexpr int o2_tiles(int nct) { return nct <= 1 ? 4 : nct <= 6 ? 2 : 1; }
 #endif
 #ifndef TA_O2_ABL
 #define TA_O2_ABL 0     // timing experiments only: 1 no MFMAs, 2 no softmax, 4 no operand split
