@@ -118,6 +118,7 @@ __device__ __forceinline__ unsigned cell_hw(const CellRegs& k, int d_ul, int v_u
 }
 
 // the carried cell on encoded values (ta::cell_update_carried_tagged), one VALU instruction per line
+template <bool SAMEGO = false>
 __device__ __forceinline__ unsigned cell_carried_tagged_hw(const CellRegs& k, int d_ul, int xg_u, int yg_l,
                                                            int t, int o, int& d, int& xg, int& yg) {
     const int cs = v_score(t, o, k.cmis, k.cmat);        // v_cmp_eq + v_cndmask
@@ -125,8 +126,10 @@ __device__ __forceinline__ unsigned cell_carried_tagged_hw(const CellRegs& k, in
     const int xr = v_and_or_x(xg_u, k.clean);             // v_and_or
     const int yr = yg_l & k.clean;                        // v_and
     d = v_max3(mr, xr, yr);
-    xg = max(d + k.gox6, xr);                             // v_add, v_max
-    yg = max(d + k.goy6, yr);                             // v_add, v_max
+    const int dgx = d + k.gox6;                           // v_add
+    const int dgy = SAMEGO ? dgx : d + k.goy6;            // v_add (none when the two gap opens are equal)
+    xg = max(dgx, xr);                                    // v_max
+    yg = max(dgy, yr);                                    // v_max
     return v_bfi3((unsigned)d_ul, v_bfi12((unsigned)xg_u, (unsigned)yg_l));
 }
 

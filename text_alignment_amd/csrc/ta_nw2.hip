@@ -498,7 +498,7 @@ constexpr int kTb2Ops = 512;
 #define TA_P2_ABLATE 0      // timing experiments only: 2 re-fill one group only, 4 no walk
 #endif
 
-template <bool CARRIED>
+template <bool CARRIED, bool SAMEGO>
 __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], int (&V)[4], int (&H)[4], int& dsave,
                                              const int (&tc)[4], const int2* hvt, const uint16_t* ow,
                                              uint4* win, int2* hvb, int g0, int g_top, int m, int lane,
@@ -516,7 +516,7 @@ __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], in
         }
     };
     auto cell = [&](int d_ul, int x_u, int y_l, int t, int o, int& d, int& x, int& y) -> unsigned {
-        if constexpr (CARRIED) return cell_carried_tagged_hw(kr, d_ul, x_u, y_l, t, o, d, x, y);
+        if constexpr (CARRIED) return cell_carried_tagged_hw<SAMEGO>(kr, d_ul, x_u, y_l, t, o, d, x, y);
         else return cell_hw(kr, d_ul, x_u, y_l, t, o, d, x, y);
     };
     load_group(g0);
@@ -529,10 +529,11 @@ __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], in
         if (g < g_top) load_group(g + 1);
         unsigned acc[4] = {0u, 0u, 0u, 0u};
         if (g >= gs_lo && g < gs_hi) {
+            int2 cap[SPG];
 #pragma unroll
             for (int q = 0; q < SPG; ++q) {
                 int v_up = hd[q].x, d_next = hd[q].y;
-                wave_shr1_pair<1>(v_up, V[R - 1], d_next, D[R - 1]);
+                wave_shr1_pair_sched(v_up, V[R - 1], d_next, D[R - 1]);
                 int d_ul = dsave, v_u = v_up;
                 unsigned b[R];
 #pragma unroll
@@ -544,8 +545,13 @@ __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], in
                 }
                 acc[q] = pack4(b[0], b[1], b[2], b[3]);
                 dsave = d_next;
-                if (lane == 63) hvb[g * SPG + q - k0] = make_int2(V[R - 1], D[R - 1]);
+                cap[q] = make_int2(V[R - 1], D[R - 1]);
             }
+            // lane 63's bottom-row outputs of the four steps; every other lane's address lies outside
+            // the workgroup's LDS and its write is dropped (no branch)
+            const int at = (lane == 63) ? g * SPG - k0 : 0x0FFFFF00;       // x 8 bytes: beyond any LDS allocation
+#pragma unroll
+            for (int q = 0; q < SPG; ++q) hvb[at + q] = cap[q];
         } else {
 #pragma unroll
             for (int q = 0; q < SPG; ++q) {
@@ -644,33 +650,57 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
         int ck = (k >> 2) / kChunk;                             // chunk the walk is in
         int g_top = k >> 2;                                     // last group to re-fill
         bool in_strip = true;
+        // Inputs of a chunk's re-fill, fetched into registers: the OCR codes ow[i] = o[(k0 - 63) + i], the
+        // row above the strip for columns k0 .. min(m, k0 + steps) (tagged only where the tags are known
+        // analytically: the table's boundary row) and the lane state at the chunk's first group.  The
+        // chunk after this one is nearly always the one before it in the same strip, whole: its inputs
+        // are requested as soon as this chunk's are in LDS and arrive under this chunk's re-fill and walk.
+        constexpr int kOwIt = (kChunkSteps + 64 + 63) / 64, kRowIt = (kChunkSteps + 1 + 63) / 64;
+        int in_ow[kOwIt], in_st[kStateInts];
+        int2 in_row[kRowIt];
+        int in_ck = -1, in_gtop = -1;                           // what the registers hold (this strip)
+        auto fetch_inputs = [&](int ck_, int gtop_) {
+            const int g0_ = ck_ * kChunk, k0_ = g0_ * SPG;
+            const int nsteps_ = (gtop_ - g0_ + 1) * SPG;
+#pragma unroll
+            for (int it = 0; it < kOwIt; ++it) {
+                const int src = k0_ - 63 + it * 64 + lane;
+                in_ow[it] = (src >= 0 && src < m) ? a.o_codes[o0 + src] : 0xFFFF;
+            }
+            const int jhi = min(m, k0_ + nsteps_);
+#pragma unroll
+            for (int it = 0; it < kRowIt; ++it) {
+                const int j = min(k0_ + it * 64 + lane, jhi);
+                if (s == 0) in_row[it] = make_int2(bnd_V_row0(c, j) + xadj6, bnd_D_row0(c, j));
+                else {
+                    const int2 e = hrow[max(j, 1)];
+                    in_row[it] = (j == 0) ? make_int2(0, bnd_D_col0(c, i_h)) : make_int2(enc_of(e.x), enc_of(e.y));
+                }
+            }
+            if (g0_ > 0) {
+                const int* stp = reinterpret_cast<const int*>(ws_p + ws.state(s, g0_ / kCkGroups)) + lane;
+#pragma unroll
+                for (int q = 0; q < kStateInts; ++q) in_st[q] = stp[q * 64];
+            }
+            in_ck = ck_; in_gtop = gtop_;
+        };
         while (in_strip) {
             const int g0 = ck * kChunk;
             const int k0 = g0 * SPG;
             const int kvalid = ck > 0 ? k0 + 2 : 0;
             const int nsteps_w = (g_top - g0 + 1) * SPG;
+            if (in_ck != ck || in_gtop != g_top) fetch_inputs(ck, g_top);
 
-            // (a) OCR codes of the chunk: ow[i] = o[(k0 - 63) + i]
+            // (a) OCR codes of the chunk, (b) the row above the strip
 #pragma unroll
-            for (int it = 0; it < (kChunkSteps + 64 + 63) / 64; ++it) {
+            for (int it = 0; it < kOwIt; ++it) {
                 const int i = it * 64 + lane;
-                const int src = k0 - 63 + i;
-                if (i < nsteps_w + 64)
-                    ow[i] = (src >= 0 && src < m) ? (uint16_t)a.o_codes[o0 + src] : (uint16_t)0xFFFF;
+                if (i < nsteps_w + 64) ow[i] = (uint16_t)in_ow[it];
             }
-            // (b) the row above the strip, columns k0 .. min(m, k0 + nsteps_w): tagged only where the
-            // tags are known analytically (the table's boundary row)
-            {
-                const int jhi = min(m, k0 + nsteps_w);
-                if (s == 0) {
-                    for (int j = k0 + lane; j <= jhi; j += 64)
-                        hvt[j - k0] = make_int2(bnd_V_row0(c, j) + xadj6, bnd_D_row0(c, j));
-                } else {
-                    for (int j = k0 + lane; j <= jhi; j += 64) {
-                        const int2 e = hrow[max(j, 1)];
-                        hvt[j - k0] = (j == 0) ? make_int2(0, bnd_D_col0(c, i_h)) : make_int2(enc_of(e.x), enc_of(e.y));
-                    }
-                }
+#pragma unroll
+            for (int it = 0; it < kRowIt; ++it) {
+                const int j = k0 + it * 64 + lane;
+                if (j <= min(m, k0 + nsteps_w)) hvt[j - k0] = in_row[it];
             }
             // (c) lane state at the start of group g0 (in the form the re-fill keeps: carried or not)
             int D[R], V[R], H[R];
@@ -685,20 +715,22 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
             dsave = bnd_D_col0(c, row0);
             static_assert(kChunk * SPG >= 64, "a lane must have started before the first checkpoint: its "
                                                "column-0 values carry tags only in the boundary form");
+            static_assert(kStateInts == 2 * R + 2, "state = D[R], H[R], V[R-1], dsave");
             if (g0 > 0) {
-                const int* stp = reinterpret_cast<const int*>(ws_p + ws.state(s, g0 / kCkGroups)) + lane;
 #pragma unroll
-                for (int rr = 0; rr < R; ++rr) { D[rr] = enc_of(stp[rr * 64]); H[rr] = enc_of(stp[(R + rr) * 64]); }
-                V[R - 1] = enc_of(stp[8 * 64]);
-                dsave = enc_of(stp[9 * 64]);
+                for (int rr = 0; rr < R; ++rr) { D[rr] = enc_of(in_st[rr]); H[rr] = enc_of(in_st[R + rr]); }
+                V[R - 1] = enc_of(in_st[2 * R]);
+                dsave = enc_of(in_st[2 * R + 1]);
             }
+            if (ck > 0) fetch_inputs(ck - 1, g0);              // the likely next chunk (registers are free again)
             __syncthreads();
             PC_LAP(pc_setup)
 
             // (d) tagged re-fill of groups g0 .. g_top into LDS
             {
-                if (carried) refill_chunk<true>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows);
-                else refill_chunk<false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows);
+                if (carried && c.gox == c.goy) refill_chunk<true, true>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows);
+                else if (carried) refill_chunk<true, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows);
+                else refill_chunk<false, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows);
             }
             __syncthreads();
             PC_LAP(pc_fill)
