@@ -832,6 +832,11 @@ static hipError_t launch_score_w(const NwArgs& a, size_t lds, bool profile, bool
 // Phase-1 launch shape.  Waves per workgroup W <= strips of the tallest problem; with the score
 // profile the LDS per workgroup is W x apad x 256 B + the codes, so W is the one that keeps the most
 // waves resident per CU.
+// What workgroups that share a CU can hold together.  One workgroup may be given 160 KiB, but measured on
+// MI355X (nw_score_kernel with its LDS request padded, tools/p1_time.py with TA_NW2_LDS_PAD): three
+// workgroups of 41.3 KiB and two of 53.3 KiB run side by side, two of 63.3 KiB do not -- the limit for
+// co-residency lies between 124 and 126 KiB.
+constexpr size_t kLdsShared = 124 * 1024;
 struct P1Plan { int mode, w, apad; size_t lds; bool samego, codes8; };
 
 static P1Plan plan_phase1(int max_n, int max_m, uint32_t flags) {
@@ -853,7 +858,7 @@ static P1Plan plan_phase1(int max_n, int max_m, uint32_t flags) {
             const size_t need = P1Lds(max_m, 2, cand * pl.apad * 256).total;
             if (need > 160 * 1024) continue;
             // resident waves per CU: whole workgroups, within the LDS and within 5 waves per SIMD (VGPRs)
-            const int res = (int)std::min<size_t>(160 * 1024 / need, 20 / cand) * cand;
+            const int res = (int)std::min<size_t>(kLdsShared / need, 20 / cand) * cand;
             if (res > best_res) { best_res = res; best_w = cand; }
         }
         // a profile that leaves fewer than 8 waves on a CU is not worth its LDS
