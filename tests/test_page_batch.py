@@ -115,3 +115,45 @@ def test_array_glue_equals_object_glue_on_random_pages():
             for p, (which, sb) in zip(part, got):
                 assert which.tolist() == p[5] and sb.tolist() == p[6].tolist()
     assert pb.syllable_boxes_batch([], [], [], [], all_boxes, [], [], []) == []
+
+
+def test_syllable_span_fast_path_equals_sequential_search():
+    """page_batch._syllable_spans_fast (array arithmetic) against the reference's one-by-one search
+    (alignToOCR.py:297-324 with str.find standing for the regex): equal wherever it applies, and it
+    declines (None) whenever its premise does not hold."""
+    from text_alignment_amd import page_batch as pb
+    from text_alignment_amd import latinSyllabification as latsyl
+    rng = np.random.default_rng(3)
+    words = "dominus deus meus alleluia gloria patri et filio a e spiritui sancto".split()
+
+    def slow(tr, syls):
+        cur, first, last = 0, [], []
+        for syl in syls:
+            if not syl:
+                continue
+            p = tr.find(syl, cur)
+            assert p >= 0
+            cur = p + len(syl)
+            first.append(p); last.append(cur - 1)
+        return first, last
+
+    taken = 0
+    for k in range(200):
+        tr = " ".join(words[int(i)] for i in rng.integers(0, len(words), size=int(rng.integers(1, 40))))
+        if k % 5 == 1:
+            tr = tr.replace(" ", "  ", 2)                      # runs of spaces
+        syls = [s for w in tr.split() for s in latsyl.syllabify_word(w)] if hasattr(latsyl, "syllabify_word") \
+            else latsyl.syllabify_text(tr)
+        if k % 7 == 2:
+            syls = syls[:len(syls) // 2] + [""] + syls[len(syls) // 2:]     # empty syllables are skipped
+        got = pb._syllable_spans_fast(tr, syls)
+        want = slow(tr, syls)
+        if got is not None:
+            taken += 1
+            assert got[0].tolist() == want[0] and got[1].tolist() == want[1], (tr, syls)
+    assert taken > 150
+    # premise broken: a syllable list that does not cover the text, a syllable across a space, a tab
+    assert pb._syllable_spans_fast("do mi nus", ["do", "mi"]) is None
+    assert pb._syllable_spans_fast("do mi", ["dom", "i"]) is None
+    assert pb._syllable_spans_fast("do\tmi", ["do", "mi"]) is None
+    assert pb._syllable_spans_fast("", []) is None

@@ -208,6 +208,25 @@ def rotate_boxes(boxes, angle, orig_dim, target_dim):
     return np.stack([rx[:, 0], ry[:, 0], rx[:, 1], ry[:, 1]], axis=1)
 
 
+def _syllable_spans_fast(tr, syls):
+    """(first, last) transcript positions of every non-empty syllable when the syllables are exactly
+    the transcript's non-space characters in order, each inside one word -- what the syllabifier
+    produces for plain text -- or None.  Then the reference's sequential search (alignToOCR.py:297-
+    324: each syllable is looked for from where the one before ended) can only find syllable i at
+    the i-th run of those characters: between the cursor and that run there are only spaces, and a
+    syllable does not start with one."""
+    syl_ne = [x for x in syls if x]
+    if not syl_ne or ''.join(syl_ne) != tr.replace(' ', ''):
+        return None
+    ns = np.flatnonzero(np.frombuffer(tr.encode('utf-32-le'), dtype=np.uint32) != 32)
+    lens = np.fromiter(map(len, syl_ne), dtype=np.int64, count=len(syl_ne))
+    end = np.cumsum(lens)
+    first, last = ns[end - lens], ns[end - 1]
+    if not np.array_equal(last - first, lens - 1):        # a syllable that spans a space: search for it
+        return None
+    return first, last
+
+
 def syllable_boxes_batch(transcripts, syls_list, ops_list, idx_list, boxes, angles, image_dims, raw_dims):
     """syllable_boxes_arrays + rotate_boxes for MANY pages in one set of array operations (the
     per-page versions spend their time in numpy's per-call overhead on 2000-element arrays): the
@@ -237,24 +256,30 @@ def syllable_boxes_batch(transcripts, syls_list, ops_list, idx_list, boxes, angl
     ulx[cols], uly_min[cols], lrx[cols], lry[cols], uly_max[cols] = b[:, 0], b[:, 1], b[:, 2], b[:, 3], b[:, 1]
     first_t, last_t, which, page = [], [], [], []
     for k, (tr, syls) in enumerate(zip(transcripts, syls_list)):
-        cur, w, base = 0, -1, int(toff[k])
-        for syl in syls:
-            if len(syl) < 1:
-                continue
-            w += 1
-            p = tr.find(syl, cur)
-            if p < 0:
-                raise AttributeError("'NoneType' object has no attribute 'start'")     # as re.search(...).start()
-            cur = p + len(syl)
-            first_t.append(base + p)
-            last_t.append(base + cur - 1)
-            which.append(w)
-            page.append(k)
+        base = int(toff[k])
+        found = _syllable_spans_fast(tr, syls)
+        if found is None:                                 # the reference's search, one syllable at a time
+            cur, first_k, last_k = 0, [], []
+            for syl in syls:
+                if len(syl) < 1:
+                    continue
+                p = tr.find(syl, cur)
+                if p < 0:
+                    raise AttributeError("'NoneType' object has no attribute 'start'")     # as re.search(...).start()
+                cur = p + len(syl)
+                first_k.append(p)
+                last_k.append(cur - 1)
+            found = (np.asarray(first_k, dtype=np.int64), np.asarray(last_k, dtype=np.int64))
+        first_t.append(found[0] + base)
+        last_t.append(found[1] + base)
+        which.append(np.arange(len(found[0]), dtype=np.int64))
+        page.append(np.full(len(found[0]), k, dtype=np.int64))
     empty = [(np.zeros(0, np.int64), np.zeros((0, 4), np.int64))] * npages
-    if not which:
+    which = np.concatenate(which) if which else np.zeros(0, np.int64)
+    if len(which) == 0:
         return list(empty)
-    which, page = np.asarray(which), np.asarray(page)
-    starts, ends = col_of_t[np.asarray(first_t)], col_of_t[np.asarray(last_t)] + 1
+    page, first_t, last_t = np.concatenate(page), np.concatenate(first_t), np.concatenate(last_t)
+    starts, ends = col_of_t[first_t], col_of_t[last_t] + 1
     bounds = np.stack([starts, ends], axis=1).reshape(-1)
     low = np.maximum.reduceat(uly_max, bounds)[0::2]
     present = low > small
