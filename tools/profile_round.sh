@@ -17,22 +17,22 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 NW="--steps 5 --warmup 2 --no-cpu-baseline --no-pipelined --no-configs --no-ocr --pages 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_nw" -o nw -- python3 "$REPO/bench.py" $NW > "$OUT/kt_nw.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_nw" -o nw -- python3 "$REPO/bench.py" $NW > "$OUT/kt_nw.log" 2>&1
 echo "nw kernel trace done"
 for w in "1920 split" "1920 f32" "5760 split"; do
   set -- $w
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_$1_$2" -o ocr -- python3 "$REPO/tools/ocr_only.py" $1 $2 > "$OUT/kt_ocr_$1_$2.log" 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_$1_$2" -o ocr -- python3 "$REPO/tools/ocr_only.py" $1 $2 > "$OUT/kt_ocr_$1_$2.log" 2>&1
   echo "ocr $1 $2 kernel trace done"
 done
 for mode in two one; do
   flag=""; [ $mode = one ] && flag="--one-pass"
   for ctr in WRITE_SIZE FETCH_SIZE; do
-    rocprofv3 --pmc $ctr --output-format csv -d "$OUT/${mode}_$ctr" -o nw -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined --no-configs --no-ocr --pages 0 $flag > "$OUT/${mode}_$ctr.log" 2>&1
+    timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/${mode}_$ctr" -o nw -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined --no-configs --no-ocr --pages 0 $flag > "$OUT/${mode}_$ctr.log" 2>&1
     echo "$mode $ctr done"
   done
 done
 for prec in split f32; do
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_$prec" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 $prec > "$OUT/ocr_pmc_$prec.log" 2>&1
+  timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_$prec" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 $prec > "$OUT/ocr_pmc_$prec.log" 2>&1
   echo "ocr pmc $prec done"
 done
 echo "now run: python3 tools/profile_summarise.py $ROUND gpurun_out/prof_$ROUND"
