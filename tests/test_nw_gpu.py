@@ -123,6 +123,29 @@ def test_ragged_batch_vs_oracle_full_pointer_matrix(tsc, two_phase):
             assert np.array_equal(got_ptr, want_ptr[1:, 1:]), (k, n, m, prm[k])
 
 
+def test_two_phase_strip_borders_and_start_probe(tsc):
+    """The two-phase traceback takes a step out of a strip with its next state pending and reads the
+    state off the strip above; a walk that STARTS in a strip's first row (n = 256 s + 1) probes the
+    strip above before its first step.  Every scoring system (gap-heavy ones make the path leave
+    strips in states 1 and 2 as well), OCR strings of 1, 2 and a few tokens, and long ones."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(11)
+    t_list, o_list, prm = [], [], []
+    shapes = [(257, 300), (513, 1), (257, 1), (513, 2), (769, 640), (257, 64), (512, 300), (258, 257),
+              (513, 513), (257, 5), (1025, 70), (1281, 1300), (2049, 2049), (256, 256), (1024, 3)]
+    for k, (n, m) in enumerate(shapes):
+        for sc in SYSTEMS:
+            t, o = _random_problem(rng, n, m, [2, 3, 27][k % 3], k % 2 == 1)
+            t_list.append(t); o_list.append(o); prm.append(sc)
+    batch = tsc.NWBatch(t_list, o_list, prm, two_phase=True)
+    batch.run()
+    torch.cuda.synchronize()
+    res = batch.results()
+    for k in range(len(t_list)):
+        want = nw_oracle.align_ids(t_list[k], o_list[k], prm[k])
+        assert res[k].tolist() == want.tolist(), (len(t_list[k]), len(o_list[k]), prm[k])
+
+
 @pytest.mark.parametrize("wide", [True, False], ids=["wide", "narrow"])
 def test_one_pass_launch_shapes(tsc, wide):
     """The one-pass fill spread over several workgroups per problem (hand-off rows in HBM, the
