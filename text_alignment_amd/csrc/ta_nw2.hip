@@ -547,11 +547,10 @@ __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], in
                 dsave = d_next;
                 cap[q] = make_int2(V[R - 1], D[R - 1]);
             }
-            // lane 63's bottom-row outputs of the four steps; every other lane's address lies outside
-            // the workgroup's LDS and its write is dropped (no branch)
-            const int at = (lane == 63) ? g * SPG - k0 : 0x0FFFFF00;       // x 8 bytes: beyond any LDS allocation
+            if (lane == 63) {                               // its bottom-row outputs of the four steps
 #pragma unroll
-            for (int q = 0; q < SPG; ++q) hvb[at + q] = cap[q];
+                for (int q = 0; q < SPG; ++q) hvb[g * SPG - k0 + q] = cap[q];
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < SPG; ++q) {
