@@ -294,6 +294,7 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
             if (g > 0 && (g % kCkGroups) == 0) checkpoint_now(g);
         };
         auto group_edge = [&](int g) {
+            if (ABL & 32) { publish(g); return; }          // timing only: what the edge groups cost
             checkpoint(g);
             int oc[SPG];
             int2 hd[SPG];

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing-only builds of libta_hip.so with parts of nw_score_kernel's steady loop removed
-# (TA_P1_ABLATE bits: 1 hand-off row writes, 2 profile reads, 4 checkpoint + plane stores,
-# 8 progress wait / publish, 16 DPP shifts).  Results of these builds are WRONG by construction;
+# (TA_P1_ABLATE bits: 1 bottom-row writes, 2 profile reads, 4 checkpoint stores,
+# 8 progress wait / publish, 16 DPP shifts, 32 edge groups).  Results of these builds are WRONG by construction;
 # only the fill time is read.  Builds in the container:  tools/p1_ablate.sh build
 # Runs on the GPU box:                                   tools/p1_ablate.sh run
 set -eo pipefail
