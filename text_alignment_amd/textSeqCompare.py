@@ -100,10 +100,11 @@ class NWBatch(object):
         # its fill is half as expensive per cell, its traceback costs ~60 us more per 256-row strip
         # of the tallest problem (one wave walks the strips one after the other), and its workspace
         # is 8x smaller.  Measured break-even on MI355X (tools/nw_breakeven.py): total cells
-        # ~ 2.5e8 x strips, i.e. once the batch fills the chip about twice.
+        # ~ 1.8e8 x strips, i.e. once the batch fills the chip about twice (re-measured after the
+        # round-2 changes of both paths: tools/nw_breakeven.py).
         if two_phase is None:
             nstrips = (self.max_n + 255) // 256
-            two_phase = (self.cells > 2.5e8 * nstrips) or (self.cells > 64e9) or \
+            two_phase = (self.cells > 1.8e8 * nstrips) or (self.cells > 64e9) or \
                 (self.max_m > _native.lib.ta_nw_max_m())       # wider than the one-pass kernel's LDS row
         self.two_phase = bool(two_phase)
         # one-pass launch shape: None = library default (a problem is spread over several
