@@ -114,7 +114,8 @@ int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
 /* What phase 1 of ta_nw2_batch would launch for a batch whose tallest / widest problem is
  * max_n x max_m under `flags` (the hints above): out[0] = 1 compare-select cell, 2 score profile
  * in LDS; out[1] = waves per workgroup; out[2] = dynamic LDS bytes per workgroup; out[3] = 1 if the
- * single-gap-open form of the cell is used.  Pure host function (no GPU call). */
+ * single-gap-open form of the cell is used.  For a batch large enough to fill the chip (the launch
+ * also weighs the number of problems when it picks out[1]).  Pure host function (no GPU call). */
 int ta_nw2_phase1_plan(int32_t max_n, int32_t max_m, uint32_t flags, int32_t* out);
 
 /*

@@ -830,8 +830,10 @@ static hipError_t launch_score_w(const NwArgs& a, size_t lds, bool profile, bool
 }
 
 // Phase-1 launch shape.  Waves per workgroup W <= strips of the tallest problem; with the score
-// profile the LDS per workgroup is W x apad x 256 B + the codes, so W is the one that keeps the most
-// waves resident per CU.
+// profile the LDS per workgroup is W x apad x 256 B + the codes.  W is chosen by a small model fitted
+// to measurements (tools/p1_time.py on 2048 x 1024^2, 1024 / 2048 x 2048^2, 4096 x 4096^2,
+// 512 x 8192^2: it picks the fastest W in each): score = min(resident waves per CU, 12)
+// x (share of a workgroup's time that is not start-up ramp) x (share of the chip the batch fills).
 // What workgroups that share a CU can hold together.  One workgroup may be given 160 KiB, but measured on
 // MI355X (nw_score_kernel with its LDS request padded, tools/p1_time.py with TA_NW2_LDS_PAD): three
 // workgroups of 41.3 KiB and two of 53.3 KiB run side by side, two of 63.3 KiB do not -- the limit for
@@ -839,7 +841,7 @@ static hipError_t launch_score_w(const NwArgs& a, size_t lds, bool profile, bool
 constexpr size_t kLdsShared = 124 * 1024;
 struct P1Plan { int mode, w, apad; size_t lds; bool samego, codes8; };
 
-static P1Plan plan_phase1(int max_n, int max_m, uint32_t flags) {
+static P1Plan plan_phase1(int max_n, int max_m, uint32_t flags, int nprob = 1 << 20) {
     P1Plan pl{};
     const int nstrips = PtrLayout<4>::nstrips(max_n);
     const int wmax = nstrips >= 8 ? 8 : nstrips >= 4 ? 4 : nstrips >= 2 ? 2 : 1;
@@ -853,13 +855,23 @@ static P1Plan plan_phase1(int max_n, int max_m, uint32_t flags) {
     if (profile) {
         pl.apad = alphabet + 1;
         int best_w = 0, best_res = 0;
+        double best_score = 0.0;
+        const int ngroups = PtrLayout<4>::ngroups(max_m);
         for (int cand : {4, 8, 2, 1}) {            // order of preference among equals (measured: 4 >= 8 > 2)
             if (cand > wmax) continue;
             const size_t need = P1Lds(max_m, 2, cand * pl.apad * 256).total;
             if (need > 160 * 1024) continue;
-            // resident waves per CU: whole workgroups, within the LDS and within 5 waves per SIMD (VGPRs)
+            // resident waves per CU: whole workgroups, within the LDS and within 5 waves per SIMD (VGPRs);
+            // beyond three per SIMD the kernel gains nothing (it is bound by VALU issue from there on)
             const int res = (int)std::min<size_t>(kLdsShared / need, 20 / cand) * cand;
-            if (res > best_res) { best_res = res; best_w = cand; }
+            // the waves of a workgroup start 25 groups apart: with few passes over the strips that
+            // ramp is a visible share of a workgroup's time (W = 8 on 8 strips of 2048 columns: 25 %)
+            const int passes = (nstrips + cand - 1) / cand;
+            const double busy = (double)passes * ngroups / ((double)passes * ngroups + 25.0 * (cand - 1));
+            // and the batch has to fill the chip: nprob x W waves for 256 CUs x 12
+            const double fill = std::min(1.0, (double)nprob * cand / (256.0 * 12.0));
+            const double score = std::min(res, 12) * busy * fill;
+            if (score > best_score + 1e-9) { best_score = score; best_res = res; best_w = cand; }
         }
         // a profile that leaves fewer than 8 waves on a CU is not worth its LDS
         if (best_w == 0 || best_res < 8) profile = false;
@@ -885,7 +897,7 @@ extern "C" int ta_nw2_phase1_plan(int32_t max_n, int32_t max_m, uint32_t flags, 
 }
 
 static hipError_t launch_score(NwArgs a, int max_n, int max_m, uint32_t flags, hipStream_t st) {
-    const P1Plan pl = plan_phase1(max_n, max_m, flags);
+    const P1Plan pl = plan_phase1(max_n, max_m, flags, a.nprob);
     if (pl.lds > 160 * 1024) return hipErrorInvalidValue;
     a.apad = pl.apad;
     switch (pl.w) {
