@@ -852,14 +852,14 @@ static P1Plan plan_phase1(int max_n, int max_m, uint32_t flags, int nprob = 1 <<
     const char* env = getenv("TA_NW2_PHASE1");                  // "compare": A/B timing and tests only
     if (env && env[0] == 'c') profile = false;
     pl.w = wmax;
-    if (profile) {
-        pl.apad = alphabet + 1;
+    const int ngroups = PtrLayout<4>::ngroups(max_m);
+    // best W for a workgroup that needs lds(W) bytes; returns the resident waves of the choice
+    auto choose = [&](auto lds_of, int w_least, int& w_out) -> int {
         int best_w = 0, best_res = 0;
         double best_score = 0.0;
-        const int ngroups = PtrLayout<4>::ngroups(max_m);
         for (int cand : {4, 8, 2, 1}) {            // order of preference among equals (measured: 4 >= 8 > 2)
-            if (cand > wmax) continue;
-            const size_t need = P1Lds(max_m, 2, cand * pl.apad * 256).total;
+            if (cand > wmax || cand < w_least) continue;
+            const size_t need = lds_of(cand);
             if (need > 160 * 1024) continue;
             // resident waves per CU: whole workgroups, within the LDS and within 5 waves per SIMD (VGPRs);
             // beyond three per SIMD the kernel gains nothing (it is bound by VALU issue from there on)
@@ -873,9 +873,23 @@ static P1Plan plan_phase1(int max_n, int max_m, uint32_t flags, int nprob = 1 <<
             const double score = std::min(res, 12) * busy * fill;
             if (score > best_score + 1e-9) { best_score = score; best_res = res; best_w = cand; }
         }
+        w_out = best_w;
+        return best_res;
+    };
+    if (profile) {
+        pl.apad = alphabet + 1;
+        int w = 0;
+        const int res = choose([&](int cand) { return P1Lds(max_m, 2, cand * pl.apad * 256).total; }, 1, w);
         // a profile that leaves fewer than 8 waves on a CU is not worth its LDS
-        if (best_w == 0 || best_res < 8) profile = false;
-        else pl.w = best_w;
+        if (w == 0 || res < 8) profile = false;
+        else pl.w = w;
+    }
+    if (!profile) {
+        int w = 0;
+        // compare-select cell: measured 4 >= 8 > 2 at 4096 x 4096^2 (14.5 / 14.9 / 16.9 ms); narrower
+        // workgroups were not fitted for this mode
+        choose([&](int) { return P1Lds(max_m, pl.codes8 ? 1 : 2).total; }, std::min(4, wmax), w);
+        if (w > 0) pl.w = w;
     }
     if (const char* ew = getenv("TA_NW2_W")) {                  // tests / tuning only
         const int v = atoi(ew);
