@@ -36,4 +36,4 @@ for rep, s in enumerate(snaps):
                 print("run", rep, "problem", p, "differs:", len(d), "ints; rows", [int(v) for v in strips], "fields", [int(v) for v in planes],
                       "cols", cols.min(), "..", cols.max(), "first", d[:8].tolist(),
                       "got", [int(s[p][tuple(x)]) for x in d[:4]], "want", [int(ref[p % 8][tuple(x)]) for x in d[:4]], flush=True)
-    print("run", rep, "problems with wrong planes:", bad, flush=True)
+    print("run", rep, "problems with differing bottom rows:", bad, flush=True)
