@@ -196,7 +196,13 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
     const int nstrips = ws.nstrips, ngroups = ws.ngroups;
     const int prev_wave = (wave + W - 1) % W;
     const int g_lo = (63 + SPG - 1) / SPG;
-    const int g_hi = (steady_ok && ws.total < kWsRange) ? m / SPG : 0;
+    // The steady loop runs from the group in which the last lane has started to the END of the strip:
+    // a lane that has passed its last column goes on over pad columns (the profile's all-mismatch
+    // entry), and what it computes there only ever reaches lanes that are past their last column
+    // too (same column, one step later), bottom-row entries beyond column m (room for 8; never read
+    // for a column > m) and checkpoint words of finished lanes (phase 2 masks them).  Only the 16
+    // start-up groups need the predicated edge body (0.35 ms of the 0.7 ms the edges took).
+    const int g_hi = (steady_ok && ws.total < kWsRange) ? ngroups : 0;
     int pass = 0;
 
     for (int s = wave; s < nstrips; s += W, ++pass) {
@@ -471,6 +477,11 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
             if (g < ngroups) {
                 if ((g % CHK) == 0) wait_span(g);
                 load_group(g);
+            } else if (W > 1) {                              // the strip ended in the block loop: all of it is out
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 63)
+                    __hip_atomic_store(&prog[wave], pass * ngroups + ngroups, __ATOMIC_RELEASE,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         for (; g < ngroups; ++g) group_edge(g);
