@@ -532,7 +532,10 @@ __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], in
         else return cell_hw(kr, d_ul, x_u, y_l, t, o, d, x, y);
     };
     load_group(g0);
-    const int gs_lo = (63 + SPG - 1) / SPG, gs_hi = m / SPG;     // steady groups [gs_lo, gs_hi)
+    // unpredicated groups: from the one in which the last lane has started on (a lane past its last column
+    // goes on over pad codes; what it computes reaches only lanes that are past theirs, pointer bytes
+    // and captured bottom-row entries of columns > m, none of which is ever read -- as in phase 1)
+    const int gs_lo = (63 + SPG - 1) / SPG, gs_hi = 0x7FFFFFFF;
     for (int g = g0; g <= g_top; ++g) {
         int oc[SPG];
         int2 hd[SPG];
