@@ -142,7 +142,7 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
     kr.cmis = prm[1] - prm[4] - prm[5]; kr.cmat = prm[0] - prm[4] - prm[5];
     kr.gox = prm[2]; kr.goy = prm[3];
     // state of a problem is kept in carried form (XG, YG) iff its gap opens are non-positive; phase 2
-    // applies the same predicate when it reads checkpoints and planes
+    // applies the same predicate when it reads checkpoints and bottom rows
     const bool carried = opens_nonpositive(kr.gox, kr.goy);
     const int xadj = carried ? kr.gox : 0, yadj = carried ? kr.goy : 0;
     const int apad = PROFILE ? a.apad : 0;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
         }
         int dsave = raw_of(bnd_D_col0(c, row0));
         // retire the transcript-code loads here: otherwise hipcc parks their s_waitcnt vmcnt(0) at
-        // the first use INSIDE the group loop, where it also drains every checkpoint / plane store
+        // the first use INSIDE the group loop, where it also drains every checkpoint / row store
         // of the previous group
 #pragma unroll
         for (int r = 0; r < R; ++r) asm volatile("" :: "v"(tc[r]));
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
                 __builtin_amdgcn_s_sleep(2);
             }
         };
-        // Progress words say "the hand-off entries of these groups are in L2": the stores must have
+        // Progress words say "the bottom-row entries of these groups are in L2": the stores must have
         // COMPLETED, not merely been issued, before the word is written (a workgroup-scope release
         // only orders the LDS side on this target: it emits no vmcnt wait).
         auto publish = [&](int g) {
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
             // groups with two input buffers (A / B): the LDS prefetch of the next group lands in the
             // other buffer, no register copies at the back-edge, and everything that depends on the
             // group index -- progress wait and publish (once per block), checkpoint (every fourth
-            // block), row / code / plane addresses (running pointers) -- stays out of the groups.
+            // block), row / code addresses (running pointers) -- stays out of the groups.
             // MODE 2 reads the OCR codes one group further ahead (X / Y) and turns them into
             // profile entries when the group's other inputs are fetched. ----
             static_assert(CHK == 4 && SPG == 4, "the block loop is written for 4 groups of 4 steps");
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
     CellRegs kr;
     kr.cmis = c.cmismatch; kr.cmat = c.cmatch; kr.gox6 = c.gox6; kr.goy6 = c.goy6;
     kr.clean = ~kTagMask;
-    // phase 1 leaves V~ + gox / H~ + goy in its checkpoints and planes when the gap opens are
+    // phase 1 leaves V~ + gox / H~ + goy in its checkpoints and bottom rows when the gap opens are
     // non-positive (carried cell), and the chunks are then re-filled in that form too
     const bool carried = opens_nonpositive(c.gox, c.goy);
     const int xadj = carried ? c.gox : 0, yadj = carried ? c.goy : 0;
