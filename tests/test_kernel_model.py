@@ -87,7 +87,7 @@ def test_sim_matches_oracle_synth(sim, R):
         assert got.tolist() == want.tolist(), (R, n, m, seed)
 
 
-@pytest.mark.parametrize("kcg,gspan", [(1, 1), (2, 3), (4, 8), (32, 96)])
+@pytest.mark.parametrize("kcg,gspan", [(1, 1), (2, 3), (4, 8), (12, 12), (16, 16), (32, 96)])
 def test_two_phase_sim_matches_oracle(sim, kcg, gspan):
     """Checkpointed score-only fill + windowed tagged re-fill (the two-phase aligner's data flow):
     tiny checkpoint periods and spans force many restarts, multi-window strips and halo steps."""

@@ -30,7 +30,16 @@
 
 namespace ta {
 
-constexpr int kCkGroups = 16;                 // state checkpoint every 16 groups (64 skewed steps)
+#ifndef TA_CK_GROUPS
+#define TA_CK_GROUPS 16
+#endif
+// State checkpoint every kCkGroups groups (a multiple of 4: the steady loop runs in blocks of 4 groups).
+// The interval is also phase 2's chunk, whose pointer bytes (1 KiB per group) are what limits the
+// number of traceback waves on a CU (measured by padding its LDS: 8 waves per CU 3.5 ms, 6: 4.8,
+// 5: 5.6, 2: 10.7).  12 groups (10 waves per CU) were tried: 4.1 ms -- 28 % more chunks to set up and
+// walk into, and 16 problems per CU do not divide into rounds of ten any better than into two of eight.
+constexpr int kCkGroups = TA_CK_GROUPS;
+static_assert(kCkGroups % 4 == 0 && kCkGroups >= 4, "whole blocks of four groups");
 constexpr int kStateInts = 10;                // D[4], H[4], V[3], dsave
 constexpr int kWsRange = 0x7ffff000;          // record count of a workspace buffer descriptor: every real offset is below
 
@@ -461,14 +470,16 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
                 }
                 g += CHK;
             };
-            // Checkpoint intervals whole (g is a multiple of kCkGroups here: g_lo = 16), so that the ten
+            // Checkpoint intervals whole, so that the ten
             // checkpoint stores sit in straight-line code: behind a branch hipcc's s_waitcnt for the
             // next loads can no longer count them and waits for all of them (a full store round trip
             // every 16 groups).
-            static_assert(kCkGroups == 4 * CHK && ((63 + SPG - 1) / SPG) % kCkGroups == 0, "interval = 4 blocks, aligned");
+            static_assert(kCkGroups % CHK == 0, "interval = whole blocks");
+            while (g < g_end && (g % kCkGroups) != 0) block();       // up to the first interval border (g_lo = 16)
             while (g + kCkGroups <= g_end) {
                 if (!(ABL & 4)) checkpoint_now(g);
-                block(); block(); block(); block();
+#pragma unroll
+                for (int b = 0; b < kCkGroups / CHK; ++b) block();
             }
             while (g < g_end) {
                 if (!(ABL & 4)) checkpoint(g);
@@ -727,10 +738,11 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
                 H[rr] = bnd_H_col0(c, i) + yadj6;
             }
             dsave = bnd_D_col0(c, row0);
-            static_assert(kChunk * SPG >= 64, "a lane must have started before the first checkpoint: its "
-                                               "column-0 values carry tags only in the boundary form");
+            // a lane that has not started by the chunk's first step (lane >= k0: first chunks of a strip
+            // when the interval is shorter than 64 steps) keeps the boundary values above: the scores are
+            // the same, and only this form carries the column-0 tags the lane's first cells point to
             static_assert(kStateInts == 2 * R + 2, "state = D[R], H[R], V[R-1], dsave");
-            if (g0 > 0) {
+            if (g0 > 0 && lane < k0) {
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) { D[rr] = enc_of(in_st[rr]); H[rr] = enc_of(in_st[R + rr]); }
                 V[R - 1] = enc_of(in_st[2 * R]);
