@@ -863,7 +863,8 @@ static hipError_t launch_score_w(const NwArgs& a, size_t lds, bool profile, bool
 // What workgroups that share a CU can hold together.  One workgroup may be given 160 KiB, but measured on
 // MI355X (nw_score_kernel with its LDS request padded, tools/p1_time.py with TA_NW2_LDS_PAD): three
 // workgroups of 41.3 KiB and two of 53.3 KiB run side by side, two of 63.3 KiB do not -- the limit for
-// co-residency lies between 124 and 126 KiB.
+// co-residency lies between 124 and 126 KiB.  (The single-wave workgroups of nw_trace2_kernel, 19.4 KiB
+// static each, do run eight to a CU; the figure below is for this kernel's launch shapes.)
 constexpr size_t kLdsShared = 124 * 1024;
 struct P1Plan { int mode, w, apad; size_t lds; bool samego, codes8; };
 
