@@ -160,10 +160,11 @@ __device__ __forceinline__ unsigned pack4(unsigned b0, unsigned b1, unsigned b2,
 template <bool TOP_PENDING = false>
 __device__ __forceinline__ int walk_window_vec(const uint4* win, int gw_lo, int klow, int x_lo,
                                                int& x, int& y, int& st, uint8_t* opsbuf, int max_ops,
-                                               int lane) {
+                                               int lane, long long* iterations = nullptr) {
     const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
     int cnt = 0;
     while (true) {
+        if (iterations) ++*iterations;
         const int up = (st != 2), left = (st != 1);
         const int xi = x - lane * up, yi = y - lane * left;
         const int li = (xi - 1 - x_lo) >> 2;

@@ -651,6 +651,7 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
 #if TA_P2_PROFILE
     long long pc_setup = 0, pc_fill = 0, pc_walk = 0, pc_chunks = 0, pc_t = __builtin_readcyclecounter(), pc_groups = 0;
     const long long pc_start = pc_t;
+    long long pc_iters = 0;
 #define PC_LAP(acc) { const long long now_ = __builtin_readcyclecounter(); acc += now_ - pc_t; pc_t = now_; }
 #else
 #define PC_LAP(acc)
@@ -784,7 +785,11 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
             if (ABL2 & 4) { x = s * L::SR; y = max(y - 300, 1); }
             bool again = !(ABL2 & 4);
             while (again) {
+#if TA_P2_PROFILE
+                const int cnt = walk_window_vec<true>(win, g0, kvalid, s * L::SR, x, y, st, opsbuf, kTb2Ops, lane, &pc_iters);
+#else
                 const int cnt = walk_window_vec<true>(win, g0, kvalid, s * L::SR, x, y, st, opsbuf, kTb2Ops, lane);
+#endif
                 __syncthreads();
                 for (int i = lane; i < cnt; i += 64) ops[cap - 1 - (len + i)] = opsbuf[i];
                 len += cnt;
@@ -814,7 +819,7 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
     if (lane == 0) {                                   // row 0 of the workspace is phase 1's: free by now
         long long* out = reinterpret_cast<long long*>(ws_p + ws.row(0));
         out[0] = pc_setup; out[1] = pc_fill; out[2] = pc_walk; out[3] = pc_chunks; out[4] = pc_groups; out[5] = len;
-        out[6] = pc_start; out[7] = __builtin_readcyclecounter();
+        out[6] = pc_iters; out[7] = __builtin_readcyclecounter() - pc_start;
     }
 #endif
 }

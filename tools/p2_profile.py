@@ -33,5 +33,6 @@ print("traceback %.3f ms; per problem: %.0f chunks, %.0f groups re-filled (%.1f 
 print("counter ticks per problem (s_memtime): set-up %.0f (%.1f %%), re-fill %.0f (%.1f %%), walk %.0f (%.1f %%)"
       % (setup.mean(), 100 * setup.sum() / tot.sum(), fill.mean(), 100 * fill.sum() / tot.sum(),
          walk.mean(), 100 * walk.sum() / tot.sum()))
+print("walk loop iterations per problem %.0f (%.1f per chunk, %.1f ops each)" % (c[:, 6].mean(), c[:, 6].sum() / chunks.sum(), ln.sum() / max(c[:, 6].sum(), 1)))
 print("per chunk: set-up %.0f, re-fill %.0f (%.1f per group), walk %.0f ticks"
       % (setup.sum() / chunks.sum(), fill.sum() / chunks.sum(), fill.sum() / groups.sum(), walk.sum() / chunks.sum()))
