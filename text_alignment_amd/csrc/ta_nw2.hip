@@ -512,7 +512,10 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
 constexpr int kChunk = kCkGroups;                 // groups per chunk
 constexpr int kChunkGroups = kChunk + 1;          // + the group holding the next chunk's two halo steps
 constexpr int kChunkSteps = kChunkGroups * 4;
-constexpr int kTb2Ops = 512;
+#ifndef TA_TB2_OPS
+#define TA_TB2_OPS 512
+#endif
+constexpr int kTb2Ops = TA_TB2_OPS;
 
 #ifndef TA_P2_PROFILE
 #define TA_P2_PROFILE 0     // cycle counters per problem into row 0 of its workspace (tools/p2_profile.py)
