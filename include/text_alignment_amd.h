@@ -117,6 +117,8 @@ int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
  * single-gap-open form of the cell is used.  For a batch large enough to fill the chip (the launch
  * also weighs the number of problems when it picks out[1]).  Pure host function (no GPU call). */
 int ta_nw2_phase1_plan(int32_t max_n, int32_t max_m, uint32_t flags, int32_t* out);
+/* the same for a batch of nprob problems: exactly what ta_nw2_batch will launch */
+int ta_nw2_phase1_plan_batch(int32_t max_n, int32_t max_m, int32_t nprob, uint32_t flags, int32_t* out);
 
 /*
  * ta_nw_general: the same aligner for scoring systems the integer kernel does not take --

@@ -83,6 +83,29 @@ def test_argument_errors_without_gpu(native):
     assert lib.ta_lstm_packed_weight_floats(0) == 2 * 7 * 4 * 38 * 64
 
 
+def test_phase1_plan_picks_the_measured_launch_shapes(native):
+    """ta_nw2_phase1_plan is a pure host function: the shapes below are the ones whose workgroup widths
+    were timed on MI355X (tools/p1_time.py) -- the model must keep choosing the fastest."""
+    import ctypes
+    from text_alignment_amd import _native
+    out = (ctypes.c_int32 * 8)()
+    same = _native.TA_NW_OPENS_SAME
+
+    def plan(n, m, nprob, alphabet):
+        assert native.lib.ta_nw2_phase1_plan_batch(n, m, nprob, (alphabet << _native.TA_NW_ALPHABET_SHIFT) | same, out) == 0
+        return {"mode": out[0], "waves": out[1], "lds": out[2], "samego": out[3]}
+    assert plan(4096, 4096, 4096, 31) == {"mode": 2, "waves": 4, "lds": 41312, "samego": 1}
+    assert plan(8192, 8192, 512, 27)["waves"] == 8     # 32 strips, a batch that needs wide workgroups to fill the chip: 6.3 ms at 8, 7.2 at 4, 13.7 at 2
+    assert plan(2048, 2048, 2048, 27)["waves"] == 2    # 1.78 ms at 2, 1.83 at 4, 2.07 at 8
+    assert plan(2048, 2048, 1024, 27)["waves"] == 4    # half the batch: 0.99 ms at 4, 1.06 at 2, 1.10 at 8
+    assert plan(1024, 1024, 2048, 27)["waves"] == 2    # 4 strips: 0.53 ms at 2, 0.59 at 4, 0.58 at 1
+    assert plan(4096, 4096, 4096, 0)["mode"] == 1      # no alphabet hint: compare-select cell
+    assert plan(4096, 4096, 4096, 0)["waves"] == 4     # 14.5 ms at 4, 14.9 at 8, 16.9 at 2
+    assert plan(300, 60000, 64, 27)["mode"] == 1       # a profile that does not fit beside 60000 codes
+    assert native.lib.ta_nw2_phase1_plan(4096, 4096, (31 << _native.TA_NW_ALPHABET_SHIFT) | same, out) == 0 and out[1] == 4
+    assert native.lib.ta_nw2_phase1_plan_batch(-1, 5, 1, 0, out) != 0
+
+
 def test_scoring_parse_and_errors():
     from text_alignment_amd import textSeqCompare as tsc
     assert tsc.default_sys == [8, -4, -7, -7, -3, 0] and tsc.gap_extend == -1

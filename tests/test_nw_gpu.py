@@ -450,7 +450,7 @@ def _phase1_plan(batch):
     from text_alignment_amd import _native
     out = (ctypes.c_int32 * 4)()
     flags = (_native.TA_NW_CODES8 if batch.codes8 else 0) | batch.hints
-    assert _native.lib.ta_nw2_phase1_plan(batch.max_n, batch.max_m, flags, out) == 0
+    assert _native.lib.ta_nw2_phase1_plan_batch(batch.max_n, batch.max_m, batch.nprob, flags, out) == 0
     return {"mode": out[0], "waves": out[1], "lds": out[2], "samego": out[3]}
 
 

@@ -938,11 +938,15 @@ static P1Plan plan_phase1(int max_n, int max_m, uint32_t flags, int nprob = 1 <<
     return pl;
 }
 
-extern "C" int ta_nw2_phase1_plan(int32_t max_n, int32_t max_m, uint32_t flags, int32_t* out) {
-    if (!out || max_n < 0 || max_m < 0) return ta_fail(TA_EINVAL, "bad argument");
-    const P1Plan pl = plan_phase1(max_n, max_m, flags);
+extern "C" int ta_nw2_phase1_plan_batch(int32_t max_n, int32_t max_m, int32_t nprob, uint32_t flags, int32_t* out) {
+    if (!out || max_n < 0 || max_m < 0 || nprob < 0) return ta_fail(TA_EINVAL, "bad argument");
+    const P1Plan pl = plan_phase1(max_n, max_m, flags, nprob);
     out[0] = pl.mode; out[1] = pl.w; out[2] = (int32_t)pl.lds; out[3] = pl.samego ? 1 : 0;
     return TA_OK;
+}
+
+extern "C" int ta_nw2_phase1_plan(int32_t max_n, int32_t max_m, uint32_t flags, int32_t* out) {
+    return ta_nw2_phase1_plan_batch(max_n, max_m, 1 << 20, flags, out);
 }
 
 static hipError_t launch_score(NwArgs a, int max_n, int max_m, uint32_t flags, hipStream_t st) {
