@@ -36,6 +36,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 F32_MFMA_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA peak (spec)
 BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (spec)
 DEFAULT_SYS = [8, -4, -7, -7, -3, 0]
+P1_VALU_PER_BLOCK = 382        # nw_score_kernel, score profile + one gap open: VALU instructions per 64 cells of a lane
+P1_NS_PER_VALU = 1.72          # measured issue interval of that instruction mix (profiles/r02_valu_issue_rates.txt)
 
 
 def _profile_file(*names):
@@ -78,7 +80,7 @@ def measured_mfma_busy(kernel):
     return None, None
 
 
-def make_nw_batch(tsc, nprob, n, m, seed0, distinct=32, two_phase=False):
+def make_nw_batch(tsc, nprob, n, m, seed0, distinct=256, two_phase=False):
     from tools.synth import synth_pair_ids      # seeded input generator shared with the tests
     uniq = [synth_pair_ids(n, m, seed0 + k) for k in range(min(nprob, distinct))]
     probs = [uniq[k % len(uniq)] for k in range(nprob)]
@@ -222,10 +224,13 @@ def bench_pipelined(tsc, args, first):
             "note": "two batches in flight, fill and traceback on separate streams"}
 
 
-def bench_ocr(args, rank, precision="split", nlines=None):
+def bench_ocr(args, rank, precision=None, nlines=None):
+    """K3 + K4 + K5 on synthetic lines; precision None = the recogniser's default mode (the mode the
+    page pipeline runs and tests/test_page_gpu.py compares with the oracle)."""
     from text_alignment_amd import ocr
     no = 96
     nlines = args.ocr_lines if nlines is None else nlines
+    precision = precision or ocr.DEFAULT_PRECISION
     rec = ocr.LineRecognizer(ocr.LineModel.random(7001, no=no), precision=precision)
     lines = synthetic_lines(nlines, 8000 + 7919 * rank)
     st = rec.prepare(lines)
@@ -246,27 +251,78 @@ def bench_ocr(args, rank, precision="split", nlines=None):
     lstm_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     out_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     dec_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
-    flops_lstm = tsteps * 238400.0                    # 2 dirs x 4 gates x 100 x 149 x 2
-    tf = flops_lstm / (lstm_ms * 1e-3) / 1e12
     f32 = precision == "f32"
-    busy, busy_src = measured_mfma_busy("lstm_seq_kernel") if nlines == 1920 and f32 else (None, None)
-    roof = {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-            "frac": tf / F32_MFMA_PEAK_TF, "traffic": None,
-            "kernel": "lstm_seq_kernel" if f32 else "lstm_seq_split_kernel",
-            "algorithmic_flops_per_timestep": 238400,
-            "peak_is": "f32-input MFMA, the rate exact-f32 arithmetic of this recurrence is bounded by"}
     if f32:
-        roof["mfma_pipe_busy_rocprof"], roof["mfma_pipe_busy_source"] = busy, busy_src
+        # exact f32 arithmetic of this recurrence is bounded by the f32-input MFMA rate; algorithmic
+        # flops per timestep: 2 dirs x 4 gates x 100 units x 149 inputs x 2
+        tf = tsteps * 238400.0 / (lstm_ms * 1e-3) / 1e12
+        busy, busy_src = measured_mfma_busy("lstm_seq_kernel") if nlines == 1920 else (None, None)
+        roof = {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": tf / F32_MFMA_PEAK_TF, "traffic": None, "kernel": "lstm_seq_kernel",
+                "flops": "algorithmic: 238400 per timestep (the kernel executes 14 % more on padded tiles)",
+                "peak_is": "f32-input MFMA (v_mfma_f32_16x16x4_f32), the instruction the kernel issues",
+                "mfma_pipe_busy_rocprof": busy, "mfma_pipe_busy_source": busy_src}
     else:
-        # what the matrix pipe executes in this mode: 4 products per k-step on 16x16x32 tiles over
-        # 160 padded inputs and 112 padded units, both directions: 2 x 7 x 80 MFMAs of 16384 flop per 16 lines
-        executed = tsteps / 16.0 * 2 * 7 * 80 * 16384.0
-        roof["executed_16bit_mfma"] = {"achieved": executed / (lstm_ms * 1e-3) / 1e12, "peak": BF16_MFMA_PEAK_TF,
-                                       "unit": "TFLOP/s", "frac": executed / (lstm_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF}
+        # what the 16-bit matrix pipe executes in this mode: 4 products per k-step on 16x16x32 tiles over
+        # 160 padded inputs and 112 padded units, both directions: 2 x 7 x 80 MFMAs of 16384 flop per 16
+        # lines and timestep -- priced against the pipe it runs on
+        tf = tsteps / 16.0 * 2 * 7 * 80 * 16384.0 / (lstm_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": tf, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": tf / BF16_MFMA_PEAK_TF, "traffic": None, "kernel": "lstm_seq_split_kernel",
+                "flops": "executed: 4 split products per k-step, 16-bit operands, padded tiles",
+                "peak_is": "dense bf16 / fp16 MFMA (v_mfma_f32_16x16x32_bf16 / _f16), the instructions the kernel issues"}
     return {"lines_per_s": nlines / dt, "timesteps_per_s": tsteps / dt, "lines": nlines,
-            "timesteps": tsteps, "classes": no,
+            "timesteps": tsteps, "classes": no, "precision": precision,
             "dtype": "f32" if f32 else "split 16-bit operands (W: bf16 + fp16, a: 3 x bf16 + fp16), f32 accumulate",
             "ms": {"lstm": lstm_ms, "output_softmax": out_ms, "decode": dec_ms}, "roofline": roof}
+
+
+def ocr_mode_agreement():
+    """Free-running agreement of both recogniser modes with oracle/ocr_ref_f64.py, as measured by
+    tools/ocr_mode_agreement.py on the GPU box and kept under profiles/ (read, not measured here)."""
+    name, path = _profile_file("r03_ocr_mode_agreement.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        keep = ("lines", "widths", "logit_err_median", "logit_err_p90", "logit_err_max", "lines_within_1e3",
+                "lines_decode_identical", "chars_ref", "chars_agree")
+        return {"source": "profiles/" + name, "vs": "oracle/ocr_ref_f64.py, free-running, spec model",
+                "by_model_and_mode": {k: {q: v[q] for q in keep} for k, v in d.items()}}
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
+def nw_roofline(batch, kname, fill_ms, tb_ms, traffic, traffic_src):
+    """The contract's roofline block for the dominant kernel (algorithmic bytes = 1 B per cell,
+    SURVEY.md 8d, over the kernel's mean launch duration against the 8 TB/s HBM peak) -- and, beside
+    it, what the numbers mean for THIS kernel: the step (fill + traceback, the metric as 8(d) times
+    it) against the same yardstick, the HBM traffic the counters actually see, and the unit that
+    binds the two-phase fill, VALU issue."""
+    cells = batch.cells
+    fill_rate = cells / (fill_ms * 1e-3)
+    step_ms = fill_ms + tb_ms
+    roof = {"bound": "hbm", "achieved": fill_rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": fill_rate / 1e9 / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": kname, "kernel_ms": fill_ms, "traceback_ms": tb_ms,
+            "traceback_kernel": "nw_trace2_kernel" if batch.two_phase else "nw_traceback_kernel",
+            "algorithmic_bytes_per_cell": 1,
+            "step_ms": step_ms, "step_frac": cells / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "step_is": "fill + traceback device time, the metric as SURVEY.md 8(d) defines it; frac is the "
+                       "dominant kernel alone"}
+    if traffic is not None:
+        roof["measured_hbm_GBps"] = traffic / (fill_ms * 1e-3) / 1e9
+        roof["measured_hbm_frac"] = roof["measured_hbm_GBps"] / HBM_PEAK_GBS
+    if batch.two_phase:
+        # the score kernel never writes the algorithmic byte (0.22 B/cell of checkpoints instead): HBM is a
+        # yardstick for it, VALU issue is what binds it.  Floor of its instruction mix: 382 VALU instructions
+        # per 64 cells of a lane at 1.72 ns per wave-instruction and SIMD (profiles/r02_valu_issue_rates.txt)
+        floor_ms = cells / 4096.0 * P1_VALU_PER_BLOCK * P1_NS_PER_VALU * 1e-6 / 1024.0
+        roof.update({"binding_unit": "valu-issue", "valu_issue_floor_ms": floor_ms,
+                     "valu_issue_frac": floor_ms / fill_ms,
+                     "valu_issue_source": "profiles/r02_valu_issue_rates.txt; %d VALU per 64 cells x 64 lanes at "
+                                          "%.2f ns per wave-instruction per SIMD" % (P1_VALU_PER_BLOCK, P1_NS_PER_VALU)})
+    return roof
 
 
 def nw_configs(tsc, torch):
@@ -429,7 +485,7 @@ def main():
         if rank == 0:
             heads = allrec[allrec[:, 1] == sharding.HEADER]
             boxes = int((allrec[:, 1] != sharding.HEADER).sum())
-            sharded = {"pages": job["total_pages"], "pages_per_gpu": args.pages, "rccl_ranks": world,
+            sharded = {"pages": job["total_pages"], "pages_per_gpu": args.pages, "ranks": world,
                        "backend": (args.backend if dist is not None else "none (single process)"),
                        "seconds": sh_dt, "pages_per_s": job["total_pages"] / sh_dt,
                        "lines_per_s": job["total_pages"] * 30 / sh_dt,
@@ -448,16 +504,22 @@ def main():
 
     ocr_res = None
     if not args.no_ocr:
-        ocr_res = bench_ocr(args, rank)
-        exact = bench_ocr(args, rank, precision="f32")
-        ocr_res["f32_mode"] = {"lines_per_s": exact["lines_per_s"], "ms": exact["ms"], "roofline": exact["roofline"],
-                               "note": "the same recurrence as an exact f32-input MFMA chain (precision='f32')"}
+        ocr_res = bench_ocr(args, rank)                      # the default mode: what pages run and tests compare
+        other = "split" if ocr_res["precision"] == "f32" else "f32"
+        alt = bench_ocr(args, rank, precision=other)
+        ocr_res["%s_mode" % other] = {
+            "lines_per_s": alt["lines_per_s"], "ms": alt["ms"], "roofline": alt["roofline"], "dtype": alt["dtype"],
+            "note": "opt-in: LineRecognizer(model, precision=%r); agreement of both modes with the float64 "
+                    "restatement under `agreement`" % other}
         if args.ocr_lines_large > args.ocr_lines:
             # 240 workgroups on 256 CUs leave the longest line group in charge of the time; with
             # several workgroups per CU (longest first) the same kernels fill the chip
             big = bench_ocr(args, rank, nlines=args.ocr_lines_large)
             ocr_res["large_batch"] = {"lines": big["lines"], "lines_per_s": big["lines_per_s"], "ms": big["ms"],
-                                      "mfma_frac": big["roofline"]["frac"]}
+                                      "roofline_frac": big["roofline"]["frac"]}
+        agree = ocr_mode_agreement()
+        if agree is not None:
+            ocr_res["agreement"] = agree
         if dist is not None:
             ocr_res["lines_per_s_all_gpus"] = reduce_sum([ocr_res["lines_per_s"]])[0]
 
@@ -494,12 +556,7 @@ def main():
                        "cells_per_step": cells_step, "parallelism": "problems sharded x%d, no data-path collective" % world,
                        "bit_exact_vs_oracle": ok, "problems_checked": len(res),
                        "distinct_problems": len(uniq)},
-            "roofline": {"bound": "hbm", "achieved": fill_rate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": fill_rate / 1e9 / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": kname, "kernel_ms": fill_ms, "traceback_ms": tb_ms,
-                         "traceback_kernel": "nw_trace2_kernel" if batch.two_phase else "nw_traceback_kernel",
-                         "algorithmic_bytes_per_cell": 1},
+            "roofline": nw_roofline(batch, kname, fill_ms, tb_ms, traffic, traffic_src),
         }
         if sharded is not None:
             out["pages_sharded"] = sharded

@@ -42,6 +42,12 @@ extern "C" {
  * them is still aligned correctly, through a slower path. */
 #define TA_NW_ALPHABET_SHIFT 8
 #define TA_NW_ALPHABET(a) (((uint32_t)(a) & 0xFFu) << TA_NW_ALPHABET_SHIFT)
+/* ta_nw2_batch launch-shape overrides (tests, A/B timing): phase 1 without the score profile even where
+ * the hints allow it; phase 1 with exactly w waves per workgroup (1, 2, 4 or 8; ignored when the tallest
+ * problem has fewer strips or the LDS does not hold it; 0 = the library's own choice). */
+#define TA_NW_NO_PROFILE 64u
+#define TA_NW_WAVES_SHIFT 16
+#define TA_NW_WAVES(w) (((uint32_t)(w) & 0xFu) << TA_NW_WAVES_SHIFT)
 
 int ta_version(void);
 const char* ta_last_error(void);

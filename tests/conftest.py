@@ -7,6 +7,8 @@ import pytest
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+if os.path.dirname(os.path.abspath(__file__)) not in sys.path:      # helper modules beside the tests (ocr_compare)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 

@@ -449,23 +449,23 @@ def _phase1_plan(batch):
     import ctypes
     from text_alignment_amd import _native
     out = (ctypes.c_int32 * 4)()
-    flags = (_native.TA_NW_CODES8 if batch.codes8 else 0) | batch.hints
+    flags = (_native.TA_NW_CODES8 if batch.codes8 else 0) | batch.phase1_flags()
     assert _native.lib.ta_nw2_phase1_plan_batch(batch.max_n, batch.max_m, batch.nprob, flags, out) == 0
     return {"mode": out[0], "waves": out[1], "lds": out[2], "samego": out[3]}
 
 
 @pytest.mark.parametrize("variant", ["profile", "compare"])
 @pytest.mark.parametrize("waves", [None, 1, 2, 4, 8])
-def test_phase1_variants_and_forced_hints(tsc, variant, waves, monkeypatch):
+def test_phase1_variants_and_forced_hints(tsc, variant, waves):
     """Phase 1 of the two-phase aligner in both forms (score profile in LDS / compare-select) and
     with every workgroup width, on a launch whose hints are FORCED on although some problems do not
     meet them (positive gap opens, gap_open_x != gap_open_y, substitution scores beyond a byte):
     those problems must still come out right, through the kernel's general path."""
     from oracle import nw_oracle
     from text_alignment_amd import _native
-    monkeypatch.setenv("TA_NW2_PHASE1", variant)
-    if waves is not None:
-        monkeypatch.setenv("TA_NW2_W", str(waves))
+    def shape(b):                                 # launch-shape overrides through the ABI's flag bits
+        b.no_profile = (variant == "compare")
+        b.waves = waves
     rng = np.random.default_rng(41)
     systems = SYSTEMS + [[120, -100, -7, -7, -3, 0], [8, -4, -7, -7, -3, 0], [6, -3, -5, -5, 0, -2],
                          [127, -128, -3, -3, 0, 0], [200, -4, -7, -7, -3, 0]]
@@ -478,6 +478,7 @@ def test_phase1_variants_and_forced_hints(tsc, variant, waves, monkeypatch):
     batch = tsc.NWBatch(t_list, o_list, prm, two_phase=True)
     assert batch.hints == 0                       # mixed systems: nothing may be assumed
     batch.hints = (31 << _native.TA_NW_ALPHABET_SHIFT) | _native.TA_NW_OPENS_SAME
+    shape(batch)
     plan = _phase1_plan(batch)
     assert plan["mode"] == (2 if variant == "profile" else 1)
     assert waves is None or plan["waves"] == waves
@@ -491,6 +492,7 @@ def test_phase1_variants_and_forced_hints(tsc, variant, waves, monkeypatch):
         same = tsc.NWBatch(t_list, o_list, system, two_phase=True)
         assert same.hints == (31 << _native.TA_NW_ALPHABET_SHIFT) | \
             (_native.TA_NW_OPENS_SAME if system[2] == system[3] else 0)
+        shape(same)
         plan = _phase1_plan(same)
         assert plan["mode"] == (2 if variant == "profile" else 1) and plan["samego"] == int(system[2] == system[3])
         same.run()

@@ -178,15 +178,40 @@ def test_continuation_equals_one_run_on_the_stable_model():
     assert float(np.abs(st["hout"].cpu().numpy() - whole).max()) < 1e-5
 
 
-def test_spec_model_long_lines_bounded():
-    """Chaotic spec model on long lines, free-running: the typical line is still at float32 noise
-    level; the worst line is only bounded loosely (tests/test_oracle_ocr.py shows a float32 numpy
-    run of the oracle's own loop drifting as far; the per-segment test above is the parity statement)."""
+@pytest.mark.parametrize("seed,no", [(7001, 96), (7002, 64)])
+@pytest.mark.parametrize("precision", [None, "split"])
+def test_spec_model_benchmark_widths_free_running(seed, no, precision):
+    """SURVEY section 8(d)'s model AS SPECIFIED at the benchmark's widths (800 .. 2000 columns),
+    FREE-RUNNING (the kernels' own state all the way), default mode (precision=None) and split mode:
+    what the north_star's "logits within 1e-3" looks like on a chaotic random-weight model.  Measured
+    on 96 lines per model (tools/ocr_mode_agreement.py, profiles/r03_ocr_mode_agreement.json): f32 median
+    1.3e-4 / 2.4e-5, 89 / 94 lines within 1e-3, worst line 1.5e-2; split median 3.5e-4 / 3.4e-5, 72 / 92
+    lines, worst 6.6e-2; decode identical on every line in both modes.  Asserted here on 16 lines:
+    the median and the share of lines within 1e-3 (per mode), a loose bound on the worst line, and that
+    every decode difference -- none so far -- is one the measured probability difference explains.
+    The per-segment test above is the parity statement that holds on EVERY line."""
+    import ocr_compare
     from oracle import ocr_ref_f64 as R
     from text_alignment_amd import ocr
-    errs = _check_lines(R, ocr, R.synthetic_model(7001, no=96), [500, 501, 800, 900, 1000, 1200],
-                        5e-2, check_decode=False)
-    assert float(np.median(errs)) < 2e-4
+    om = R.synthetic_model(seed, no=no)
+    rng = np.random.default_rng(seed + 5)
+    widths = [800, 2000] + [int(w) for w in rng.integers(800, 2001, size=14)]
+    lines = [R.synthetic_line(8300 + k, width=w) for k, w in enumerate(widths)]
+    kw = {} if precision is None else {"precision": precision}
+    rec = ocr.LineRecognizer(ocr.LineModel(om.fwd, om.rev, om.W2, om.codec), **kw)
+    c = ocr_compare.compare_lines(R, om, rec, lines)
+    errs = c["logit_err"]
+    within = sum(e < TOL for e in errs)
+    print("%s seed %d: logit error median %.3g, p90 %.3g, max %.3g; %d / %d lines within 1e-3; characters "
+          "%d / %d agree, %d lines with explained differences"
+          % (precision or ocr.DEFAULT_PRECISION, seed, float(np.median(errs)), float(np.quantile(errs, 0.9)),
+             max(errs), within, len(errs), c["chars_agree"], c["chars"], sum(1 for e in c["explained"] if e)))
+    f32 = (precision or ocr.DEFAULT_PRECISION) == "f32"
+    assert float(np.median(errs)) < (5e-4 if f32 else 1e-3)
+    assert within >= (12 if f32 else 9)
+    assert max(errs) < 0.2
+    assert not any(c["unexplained"]), c["unexplained"]
+    assert c["chars_agree"] >= 0.99 * c["chars"]
 
 
 def test_group_boundaries_and_order():

@@ -89,6 +89,8 @@ def _fake_process_batch(pages, transcripts, model, seq_align_params=None, indice
     from text_alignment_amd import alignToOCR as atocr, latinSyllabification as latsyl
     out = []
     for pg, tr in zip(pages, transcripts):
+        if pg.get("bad"):                      # e.g. page.prepared_lines' 'empty or constant text-line image'
+            raise ValueError("empty or constant text-line image")
         syls = [s for s in latsyl.syllabify_text(tr) if len(s) >= 1]
         boxes, idx = [], []
         for k, s in enumerate(syls):
@@ -106,19 +108,27 @@ _TEXTS = ["dominus dixit ad me", "filius meus es tu alleluia", "gloria patri et 
           "laudate eum omnes gentes", "quoniam confirmata est super nos misericordia eius", "et"]
 
 
-def _pages_worker(rank, world, port, q):
+def _pages_worker(rank, world, port, q, bad_page=None, capacity_bug=False):
+    import warnings
     import torch.distributed as dist
     from text_alignment_amd import alignToOCR as atocr, sharding
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
     atocr.process_batch = _fake_process_batch
     sharding.estimate_cost = lambda pg, tr: float(len(tr))
-    pages = [{"seed": k, "empty": k == 3, "peaks": [100, 220 + k, 340, 470 + 3 * k]} for k in range(len(_TEXTS))]
+    pages = [{"seed": k, "empty": k == 3, "peaks": [100, 220 + k, 340, 470 + 3 * k], "bad": k == bad_page}
+             for k in range(len(_TEXTS))]
+    if capacity_bug:                           # a capacity that one rank's records exceed
+        sharding.record_capacity = lambda tr: 2
+    warnings.simplefilter("ignore")
     models = [{"shift": 0} if k % 2 == 0 else {"shift": 1000} for k in range(len(_TEXTS))]
     models = [models[0] if k % 2 == 0 else models[1] for k in range(len(_TEXTS))]     # two distinct model objects
-    out = sharding.process_pages(pages, _TEXTS, models, None)
+    try:
+        out = sharding.process_pages(pages, _TEXTS, models, None)
+    except ValueError as exc:                  # raised AFTER the collective: no rank is left waiting in it
+        out = "ValueError: %s" % exc
     q.put((rank, out))
     if world > 1:
         dist.destroy_process_group()
@@ -150,8 +160,54 @@ def test_process_pages_world2_equals_single_process():
     assert results[2][0] == single
 
 
+def _run_pages(world, **kw):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pages_worker, args=(r, world, port, q), kwargs=kw) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_bad_page_on_one_rank_is_skipped_and_nobody_hangs():
+    """A page that raises on ITS rank (here: page 5, a blank strip) must cost that page only: the rank
+    retries its batch page by page, sends a status record for the page that still fails and enters
+    the one collective like every other rank; rank 0 reports the page as None (the reference's loop
+    prints 'OCRopus failed! Skipping current file.' and goes on, alignToOCR.py:240-243, :430-431)
+    and every other page exactly as a run without the failure."""
+    good = _run_pages(1)[0]
+    for world in (1, 2):
+        got = _run_pages(world, bad_page=5)
+        out = got[0]
+        assert sorted(out) == list(range(len(_TEXTS)))
+        assert out[5] is None
+        assert all(out[k] == good[k] for k in range(len(_TEXTS)) if k != 5)
+        if world == 2:
+            assert got[1] is None
+
+
+def test_capacity_overflow_raises_after_the_collective_on_every_rank_involved():
+    """Records beyond the agreed capacity (a capacity bug): the offending rank still enters the
+    gather -- with a buffer that says how many records it had -- and raises afterwards; rank 0
+    raises when it unpacks.  No rank waits for a peer that has already left."""
+    got = _run_pages(2, capacity_bug=True)
+    assert isinstance(got[0], str) and got[0].startswith("ValueError")
+    assert got[1] is None or (isinstance(got[1], str) and got[1].startswith("ValueError"))
+
+
 def test_capacity_is_an_upper_bound_and_plan_is_deterministic():
     from text_alignment_amd import sharding, latinSyllabification as latsyl
+    # tokens made of whitespace other than ' ' are syllables of their own (words split on ' ' only, a
+    # vowel-less word comes back whole): they can get a box and must be counted
+    for tr in ["a \n b", "a\tb \t c", "dominus \u00a0 deus", "\n", " \t "]:
+        nsyl = len([s for s in latsyl.syllabify_text(tr) if len(s) >= 1])
+        assert sharding.record_capacity(tr) == 1 + nsyl
+    assert sharding.record_capacity("a \n b") == 4
     for tr in _TEXTS + ["", "  ", "a e i o u"]:
         nsyl = len([s for s in latsyl.syllabify_text(tr) if len(s) >= 1])
         assert sharding.record_capacity(tr) >= 1 + nsyl

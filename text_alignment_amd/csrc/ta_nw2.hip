@@ -21,7 +21,7 @@
 // Data flow and the halo argument are replayed on the CPU by tests/native/sim_nw.cpp (run2).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 #include "nw_cell.h"
@@ -367,8 +367,12 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
             // SGPR offset hipcc does not cover the store-data hazard of 16-byte buffer stores on this
             // chip (a VALU write to a data register in the two issue slots behind the store is what
             // gets stored; seen as ~12 % wrong first words when a second workgroup shares the CU).
-            const int only63 = (lane == 63) ? 0 : kWsRange;       // in range for lane 63 only
-            int vo_w = only63 + (int)(ws.row(s + 1) + 8 + (int64_t)(g * SPG - 62) * 8);
+            // (32-bit UNSIGNED arithmetic: kWsRange + any real offset < 2^32 wraps nowhere, and the sum is
+            // >= kWsRange, i.e. out of the descriptor's range, for every lane but 63; g_hi != 0 only when
+            // ws.total < kWsRange, so lane 63's own offsets are all in range)
+            static_assert((uint64_t)kWsRange * 2 < (1ull << 32), "only63 + offset stays below 2^32");
+            const uint32_t only63 = (lane == 63) ? 0u : (uint32_t)kWsRange;       // in range for lane 63 only
+            uint32_t vo_w = only63 + (uint32_t)(ws.row(s + 1) + 8 + (int64_t)(g * SPG - 62) * 8);
             int crd = (kOPad + g * SPG - lane) * (int)sizeof(LC); // byte offset of the next group's codes (per lane)
             asm volatile("" : "+v"(crd));                         // a running VGPR pointer, immediate offsets below
             const unsigned char* const oc_b = reinterpret_cast<const unsigned char*>(ocode);
@@ -432,8 +436,8 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
                 }
                 typedef int v4i __attribute__((ext_vector_type(4)));
                 if (!(ABL & 1)) {                                  // the strip's bottom row, by its owner
-                    __builtin_amdgcn_raw_buffer_store_b128((v4i){bv[0], bd[0], bv[1], bd[1]}, wsrc, vo_w + B * 32, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128((v4i){bv[2], bd[2], bv[3], bd[3]}, wsrc, vo_w + B * 32 + 16, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128((v4i){bv[0], bd[0], bv[1], bd[1]}, wsrc, (int)(vo_w + B * 32u), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128((v4i){bv[2], bd[2], bv[3], bd[3]}, wsrc, (int)(vo_w + B * 32u + 16u), 0, 0);
                 }
             };
             // (hvd of group g was waited for by the last edge group's prefetch)
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
                 // operations, + 10 checkpoint stores in every fourth block), so once all but the 16
                 // youngest are done, every store of the blocks before this one has completed -- without
                 // waiting for the stores just issued.  Published: groups < g.
-                vo_w += CHK * SPG * 8;
+                vo_w += (uint32_t)(CHK * SPG * 8);
                 if (W > 1 && !(ABL & 8)) {
                     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                     if (lane == 63)
@@ -839,12 +843,20 @@ extern "C" int64_t ta_nw2_workspace_bytes(int32_t n, int32_t m) {
     return (Ws2(n, m).total + 15) & ~(int64_t)15;
 }
 
-// one-time raise of a kernel's dynamic LDS limit (thread-safe function-local static per instantiation)
+// raise of a kernel's dynamic LDS limit, once per instantiation AND device (the attribute belongs to the
+// device's copy of the code object; a process that drives several GPUs needs it on each)
 template <typename K>
 static hipError_t allow_full_lds(K kernel) {
-    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    return once;
+    constexpr int kMaxDev = 64;
+    static std::atomic<int> done[kMaxDev];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < kMaxDev && done[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && dev >= 0 && dev < kMaxDev) done[dev].store(1, std::memory_order_release);
+    return e;
 }
 
 template <int W, int MODE, bool SAMEGO, typename OC>
@@ -883,9 +895,7 @@ static P1Plan plan_phase1(int max_n, int max_m, uint32_t flags, int nprob = 1 <<
     pl.codes8 = (flags & TA_NW_CODES8) != 0;
     pl.samego = (flags & TA_NW_OPENS_SAME) != 0;
     const int alphabet = (int)((flags >> TA_NW_ALPHABET_SHIFT) & 0xFFu);
-    bool profile = alphabet > 0 && alphabet < 255;
-    const char* env = getenv("TA_NW2_PHASE1");                  // "compare": A/B timing and tests only
-    if (env && env[0] == 'c') profile = false;
+    bool profile = alphabet > 0 && alphabet < 255 && !(flags & TA_NW_NO_PROFILE);
     pl.w = wmax;
     const int ngroups = PtrLayout<4>::ngroups(max_m);
     // best W for a workgroup that needs lds(W) bytes; returns the resident waves of the choice
@@ -926,8 +936,7 @@ static P1Plan plan_phase1(int max_n, int max_m, uint32_t flags, int nprob = 1 <<
         choose([&](int) { return P1Lds(max_m, pl.codes8 ? 1 : 2).total; }, std::min(4, wmax), w);
         if (w > 0) pl.w = w;
     }
-    if (const char* ew = getenv("TA_NW2_W")) {                  // tests / tuning only
-        const int v = atoi(ew);
+    if (const int v = (int)((flags >> TA_NW_WAVES_SHIFT) & 0xFu)) {      // caller fixes the width (tests / tuning)
         if ((v == 1 || v == 2 || v == 4 || v == 8) && v <= wmax &&
             (!profile || P1Lds(max_m, 2, v * pl.apad * 256).total <= 160 * 1024))
             pl.w = v;

@@ -26,6 +26,8 @@ class RecognitionError(Exception):
 
 
 MAX_CLASSES = 128        # csrc/ta_lstm.hip: kMaxCT = 8 class tiles of 16
+PRECISIONS = ("f32", "split")
+DEFAULT_PRECISION = "f32"
 
 
 class LineModel(object):
@@ -168,14 +170,20 @@ def _copy_pool():
 
 
 class LineRecognizer(object):
-    """precision: "f32" runs the recurrence as an exact f32-input MFMA chain.  "split" runs it on
-    the 16-bit matrix cores with split operands (weights bf16 + fp16 = 19 significant bits,
-    activations three bf16 terms + one fp16, f32 accumulation, four products per k-step): twice as
-    fast, pre-activation error ~2e-6.  Both hold the 1e-3 logit parity of the spec model per
-    128-step segment (tests/test_ocr_gpu.py).  ("bf16x3", the name of this mode's first form, is
-    accepted.)"""
+    """precision:
+    "f32" (the default) runs the recurrence as an exact f32-input MFMA chain -- bit for bit a k-ordered
+    float32 fmaf chain, i.e. what any float32 implementation of ocropy's loop computes.
+    "split" (opt-in, 2.1x faster) runs it on the 16-bit matrix cores with split operands (weights
+    bf16 + fp16 = 19 significant bits, activations three bf16 terms + one fp16, f32 accumulation,
+    four products per k-step); its pre-activation error is about three times the f32 mode's.
+    Both hold the 1e-3 logit parity of the spec model per 128-step segment; FREE-RUNNING on that
+    (chaotic) model at 800 .. 2000 columns, against the float64 restatement (96 lines per model,
+    tools/ocr_mode_agreement.py, profiles/r03_ocr_mode_agreement.json): f32 median logit error
+    1.3e-4 / 2.4e-5 (models 7001 / 7002), 89 / 94 of 96 lines within 1e-3; split 3.5e-4 / 3.4e-5,
+    72 / 92 of 96; decoded characters identical in both modes on all 19 697 characters of the sample.
+    ("bf16x3", the name of the split mode's first form, is accepted.)"""
 
-    def __init__(self, model, device="cuda", precision="split"):
+    def __init__(self, model, device="cuda", precision=DEFAULT_PRECISION):
         if not torch.cuda.is_available():
             raise RuntimeError("text_alignment_amd needs an AMD GPU (MI355X); there is no CPU fallback")
         if precision not in ("split", "bf16x3", "f32"):

@@ -69,16 +69,22 @@ def gather_records(local, group=None, device=None):
     return np.concatenate([allrec_h[r, :int(counts_h[r])] for r in range(world)], axis=0)
 
 
-def pack_records_device(local, cap, device):
+def pack_records_device(local, cap, device, strict=True):
     """Host records -> a device tensor of fixed capacity [cap + 1, 6] whose row 0 carries the
     record count.  With a capacity agreed beforehand (pages per rank x an upper bound of boxes per
-    page) the gather needs no size exchange and no host synchronisation."""
+    page) the gather needs no size exchange and no host synchronisation.
+    More records than the capacity: ValueError -- or, with strict=False (process_shard: a rank
+    must still enter the collective), a buffer whose count word is MINUS the number of records it
+    would have needed and that carries none; unpack_gathered raises on it, after the gather."""
     local = np.ascontiguousarray(local, dtype=np.int32).reshape(-1, RECORD_FIELDS)
-    if local.shape[0] > cap:
-        raise ValueError("more records (%d) than the agreed capacity (%d)" % (local.shape[0], cap))
     buf = np.zeros((cap + 1, RECORD_FIELDS), dtype=np.int32)
-    buf[0, 0] = local.shape[0]
-    buf[1:1 + local.shape[0]] = local
+    if local.shape[0] > cap:
+        if strict:
+            raise ValueError("more records (%d) than the agreed capacity (%d)" % (local.shape[0], cap))
+        buf[0, 0] = -local.shape[0]
+    else:
+        buf[0, 0] = local.shape[0]
+        buf[1:1 + local.shape[0]] = local
     return torch.from_numpy(buf).to(device)
 
 
@@ -102,10 +108,15 @@ def gather_to_root(packed, group=None, dst=0, async_op=False):
 def unpack_gathered(out):
     """[world, cap + 1, 6] gathered tensor -> concatenated host records in rank order."""
     h = out.cpu().numpy()
+    over = [(r, -int(h[r, 0, 0])) for r in range(h.shape[0]) if int(h[r, 0, 0]) < 0]
+    if over:
+        raise ValueError("rank(s) %s produced more records than the agreed capacity of %d: %s"
+                         % ([r for r, _ in over], h.shape[1] - 1, [c for _, c in over]))
     return np.concatenate([h[r, 1:1 + int(h[r, 0, 0])] for r in range(h.shape[0])], axis=0)
 
 
 HEADER = -1              # syl_index of a page's header record
+FAILED = -2              # syl_index of the status record of a page its rank could not process
 
 
 def page_header(page_id, lines_peak_locs, nboxes):
@@ -118,10 +129,19 @@ def page_header(page_id, lines_peak_locs, nboxes):
     return np.array([[page_id, HEADER, int(lo), int(hi), int(nboxes), 0]], dtype=np.int32)
 
 
+def page_failed(page_id):
+    """The status record a rank sends for a page it could not process (the reference's loop skips
+    such a page: alignToOCR.py:240-243, :430-431): rank `dst` reports the page as None."""
+    return np.array([[page_id, FAILED, 0, 0, 0, 0]], dtype=np.int32)
+
+
 def record_capacity(transcript):
     """Upper bound of the records one page can emit, computable on every rank without talking:
-    the header plus one box per syllable, and a syllable has at least one non-blank character."""
-    return 1 + sum(1 for ch in transcript if not ch.isspace())
+    the header plus one box per non-empty syllable the pipeline can name -- counted with the
+    syllabifier itself (words split on ' ' only, and a vowel-less word comes back whole, so a token
+    made of tabs, newlines or no-break spaces IS a syllable and can get a box)."""
+    from . import latinSyllabification as latsyl
+    return 1 + sum(1 for s in latsyl.syllabify_text(transcript) if len(s) >= 1)
 
 
 def records_to_json(records, transcripts, lines_peak_locs=None):
@@ -137,6 +157,9 @@ def records_to_json(records, transcripts, lines_peak_locs=None):
     bounds = np.flatnonzero(np.diff(records[:, 0])) + 1
     for rows in np.split(records, bounds) if len(records) else []:
         pid = int(rows[0, 0])
+        if (rows[:, 1] == FAILED).any():           # the page's rank could not process it
+            out[pid] = None
+            continue
         head = rows[rows[:, 1] == HEADER]
         rows = rows[rows[:, 1] != HEADER]
         rows = rows[np.argsort(rows[:, 1], kind="stable")]
@@ -187,29 +210,51 @@ def process_shard(my_pages, my_transcripts, my_ids, my_models, capacity, seq_ali
     the concatenated records on `dst`, None elsewhere."""
     from . import alignToOCR as atocr
     import torch.distributed as dist
+    import warnings
     recs = []
     by_model = {}
     for k, mdl in enumerate(my_models):
         by_model.setdefault(id(mdl), (mdl, []))[1].append(k)
-    for mdl, ks in by_model.values():
-        idx, arrs = [], []
+
+    def run(mdl, ks):
+        """records of pages ks through one process_batch"""
+        out, idx, arrs = [], [], []
         res = atocr.process_batch([my_pages[k] for k in ks], [my_transcripts[k] for k in ks], mdl,
                                   seq_align_params, indices_out=idx, arrays_out=arrs)
         for j, (k, r, ix) in enumerate(zip(ks, res, idx)):
-            recs.append(page_header(my_ids[k], r[2], len(r[0])))
+            out.append(page_header(my_ids[k], r[2], len(r[0])))
             if j < len(arrs):                     # the array pipeline hands the boxes over as they are
                 rec = np.empty((len(ix), RECORD_FIELDS), dtype=np.int32)
                 rec[:, 0] = my_ids[k]
                 rec[:, 1] = ix
                 rec[:, 2:6] = arrs[j]
-                recs.append(rec)
+                out.append(rec)
             else:
-                recs.append(boxes_to_records(my_ids[k], r[0], ix))
+                out.append(boxes_to_records(my_ids[k], r[0], ix))
+        return out
+
+    # Whatever happens on this rank, it must reach the collective: the other ranks are (or will be)
+    # waiting in it.  A batch that fails is retried page by page, and a page that still fails is
+    # reported by a status record instead of boxes -- one bad page (a blank strip, an over-long line,
+    # a syllable the search cannot place) costs that page, as in the reference's loop
+    # (alignToOCR.py:240-243: 'OCRopus failed! Skipping current file.'), not the rank's share.
+    for mdl, ks in by_model.values():
+        try:
+            recs += run(mdl, ks)
+        except Exception:                         # noqa: BLE001 -- see above
+            for k in ks:
+                try:
+                    recs += run(mdl, [k])
+                except Exception as exc:          # noqa: BLE001
+                    warnings.warn("page %d failed on this rank and is skipped: %r" % (my_ids[k], exc))
+                    recs.append(page_failed(my_ids[k]))
     local = np.concatenate(recs, axis=0) if recs else np.zeros((0, RECORD_FIELDS), np.int32)
     if device is None:
         nccl = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
         device = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
-    work, out = gather_to_root(pack_records_device(local, capacity, device), group=group, dst=dst)
+    work, out = gather_to_root(pack_records_device(local, capacity, device, strict=False), group=group, dst=dst)
+    if local.shape[0] > capacity:                 # after the collective: nobody is left waiting
+        raise ValueError("more records (%d) than the agreed capacity (%d)" % (local.shape[0], capacity))
     return None if out is None else unpack_gathered(out)
 
 
@@ -219,7 +264,8 @@ def process_pages(pages, transcripts, ocropus_model, seq_align_params=None, grou
     round-robin), then one gather of syllable-box records to rank `dst`.  `ocropus_model` is one
     model for all pages or a list with one per page (the reference's two manuscripts have one
     each, alignToOCR.py:390-405).  Returns {page index: JSON dict as alignToOCR.to_JSON_dict} on
-    rank `dst` (every page present, pages without boxes with an empty list), None on other ranks."""
+    rank `dst` (every page present, pages without boxes with an empty list, pages that failed on
+    their rank -- skipped, as the reference's loop skips them -- with None), None on other ranks."""
     world, rank = _world(group)
     models = list(ocropus_model) if isinstance(ocropus_model, (list, tuple)) else [ocropus_model] * len(pages)
     if len(models) != len(pages) or len(transcripts) != len(pages):

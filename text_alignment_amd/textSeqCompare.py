@@ -110,6 +110,10 @@ class NWBatch(object):
         # one-pass launch shape: None = library default (a problem is spread over several
         # workgroups when the batch has fewer problems than the GPU has CUs), True / False force it
         self.wide = wide
+        # two-phase launch-shape overrides (tests, A/B timing): phase 1 without the score profile;
+        # phase 1 with exactly this many waves per workgroup (None = the library's own choice)
+        self.no_profile = False
+        self.waves = None
         p = np.asarray(params, dtype=np.int64)
         if p.ndim == 1:
             p = p.reshape(1, 6)
@@ -173,7 +177,7 @@ class NWBatch(object):
         if self.codes8:
             flags |= _native.TA_NW_CODES8
         if self.two_phase:
-            flags |= self.hints
+            flags |= self.phase1_flags()
         if self.wide is not None and not self.two_phase:
             flags |= _native.TA_NW_WIDE if self.wide else _native.TA_NW_NARROW
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -186,6 +190,15 @@ class NWBatch(object):
             self.ops.data_ptr(), self.ops_off.data_ptr(), self.ops_len.data_ptr(),
             self.max_n, self.max_m, self.score_bound, flags, stream)
         _native.check(rc, "ta_nw2_batch" if self.two_phase else "ta_nw_batch")
+
+    def phase1_flags(self):
+        """Hint and override bits of a ta_nw2_batch / ta_nw2_phase1_plan_batch call for this batch."""
+        flags = self.hints
+        if self.no_profile:
+            flags |= _native.TA_NW_NO_PROFILE
+        if self.waves:
+            flags |= (int(self.waves) & 0xF) << _native.TA_NW_WAVES_SHIFT
+        return flags
 
     def results(self):
         """Host copies of the alignment columns, one uint8 array per problem."""
