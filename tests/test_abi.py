@@ -169,3 +169,29 @@ def test_c_example_runs_and_matches_oracle(native):
         out = subprocess.run([exe, t, o], check=True, capture_output=True, text=True, timeout=120).stdout.split("\n")
         tra, ocr = nw_oracle.perform_alignment(list(t), list(o))
         assert out[0] == "".join(tra) and out[1] == "".join(ocr), (t, o, out)
+
+
+def test_no_buffer_store_data_hazard_in_the_built_library():
+    """16-byte buffer stores must not carry an SGPR soffset, and no VALU
+    instruction may write a store's data VGPRs within two issue slots behind it.  Checked on the
+    disassembly of the gfx950 code objects inside the built libta_hip.so (tools/check_store_hazard.py):
+    a compiler update that re-introduces the form would otherwise only show as a numerically wrong batch."""
+    from tools import check_store_hazard as chk
+    from text_alignment_amd import _native
+    found, nstores, nco = chk.check(_native.LIB_PATH)
+    assert nco >= 1 and nstores >= 16            # the straight-line bottom-row stores of nw_score_kernel are there
+    assert found == []
+    # the checker itself, on the two forms it exists for
+    bad = """
+0000000000001000 <kern>:
+	buffer_store_dwordx4 v[4:7], v30, s[16:19], s3 offen offset:16 // 000000001000: E07C1010 03040 41E
+	v_add_u32_e32 v9, v1, v2                                   // 000000001008: 68120501
+	buffer_store_dwordx4 v[8:11], v30, s[16:19], 0 offen       // 00000000100C: E07C1000 8004081E
+	s_nop 0                                                    // 000000001014: BF800000
+	v_max_i32_e32 v10, v1, v2                                  // 000000001018: 1A140501
+	buffer_store_dwordx4 v[12:15], v30, s[16:19], 0 offen      // 00000000101C: E07C1000 80040C1E
+	s_nop 1                                                    // 000000001024: BF800001
+	v_max_i32_e32 v12, v1, v2                                  // 000000001028: 1A180501
+"""
+    got = chk.findings(bad)
+    assert len(got) == 2 and "soffset" in got[0] and "v_max_i32_e32 v10" in got[1], got

@@ -416,6 +416,35 @@ def test_two_phase_with_16_bit_codes(tsc):
         assert got.tolist() == nw_oracle.align_ids(t, o, SYSTEMS[1]).tolist()
 
 
+def test_two_phase_walk_runs_off_the_lane_window(tsc):
+    """Phase 2 keeps the pointer bytes of 32 lanes (128 rows) around the point where the walk enters a
+    chunk.  Transcript-side gap runs of 100 .. 900 tokens at various row offsets (in strips, across
+    strip borders, at the start / end of the transcript) make the walk climb out of that window --
+    several times within one chunk for the long ones -- and the chunk is re-filled around the new
+    position; scoring systems with free and with costly gap extension."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(2024)
+    t_list, o_list, prm = [], [], []
+    for runlen, at, system in [(100, 300, [8, -4, -7, -7, 0, 0]), (130, 250, SYSTEMS[0]), (300, 0, [8, -4, -7, -7, 0, 0]),
+                               (517, 700, [8, -4, -7, -7, -1, -1]), (900, 130, [8, -4, -7, -7, 0, 0]),
+                               (256, 1024, SYSTEMS[0]), (400, 1400, [11, -4, -2, -2, 0, 0]),
+                               (129, 1, [5, -10, -2, -7, 0, -5]), (640, 896, [3, -3, 0, 0, 0, 0])]:
+        base = rng.integers(0, 27, size=1500).astype(np.int32)
+        junk = (27 + rng.integers(0, 4, size=runlen)).astype(np.int32)          # tokens the OCR string never has
+        t = np.concatenate([base[:at], junk, base[at:]])
+        o = base.copy()
+        o[rng.random(o.size) < 0.05] = 26
+        t_list.append(t); o_list.append(o); prm.append(system)
+        t_list.append(np.concatenate([base, junk])); o_list.append(o); prm.append(system)      # the run ends the transcript
+    batch = tsc.NWBatch(t_list, o_list, prm, two_phase=True)
+    for _ in range(2):
+        batch.run()
+    for k, got in enumerate(batch.results()):
+        want = nw_oracle.align_ids(t_list[k], o_list[k], prm[k])
+        assert got.tolist() == want.tolist(), (k, len(t_list[k]), prm[k])
+        assert (want == 1).sum() >= len(t_list[k]) - len(o_list[k])
+
+
 def test_adversarial_paths(tsc, two_phase):
     """Paths that stress the windowed traceback and the tie rules: disjoint alphabets (the path
     hugs the table edges), a 3000-token insertion in the middle (one horizontal / vertical run

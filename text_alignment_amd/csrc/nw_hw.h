@@ -157,10 +157,18 @@ __device__ __forceinline__ unsigned pack4(unsigned b0, unsigned b1, unsigned b2,
 // TOP_PENDING (two-phase aligner): the window's first-row cells hold no PM / PX (the row above came
 // without winner tags).  A step that leaves a strip below the first one upwards is still taken,
 // and ends the walk with st = 3 + (the state it was taken in): the caller resolves it.
-template <bool TOP_PENDING = false>
+//
+// WL < 64 (two-phase aligner): the window holds only the lanes l_lo .. l_lo + WL - 1 of every group
+// (pieces at [(group - gw_lo) * WL + (lane - l_lo)]); the walk also stops when it needs a lane above
+// l_lo (the caller re-fills around the new position).  WL = 64: whole strips, l_lo = 0.
+//
+// OPS_REV: opsbuf points at the slot of the FIRST column this call emits in the caller's
+// right-aligned output and columns go to descending addresses (opsbuf[-i]): the walk writes the
+// alignment straight to memory, no staging buffer.  Otherwise opsbuf[i], ascending (LDS staging).
+template <bool TOP_PENDING = false, int WL = 64, bool OPS_REV = false>
 __device__ __forceinline__ int walk_window_vec(const uint4* win, int gw_lo, int klow, int x_lo,
                                                int& x, int& y, int& st, uint8_t* opsbuf, int max_ops,
-                                               int lane, long long* iterations = nullptr) {
+                                               int lane, long long* iterations = nullptr, int l_lo = 0) {
     const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
     int cnt = 0;
     while (true) {
@@ -169,9 +177,9 @@ __device__ __forceinline__ int walk_window_vec(const uint4* win, int gw_lo, int 
         const int xi = x - lane * up, yi = y - lane * left;
         const int li = (xi - 1 - x_lo) >> 2;
         const int ki = (yi - 1) + li;
-        const bool valid = (xi > x_lo) & (yi > 0) & (ki >= klow);
+        const bool valid = (xi > x_lo) & (yi > 0) & (ki >= klow) & (WL == 64 || li >= l_lo);
         unsigned b = 0;
-        if (valid) b = wb[((ki >> 2) - gw_lo) * 1024 + li * 16 + (ki & 3) * 4 + ((xi - 1) & 3)];
+        if (valid) b = wb[((ki >> 2) - gw_lo) * (WL * 16) + (li - l_lo) * 16 + (ki & 3) * 4 + ((xi - 1) & 3)];
         int nxt = 2 - (int)((b >> (2 * st)) & 3u);
         if (TOP_PENDING && up && x_lo > 0 && xi == x_lo + 1) nxt = 3 + st;
         const unsigned long long vmask = __ballot(valid);
@@ -185,7 +193,10 @@ __device__ __forceinline__ int walk_window_vec(const uint4* win, int gw_lo, int 
         }
         steps = min(steps, max_ops - cnt);
         if (steps < run + 1) st_new = st;                         // truncated inside the run
-        if (lane < steps) opsbuf[cnt + lane] = (uint8_t)st;
+        if (lane < steps) {
+            if (OPS_REV) opsbuf[-(cnt + lane)] = (uint8_t)st;
+            else opsbuf[cnt + lane] = (uint8_t)st;
+        }
         cnt += steps;
         x -= steps * up;
         y -= steps * left;

@@ -516,10 +516,19 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
 constexpr int kChunk = kCkGroups;                 // groups per chunk
 constexpr int kChunkGroups = kChunk + 1;          // + the group holding the next chunk's two halo steps
 constexpr int kChunkSteps = kChunkGroups * 4;
-#ifndef TA_TB2_OPS
-#define TA_TB2_OPS 512
+// Lanes of a chunk whose pointer bytes are kept.  The walk enters a chunk at a lane l and only ever
+// moves to smaller lanes (a step up is a quarter of a lane, a step left none), a quarter lane per
+// alignment column at most: the 64 .. 68 skewed steps of a chunk take a diagonal path across ~13 lanes.
+// Keeping lanes l - 31 .. l instead of all 64 halves the chunk's LDS (10.1 KB per wave with the ops
+// staging buffer gone: the walk writes its columns straight to memory), i.e. SIXTEEN traceback waves per
+// CU instead of eight -- the 16 problems a CU gets at 4096 problems are then all resident at once.  A walk
+// that does run off the window's top lane (a long run of transcript-side gaps) re-fills the same chunk,
+// up to the group it stands in, with the window moved to its lane.
+#ifndef TA_TB2_LANES
+#define TA_TB2_LANES 32
 #endif
-constexpr int kTb2Ops = TA_TB2_OPS;
+constexpr int kWinLanes = TA_TB2_LANES;
+static_assert(kWinLanes >= 8 && kWinLanes <= 64, "window lanes");
 
 #ifndef TA_P2_PROFILE
 #define TA_P2_PROFILE 0     // cycle counters per problem into row 0 of its workspace (tools/p2_profile.py)
@@ -532,7 +541,7 @@ template <bool CARRIED, bool SAMEGO>
 __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], int (&V)[4], int (&H)[4], int& dsave,
                                              const int (&tc)[4], const int2* hvt, const uint16_t* ow,
                                              uint4* win, int2* hvb, int g0, int g_top, int m, int lane,
-                                             bool lane_has_rows) {
+                                             bool lane_has_rows, int l_lo) {
     constexpr int R = 4, SPG = 4;
     const int k0 = g0 * SPG;
     int oc_next[SPG];
@@ -549,6 +558,7 @@ __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], in
         if constexpr (CARRIED) return cell_carried_tagged_hw<SAMEGO>(kr, d_ul, x_u, y_l, t, o, d, x, y);
         else return cell_hw(kr, d_ul, x_u, y_l, t, o, d, x, y);
     };
+    const bool in_win = (unsigned)(lane - l_lo) < (unsigned)kWinLanes;
     load_group(g0);
     // unpredicated groups: from the one in which the last lane has started on (a lane past its last column
     // goes on over pad codes; what it computes reaches only lanes that are past theirs, pointer bytes
@@ -608,7 +618,7 @@ __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], in
                 }
             }
         }
-        win[(g - g0) * 64 + lane] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+        if (kWinLanes == 64 || in_win) win[(g - g0) * kWinLanes + (lane - l_lo)] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
 
@@ -617,11 +627,10 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
     constexpr int R = 4;
     using L = PtrLayout<R>;
     constexpr int SPG = L::SPG;
-    __shared__ uint4 win[kChunkGroups * 64];                    // pointer bytes of the chunk, strip layout
+    __shared__ uint4 win[kChunkGroups * kWinLanes];             // pointer bytes of the chunk: [group][lane - l_lo]
     __shared__ int2 hvt[kChunkSteps + 8];                       // (V~ or XG, D) of the row above, columns k0..
     __shared__ int2 hvb[kChunkSteps];                           // tagged (V~ or XG, D) the strip's bottom row puts out, per step
     __shared__ uint16_t ow[kChunkSteps + 64 + 8];               // OCR codes, o index (k0 - 63) + i
-    __shared__ uint8_t opsbuf[kTb2Ops];
 
     const int p = blockIdx.x, lane = threadIdx.x;
     const int64_t t0 = a.t_off[p], o0 = a.o_off[p];
@@ -722,6 +731,7 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
             const int k0 = g0 * SPG;
             const int kvalid = ck > 0 ? k0 + 2 : 0;
             const int nsteps_w = (g_top - g0 + 1) * SPG;
+            const int l_lo = kWinLanes == 64 ? 0 : max(0, l - (kWinLanes - 1));   // the window: lanes l_lo .. l_lo + kWinLanes - 1
             if (in_ck != ck || in_gtop != g_top) fetch_inputs(ck, g_top);
 
             // (a) OCR codes of the chunk, (b) the row above the strip
@@ -762,9 +772,9 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
 
             // (d) tagged re-fill of groups g0 .. g_top into LDS
             {
-                if (carried && c.gox == c.goy) refill_chunk<true, true>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows);
-                else if (carried) refill_chunk<true, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows);
-                else refill_chunk<false, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows);
+                if (carried && c.gox == c.goy) refill_chunk<true, true>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows, l_lo);
+                else if (carried) refill_chunk<true, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows, l_lo);
+                else refill_chunk<false, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows, l_lo);
             }
             __syncthreads();
             PC_LAP(pc_fill)
@@ -786,22 +796,18 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
                 }
             }
             if (first && k >= kvalid) {                        // start state, textSeqCompare.py:102
-                st = ptr_pm(wb[(((k >> 2) - g0) * 64 + l) * 16 + (k & 3) * R + r]);
+                st = ptr_pm(wb[(((k >> 2) - g0) * kWinLanes + (l - l_lo)) * 16 + (k & 3) * R + r]);
                 first = false;
             }
             if (ABL2 & 4) { x = s * L::SR; y = max(y - 300, 1); }
-            bool again = !(ABL2 & 4);
-            while (again) {
+            if (!(ABL2 & 4)) {                                  // columns go straight to the right-aligned output
 #if TA_P2_PROFILE
-                const int cnt = walk_window_vec<true>(win, g0, kvalid, s * L::SR, x, y, st, opsbuf, kTb2Ops, lane, &pc_iters);
+                long long* const itp = &pc_iters;
 #else
-                const int cnt = walk_window_vec<true>(win, g0, kvalid, s * L::SR, x, y, st, opsbuf, kTb2Ops, lane);
+                long long* const itp = nullptr;
 #endif
-                __syncthreads();
-                for (int i = lane; i < cnt; i += 64) ops[cap - 1 - (len + i)] = opsbuf[i];
-                len += cnt;
-                __syncthreads();
-                again = (cnt == kTb2Ops);                       // the ops buffer was full: keep walking this chunk
+                len += walk_window_vec<true, kWinLanes, true>(win, g0, kvalid, s * L::SR, x, y, st,
+                                                              ops + (cap - 1 - len), cap - len, lane, itp, l_lo);
             }
             if (st >= 3) { pend = st; st = 0; }                // left the strip upwards: state pending
             PC_LAP(pc_walk)
@@ -811,6 +817,10 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
             k = (y - 1) + l;
             if ((x <= 0) | (y <= 0) | (l < 0)) {
                 in_strip = false;                              // the walk left the strip or finished
+            } else if (k >= kvalid) {
+                // still inside this chunk: the walk ran off the top lane of the window.  The same chunk
+                // again, up to the group the walk stands in, with the window at its lane.
+                g_top = k >> 2;
             } else {
                 // it ran into the chunk's two halo steps (k < kvalid): the chunk before, extended by
                 // the group that holds them
