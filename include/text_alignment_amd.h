@@ -36,10 +36,16 @@ extern "C" {
 #define TA_NW_WIDE 8u        /* ta_nw_batch: force one problem over several workgroups (HBM hand-off rows) */
 #define TA_NW_NARROW 16u     /* ta_nw_batch: force one workgroup per problem; default: wide iff nprob < 256 */
 #define TA_NW_OPENS_SAME 32u /* ta_nw2_batch hint: gap_open_x == gap_open_y in every scoring system of the batch */
-/* ta_nw2_batch hint: every token id of the batch is < a (1 <= a <= 254), every gap open is <= 0 and
- * match/mismatch minus both gap extends fit a signed byte: phase 1 then keeps a score profile in LDS
- * instead of comparing token ids per cell.  Hints change speed only: a problem that does not meet
- * them is still aligned correctly, through a slower path. */
+/* ta_nw2_batch, score profile in LDS.  TA_NW_ALPHABET(a) with 1 <= a <= 254 makes two statements about the
+ * batch, of different kinds:
+ *   - a caller ASSERTION, like TA_NW_CODES8: every token id of every problem is < a.  It is not checked.  The
+ *     OCR ids index the per-wave profile directly (row pitch 256 B, a + 1 rows), so an id >= a reads another
+ *     wave's table or LDS beyond the profile and ids >= 256 wrap: the alignment comes out silently WRONG,
+ *     not slower.  Derive `a` from the data (max id + 1), as text_alignment_amd.textSeqCompare.NWBatch does.
+ *   - HINTS that change speed only: every gap open is <= 0 and match/mismatch minus both gap extends fit a
+ *     signed byte.  A problem that does not meet them (and, under TA_NW_OPENS_SAME, one whose two gap opens
+ *     differ) is still aligned correctly, through the kernel's general cell.
+ * Leave the field 0 (no profile: token ids are compared per cell) when the id bound is not known. */
 #define TA_NW_ALPHABET_SHIFT 8
 #define TA_NW_ALPHABET(a) (((uint32_t)(a) & 0xFFu) << TA_NW_ALPHABET_SHIFT)
 /* ta_nw2_batch launch-shape overrides (tests, A/B timing): phase 1 without the score profile even where

@@ -1,9 +1,12 @@
-"""Text-line height normalisation in front of the recogniser (host side, numpy/scipy).
+"""oracle/lineest_ref.py -- float64 scipy restatement of `ocropus-rpred`'s line normaliser.
+TEST INFRASTRUCTURE ONLY (never imported by text_alignment_amd/): the checker of
+csrc/ta_lineest.hip (tests/test_lineest_gpu.py).
 
-Restates ocropy 1.3.3's `CenterNormalizer` (measure / dewarp / normalize) and `prepare_line`
-as recorded in SURVEY.md Appendix B.0-B.2 -- what `ocropus-rpred` does to each PNG strip that
-reference alignToOCR.py:131-147 hands it, before the LSTM sees it.  Third-party arithmetic,
-absent from the reference tree: parity unpinned.  Row N1 of section 8f.
+PARITY UNPINNED.  Restates ocropy 1.3.3's `CenterNormalizer` (measure / dewarp / normalize) and
+`prepare_line` as recorded in SURVEY.md Appendix B.0-B.2 -- what `ocropus-rpred` does to each PNG
+strip that reference alignToOCR.py:131-147 hands it, before the LSTM sees it.  The arithmetic is
+third-party (ocropy==1.3.3, reference requirements.txt:2), absent from /root/reference and not
+installed; no reference test touches it.  Row N1 of section 8f.
 """
 import numpy as np
 from scipy.ndimage import affine_transform, gaussian_filter, uniform_filter

@@ -1,7 +1,6 @@
-"""Device line normaliser (csrc/ta_lineest.hip) against the host restatement
-(text_alignment_amd/lineest.py: scipy.ndimage in float64; ocropy itself
-is absent, so both are parity-unpinned restatements -- this test pins them to each other):
-identical centre line and band height, resampled input rows equal to float32 rounding."""
+"""Device line normaliser (csrc/ta_lineest.hip) against the checker oracle/lineest_ref.py (scipy.ndimage
+in float64; ocropy itself is absent, so the checker is a parity-unpinned
+restatement): identical centre line and band height, resampled input rows equal to float32 rounding."""
 import numpy as np
 import pytest
 
@@ -28,7 +27,8 @@ def _strip(rng, h, w, wobble=0.0):
 
 def test_device_normaliser_matches_host():
     assert torch.cuda.is_available()
-    from text_alignment_amd import lineest, lineest_gpu
+    from oracle import lineest_ref as lineest
+    from text_alignment_amd import lineest_gpu
     rng = np.random.default_rng(5)
     shapes = [(44, 1216), (61, 900), (70, 1500), (33, 300), (96, 700), (20, 120), (52, 2000), (45, 64)]
     strips = [_strip(rng, h, w, wobble=(3.0 if k % 2 else 0.0)) for k, (h, w) in enumerate(shapes)]
@@ -49,7 +49,7 @@ def test_device_normaliser_matches_host():
     assert row == x.shape[0]
 
 
-def test_device_normaliser_rejects_what_the_host_rejects():
+def test_device_normaliser_rejects_what_the_checker_rejects():
     from text_alignment_amd import lineest_gpu
     with pytest.raises(ValueError):
         lineest_gpu.normalize_strips([np.full((30, 100), 255, np.uint8)])
@@ -61,8 +61,9 @@ def test_device_normaliser_rejects_what_the_host_rejects():
 
 def test_recogniser_takes_raw_strips():
     """LineRecognizer.prepare: raw uint8 strips (device normaliser) mixed with host-prepared lines
-    give the rows the all-host path gives, and the same decoded characters."""
-    from text_alignment_amd import lineest, ocr
+    give the rows the checker's normaliser gives, and the same decoded characters."""
+    from oracle import lineest_ref as lineest
+    from text_alignment_amd import ocr
     rng = np.random.default_rng(9)
     strips = [_strip(rng, h, w) for h, w in [(44, 600), (50, 420), (61, 800), (38, 256), (44, 333)]]
     host = [lineest.prepare_raw_strip(s).astype(np.float32) for s in strips]

@@ -73,8 +73,9 @@ def test_restricted_unpickler_rejects_other_globals(tmp_path):
         model_io.load_pyrnn(path)
 
 
-def test_line_normaliser_shapes_and_polarity():
-    from text_alignment_amd import lineest
+def test_line_normaliser_checker_shapes_and_polarity():
+    """oracle/lineest_ref.py (the checker of csrc/ta_lineest.hip) on a synthetic strip"""
+    from oracle import lineest_ref as lineest
     rng = np.random.default_rng(0)
     img = np.ones((70, 300))                           # white page, a dark band of "text"
     band = rng.random((24, 300)) < 0.4
@@ -89,32 +90,26 @@ def test_line_normaliser_shapes_and_polarity():
         lineest.prepare_raw_strip(np.full((40, 100), 255, np.uint8))
 
 
-def test_normaliser_pool_matches_inline():
-    """page.prepared_lines: raw strips normalised in spawned worker processes (the reference's
-    `parallel` = number of ocropus workers, alignToOCR.py:24, :142-147) give exactly what the
-    in-process path gives; prepared strips pass through untouched."""
-    import numpy as np
+def test_prepared_lines_hand_raw_strips_to_the_device_normaliser():
+    """page.prepared_lines: strips that carry `.prepared` pass through; raw strips are handed on as 2-D
+    uint8 images (bool: True = ink -> black on white) for the device normaliser; blank strips and
+    pixel types the reference's PNG seam never saw are refused on the host, before any GPU work."""
     from text_alignment_amd import page as page_mod
     rng = np.random.default_rng(3)
-    strips = []
-    for k in range(6):
-        h, w = int(rng.integers(40, 70)), int(rng.integers(200, 400))
-        ink = np.zeros((h, w), bool)
-        ink[h // 3: 2 * h // 3] = rng.random((2 * h // 3 - h // 3, w)) < 0.4
-        strips.append(page_mod.Strip(10, 20 * k, h, pixels=np.where(ink, 0, 255).astype(np.uint8)))
+    ink = rng.random((50, 300)) < 0.3
+    raw = page_mod.Strip(10, 20, 50, pixels=np.where(ink, 0, 255).astype(np.uint8))
+    onebit = page_mod.Strip(10, 80, 50, pixels=ink)
     ready = np.zeros((100, 48), np.float32)
-    strips.insert(2, page_mod.Strip(0, 0, 48, width=136, prepared=ready))
-    try:
-        pooled = page_mod.prepared_lines(strips, workers=2, device_normaliser=False)
-    finally:
-        page_mod.close_pool()
-    inline = page_mod.prepared_lines(strips, workers=1, device_normaliser=False)
-    handed_on = page_mod.prepared_lines(strips, workers=1)          # default: raw uint8 strips go to the GPU as they are
-    assert handed_on[0][0].dtype == np.uint8 and handed_on[0][1] == strips[0].pixels.shape[1]
-    assert len(pooled) == len(inline) == 7
-    for (a, wa), (b, wb) in zip(pooled, inline):
-        assert wa == wb and a.shape == b.shape and np.array_equal(a, b)
-    assert pooled[2][0] is ready and pooled[2][1] == 136
+    got = page_mod.prepared_lines([raw, page_mod.Strip(0, 0, 48, width=136, prepared=ready), onebit], workers=2)
+    assert got[0][0].dtype == np.uint8 and got[0][1] == 300 and got[0][0] is raw.pixels
+    assert got[1][0] is ready and got[1][1] == 136
+    assert got[2][0].dtype == np.uint8 and np.array_equal(got[2][0], raw.pixels)
+    with pytest.raises(ValueError, match="empty or constant"):
+        page_mod.prepared_lines([page_mod.Strip(0, 0, 40, pixels=np.full((40, 100), 255, np.uint8))])
+    with pytest.raises(TypeError):
+        page_mod.prepared_lines([page_mod.Strip(0, 0, 40, pixels=np.zeros((40, 100), np.float32))])
+    with pytest.raises(TypeError):
+        page_mod.prepared_lines([page_mod.Strip(0, 0, 40, pixels=np.zeros((40, 100, 3), np.uint8))])
 
 
 def test_class_count_limit_is_refused_up_front():

@@ -1,7 +1,7 @@
-"""Device page preprocessing (csrc/ta_preproc.hip, preproc_gpu.py) against the host restatement
-(textAlignPreprocessing.py, numpy / scipy.ndimage): same components, same skew angle, same rotated
-and filtered bits, same line strips.  (Gamera is absent: both are parity-unpinned restatements of
-reference textAlignPreprocessing.py:160-285; this pins them to each other.)"""
+"""Device page preprocessing (csrc/ta_preproc.hip, preproc_gpu.py) against the checker
+oracle/preproc_ref.py (numpy / scipy.ndimage): same components, same skew angle, same rotated and
+filtered bits, same line strips.  (Gamera is absent: the checker is a parity-unpinned restatement of
+reference textAlignPreprocessing.py:160-285.)"""
 import numpy as np
 import pytest
 
@@ -57,8 +57,8 @@ def test_labels_match_scipy():
 
 @pytest.mark.parametrize("seed,angle", [(0, 0.0), (3, 2.0), (5, -3.3)])
 def test_preprocess_and_lines_match_host(seed, angle):
+    from oracle import preproc_ref as H
     from text_alignment_amd import preproc_gpu as G
-    from text_alignment_amd import textAlignPreprocessing as H
     grey = _noisy_page(seed, angle=angle)
     b0, e0, a0, s0, p0 = H.find_lines(grey)
     b1, e1, a1, s1, p1 = G.find_lines(grey)
@@ -72,15 +72,17 @@ def test_preprocess_and_lines_match_host(seed, angle):
         assert np.array_equal(x.pixels, y.pixels)
 
 
-def test_colour_and_float_pages_take_the_device_path():
-    """find_lines_all reduces colour / float pages to uint8 greyscale as to_onebit does and sends
-    them through the device kernels: same strips as the host restatement on the original array"""
+def test_colour_float_and_onebit_pages_take_the_device_path():
+    """find_lines_all reduces colour / float / already-binarised (bool) pages to uint8 greyscale and
+    sends them through the device kernels: same strips as the checker on the original array (whose
+    to_onebit takes a bool page as it is)"""
+    from oracle import preproc_ref as H
     from text_alignment_amd import alignToOCR as atocr
-    from text_alignment_amd import textAlignPreprocessing as H
     grey = _noisy_page(7)
     rgb = np.stack([grey, grey, grey], axis=2)
     flt = grey.astype(np.float32) / 255.0
-    for page in (rgb, flt):
+    onebit = H.to_onebit(grey)
+    for page in (rgb, flt, onebit):
         want = H.find_lines(page)
         got = atocr.find_lines_all([page])[0]
         assert want[2] == got[2] and np.array_equal(want[0].ink, got[0].ink)

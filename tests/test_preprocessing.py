@@ -1,14 +1,26 @@
-"""Row N3: Gamera-free preprocessing.  The projection / peak numerics are pinned to golden vectors
-captured from the imported reference (textAlignPreprocessing.py:38-157); the scipy image
-operations that stand in for Gamera are checked on a synthetic page (parity unpinned)."""
+"""Row N3: Gamera-free preprocessing.  The projection / peak numerics -- the product's copy
+(text_alignment_amd/textAlignPreprocessing.py, host Python as in the reference) and the checker's
+(oracle/preproc_ref.py) -- are pinned to golden vectors captured from the imported reference
+(textAlignPreprocessing.py:38-157); the checker's scipy image operations that stand in for Gamera
+are exercised on a synthetic page (parity unpinned); the product's image operations are HIP kernels,
+compared with the checker in tests/test_preproc_gpu.py."""
 import numpy as np
 import pytest
 
 from conftest import load_golden
 
 
-def test_peak_numerics_golden():
-    from text_alignment_amd import textAlignPreprocessing as pp
+def _numerics(which):
+    if which == "product":
+        from text_alignment_amd import textAlignPreprocessing as pp
+    else:
+        from oracle import preproc_ref as pp
+    return pp
+
+
+@pytest.mark.parametrize("which", ["product", "checker"])
+def test_peak_numerics_golden(which):
+    pp = _numerics(which)
     g = load_golden("preproc.json")
     for c in g["profiles"]:
         data = np.array(c["data"], dtype=float)
@@ -52,7 +64,7 @@ def _synthetic_page(nlines=6, angle=0.0, seed=0):
 
 
 def test_lines_found_on_synthetic_page():
-    from text_alignment_amd import textAlignPreprocessing as pp
+    from oracle import preproc_ref as pp
     img, centres = _synthetic_page(6)
     image_bin, eroded, angle = pp.preprocess_images(img)
     assert abs(angle) <= 0.3
@@ -74,9 +86,12 @@ def test_deskew_sign_and_box_unrotation(skew):
     """A page skewed by a known signed angle: the reported angle has the sign that makes
     rotate_bbox(box, -angle, image.dim, raw.dim) -- what process() applies to every syllable box
     (reference alignToOCR.py:327-328) -- land boxes of the deskewed page back on the raw page's ink.
-    (With the opposite sign a point 400 px from the centre misses by ~60 px.)"""
-    from text_alignment_amd import alignToOCR as atocr, textAlignPreprocessing as pp
+    (With the opposite sign a point 400 px from the centre misses by ~60 px.)  The checker's
+    pipeline here; the device pipeline reports the same angles (tests/test_preproc_gpu.py)."""
+    from oracle import preproc_ref as pp
+    from text_alignment_amd import alignToOCR as atocr, textAlignPreprocessing as product
     from text_alignment_amd.page import Image
+    assert product.reported_angle(1.25) == pp.reported_angle(1.25) == -1.25 and product.reported_angle(0) == 0.0
     img, _ = _synthetic_page(5, angle=skew, seed=3)
     image_bin, _, angle = pp.preprocess_images(img)
     assert abs(angle - skew) <= 0.4               # same sense as the scipy rotation that skewed the page
@@ -128,30 +143,11 @@ def test_process_from_raw_image():
         assert 0 <= b["ul"][0] <= b["lr"][0] <= image.dim.ncols
 
 
-def test_find_lines_in_worker_processes_matches_inline():
-    """page.map_host: per-page preprocessing + line finding in spawned workers (what process_batch
-    does with `parallel` > 1) returns what the in-process call returns."""
-    from text_alignment_amd import page as page_mod
-    from text_alignment_amd import textAlignPreprocessing as pp
-    pages = [_synthetic_page(4, seed=k)[0] for k in range(3)]
-    inline = [pp.find_lines(pg) for pg in pages]
-    try:
-        pooled = page_mod.map_host(pp.find_lines, pages, workers=2)
-    finally:
-        page_mod.close_pool()
-    for (b0, e0, a0, s0, p0), (b1, e1, a1, s1, p1) in zip(inline, pooled):
-        assert a0 == a1 and list(p0) == list(p1) and len(s0) == len(s1)
-        assert np.array_equal(b0.ink, b1.ink) and np.array_equal(e0.ink, e1.ink)
-        for x, y in zip(s0, s1):
-            assert (x.offset_x, x.offset_y, x.height) == (y.offset_x, y.offset_y, y.height)
-            assert np.array_equal(x.pixels, y.pixels)
-
-
 @pytest.mark.gpu
-def test_process_batch_from_raw_images_with_workers():
-    """process_batch on raw page arrays, host stages in two worker processes: per page the same
-    boxes as process() on that page alone."""
-    from text_alignment_amd import alignToOCR as atocr, ocr, page as page_mod
+def test_process_batch_from_raw_images():
+    """process_batch on raw page arrays (`parallel` is accepted and unused): per page the same boxes
+    as process() on that page alone."""
+    from text_alignment_amd import alignToOCR as atocr, ocr
     from text_alignment_amd.page import Image
 
     class Raw(object):
@@ -164,10 +160,7 @@ def test_process_batch_from_raw_images_with_workers():
     params = [8, -1, -9, -9, -4, -4]
     pages = [Raw(_synthetic_page(4, seed=k)[0]) for k in range(3)]
     trs = ["dominus dixit ad me filius meus es tu", "ego hodie genui te alleluia", "quare fremuerunt gentes"]
-    try:
-        batch = atocr.process_batch(pages, trs, rec, params, parallel=2)
-    finally:
-        page_mod.close_pool()
+    batch = atocr.process_batch(pages, trs, rec, params, parallel=2)
     for pg, tr, got in zip(pages, trs, batch):
         alone = atocr.process(pg, tr, rec, seq_align_params=params, verbose=False)
         assert atocr.to_JSON_dict(got[0], got[2]) == atocr.to_JSON_dict(alone[0], alone[2])

@@ -12,8 +12,8 @@ string/box work restated from the reference.
 
 Gamera (the reference's image toolkit, alignToOCR.py:3-5) is not needed: a page arrives either
 as a `text_alignment_amd.page.PreparedPage` carrying its text-line strips, or as a raw text-layer
-image (numpy array), which `preproc` (text_alignment_amd.textAlignPreprocessing, scipy-based)
-binarises, deskews and cuts into lines -- the two calls `process` makes at alignToOCR.py:216-218.
+image (numpy array), which `preproc` (text_alignment_amd.textAlignPreprocessing over the HIP kernels
+of csrc/ta_preproc.hip) binarises, deskews and cuts into lines -- the two calls `process` makes at alignToOCR.py:216-218.
 """
 import io
 import json  # noqa: F401  (callers json.dump the result of to_JSON_dict, alignToOCR.py:434)
@@ -185,10 +185,10 @@ def perform_ocr_with_ocropus(cc_strips, ocropus_model, wkdir_name=None, parallel
     (strip order, then x), as reference alignToOCR.py:128-184 does through `ocropus-rpred`.
 
     cc_strips: objects with offset_x, offset_y, height and either `prepared` (a (T, 48) array,
-    ink = 1, already normalised and padded) or `pixels` (raw strip, normalised on the host by
-    text_alignment_amd.lineest).  wkdir_name is accepted and unused: all strips of
-    the page go to the GPU in one batch.  `parallel` (the reference's number of ocropus worker
-    processes) is the number of host processes that normalise raw strips.
+    ink = 1, already normalised and padded) or `pixels` (raw 2-D uint8 strip, white background:
+    normalised on the device, csrc/ta_lineest.hip).  wkdir_name and `parallel` (the reference's
+    temp directory and number of ocropus worker processes) are accepted and unused: all strips of
+    the page go to the GPU in one batch and no host-side image work is left to spread.
     """
     from . import ocr
     rec = _recognizer_for(ocropus_model)
@@ -286,24 +286,11 @@ def align_page(transcript, all_chars, angle, image_dim, raw_dim, seq_align_param
 
 def find_lines_all(pages, workers=1):
     """preprocessing + text-line finding of every page: (image_bin, image_eroded, angle, strips,
-    peak locations) per page.  Page images (greyscale or colour, any numeric type: reduced to uint8
-    greyscale exactly as the host's to_onebit does) go through the device kernels (preproc_gpu,
-    csrc/ta_preproc.hip); PreparedPages pass through; already-binarised (bool) pages take the host
-    restatement, in `workers` processes when there are several."""
-    out = [None] * len(pages)
-    rest = []
-    for k, pg in enumerate(pages):
-        px = getattr(pg, "pixels", pg)
-        if not isinstance(pg, page_mod.PreparedPage) and isinstance(px, np.ndarray) and \
-                px.dtype != bool and px.ndim in (2, 3):
-            from . import preproc_gpu
-            out[k] = preproc_gpu.find_lines(preproc.to_grey_u8(px))
-        else:
-            rest.append(k)
-    if rest:
-        for k, r in zip(rest, page_mod.map_host(preproc.find_lines, [pages[k] for k in rest], workers=workers)):
-            out[k] = r
-    return out
+    peak locations) per page.  Page images (greyscale, colour or onebit, any numeric type: reduced to
+    uint8 greyscale by preproc.to_grey_u8) go through the device kernels (preproc_gpu,
+    csrc/ta_preproc.hip); PreparedPages pass through.  `workers` -- the reference's `parallel` -- is
+    accepted and unused: there is no host-side image work left to spread."""
+    return [preproc.find_lines(pg) for pg in pages]
 
 
 def _raw_dim(pg):

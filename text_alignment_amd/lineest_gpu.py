@@ -1,14 +1,16 @@
 """Device side of the line normaliser (csrc/ta_lineest.hip): raw greyscale strips in, the
-recogniser's input rows out, without a host round trip.  Same arithmetic as `lineest.py` (the
-scipy restatement of ocropy 1.3.3's CenterNormalizer + prepare_line, SURVEY.md Appendix B.0-B.2;
-parity unpinned), which the GPU tests use as the checker.  uint8 greyscale strips only: colour or
-float images take the host path (`lineest.prepare_raw_strip`).
+recogniser's input rows out, without a host round trip: ocropy 1.3.3's CenterNormalizer +
+prepare_line (parity unpinned).  The GPU tests check it against the
+float64 scipy restatement oracle/lineest_ref.py.  Strips are 2-D uint8 greyscale images, as the PNG
+files the reference hands to ocropus-rpred (alignToOCR.py:131-132); there is no host path.
 """
 import numpy as np
 import torch
 
 from . import _native
-from .lineest import PAD, TARGET_HEIGHT
+
+TARGET_HEIGHT = 48          # CenterNormalizer target_height
+PAD = 16                    # prepare_line pad (Appendix B.2)
 
 _kernels = {}
 

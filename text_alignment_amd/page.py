@@ -28,7 +28,7 @@ class Strip(object):
     offset_x, offset_y, height: as the reference reads them (alignToOCR.py:160-162).
     prepared: (T, 48) float array, ink = 1, normalised to height 48 and padded by 16 columns on
         each side (what ocropus-rpred feeds its network); or
-    pixels: raw (H, W) strip with white background, normalised on demand by lineest.
+    pixels: raw (H, W) uint8 strip with white background, normalised on the device (lineest_gpu).
     width: raw strip width in pixels (sets the scale of the reported character positions).
     """
 
@@ -70,62 +70,31 @@ def identify_text_lines(image, eroded):
     return pg.strips, pg.lines_peak_locs, None
 
 
+def raw_strip_pixels(strip):
+    """The 2-D uint8 greyscale image of a raw strip (white background), as the PNG the reference
+    saves for ocropus-rpred (alignToOCR.py:131-132: Gamera writes onebit / greyscale PNGs).  A bool
+    strip (True = ink) becomes black on white.  Anything else -- colour, float -- is not something
+    the reference's seam ever saw and is refused: convert it to uint8 greyscale first."""
+    px = np.asarray(strip.pixels)
+    if px.dtype == bool and px.ndim == 2:
+        px = np.where(px, 0, 255).astype(np.uint8)
+    if px.dtype != np.uint8 or px.ndim != 2:
+        raise TypeError("a raw text-line strip is a 2-D uint8 greyscale image (bool: True = ink); got %s, %d-D"
+                        % (px.dtype, px.ndim))
+    if px.size == 0 or _is_constant(px):
+        raise ValueError("empty or constant text-line image")
+    return px
+
+
 def prepared_line(strip):
-    """(xs, raw_width): the (T, 48) network input of a strip and its raw pixel width."""
+    """(line, raw_width): what LineRecognizer.prepare takes for a strip -- its (T, 48) network input
+    if the strip carries one, else its raw uint8 pixels (normalised on the device,
+    csrc/ta_lineest.hip) -- and its raw pixel width."""
     if getattr(strip, "prepared", None) is not None:
         xs = np.asarray(strip.prepared)
         return xs, int(getattr(strip, "width", xs.shape[0] - 32))
-    from . import lineest
-    xs = lineest.prepare_raw_strip(strip.pixels)
-    return xs, int(strip.pixels.shape[1])
-
-
-# ---- host-side line normalisation in worker processes -----------------------------------------
-# The reference hands its strips to `ocropus-rpred -Q <parallel>` (alignToOCR.py:142-147), whose
-# worker processes spend most of their time in the line normaliser; here the recogniser runs on the
-# GPU and `parallel` keeps its meaning for the part that is still host work (lineest, ~50 ms per
-# raw strip in scipy).  Workers are spawned (never forked: the parent may hold a GPU context), only
-# import numpy/scipy, and stay alive for the next page.
-_pool = None
-_pool_size = 0
-
-
-def _normaliser_pool(workers):
-    global _pool, _pool_size
-    if _pool is None or _pool_size != workers:
-        close_pool()
-        import atexit
-        import multiprocessing
-        _pool = multiprocessing.get_context("spawn").Pool(workers)
-        _pool_size = workers
-        atexit.register(close_pool)
-    return _pool
-
-
-def close_pool():
-    global _pool, _pool_size
-    if _pool is not None:
-        _pool.terminate()
-        _pool.join()
-        _pool, _pool_size = None, 0
-
-
-def map_host(fn, items, workers=1, min_batch=2):
-    """[fn(x) for x in items] for a picklable module-level fn of pure host work; raw page arrays
-    go to the worker pool when there are enough of them, PreparedPages (nothing to compute) and
-    small jobs stay in-process."""
-    heavy = [k for k, it in enumerate(items) if not isinstance(it, PreparedPage)]
-    if workers > 1 and len(heavy) >= min_batch:
-        out = [None] * len(items)
-        # workers get the bare pixel array (callers' page objects need not be picklable)
-        done = _normaliser_pool(int(workers)).map(fn, [getattr(items[k], "pixels", items[k]) for k in heavy])
-        for k, r in zip(heavy, done):
-            out[k] = r
-        for k, it in enumerate(items):
-            if out[k] is None:
-                out[k] = fn(it)
-        return out
-    return [fn(it) for it in items]
+    px = raw_strip_pixels(strip)
+    return px, int(px.shape[1])
 
 
 def _is_constant(px):
@@ -138,32 +107,10 @@ def _is_constant(px):
     return bool(px.max() == px.min())
 
 
-def prepared_lines(strips, workers=1, min_batch=4, device_normaliser=True):
-    """[(line, raw_width)] for a list of strips, `line` being what LineRecognizer.prepare takes.
-    Strips that carry `.prepared` pass through.  Raw uint8 greyscale strips are handed on as they
-    are when `device_normaliser` is set (the recogniser normalises them on the GPU); anything else
-    (colour, float) is normalised on the host, in `workers` processes when there are enough."""
-    out = [None] * len(strips)
-    raw = []
-    for k, strip in enumerate(strips):
-        if getattr(strip, "prepared", None) is not None:
-            out[k] = prepared_line(strip)
-            continue
-        px = np.asarray(strip.pixels)
-        if device_normaliser and px.dtype == np.uint8 and px.ndim == 2:
-            if px.size == 0 or _is_constant(px):
-                raise ValueError("empty or constant text-line image")
-            out[k] = (px, int(px.shape[1]))
-        else:
-            raw.append(k)
-    if workers > 1 and len(raw) >= min_batch:
-        from . import lineest
-        pool = _normaliser_pool(int(workers))
-        done = pool.map(lineest.prepare_raw_strip, [strips[k].pixels for k in raw],
-                        chunksize=max(1, len(raw) // (4 * int(workers))))
-        for k, xs in zip(raw, done):
-            out[k] = (xs, int(strips[k].pixels.shape[1]))
-    else:
-        for k in raw:
-            out[k] = prepared_line(strips[k])
-    return out
+def prepared_lines(strips, workers=1):
+    """[(line, raw_width)] for a list of strips, `line` being what LineRecognizer.prepare takes:
+    strips that carry `.prepared` pass through, raw strips are handed on as uint8 images (the
+    recogniser normalises them on the GPU).  `workers` -- the reference's `parallel`, its number of
+    ocropus-rpred worker processes (alignToOCR.py:24, :142-147) -- is accepted and unused: there is no
+    host-side normalisation left to spread."""
+    return [prepared_line(strip) for strip in strips]

@@ -1,10 +1,11 @@
 """Device side of the page preprocessing (csrc/ta_preproc.hip): the image operations of
 `textAlignPreprocessing.preprocess_images` / `identify_text_lines` (the Gamera-free restatement of
 reference textAlignPreprocessing.py:160-285) on the GPU, one page at a time.  Control flow, the
-projection / peak numerics and the selection of components stay in Python exactly as in the host
-module; what moves is every full-page pass: Otsu histogram, thresholding, connected components
-(despeckle, hole filling, tall-component removal, line components), the skew search, the
-rotation, the run filters and the row projection.  uint8 greyscale pages only.
+projection / peak numerics and the selection of components are Python, as in the reference; every
+full-page pass is a kernel: Otsu histogram, thresholding, connected components (despeckle, hole
+filling, tall-component removal, line components), the skew search, the rotation, the run filters
+and the row projection.  uint8 greyscale pages (textAlignPreprocessing.to_grey_u8 reduces anything
+else).  Checked against the scipy restatement oracle/preproc_ref.py (tests/test_preproc_gpu.py).
 """
 import numpy as np
 import torch
@@ -12,16 +13,17 @@ from scipy import special
 
 from . import _native
 from . import page as page_mod
-from . import textAlignPreprocessing as host
+from . import textAlignPreprocessing as host      # parameters + the pinned projection / peak numerics
 
 
 class DeviceBinImage(page_mod.Image):
     """A binarised page that lives on the device: `dim` / `ncols` / `nrows` as `process` and its
     callers read them; `.ink` (bool array, True = ink) is downloaded on first use."""
 
-    def __init__(self, plane):
+    def __init__(self, plane, dev=None):
         page_mod.Image.__init__(self, int(plane.shape[1]), int(plane.shape[0]))
         self.plane = plane
+        self.dev = dev
         self._ink = None
 
     @property
@@ -34,6 +36,9 @@ class DeviceBinImage(page_mod.Image):
 class _Dev(object):
     def __init__(self, device="cuda"):
         self.dev = torch.device(device)
+        if self.dev.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("text_alignment_amd needs an AMD GPU (MI355X): page preprocessing runs as HIP "
+                               "kernels and there is no CPU fallback")
         self.lib = _native.lib
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.count = torch.zeros(1, dtype=torch.int32, device=self.dev)
@@ -182,9 +187,18 @@ def preprocess_images(input_image, despeckle_amt=host.despeckle_amt, filter_runs
 
 
 def find_lines(input_image, device="cuda"):
-    """device counterpart of textAlignPreprocessing.find_lines: (image_bin, image_eroded, angle,
-    strips, peak locations) with host-side BinImages (one download of the binarised page)"""
+    """(image_bin, image_eroded, angle, strips, peak locations) of one uint8 greyscale page"""
     d, ink, eroded, angle = preprocess_images(input_image, device=device)
+    image_bin, image_eroded = DeviceBinImage(ink, d), DeviceBinImage(eroded, d)
+    strips, peaks, _ = identify_text_lines(image_bin, image_eroded)
+    return image_bin, image_eroded, angle, strips, peaks
+
+
+def identify_text_lines(image_bin, image_eroded):
+    """text lines of a preprocessed page (reference textAlignPreprocessing.py:198-285) from the two
+    device planes: (line strips, peak locations, smoothed projection)"""
+    ink, eroded = image_bin.plane, image_eroded.plane
+    d = image_bin.dev or _Dev(ink.device)
     h, w = eroded.shape
     sums = torch.empty(h, dtype=torch.int32, device=d.dev)
     _native.check(d.lib.ta_pp_row_sums(eroded.data_ptr(), h, w, sums.data_ptr(), d.stream), "ta_pp_row_sums")
@@ -202,10 +216,9 @@ def find_lines(input_image, device="cuda"):
                       "ta_pp_clear_rows")
     lab, stats = d.label(work)
     recs = d.components(lab, stats)
-    image_bin, image_eroded = DeviceBinImage(ink), DeviceBinImage(eroded)
     comps = [(int(r[2]), int(r[3]), int(r[4]), int(r[5])) for r in recs if r[1] > host.noise_area_thresh]
     if not comps:
-        return image_bin, image_eroded, angle, [], peaks
+        return [], peaks, smoothed
     heights = [c[3] - c[1] + 1 for c in comps]
     med = np.median(heights)
     comps = [c for c, hgt in zip(comps, heights) if hgt < med * host.remove_capitals_scale]
@@ -227,4 +240,4 @@ def find_lines(input_image, device="cuda"):
         pixels = packed[pos:pos + hh * ww].reshape(hh, ww)
         pos += hh * ww
         strips.append(page_mod.Strip(ulx, uly, hh, width=ww, pixels=pixels))
-    return image_bin, image_eroded, angle, strips, peaks
+    return strips, peaks, smoothed

@@ -1,24 +1,24 @@
-"""Gamera-free preprocessing and text-line finding -- host side,
-numpy / scipy.ndimage.  Counterpart of the reference module of the same name
-(reference textAlignPreprocessing.py:38-285), so that `alignToOCR.process` can start from a
-raw text-layer image (a numpy array) instead of a `page.PreparedPage`.
-
-Two kinds of code live here, with different parity status:
+"""Gamera-free preprocessing and text-line finding.  Counterpart of
+the reference module of the same name (reference textAlignPreprocessing.py:38-285), so that
+`alignToOCR.process` can start from a raw text-layer image (a numpy array) instead of a
+`page.PreparedPage`.
 
 * The projection / peak-finding numerics (`moving_avg_filter` :147, `calculate_peak_prominence`
   :59, `find_peak_locations` :113, `vertically_coincide` :38 of the reference) are plain numpy in
-  the reference too; they are restated here and PINNED to golden vectors captured from the
-  imported reference (tests/golden/preproc.json).
+  the reference too; they are restated here, on the host as in the reference, and PINNED to golden
+  vectors captured from the imported reference (tests/golden/preproc.json).
 * The image operations the reference delegates to the Gamera C++ toolkit (`to_onebit`,
   `despeckle`, `cc_analysis`, `rotation_angle_projections`, `rotate`, `filter_short_runs`,
   `filter_narrow_runs`, `projection_rows`, `draw_line`, `subimage`; reference :167-195, :212-253)
-  are re-expressed with scipy.ndimage from Gamera's documented behaviour.  Gamera is not
-  installed here, so these are PARITY UNPINNED: same pipeline, same parameters, not bit-checked.
+  run as HIP kernels (csrc/ta_preproc.hip, driven by preproc_gpu.py).  There is no host version of
+  them in the package: `preprocess_images` / `identify_text_lines` / `find_lines` below are the
+  reference's entry points over the device path, and the restatement the kernels are checked
+  against lives with the other checkers (oracle/preproc_ref.py).  Gamera is not installed here, so
+  both are PARITY UNPINNED: same pipeline, same parameters, not bit-checked against Gamera.
 
-Images are numpy arrays; a "onebit" image is a bool array with True = ink (Gamera's black).
+Pages are numpy arrays (greyscale or colour of any numeric type, or bool with True = ink).
 """
 import numpy as np
-from scipy import ndimage
 
 from . import page as page_mod
 
@@ -34,7 +34,6 @@ prominence_tolerance = 0.70
 collision_strip_scale = 1
 remove_capitals_scale = 10000
 
-_EIGHT = np.ones((3, 3), dtype=bool)          # Gamera labels connected components 8-connected
 
 
 # --------------------------------------------------------------------------- pinned numerics
@@ -126,23 +125,14 @@ def moving_avg_filter(data, filter_size=filter_size):
     return smoothed
 
 
-# --------------------------------------------------------------------------- image operations
-def otsu_threshold(grey):
-    """Otsu's threshold of a uint8 image (Gamera's to_onebit on a greyscale image)."""
-    hist = np.bincount(grey.ravel(), minlength=256).astype(np.float64)
-    total = hist.sum()
-    cum = np.cumsum(hist)
-    mean_cum = np.cumsum(hist * np.arange(256))
-    mean_all = mean_cum[-1]
-    with np.errstate(divide='ignore', invalid='ignore'):
-        between = (mean_all * cum - mean_cum * total) ** 2 / (cum * (total - cum))
-    between[~np.isfinite(between)] = 0
-    return int(np.argmax(between))
-
-
+# --------------------------------------------------------------------------- page images
 def to_grey_u8(image):
-    """RGB / greyscale of any numeric type -> 2-D uint8 greyscale (what the threshold works on)"""
+    """RGB / greyscale of any numeric type, or a bool onebit image (True = ink) -> 2-D uint8 greyscale,
+    what the device threshold works on.  (A two-valued image thresholds to itself: Otsu's first
+    maximum on a histogram with spikes at 0 and 255 is 0.)"""
     a = np.asarray(image)
+    if a.dtype == bool:
+        return np.where(a, 0, 255).astype(np.uint8)
     if a.ndim == 3:
         a = a[..., :3].mean(axis=2)
     if a.dtype != np.uint8:
@@ -150,143 +140,37 @@ def to_grey_u8(image):
     return a
 
 
-def to_onebit(image):
-    """RGB / greyscale / bool array -> bool array, True = ink."""
-    a = np.asarray(image)
-    if a.dtype == bool:
-        return a.copy()
-    a = to_grey_u8(a)
-    return a <= otsu_threshold(a)
-
-
-def despeckle(onebit, size):
-    """remove ink components of fewer than `size` pixels"""
-    lab, n = ndimage.label(onebit, structure=_EIGHT)
-    if n == 0:
-        return onebit
-    area = np.bincount(lab.ravel(), minlength=n + 1)
-    keep = area >= size
-    keep[0] = False
-    return keep[lab]
-
-
-def components(onebit):
-    """[(label slice pair, label id)] of the 8-connected ink components, plus the label image"""
-    lab, n = ndimage.label(onebit, structure=_EIGHT)
-    return lab, ndimage.find_objects(lab)
-
-
-def rotation_angle_projections(onebit, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
-    """angle in [lo, hi] degrees whose rotation (as `rotate` below applies it) makes the row
-    projection sharpest (largest variance): coarse sweep, then a fine sweep around the best.
-    The projection of the rotated page is formed directly from the ink coordinates -- pixel (y, x)
-    lands on row cy + (y - cy) cos a - (x - cx) sin a -- instead of rotating the image once per
-    candidate angle (60 rotations of a page cost seconds; this costs milliseconds)."""
-    step = max(1, int(max(onebit.shape) / 1200))          # large pages: every step-th row and column
-    small = onebit[::step, ::step]
-    ys, xs = np.nonzero(small)
-    if ys.size == 0:
-        return 0.0
-    h, w = small.shape
-    cy, cx = (h - 1) / 2.0, (w - 1) / 2.0
-    dy, dx = ys - cy, xs - cx
-
-    def score(ang):
-        a = np.deg2rad(ang)
-        rows = np.rint(cy + dy * np.cos(a) - dx * np.sin(a)).astype(np.int64)
-        rows = rows[(rows >= 0) & (rows < h)]
-        return float(np.var(np.bincount(rows, minlength=h)))
-    grid = np.arange(lo, hi + 1e-9, coarse)
-    best = grid[int(np.argmax([score(a) for a in grid]))]
-    grid = np.arange(best - coarse, best + coarse + 1e-9, fine)
-    best = grid[int(np.argmax([score(a) for a in grid]))]
-    return float(np.round(best, 3))
-
-
 def reported_angle(skew):
     """The angle `preprocess_images` hands to `process`.  `process` maps syllable boxes back onto the
     raw page with rotate_bbox(box, -angle, ...) (reference alignToOCR.py:327-328), whose rotation
     x' = x cos a - y sin a, y' = x sin a + y cos a (image coordinates, y down; alignToOCR.py:104-112)
-    turns the opposite way from scipy.ndimage.rotate(img, a).  `rotate` below (and the device
-    kernel) deskew with scipy's sense, so the angle that makes rotate_bbox(-angle) the exact inverse
-    of the deskewing is minus the scipy angle that was applied."""
+    turns the opposite way from the device rotation (which follows scipy.ndimage.rotate(img, a)), so
+    the angle that makes rotate_bbox(-angle) the exact inverse of the deskewing is minus the angle
+    that was applied."""
     return -skew if skew != 0 else 0.0
 
 
-def rotate(onebit, angle):
-    """rotate about the centre, growing the canvas to hold the whole page (as Gamera's rotate;
-    alignToOCR.rotate_bbox undoes exactly this padding, reference alignToOCR.py:93-96)"""
-    if angle == 0:
-        return onebit.copy()
-    rot = ndimage.rotate(onebit.astype(np.float32), angle, reshape=True, order=1, mode='constant', cval=0.0)
-    return rot > 0.5
-
-
-def _filter_runs(onebit, length, axis):
-    """remove ink runs shorter than `length` along `axis`: a morphological opening with a
-    `length` x 1 line (what scipy.ndimage.binary_opening computes, here with shifted views: a pixel
-    survives iff it lies in a window of `length` consecutive ink pixels)"""
-    if length <= 1:
-        return onebit
-    a = np.moveaxis(np.asarray(onebit, dtype=bool), axis, 0)
-    n = a.shape[0]
-    out = np.zeros_like(a)
-    if n >= length:
-        full = a[:n - length + 1].copy()                  # full[i]: a[i .. i+length-1] all ink
-        for k in range(1, length):
-            full &= a[k:n - length + 1 + k]
-        for k in range(length):
-            out[k:n - length + 1 + k] |= full
-    return np.moveaxis(out, 0, axis)
-
-
-def filter_short_runs(onebit, length):      # vertical runs (Gamera: filter_short_runs)
-    return _filter_runs(onebit, length, 0)
-
-
-def filter_narrow_runs(onebit, length):     # horizontal runs (Gamera: filter_narrow_runs)
-    return _filter_runs(onebit, length, 1)
-
-
 # --------------------------------------------------------------------------- the two entry points
-class BinImage(page_mod.Image):
-    """A onebit page image with the `dim` / `ncols` / `nrows` attributes `process` reads."""
-
-    def __init__(self, ink):
-        page_mod.Image.__init__(self, ink.shape[1], ink.shape[0])
-        self.ink = ink
+def _pixels(input_image):
+    px = np.asarray(getattr(input_image, "pixels", input_image))
+    if px.ndim not in (2, 3):
+        raise TypeError("a page image is a 2-D (greyscale / onebit) or 3-D (colour) array")
+    return to_grey_u8(px)
 
 
 def preprocess_images(input_image, despeckle_amt=despeckle_amt, filter_runs=1, filter_runs_amt=2,
                       correct_rotation=True):
-    '''denoise and deskew the text layer before text-line segmentation (reference :160-195).
-    Returns (image_bin, image_eroded, angle).  A PreparedPage passes straight through.'''
+    '''denoise and deskew the text layer before text-line segmentation (reference :160-195), on the
+    GPU.  Returns (image_bin, image_eroded, angle); the two images stay on the device
+    (preproc_gpu.DeviceBinImage: `.dim` / `.ncols` / `.nrows`, `.ink` downloads the bits).
+    A PreparedPage passes straight through.'''
     if isinstance(input_image, page_mod.PreparedPage):
         return page_mod.preprocess_images(input_image)
-    ink = to_onebit(getattr(input_image, "pixels", input_image))
-    ink = despeckle(ink, despeckle_amt)
-    ink = ~despeckle(~ink, despeckle_amt)                      # fill small holes
-    lab, objs = components(ink)
-    for k, sl in enumerate(objs):                              # drop components taller than the threshold
-        if sl is not None and sat_area_thresh < (sl[0].stop - sl[0].start):
-            ink[sl][lab[sl] == k + 1] = False
-    skew = rotation_angle_projections(ink, -6, 6)
-    if correct_rotation:
-        ink = rotate(ink, skew)
-    eroded = ink.copy()
-    for _ in range(filter_runs):
-        eroded = filter_short_runs(eroded, filter_runs_amt)
-        eroded = filter_narrow_runs(eroded, filter_runs_amt)
-    return BinImage(ink), BinImage(eroded), reported_angle(skew)
-
-
-def find_lines(input_image):
-    """preprocess_images + identify_text_lines of one page in one call (a unit of host work the
-    batched page driver can hand to a worker process): (image_bin, image_eroded, angle, line
-    strips, peak locations)."""
-    image_bin, image_eroded, angle = preprocess_images(input_image)
-    strips, peaks, _ = identify_text_lines(image_bin, image_eroded)
-    return image_bin, image_eroded, angle, strips, peaks
+    from . import preproc_gpu
+    d, ink, eroded, angle = preproc_gpu.preprocess_images(_pixels(input_image), despeckle_amt=despeckle_amt,
+                                                          filter_runs=filter_runs, filter_runs_amt=filter_runs_amt,
+                                                          correct_rotation=correct_rotation)
+    return preproc_gpu.DeviceBinImage(ink, d), preproc_gpu.DeviceBinImage(eroded, d), angle
 
 
 def identify_text_lines(image_bin, image_eroded):
@@ -296,36 +180,13 @@ def identify_text_lines(image_bin, image_eroded):
     Returns (line_strips, peak_locations, smoothed_projection).'''
     if hasattr(image_bin, "_page"):
         return page_mod.identify_text_lines(image_bin, image_eroded)
-    ink = image_eroded.ink.copy()
-    project = ink.sum(axis=1)
-    smoothed = moving_avg_filter(project, filter_size)
-    peaks = find_peak_locations(smoothed)
-    for a, b in zip(peaks[:-1], peaks[1:]):
-        idx = int(np.argmin(smoothed[a:b])) + a
-        ink[max(idx - 1, 0):idx + 1, :] = False                # 2-pixel white line
-    lab, objs = components(ink)
-    comps = []
-    for k, sl in enumerate(objs):
-        if sl is None:
-            continue
-        area = int((lab[sl] == k + 1).sum())
-        if area > noise_area_thresh:
-            comps.append((sl[1].start, sl[0].start, sl[1].stop - 1, sl[0].stop - 1))   # ulx, uly, lrx, lry
-    if not comps:
-        return [], peaks, smoothed
-    heights = [c[3] - c[1] + 1 for c in comps]
-    med = np.median(heights)
-    comps = [c for c, h in zip(comps, heights) if h < med * remove_capitals_scale]
-    cc_median_height = np.median([c[3] - c[1] + 1 for c in comps])
-    strips = []
-    box = np.asarray(comps, dtype=np.int64)
-    for loc in peaks:
-        hit = box[coincide_mask(loc, box[:, 1], box[:, 3] - box[:, 1] + 1, cc_median_height)]
-        if not len(hit):
-            continue
-        ulx, uly = int(hit[:, 0].min()), int(hit[:, 1].min())
-        lrx, lry = int(hit[:, 2].max()), int(hit[:, 3].max())
-        sub = image_bin.ink[uly:lry + 1, ulx:lrx + 1]
-        pixels = np.where(sub, 0, 255).astype(np.uint8)        # as the saved PNG: ink black on white
-        strips.append(page_mod.Strip(ulx, uly, lry - uly + 1, width=lrx - ulx + 1, pixels=pixels))
-    return strips, peaks, smoothed
+    from . import preproc_gpu
+    return preproc_gpu.identify_text_lines(image_bin, image_eroded)
+
+
+def find_lines(input_image):
+    """preprocess_images + identify_text_lines of one page in one call: (image_bin, image_eroded,
+    angle, line strips, peak locations)."""
+    image_bin, image_eroded, angle = preprocess_images(input_image)
+    strips, peaks, _ = identify_text_lines(image_bin, image_eroded)
+    return image_bin, image_eroded, angle, strips, peaks

@@ -1,5 +1,5 @@
 """Times the device line normaliser (csrc/ta_lineest.hip) against the host restatement
-(lineest.py, scipy) on synthetic raw strips of page-like size.  python tools/linenorm_bench.py [n]"""
+(oracle/lineest_ref.py, scipy) on synthetic raw strips of page-like size.  python tools/linenorm_bench.py [n]"""
 import os
 import sys
 import time
@@ -22,7 +22,8 @@ def make_strips(n, seed=0):
 
 def main():
     import torch
-    from text_alignment_amd import lineest, lineest_gpu
+    from oracle import lineest_ref as lineest
+    from text_alignment_amd import lineest_gpu
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 960
     strips = make_strips(n)
     px = sum(s.size for s in strips)

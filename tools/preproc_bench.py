@@ -1,5 +1,5 @@
 """Times the device page preprocessing + line finding (csrc/ta_preproc.hip) against the host
-restatement (textAlignPreprocessing.py) on a synthetic page.  python tools/preproc_bench.py [nlines]"""
+checker (oracle/preproc_ref.py) on a synthetic page.  python tools/preproc_bench.py [nlines]"""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ def main():
     import torch
     from test_preprocessing import _synthetic_page
     from text_alignment_amd import preproc_gpu as G
-    from text_alignment_amd import textAlignPreprocessing as H
+    from oracle import preproc_ref as H
     nlines = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     img, _ = _synthetic_page(nlines, angle=1.5)
     G.find_lines(img)
