@@ -274,6 +274,10 @@ int ta_pp_histogram(const uint8_t* img, int64_t n, uint32_t* hist256, void* stre
 int ta_pp_threshold(const uint8_t* img, int64_t n, int32_t thr, int32_t invert, uint8_t* ink, void* stream);
 int ta_pp_label(const uint8_t* ink, int32_t h, int32_t w, int32_t* lab, int32_t* stats, int32_t* flag,
                 void* stream);
+/* ta_pp_label for nimg images with shared waits: ink / lab / stats are [host] arrays of [dev] pointers,
+ * h / w [host] arrays, flags nimg [dev] ints */
+int ta_pp_label_batch(int32_t nimg, const uint8_t* const* ink, const int32_t* h, const int32_t* w,
+                      int32_t* const* lab, int32_t* const* stats, int32_t* flags, void* stream);
 int ta_pp_components(const int32_t* lab, const int32_t* stats, int32_t h, int32_t w, int32_t* recs,
                      int32_t cap, int32_t* count, void* stream);
 int ta_pp_filter_components(uint8_t* ink, const int32_t* lab, const int32_t* stats, int32_t h, int32_t w,

@@ -37,6 +37,37 @@ def test_peak_numerics_golden(which):
         assert bool(pp.vertically_coincide(*c["args"])) == c["result"], c
 
 
+def test_product_peak_finder_equals_the_reference_loop():
+    """The product scores only the local maxima of a projection (everything else has prominence 0); the
+    checker keeps the reference's loop over every row (textAlignPreprocessing.py:113-144).  Same peaks,
+    same ranked prominences, on integer, smoothed, tie-rich and sub-unit (negative log) profiles, for
+    tolerances on both sides of 0, and the same exception on empty data."""
+    from oracle import preproc_ref as ref
+    from text_alignment_amd import textAlignPreprocessing as pp
+    rng = np.random.default_rng(1)
+    for k in range(200):
+        n = int(rng.integers(1, 300))
+        kind = k % 5
+        if kind == 0:
+            d = rng.integers(0, 50, size=n).astype(float)
+        elif kind == 1:
+            d = ref.moving_avg_filter(rng.integers(0, 400, size=n), int(rng.integers(1, 20)))
+        elif kind == 2:
+            d = np.round(rng.random(n) * 5)
+        elif kind == 3:
+            d = rng.random(n) * 0.9
+        else:
+            d = rng.integers(0, 3, size=n)
+        for tol in (0.7, 0.5, 0.0, -0.1):
+            assert pp.find_peak_locations(d, tol=tol) == ref.find_peak_locations(d, tol=tol), (k, tol)
+            a = [(int(i), float(v)) for i, v in pp.find_peak_locations(d, tol=tol, ranked=True)]
+            b = [(int(i), float(v)) for i, v in ref.find_peak_locations(d, tol=tol, ranked=True)]
+            assert a == b, (k, tol)
+    for fn in (pp.find_peak_locations, ref.find_peak_locations):
+        with pytest.raises(ValueError):
+            fn(np.zeros(0))
+
+
 def _synthetic_page(nlines=6, angle=0.0, seed=0):
     """White page with `nlines` rows of word-like ink blobs (ink density bell-shaped across each
     line, like text); returns (uint8 image, line centres)."""

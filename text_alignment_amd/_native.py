@@ -85,7 +85,8 @@ def _load():
     lib.ta_linenorm_resample.restype = ctypes.c_int
     lib.ta_linenorm_resample.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     pp = {"ta_pp_histogram": [vp, i64, vp, vp], "ta_pp_threshold": [vp, i64, i32, i32, vp, vp],
-          "ta_pp_label": [vp, i32, i32, vp, vp, vp, vp], "ta_pp_components": [vp, vp, i32, i32, vp, i32, vp, vp],
+          "ta_pp_label": [vp, i32, i32, vp, vp, vp, vp], "ta_pp_label_batch": [i32, vp, vp, vp, vp, vp, vp, vp],
+          "ta_pp_components": [vp, vp, i32, i32, vp, i32, vp, vp],
           "ta_pp_filter_components": [vp, vp, vp, i32, i32, i32, i32, vp], "ta_pp_invert": [vp, i64, vp],
           "ta_pp_angle_histograms": [vp, i32, i32, i32, vp, i32, vp, vp],
           "ta_pp_rotate": [vp, i32, i32, vp, i32, i32, vp, vp], "ta_pp_open_runs": [vp, vp, i32, i32, i32, i32, vp],
@@ -102,7 +103,7 @@ EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m"
            "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general", "ta_nw_general_batch",
            "ta_lstm_packed_weight_floats", "ta_lstm_forward", "ta_lstm_output", "ta_lstm_output_split_weight_bytes", "ta_lstm_output_split", "ta_decode",
            "ta_decode_summary", "ta_linenorm_measure", "ta_linenorm_resample",
-           "ta_pp_histogram", "ta_pp_threshold", "ta_pp_label", "ta_pp_components", "ta_pp_filter_components",
+           "ta_pp_histogram", "ta_pp_threshold", "ta_pp_label", "ta_pp_label_batch", "ta_pp_components", "ta_pp_filter_components",
            "ta_pp_invert", "ta_pp_angle_histograms", "ta_pp_rotate", "ta_pp_open_runs", "ta_pp_row_sums",
            "ta_pp_clear_rows"]
 

@@ -288,9 +288,10 @@ def find_lines_all(pages, workers=1):
     """preprocessing + text-line finding of every page: (image_bin, image_eroded, angle, strips,
     peak locations) per page.  Page images (greyscale, colour or onebit, any numeric type: reduced to
     uint8 greyscale by preproc.to_grey_u8) go through the device kernels (preproc_gpu,
-    csrc/ta_preproc.hip); PreparedPages pass through.  `workers` -- the reference's `parallel` -- is
-    accepted and unused: there is no host-side image work left to spread."""
-    return [preproc.find_lines(pg) for pg in pages]
+    csrc/ta_preproc.hip), several pages per batch so that the pipeline's data-dependent host decisions
+    share their waits for the device; PreparedPages pass through.  `workers` -- the reference's
+    `parallel` -- is accepted and unused: there is no host-side image work left to spread."""
+    return preproc.find_lines_many(list(pages))
 
 
 def _raw_dim(pg):

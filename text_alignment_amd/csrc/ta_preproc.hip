@@ -14,6 +14,7 @@
 // tile borders).  The final label of a component is the linear index of its first pixel in raster
 // order.
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stdint.h>
 
 #include "ta_common.h"
@@ -135,8 +136,23 @@ __device__ __forceinline__ int wave_max(int v) {
     for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
     return v;
 }
+// Per-component area and bounding box.  A wave first combines its lanes per distinct root (the page
+// background -- one component of millions of pixels once the image is inverted -- would otherwise
+// serialise on five atomics); the combined items then go into a small hash table in LDS, one per
+// workgroup, and only what a workgroup has gathered over ALL its pixels goes to memory at the end: a
+// few atomics per component and workgroup instead of per component and wave-load (the stats kernel was
+// a third of a page's device time, 0.28 ms per call, almost all of it contended atomics on the
+// background's five words).  A table that fills up (more than kStatSlots distinct roots in one
+// workgroup's pixels) sends the overflow straight to memory, as before.
+constexpr int kStatSlots = 256;
 __global__ __launch_bounds__(kPpThreads) void pp_stats_kernel(const int32_t* lab, int h, int w, int32_t* area,
                                                               int32_t* x0, int32_t* y0, int32_t* x1, int32_t* y1) {
+    __shared__ int32_t t_key[kStatSlots], t_area[kStatSlots], t_x0[kStatSlots], t_y0[kStatSlots],
+        t_x1[kStatSlots], t_y1[kStatSlots];
+    for (int k = threadIdx.x; k < kStatSlots; k += kPpThreads) {
+        t_key[k] = -1; t_area[k] = 0; t_x0[k] = 0x7fffffff; t_y0[k] = 0x7fffffff; t_x1[k] = -1; t_y1[k] = -1;
+    }
+    __syncthreads();
     const int64_t n = (int64_t)h * w;
     const int64_t span = (int64_t)gridDim.x * kPpThreads;
     const int lane = threadIdx.x & 63;
@@ -153,14 +169,38 @@ __global__ __launch_bounds__(kPpThreads) void pp_stats_kernel(const int32_t* lab
             const int mnx = wave_min(same ? x : 0x7fffffff), mny = wave_min(same ? y : 0x7fffffff);
             const int mxx = wave_max(same ? x : -1), mxy = wave_max(same ? y : -1);
             if (lane == leader) {
-                atomicAdd(&area[root], (int)__popcll(grp));
-                atomicMin(&x0[root], mnx); atomicMin(&y0[root], mny);
-                atomicMax(&x1[root], mxx); atomicMax(&y1[root], mxy);
+                const int cnt = (int)__popcll(grp);
+                unsigned slot = ((unsigned)root * 2654435761u) >> 24;            // 8 bits: kStatSlots = 256
+                int found = -1;
+                for (int probe = 0; probe < 8; ++probe) {
+                    const int32_t was = atomicCAS(&t_key[slot], -1, root);
+                    if (was == -1 || was == root) { found = (int)slot; break; }
+                    slot = (slot + 1) & (kStatSlots - 1);
+                }
+                if (found >= 0) {
+                    atomicAdd(&t_area[found], cnt);
+                    atomicMin(&t_x0[found], mnx); atomicMin(&t_y0[found], mny);
+                    atomicMax(&t_x1[found], mxx); atomicMax(&t_y1[found], mxy);
+                } else {
+                    atomicAdd(&area[root], cnt);
+                    atomicMin(&x0[root], mnx); atomicMin(&y0[root], mny);
+                    atomicMax(&x1[root], mxx); atomicMax(&y1[root], mxy);
+                }
             }
             todo &= ~grp;
         }
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kStatSlots; k += kPpThreads) {
+        const int32_t root = t_key[k];
+        if (root < 0) continue;
+        atomicAdd(&area[root], t_area[k]);
+        atomicMin(&x0[root], t_x0[k]); atomicMin(&y0[root], t_y0[k]);
+        atomicMax(&x1[root], t_x1[k]); atomicMax(&y1[root], t_y1[k]);
+    }
 }
+static_assert(kStatSlots == 256, "the hash keeps 8 bits");
+constexpr int kStatBlocks = 1024;         // workgroups of the stats kernel (grid-stride over the page)
 
 // records {root, area, x0, y0, x1, y1} of every component, in no particular order
 __global__ __launch_bounds__(kPpThreads) void pp_collect_kernel(const int32_t* lab, int64_t n, const int32_t* area,
@@ -195,21 +235,84 @@ __global__ __launch_bounds__(kPpThreads) void pp_invert_kernel(uint8_t* ink, int
 }
 
 // row histogram of the page rotated by each candidate angle, from the ink coordinates of the
-// decimated page: pixel (y, x) lands on row rint(cy + dy cos a - dx sin a)
+// decimated page: pixel (y, x) lands on row rint(cy + dy cos a - dx sin a).
+// Workgroup (c, a) histograms slice c of the pixels for angle a in LDS and adds its non-empty bins to
+// hist[a][*] at the end (the first form -- one global atomic per ink pixel and angle, 3 M per sweep --
+// took 0.3 ms per sweep, a fifth of a page's device time).  More rows than the LDS histogram holds:
+// straight to memory, as before.
+constexpr int kAngleBins = 4096;
+constexpr int kAngleRun = 16;             // consecutive decimated pixels of one row per thread
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+// A thread takes kAngleRun consecutive pixels of one decimated row: at these angles (|a| <= 6 degrees)
+// they land on one or two rows, so it counts runs of equal rows and the lanes of a wave -- neighbouring
+// runs, mostly on the same rows again -- combine equal rows before anything touches the histogram: one
+// LDS atomic per distinct row and wave instead of one per ink pixel (same-address LDS atomics of a wave
+// serialise, and a text line puts most of a wave's ink on one bin).
 __global__ __launch_bounds__(kPpThreads) void pp_angle_hist_kernel(const uint8_t* ink, int h, int w, int step,
                                                                    const double* cs, int nang, uint32_t* hist) {
+    __shared__ uint32_t bins[kAngleBins];
     const int hs = (h + step - 1) / step, wsm = (w + step - 1) / step;
     const double cy = (hs - 1) / 2.0, cx = (wsm - 1) / 2.0;
-    const int64_t n = (int64_t)hs * wsm;
-    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
-        const int ys = (int)(e / wsm), xs = (int)(e % wsm);
-        if (!ink[(int64_t)ys * step * w + (int64_t)xs * step]) continue;
-        const double dy = __dadd_rn((double)ys, -cy), dx = __dadd_rn((double)xs, -cx);
-        for (int a = 0; a < nang; ++a) {
-            const double v = __dadd_rn(__dadd_rn(cy, __dmul_rn(dy, cs[2 * a])), -__dmul_rn(dx, cs[2 * a + 1]));
-            const long long row = (long long)rint(v);
-            if (row >= 0 && row < hs) atomicAdd(&hist[(int64_t)a * hs + row], 1u);
+    const int runs_per_row = (wsm + kAngleRun - 1) / kAngleRun;
+    const int64_t nitems = (int64_t)hs * runs_per_row;
+    const int a = blockIdx.y;
+    const bool in_lds = hs <= kAngleBins;
+    if (in_lds) {
+        for (int k = threadIdx.x; k < hs; k += kPpThreads) bins[k] = 0u;
+        __syncthreads();
+    }
+    const double ca = cs[2 * a], sa = cs[2 * a + 1];
+    uint32_t* const out = hist + (int64_t)a * hs;
+    const int lane = threadIdx.x & 63;
+    const int64_t span = (int64_t)gridDim.x * kPpThreads;
+    for (int64_t base = (int64_t)blockIdx.x * kPpThreads; base < nitems; base += span) {   // uniform trip count per wave
+        const int64_t item = base + threadIdx.x;
+        // up to two (row, count) runs per thread; a third distinct row inside 16 pixels cannot occur for
+        // |sin a| * 16 < 2, and is flushed on its own if it ever does
+        int row_a = -1, cnt_a = 0, row_b = -1, cnt_b = 0;
+        if (item < nitems) {
+            const int ys = (int)(item / runs_per_row), x_lo = (int)(item % runs_per_row) * kAngleRun;
+            const double dy = __dadd_rn((double)ys, -cy);
+            const double t0 = __dadd_rn(cy, __dmul_rn(dy, ca));
+            const uint8_t* src = ink + (int64_t)ys * step * w;
+            const int x_hi = min(x_lo + kAngleRun, wsm);
+            for (int xs = x_lo; xs < x_hi; ++xs) {
+                if (!src[(int64_t)xs * step]) continue;
+                const double dx = __dadd_rn((double)xs, -cx);
+                const double v = __dadd_rn(t0, -__dmul_rn(dx, sa));
+                const long long rl = (long long)rint(v);
+                if (rl < 0 || rl >= hs) continue;
+                const int row = (int)rl;
+                if (row == row_a) ++cnt_a;
+                else if (row == row_b) ++cnt_b;
+                else if (row_a < 0) { row_a = row; cnt_a = 1; }
+                else if (row_b < 0) { row_b = row; cnt_b = 1; }
+                else { if (in_lds) atomicAdd(&bins[row], 1u); else atomicAdd(&out[row], 1u); }
+            }
         }
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const int row = which ? row_b : row_a, cnt = which ? cnt_b : cnt_a;
+            unsigned long long todo = __ballot(row >= 0);
+            while (todo) {
+                const int leader = __builtin_ctzll(todo);
+                const int r = __shfl(row, leader, 64);
+                const bool same = (row == r);
+                const unsigned long long grp = __ballot(same);
+                const int total = wave_sum(same ? cnt : 0);
+                if (lane == leader) { if (in_lds) atomicAdd(&bins[r], (unsigned)total); else atomicAdd(&out[r], (unsigned)total); }
+                todo &= ~grp;
+            }
+        }
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < hs; k += kPpThreads)
+            if (bins[k]) atomicAdd(&out[k], bins[k]);
     }
 }
 
@@ -353,8 +456,67 @@ extern "C" int ta_pp_label(const uint8_t* ink, int32_t h, int32_t w, int32_t* la
     hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, area, n, 0);
     hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, x0, 2 * n, 0x7fffffff);
     hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, x1, 2 * n, -1);
-    hipLaunchKernelGGL(pp_stats_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, h, w, area, x0, y0, x1, y1);
+    hipLaunchKernelGGL(pp_stats_kernel, dim3(nb > kStatBlocks ? kStatBlocks : nb), dim3(kPpThreads), 0, st, lab, h, w, area, x0, y0, x1, y1);
     PP_LAUNCH_CHECK("pp_label kernels");
+    return TA_OK;
+}
+
+// The same for `nimg` images at once: ink / lab / stats are HOST arrays of device pointers, h / w host
+// arrays, flags nimg device ints.  The data-dependent iteration is shared: every image that is still
+// changing gets a round of two scan / flatten pairs, then ONE copy of all flags and ONE wait for the
+// stream -- two to four waits per batch instead of per image (a page's preprocessing labels four
+// times, and the waits, not the kernels, are what a page costs).
+extern "C" int ta_pp_label_batch(int32_t nimg, const uint8_t* const* ink, const int32_t* h, const int32_t* w,
+                                 int32_t* const* lab, int32_t* const* stats, int32_t* flags, void* stream) {
+    if (nimg < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (nimg == 0) return TA_OK;
+    if (!ink || !h || !w || !lab || !stats || !flags) return ta_fail(TA_EINVAL, "null pointer argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    std::vector<int32_t> changed(nimg, 0);
+    std::vector<char> active(nimg, 0);
+    for (int i = 0; i < nimg; ++i) {
+        if (h[i] < 0 || w[i] < 0) return ta_fail(TA_EINVAL, "negative size");
+        const int64_t n = (int64_t)h[i] * w[i];
+        if (n == 0) continue;
+        if (n >= (1ll << 31)) return ta_fail(TA_ELIMIT, "page too large for 32-bit labels");
+        if (!ink[i] || !lab[i] || !stats[i]) return ta_fail(TA_EINVAL, "null pointer argument");
+        active[i] = 1;
+        hipLaunchKernelGGL(pp_label_tile_kernel, dim3((w[i] + kTileW - 1) / kTileW, (h[i] + kTileH - 1) / kTileH),
+                           dim3(kTileH * kTileW), 0, st, ink[i], h[i], w[i], lab[i]);
+    }
+    for (int round = 0; round < 100000; ++round) {
+        hipError_t e = hipMemsetAsync(flags, 0, sizeof(int32_t) * nimg, st);
+        if (e != hipSuccess) return ta_fail_hip(e, "label flag memset");
+        bool any = false;
+        for (int i = 0; i < nimg; ++i) {
+            if (!active[i]) continue;
+            any = true;
+            const int64_t n = (int64_t)h[i] * w[i];
+            const int nb = pp_blocks(n);
+            for (int k = 0; k < 2; ++k) {
+                hipLaunchKernelGGL(pp_label_scan_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab[i], h[i], w[i], flags + i);
+                hipLaunchKernelGGL(pp_label_flatten_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab[i], n);
+            }
+        }
+        if (!any) break;
+        e = hipMemcpyAsync(changed.data(), flags, sizeof(int32_t) * nimg, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return ta_fail_hip(e, "label iteration");
+        for (int i = 0; i < nimg; ++i)
+            if (active[i] && !changed[i]) active[i] = 0;
+    }
+    for (int i = 0; i < nimg; ++i) {
+        const int64_t n = (int64_t)h[i] * w[i];
+        if (n == 0) continue;
+        const int nb = pp_blocks(n);
+        int32_t* area = stats[i]; int32_t* x0 = area + n; int32_t* y0 = area + 2 * n;
+        int32_t* x1 = area + 3 * n; int32_t* y1 = area + 4 * n;
+        hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, area, n, 0);
+        hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, x0, 2 * n, 0x7fffffff);
+        hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, x1, 2 * n, -1);
+        hipLaunchKernelGGL(pp_stats_kernel, dim3(nb > kStatBlocks ? kStatBlocks : nb), dim3(kPpThreads), 0, st, lab[i], h[i], w[i], area, x0, y0, x1, y1);
+    }
+    PP_LAUNCH_CHECK("pp_label_batch kernels");
     return TA_OK;
 }
 
@@ -406,7 +568,13 @@ extern "C" int ta_pp_angle_histograms(const uint8_t* ink, int32_t h, int32_t w, 
     hipError_t e = hipMemsetAsync(hist, 0, sizeof(uint32_t) * (size_t)nang * hs, st);
     if (e != hipSuccess) return ta_fail_hip(e, "angle histogram memset");
     const int64_t n = (int64_t)hs * wsm;
-    if (n && nang) hipLaunchKernelGGL(pp_angle_hist_kernel, dim3(pp_blocks(n)), dim3(kPpThreads), 0, st, ink, h, w,
+    // pixel slices per angle: enough workgroups to fill the chip, few enough that the per-workgroup flush
+    // (hs atomics) stays small beside the slice's own work
+    int slices = 512 / (nang > 0 ? nang : 1);
+    slices = slices < 1 ? 1 : (slices > 32 ? 32 : slices);
+    const int64_t nitems = (int64_t)hs * ((wsm + kAngleRun - 1) / kAngleRun);
+    if (slices > pp_blocks(nitems)) slices = pp_blocks(nitems) > 0 ? pp_blocks(nitems) : 1;
+    if (n && nang) hipLaunchKernelGGL(pp_angle_hist_kernel, dim3(slices, nang), dim3(kPpThreads), 0, st, ink, h, w,
                                       step, cos_sin, nang, hist);
     PP_LAUNCH_CHECK("pp_angle_hist_kernel");
     return TA_OK;

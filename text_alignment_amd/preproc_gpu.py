@@ -1,12 +1,21 @@
 """Device side of the page preprocessing (csrc/ta_preproc.hip): the image operations of
 `textAlignPreprocessing.preprocess_images` / `identify_text_lines` (the Gamera-free restatement of
-reference textAlignPreprocessing.py:160-285) on the GPU, one page at a time.  Control flow, the
-projection / peak numerics and the selection of components are Python, as in the reference; every
-full-page pass is a kernel: Otsu histogram, thresholding, connected components (despeckle, hole
-filling, tall-component removal, line components), the skew search, the rotation, the run filters
-and the row projection.  uint8 greyscale pages (textAlignPreprocessing.to_grey_u8 reduces anything
-else).  Checked against the scipy restatement oracle/preproc_ref.py (tests/test_preproc_gpu.py).
+reference textAlignPreprocessing.py:160-285) on the GPU.  Control flow, the projection / peak
+numerics and the selection of components are Python, as in the reference; every full-page pass is a
+kernel: Otsu histogram, thresholding, connected components (despeckle, hole filling, tall-component
+removal, line components), the skew search, the rotation, the run filters and the row projection.
+uint8 greyscale pages (textAlignPreprocessing.to_grey_u8 reduces anything else).  Checked against the
+scipy restatement oracle/preproc_ref.py (tests/test_preproc_gpu.py).
+
+Batched by STAGE: a page's preprocessing is ~40 small kernels with a dozen data-dependent host
+decisions in between (Otsu threshold, labelling rounds, the two skew sweeps, peaks, component
+selection, strip sizes).  Each decision costs a wait for the device, and one page at a time those
+waits -- not the kernels -- were what a page cost.  The functions below take a LIST of pages and wait
+once per stage for all of them (`find_lines` of one page is a batch of one): per-page results are
+unchanged, the waits per page fall from ~16 to ~16 / batch.
 """
+import ctypes
+
 import numpy as np
 import torch
 from scipy import special
@@ -33,6 +42,10 @@ class DeviceBinImage(page_mod.Image):
         return self._ink
 
 
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
 class _Dev(object):
     def __init__(self, device="cuda"):
         self.dev = torch.device(device)
@@ -47,14 +60,10 @@ class _Dev(object):
     def stream(self):
         return torch.cuda.current_stream(self.dev).cuda_stream
 
+    # ---- one image (kept for tests and tools) ------------------------------------------------
     def label(self, ink):
         """(lab, stats) of a uint8 ink plane: labels and the five per-root statistics planes"""
-        h, w = ink.shape
-        lab = torch.empty((h, w), dtype=torch.int32, device=self.dev)
-        stats = torch.empty((5, h, w), dtype=torch.int32, device=self.dev)
-        _native.check(self.lib.ta_pp_label(ink.data_ptr(), h, w, lab.data_ptr(), stats.data_ptr(),
-                                           self.flag.data_ptr(), self.stream), "ta_pp_label")
-        return lab, stats
+        return self.label_many([ink])[0]
 
     def filter(self, ink, lab, stats, min_area=0, max_height=2 ** 30):
         h, w = ink.shape
@@ -62,31 +71,69 @@ class _Dev(object):
                                                        int(min_area), int(max_height), self.stream),
                       "ta_pp_filter_components")
 
-    def components(self, lab, stats, cap=1 << 16):
+    def components(self, lab, stats, cap=1 << 12):
         """host array [ncomp][6] = {root, area, x0, y0, x1, y1}, sorted by root (raster order)"""
-        h, w = lab.shape
-        while True:
-            recs = torch.empty((cap, 6), dtype=torch.int32, device=self.dev)
-            _native.check(self.lib.ta_pp_components(lab.data_ptr(), stats.data_ptr(), h, w, recs.data_ptr(),
-                                                    cap, self.count.data_ptr(), self.stream), "ta_pp_components")
-            n = int(self.count.item())
-            if n <= cap:
-                out = recs[:n].cpu().numpy()
-                return out[np.argsort(out[:, 0], kind="stable")]
-            cap = n
+        return self.components_many([(lab, stats)], cap)[0]
 
     def despeckle(self, ink, size):
-        lab, stats = self.label(ink)
-        self.filter(ink, lab, stats, min_area=size)
+        self.despeckle_many([ink], size)
 
     def invert(self, ink):
         _native.check(self.lib.ta_pp_invert(ink.data_ptr(), ink.numel(), self.stream), "ta_pp_invert")
 
+    # ---- many images, one wait per stage -----------------------------------------------------
+    def label_many(self, inks):
+        """[(lab, stats)] of uint8 ink planes; the labelling rounds of all images share their waits"""
+        n = len(inks)
+        if n == 0:
+            return []
+        labs = [torch.empty(k.shape, dtype=torch.int32, device=self.dev) for k in inks]
+        stats = [torch.empty((5,) + tuple(k.shape), dtype=torch.int32, device=self.dev) for k in inks]
+        flags = torch.zeros(n, dtype=torch.int32, device=self.dev)
+        hh = (ctypes.c_int32 * n)(*[int(k.shape[0]) for k in inks])
+        ww = (ctypes.c_int32 * n)(*[int(k.shape[1]) for k in inks])
+        _native.check(self.lib.ta_pp_label_batch(n, _ptr_array(inks), hh, ww, _ptr_array(labs), _ptr_array(stats),
+                                                 flags.data_ptr(), self.stream), "ta_pp_label_batch")
+        return list(zip(labs, stats))
 
-def otsu_threshold_device(d, img):
-    hist = torch.empty(256, dtype=torch.int32, device=d.dev)
-    _native.check(d.lib.ta_pp_histogram(img.data_ptr(), img.numel(), hist.data_ptr(), d.stream), "ta_pp_histogram")
-    hist = hist.cpu().numpy().astype(np.float64)
+    def despeckle_many(self, inks, size):
+        for ink, (lab, stats) in zip(inks, self.label_many(inks)):
+            self.filter(ink, lab, stats, min_area=size)
+
+    def components_many(self, labelled, cap=1 << 12):
+        """component tables of [(lab, stats)]: host arrays [ncomp][6] = {root, area, x0, y0, x1, y1} sorted
+        by root (raster order); one download for all images (an image with more than `cap` components is
+        collected again with room for them)"""
+        n = len(labelled)
+        if n == 0:
+            return []
+        counts = torch.zeros(n, dtype=torch.int32, device=self.dev)
+        recs = torch.empty((n, cap, 6), dtype=torch.int32, device=self.dev)
+        for k, (lab, stats) in enumerate(labelled):
+            h, w = lab.shape
+            _native.check(self.lib.ta_pp_components(lab.data_ptr(), stats.data_ptr(), h, w, recs[k].data_ptr(),
+                                                    cap, counts[k:].data_ptr(), self.stream), "ta_pp_components")
+        cnt = counts.cpu().numpy()
+        small = int(min(cap, max(int(cnt.max()), 1)))
+        host_recs = recs[:, :small].cpu().numpy()
+        out = []
+        for k, (lab, stats) in enumerate(labelled):
+            c = int(cnt[k])
+            if c > cap:                                    # rare: a page with thousands of components
+                big = torch.empty((c, 6), dtype=torch.int32, device=self.dev)
+                h, w = lab.shape
+                _native.check(self.lib.ta_pp_components(lab.data_ptr(), stats.data_ptr(), h, w, big.data_ptr(),
+                                                        c, self.count.data_ptr(), self.stream), "ta_pp_components")
+                r = big.cpu().numpy()
+            else:
+                r = host_recs[k, :c]
+            out.append(r[np.argsort(r[:, 0], kind="stable")])
+        return out
+
+
+def otsu_from_histogram(hist):
+    """Otsu's threshold from a 256-bin histogram (first maximum of the between-class variance)"""
+    hist = hist.astype(np.float64)
     total = hist.sum()
     cum = np.cumsum(hist)
     mean_cum = np.cumsum(hist * np.arange(256))
@@ -97,35 +144,65 @@ def otsu_threshold_device(d, img):
     return int(np.argmax(between))
 
 
-def rotation_angle_device(d, ink, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
-    """host.rotation_angle_projections with the per-angle row histograms built on the device"""
-    h, w = ink.shape
-    step = max(1, int(max(h, w) / 1200))
-    hs = (h + step - 1) // step
+def otsu_threshold_device(d, img):
+    return otsu_thresholds_device(d, [img])[0]
 
-    def scores(grid):
-        cs = np.empty(2 * len(grid), np.float64)
-        rad = np.deg2rad(grid)
-        cs[0::2], cs[1::2] = np.cos(rad), np.sin(rad)
-        d_cs = torch.from_numpy(cs).to(d.dev)
-        hist = torch.empty((len(grid), hs), dtype=torch.int32, device=d.dev)
-        _native.check(d.lib.ta_pp_angle_histograms(ink.data_ptr(), h, w, step, d_cs.data_ptr(), len(grid),
-                                                   hist.data_ptr(), d.stream), "ta_pp_angle_histograms")
-        hh = hist.cpu().numpy()
-        return [float(np.var(hh[k])) for k in range(len(grid))]
-    if not bool(ink.any()):
-        return 0.0
+
+def otsu_thresholds_device(d, imgs):
+    hist = torch.empty((len(imgs), 256), dtype=torch.int32, device=d.dev)
+    for k, img in enumerate(imgs):
+        _native.check(d.lib.ta_pp_histogram(img.data_ptr(), img.numel(), hist[k].data_ptr(), d.stream), "ta_pp_histogram")
+    hh = hist.cpu().numpy()
+    return [otsu_from_histogram(hh[k]) for k in range(len(imgs))]
+
+
+def rotation_angles_device(d, inks, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
+    """the skew angle of every page: the angle in [lo, hi] degrees whose rotation makes the row projection
+    sharpest (largest variance), coarse sweep then a fine sweep around the best, with the per-angle
+    row histograms built on the device from the ink coordinates (pixel (y, x) lands on row
+    cy + (y - cy) cos a - (x - cx) sin a of the page decimated to <= 1200 rows / columns); one download
+    per sweep for all pages.  A page without ink reports 0."""
+    n = len(inks)
+    steps = [max(1, int(max(k.shape) / 1200)) for k in inks]
+    hs = [(int(k.shape[0]) + st - 1) // st for k, st in zip(inks, steps)]
+
+    def sweep(grids):
+        parts = []
+        for k, ink in enumerate(inks):
+            g = grids[k]
+            cs = np.empty(2 * len(g), np.float64)
+            rad = np.deg2rad(g)
+            cs[0::2], cs[1::2] = np.cos(rad), np.sin(rad)
+            d_cs = torch.from_numpy(cs).to(d.dev)
+            hist = torch.empty((len(g), hs[k]), dtype=torch.int32, device=d.dev)
+            h, w = ink.shape
+            _native.check(d.lib.ta_pp_angle_histograms(ink.data_ptr(), h, w, steps[k], d_cs.data_ptr(), len(g),
+                                                       hist.data_ptr(), d.stream), "ta_pp_angle_histograms")
+            parts.append(hist.reshape(-1))
+        flat = torch.cat(parts).cpu().numpy()
+        out, pos = [], 0
+        for k in range(n):
+            m = len(grids[k]) * hs[k]
+            out.append(flat[pos:pos + m].reshape(len(grids[k]), hs[k]))
+            pos += m
+        return out
     grid = np.arange(lo, hi + 1e-9, coarse)
-    best = grid[int(np.argmax(scores(grid)))]
-    grid = np.arange(best - coarse, best + coarse + 1e-9, fine)
-    best = grid[int(np.argmax(scores(grid)))]
-    return float(np.round(best, 3))
+    hh = sweep([grid] * n)
+    empty = [not bool(h.any()) for h in hh]
+    best = [grid[int(np.argmax(np.var(h, axis=1)))] for h in hh]          # np.var per row, bit for bit
+    fine_grids = [np.arange(b - coarse, b + coarse + 1e-9, fine) for b in best]
+    hh = sweep(fine_grids)
+    return [0.0 if e else float(np.round(g[int(np.argmax(np.var(h, axis=1)))], 3))
+            for e, g, h in zip(empty, fine_grids, hh)]
+
+
+def rotation_angle_device(d, ink, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
+    return rotation_angles_device(d, [ink], lo, hi, coarse, fine)[0]
 
 
 def rotate_device(d, ink, angle):
-    """host.rotate: scipy.ndimage.rotate(float32(ink), angle, reshape=True, order=1) > 0.5, with
-    scipy's own geometry (ndimage/_interpolation.py rotate) computed here and the resampling on
-    the device"""
+    """scipy.ndimage.rotate(float32(ink), angle, reshape=True, order=1) > 0.5, with scipy's own
+    geometry (ndimage/_interpolation.py rotate) computed here and the resampling on the device"""
     if angle == 0:
         return ink.clone()
     h, w = ink.shape
@@ -155,89 +232,134 @@ def open_runs_device(d, ink, length, axis):
     return out
 
 
+def preprocess_images_batch(pages, despeckle_amt=host.despeckle_amt, filter_runs=1, filter_runs_amt=2,
+                            correct_rotation=True, device="cuda"):
+    """[(ink, eroded, angle)] as uint8 device planes + the device handle: reference
+    textAlignPreprocessing.py:160-195 for a list of uint8 greyscale pages"""
+    d = _Dev(device)
+    imgs = []
+    for pg in pages:
+        px = np.asarray(getattr(pg, "pixels", pg))
+        if px.dtype != np.uint8 or px.ndim != 2:
+            raise TypeError("the device preprocessing takes 2-D uint8 pages")
+        imgs.append(torch.from_numpy(np.ascontiguousarray(px)).to(d.dev))
+    thrs = otsu_thresholds_device(d, imgs)
+    inks = []
+    for img, thr in zip(imgs, thrs):
+        ink = torch.empty_like(img)
+        _native.check(d.lib.ta_pp_threshold(img.data_ptr(), img.numel(), thr, 0, ink.data_ptr(), d.stream),
+                      "ta_pp_threshold")
+        inks.append(ink)
+    d.despeckle_many(inks, despeckle_amt)
+    for ink in inks:
+        d.invert(ink)                                        # fill small holes: despeckle the background
+    d.despeckle_many(inks, despeckle_amt)
+    for ink in inks:
+        d.invert(ink)
+    for ink, (lab, stats) in zip(inks, d.label_many(inks)):  # drop components taller than the threshold
+        d.filter(ink, lab, stats, max_height=host.sat_area_thresh)
+    skews = rotation_angles_device(d, inks, -6, 6)
+    out = []
+    for ink, skew in zip(inks, skews):
+        if correct_rotation:
+            ink = rotate_device(d, ink, skew)
+        eroded = ink
+        for _ in range(filter_runs):
+            eroded = open_runs_device(d, eroded, filter_runs_amt, 0)
+            eroded = open_runs_device(d, eroded, filter_runs_amt, 1)
+        if eroded is ink:
+            eroded = ink.clone()
+        out.append((ink, eroded, host.reported_angle(skew)))     # sign: see host.reported_angle
+    return d, out
+
+
 def preprocess_images(input_image, despeckle_amt=host.despeckle_amt, filter_runs=1, filter_runs_amt=2,
                       correct_rotation=True, device="cuda"):
-    """(ink, eroded, angle) as uint8 device planes: the device counterpart of
-    textAlignPreprocessing.preprocess_images for a uint8 greyscale page"""
-    px = np.asarray(getattr(input_image, "pixels", input_image))
-    if px.dtype != np.uint8 or px.ndim != 2:
-        raise TypeError("the device preprocessing takes 2-D uint8 pages")
-    d = _Dev(device)
-    img = torch.from_numpy(np.ascontiguousarray(px)).to(d.dev)
-    thr = otsu_threshold_device(d, img)
-    ink = torch.empty_like(img)
-    _native.check(d.lib.ta_pp_threshold(img.data_ptr(), img.numel(), thr, 0, ink.data_ptr(), d.stream),
-                  "ta_pp_threshold")
-    d.despeckle(ink, despeckle_amt)
-    d.invert(ink)                                            # fill small holes: despeckle the background
-    d.despeckle(ink, despeckle_amt)
-    d.invert(ink)
-    lab, stats = d.label(ink)                                # drop components taller than the threshold
-    d.filter(ink, lab, stats, max_height=host.sat_area_thresh)
-    skew = rotation_angle_device(d, ink, -6, 6)
-    if correct_rotation:
-        ink = rotate_device(d, ink, skew)
-    eroded = ink
-    for _ in range(filter_runs):
-        eroded = open_runs_device(d, eroded, filter_runs_amt, 0)
-        eroded = open_runs_device(d, eroded, filter_runs_amt, 1)
-    if eroded is ink:
-        eroded = ink.clone()
-    return d, ink, eroded, host.reported_angle(skew)     # sign: see host.reported_angle
+    """(d, ink, eroded, angle) of one uint8 greyscale page"""
+    d, out = preprocess_images_batch([input_image], despeckle_amt, filter_runs, filter_runs_amt,
+                                     correct_rotation, device)
+    return (d,) + out[0]
+
+
+def identify_text_lines_batch(d, planes):
+    """text lines of preprocessed pages (reference textAlignPreprocessing.py:198-285) from their
+    (ink, eroded) device planes: [(line strips, peak locations, smoothed projection)]"""
+    n = len(planes)
+    sums = []
+    for ink, eroded in planes:
+        h, w = eroded.shape
+        s = torch.empty(h, dtype=torch.int32, device=d.dev)
+        _native.check(d.lib.ta_pp_row_sums(eroded.data_ptr(), h, w, s.data_ptr(), d.stream), "ta_pp_row_sums")
+        sums.append(s)
+    flat = torch.cat(sums).cpu().numpy().astype(np.int64) if n else np.zeros(0, np.int64)
+    smoothed_all, peaks_all, works, pos = [], [], [], 0
+    for ink, eroded in planes:
+        h, w = eroded.shape
+        project = flat[pos:pos + h]
+        pos += h
+        smoothed = host.moving_avg_filter(project, host.filter_size)
+        peaks = host.find_peak_locations(smoothed)
+        rows = []
+        for a, b in zip(peaks[:-1], peaks[1:]):
+            idx = int(np.argmin(smoothed[a:b])) + a
+            rows.extend(range(max(idx - 1, 0), idx + 1))          # 2-pixel white line
+        work = eroded.clone()
+        if rows:
+            d_rows = torch.tensor(sorted(set(rows)), dtype=torch.int32, device=d.dev)
+            _native.check(d.lib.ta_pp_clear_rows(work.data_ptr(), w, d_rows.data_ptr(), d_rows.numel(), d.stream),
+                          "ta_pp_clear_rows")
+        smoothed_all.append(smoothed); peaks_all.append(peaks); works.append(work)
+    recs_all = d.components_many(d.label_many(works))
+    boxes_all, pieces = [], []
+    for (ink, eroded), peaks, recs in zip(planes, peaks_all, recs_all):
+        boxes = []
+        big = recs[recs[:, 1] > host.noise_area_thresh]
+        if len(big):
+            comps = big[:, 2:6].astype(np.int64)                  # ulx, uly, lrx, lry
+            heights = comps[:, 3] - comps[:, 1] + 1
+            med = np.median(heights)
+            comps = comps[heights < med * host.remove_capitals_scale]
+            cc_median_height = np.median(comps[:, 3] - comps[:, 1] + 1)
+            for loc in peaks:
+                hit = comps[host.coincide_mask(loc, comps[:, 1], comps[:, 3] - comps[:, 1] + 1, cc_median_height)]
+                if not len(hit):
+                    continue
+                boxes.append((int(hit[:, 0].min()), int(hit[:, 1].min()), int(hit[:, 2].max()), int(hit[:, 3].max())))
+        boxes_all.append(boxes)
+        if boxes:
+            # cut the strips on the device (ink black on white, as the reference saves them) and bring
+            # only those over: the page itself stays where it is
+            white = (1 - ink) * 255
+            pieces += [white[uly:lry + 1, ulx:lrx + 1].reshape(-1) for ulx, uly, lrx, lry in boxes]
+    packed = torch.cat(pieces).cpu().numpy() if pieces else np.zeros(0, np.uint8)
+    out, pos = [], 0
+    for boxes, peaks, smoothed in zip(boxes_all, peaks_all, smoothed_all):
+        strips = []
+        for ulx, uly, lrx, lry in boxes:
+            hh, ww = lry - uly + 1, lrx - ulx + 1
+            pixels = packed[pos:pos + hh * ww].reshape(hh, ww)
+            pos += hh * ww
+            strips.append(page_mod.Strip(ulx, uly, hh, width=ww, pixels=pixels))
+        out.append((strips, peaks, smoothed))
+    return out
+
+
+def identify_text_lines(image_bin, image_eroded):
+    """(line strips, peak locations, smoothed projection) of one preprocessed page"""
+    d = image_bin.dev or _Dev(image_bin.plane.device)
+    return identify_text_lines_batch(d, [(image_bin.plane, image_eroded.plane)])[0]
+
+
+def find_lines_batch(pages, device="cuda"):
+    """[(image_bin, image_eroded, angle, strips, peak locations)] of uint8 greyscale pages"""
+    if not pages:
+        return []
+    d, pre = preprocess_images_batch(pages, device=device)
+    lines = identify_text_lines_batch(d, [(ink, eroded) for ink, eroded, _ in pre])
+    return [(DeviceBinImage(ink, d), DeviceBinImage(eroded, d), angle, strips, peaks)
+            for (ink, eroded, angle), (strips, peaks, _) in zip(pre, lines)]
 
 
 def find_lines(input_image, device="cuda"):
     """(image_bin, image_eroded, angle, strips, peak locations) of one uint8 greyscale page"""
-    d, ink, eroded, angle = preprocess_images(input_image, device=device)
-    image_bin, image_eroded = DeviceBinImage(ink, d), DeviceBinImage(eroded, d)
-    strips, peaks, _ = identify_text_lines(image_bin, image_eroded)
-    return image_bin, image_eroded, angle, strips, peaks
-
-
-def identify_text_lines(image_bin, image_eroded):
-    """text lines of a preprocessed page (reference textAlignPreprocessing.py:198-285) from the two
-    device planes: (line strips, peak locations, smoothed projection)"""
-    ink, eroded = image_bin.plane, image_eroded.plane
-    d = image_bin.dev or _Dev(ink.device)
-    h, w = eroded.shape
-    sums = torch.empty(h, dtype=torch.int32, device=d.dev)
-    _native.check(d.lib.ta_pp_row_sums(eroded.data_ptr(), h, w, sums.data_ptr(), d.stream), "ta_pp_row_sums")
-    project = sums.cpu().numpy().astype(np.int64)
-    smoothed = host.moving_avg_filter(project, host.filter_size)
-    peaks = host.find_peak_locations(smoothed)
-    rows = []
-    for a, b in zip(peaks[:-1], peaks[1:]):
-        idx = int(np.argmin(smoothed[a:b])) + a
-        rows.extend(range(max(idx - 1, 0), idx + 1))          # 2-pixel white line
-    work = eroded.clone()
-    if rows:
-        d_rows = torch.tensor(sorted(set(rows)), dtype=torch.int32, device=d.dev)
-        _native.check(d.lib.ta_pp_clear_rows(work.data_ptr(), w, d_rows.data_ptr(), d_rows.numel(), d.stream),
-                      "ta_pp_clear_rows")
-    lab, stats = d.label(work)
-    recs = d.components(lab, stats)
-    comps = [(int(r[2]), int(r[3]), int(r[4]), int(r[5])) for r in recs if r[1] > host.noise_area_thresh]
-    if not comps:
-        return [], peaks, smoothed
-    heights = [c[3] - c[1] + 1 for c in comps]
-    med = np.median(heights)
-    comps = [c for c, hgt in zip(comps, heights) if hgt < med * host.remove_capitals_scale]
-    cc_median_height = np.median([c[3] - c[1] + 1 for c in comps])
-    boxes = []
-    box = np.asarray(comps, dtype=np.int64)
-    for loc in peaks:
-        hit = box[host.coincide_mask(loc, box[:, 1], box[:, 3] - box[:, 1] + 1, cc_median_height)]
-        if not len(hit):
-            continue
-        boxes.append((int(hit[:, 0].min()), int(hit[:, 1].min()), int(hit[:, 2].max()), int(hit[:, 3].max())))
-    # cut the strips on the device (ink black on white, as the reference saves them) and bring
-    # only those over: the page itself stays where it is
-    flat = [((1 - ink[uly:lry + 1, ulx:lrx + 1]) * 255).reshape(-1) for ulx, uly, lrx, lry in boxes]
-    packed = torch.cat(flat).cpu().numpy() if flat else np.zeros(0, np.uint8)
-    strips, pos = [], 0
-    for ulx, uly, lrx, lry in boxes:
-        hh, ww = lry - uly + 1, lrx - ulx + 1
-        pixels = packed[pos:pos + hh * ww].reshape(hh, ww)
-        pos += hh * ww
-        strips.append(page_mod.Strip(ulx, uly, hh, width=ww, pixels=pixels))
-    return strips, peaks, smoothed
+    return find_lines_batch([input_image], device=device)[0]

@@ -78,30 +78,52 @@ def calculate_peak_prominence(data, index, data_max=None):
     nearest_left = higher[cut - 1] if cut > 0 else -np.inf
     nearest = nearest_left if (nearest_right - index) > (index - nearest_left) else nearest_right
     lo, hi = min(nearest, index), max(nearest, index)
-    key_col = min(data[int(lo):int(hi)])
+    key_col = np.min(data[int(lo):int(hi)]) if isinstance(data, np.ndarray) else min(data[int(lo):int(hi)])
     return np.log(data[index] - key_col + 1)
 
 
 def find_peak_locations(data, tol=prominence_tolerance, ranked=False):
     '''indices of the prominent peaks of a row projection (reference :113-144)'''
-    data_max = max(data) if len(data) else None
-    # only local maxima can score: find them in one array pass (the same test
-    # calculate_peak_prominence starts with), everything else has prominence 0
     d = np.asarray(data)
+    if len(d) == 0 or tol < 0:
+        return _find_peak_locations_all_rows(data, tol, ranked)
+    data_max = d.max()
+    # only local maxima can score: find them in one array pass (the same test
+    # calculate_peak_prominence starts with); every other row has prominence 0, which never
+    # exceeds a tolerance >= 0, so only the candidates are scored and normalised
     cand = np.zeros(len(d), dtype=bool)
     if len(d) > 2:
         mid, left, right = d[1:-1], d[:-2], d[2:]
         cand[1:-1] = ~((left > mid) | (right > mid) | ((left == mid) & (right == mid)))
-    proms = [(i, calculate_peak_prominence(data, i, data_max) if cand[i] else 0) for i in range(len(data))]
+    idx = np.flatnonzero(cand).tolist()
+    vals = [calculate_peak_prominence(d, i, data_max) for i in idx]
+    top = max(vals + [0])             # rows that are no candidates score 0 (the first and the last row always do)
+    if top == 0:
+        return []
+    peaks = [(i, v / top) for i, v in zip(idx, vals) if v / top > tol]
+    # both corners of a flat-topped peak are prominent: drop the first of two equal neighbours
+    dupes = [peaks[i] for i in range(len(peaks) - 2) if peaks[i][1] == peaks[i + 1][1]]
+    for dup in dupes:
+        peaks.remove(dup)
+    if ranked:
+        peaks.sort(key=lambda p: p[1] * -1)
+        return peaks
+    return [p[0] for p in peaks]
+
+
+def _find_peak_locations_all_rows(data, tol, ranked):
+    """the reference's loop over every row, for the cases the candidate form does not cover (a
+    negative tolerance makes rows of prominence 0 peaks; empty data raises as the reference does)"""
+    data_max = max(data) if len(data) else None
+    proms = [(i, calculate_peak_prominence(data, i, data_max)) for i in range(len(data))]
     top = max([p[1] for p in proms])
     if top == 0 or len(proms) == 0:
         return []
     proms = [(i, v / top) for i, v in proms]
     peaks = [p for p in proms if p[1] > tol]
-    # both corners of a flat-topped peak are prominent: drop the first of two equal neighbours
     dupes = [peaks[i] for i in range(len(peaks) - 2) if peaks[i][1] == peaks[i + 1][1]]
-    for d in dupes:
-        peaks.remove(d)
+    for dup in dupes:
+        peaks.remove(dup)
     if ranked:
         peaks.sort(key=lambda p: p[1] * -1)
         return peaks
@@ -187,6 +209,74 @@ def identify_text_lines(image_bin, image_eroded):
 def find_lines(input_image):
     """preprocess_images + identify_text_lines of one page in one call: (image_bin, image_eroded,
     angle, line strips, peak locations)."""
-    image_bin, image_eroded, angle = preprocess_images(input_image)
-    strips, peaks, _ = identify_text_lines(image_bin, image_eroded)
-    return image_bin, image_eroded, angle, strips, peaks
+    return find_lines_many([input_image])[0]
+
+
+PAGES_PER_BATCH = 8      # pages whose preprocessing shares its waits for the device (~0.2 GB of planes each)
+PAGE_THREADS = 2         # batches in flight at once, each driven by a host thread on a HIP stream of its own
+
+
+def find_lines_many(pages):
+    """find_lines of every page.  The page images go through the device pipeline in batches whose
+    data-dependent host decisions share their waits for the device (preproc_gpu.find_lines_batch),
+    and a few batches are in flight at once -- one host thread and one HIP stream each -- so that one
+    batch's Python (peak finding, component selection) runs while another's kernels do; ctypes and
+    torch release the GIL while a call waits for the device.  PreparedPages pass through.  Per page
+    the result is that of find_lines, whatever the interleaving."""
+    out = [None] * len(pages)
+    todo = []
+    for k, pg in enumerate(pages):
+        if isinstance(pg, page_mod.PreparedPage):
+            image, eroded, angle = page_mod.preprocess_images(pg)
+            strips, peaks, _ = page_mod.identify_text_lines(image, eroded)
+            out[k] = (image, eroded, angle, strips, peaks)
+        else:
+            todo.append(k)
+    if not todo:
+        return out
+    from . import preproc_gpu
+    grey = [_pixels(pages[k]) for k in todo]                   # bad page types fail before any GPU work
+    spans = [(a, min(a + PAGES_PER_BATCH, len(todo))) for a in range(0, len(todo), PAGES_PER_BATCH)]
+
+    def run(span):
+        res = preproc_gpu.find_lines_batch(grey[span[0]:span[1]])
+        for k, r in zip(todo[span[0]:span[1]], res):
+            out[k] = r
+    nthreads = min(PAGE_THREADS, len(spans))
+    if nthreads <= 1:
+        for span in spans:
+            run(span)
+        return out
+    import torch
+    main = torch.cuda.current_stream()
+    device = main.device
+    streams = _page_streams(device, nthreads)
+
+    def worker(t):
+        torch.cuda.set_device(device)
+        streams[t].wait_stream(main)
+        with torch.cuda.stream(streams[t]):
+            for span in spans[t::nthreads]:
+                run(span)
+        streams[t].synchronize()                  # the planes are read on the caller's stream afterwards
+    list(_page_pool(nthreads).map(worker, range(nthreads)))
+    return out
+
+
+_pool_state = {}
+
+
+def _page_pool(n):
+    from concurrent.futures import ThreadPoolExecutor
+    if _pool_state.get("n", 0) < n:
+        _pool_state["pool"] = ThreadPoolExecutor(n, thread_name_prefix="ta-page")
+        _pool_state["n"] = n
+    return _pool_state["pool"]
+
+
+def _page_streams(device, n):
+    import torch
+    have = _pool_state.setdefault(("streams", str(device)), [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=device))
+    return have
