@@ -51,6 +51,11 @@ extern "C" {
 /* ta_nw2_batch launch-shape overrides (tests, A/B timing): phase 1 without the score profile even where
  * the hints allow it; phase 1 with exactly w waves per workgroup (1, 2, 4 or 8; ignored when the tallest
  * problem has fewer strips or the LDS does not hold it; 0 = the library's own choice). */
+/* ta_nw_batch launch-shape override (tests, timing): rows per lane of the one-pass fill, 2 or 4 (0 = the
+ * library's choice: 2 for batches too small to give every SIMD a 256-row strip).  Fill and traceback of
+ * one batch must be given the same value (and the same nprob / max_n), also when issued as two calls. */
+#define TA_NW_ROWS_SHIFT 20
+#define TA_NW_ROWS(r) (((uint32_t)(r) & 0x7u) << TA_NW_ROWS_SHIFT)
 #define TA_NW_NO_PROFILE 64u
 #define TA_NW_WAVES_SHIFT 16
 #define TA_NW_WAVES(w) (((uint32_t)(w) & 0xFu) << TA_NW_WAVES_SHIFT)
@@ -63,8 +68,9 @@ const char* ta_last_error(void);
  * (reference textSeqCompare.py:13-177; called from alignToOCR.py:273).
  *
  * ta_nw_workspace_bytes: bytes of pointer-matrix workspace one n x m problem needs
- * (1 byte per DP cell plus the skew padding of the strip layout, plus one 8(m+2)-byte hand-off row
- * per 1024 transcript rows for the wide launch; multiple of 1024).
+ * (1 byte per DP cell plus the skew padding of the strip layout -- 63 columns per 128- or 256-row strip,
+ * whichever the launch picks -- plus one 8(m+2)-byte hand-off row per four strips for the wide launch;
+ * multiple of 1024).
  */
 int64_t ta_nw_workspace_bytes(int32_t n, int32_t m);
 

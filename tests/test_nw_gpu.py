@@ -24,6 +24,12 @@ def two_phase(request):
     return request.param
 
 
+@pytest.fixture(params=[4, 2], ids=["rows4", "rows2"])
+def rows(request):
+    """rows per lane of the one-pass fill (256- / 128-row strips); ignored by the two-phase aligner"""
+    return request.param
+
+
 def _sha16(tra, ocr):
     return hashlib.sha256(("".join(tra) + "|" + "".join(ocr)).encode()).hexdigest()[:16]
 
@@ -96,7 +102,7 @@ def _random_problem(rng, n, m, asz, related):
     return t, o
 
 
-def test_ragged_batch_vs_oracle_full_pointer_matrix(tsc, two_phase):
+def test_ragged_batch_vs_oracle_full_pointer_matrix(tsc, two_phase, rows):
     """Ragged sizes around every strip / group boundary, per-problem scoring systems; compares
     the whole pointer matrix (not only the traceback path) with the oracle."""
     from oracle import nw_oracle
@@ -109,7 +115,10 @@ def test_ragged_batch_vs_oracle_full_pointer_matrix(tsc, two_phase):
     for k, (n, m) in enumerate(sizes):
         t, o = _random_problem(rng, n, m, [2, 4, 27][k % 3], k % 2 == 0)
         t_list.append(t); o_list.append(o); prm.append(SYSTEMS[k % len(SYSTEMS)])
+    if two_phase and rows != 4:
+        pytest.skip("rows per lane is a one-pass launch shape")
     batch = tsc.NWBatch(t_list, o_list, prm, two_phase=two_phase)
+    batch.rows = rows
     batch.run()
     torch.cuda.synchronize()
     res = batch.results()
@@ -119,7 +128,7 @@ def test_ragged_batch_vs_oracle_full_pointer_matrix(tsc, two_phase):
         want_ops, want_ptr, _ = nw_oracle.align_ids(t_list[k], o_list[k], prm[k], want_ptr=True)
         assert res[k].tolist() == want_ops.tolist(), (k, n, m, prm[k])
         if n and m and not two_phase:
-            got_ptr = _decode_ptr(ws[ws_off[k]:], n, m)
+            got_ptr = _decode_ptr(ws[ws_off[k]:], n, m, R=rows)
             assert np.array_equal(got_ptr, want_ptr[1:, 1:]), (k, n, m, prm[k])
 
 
@@ -147,7 +156,7 @@ def test_two_phase_strip_borders_and_start_probe(tsc):
 
 
 @pytest.mark.parametrize("wide", [True, False], ids=["wide", "narrow"])
-def test_one_pass_launch_shapes(tsc, wide):
+def test_one_pass_launch_shapes(tsc, wide, rows):
     """The one-pass fill spread over several workgroups per problem (hand-off rows in HBM, the
     default for batches smaller than the CU count) against one workgroup per problem: whole
     pointer matrices and alignments vs the oracle, ragged strip counts in one launch."""
@@ -160,6 +169,7 @@ def test_one_pass_launch_shapes(tsc, wide):
         t, o = _random_problem(rng, n, m, [2, 4, 27][k % 3], k % 2 == 0)
         t_list.append(t); o_list.append(o); prm.append(SYSTEMS[k % len(SYSTEMS)])
     batch = tsc.NWBatch(t_list, o_list, prm, two_phase=False, wide=wide)
+    batch.rows = rows
     for _ in range(2):                       # second run: progress words are re-armed per launch
         batch.run()
     torch.cuda.synchronize()
@@ -170,7 +180,7 @@ def test_one_pass_launch_shapes(tsc, wide):
         want_ops, want_ptr, _ = nw_oracle.align_ids(t_list[k], o_list[k], prm[k], want_ptr=True)
         assert res[k].tolist() == want_ops.tolist(), (k, n, m, prm[k])
         if n and m:
-            got_ptr = _decode_ptr(ws[ws_off[k]:], n, m)
+            got_ptr = _decode_ptr(ws[ws_off[k]:], n, m, R=rows)
             assert np.array_equal(got_ptr, want_ptr[1:, 1:]), (k, n, m, prm[k])
 
 

@@ -133,6 +133,40 @@ __device__ __forceinline__ unsigned cell_carried_tagged_hw(const CellRegs& k, in
     return v_bfi3((unsigned)d_ul, v_bfi12((unsigned)xg_u, (unsigned)yg_l));
 }
 
+// The same cell in plain C.  hipcc selects v_and_or_b32 / v_max3_i32 / v_bfi_b32 for these forms by itself,
+// and -- unlike between asm statements, where it pads every def-use with an s_nop (two per cell around the
+// max3: issue slots a VALU-bound kernel pays for, and a lone wave pays 5.5 cycles each) -- schedules them
+// without wait states.  The constants stay in registers (kr), so nothing is un-folded.
+template <bool SAMEGO = false>
+__device__ __forceinline__ unsigned cell_carried_tagged_c(const CellRegs& k, int d_ul, int xg_u, int yg_l,
+                                                          int t, int o, int& d, int& xg, int& yg) {
+    const int cs = (t == o) ? k.cmat : k.cmis;
+    const int mr = (d_ul & k.clean) + cs;
+    const int xr = (xg_u & k.clean) | kTagX;
+    const int yr = yg_l & k.clean;
+    d = max(max(mr, xr), yr);
+    const int dgx = d + k.gox6;
+    const int dgy = SAMEGO ? dgx : d + k.goy6;
+    xg = max(dgx, xr);
+    yg = max(dgy, yr);
+    // (the pointer byte through the asm v_bfi_b32 helpers: hipcc would split each into two v_and + an or;
+    // their results are not needed before the group's bytes are packed, so no pad lands behind them)
+    return v_bfi3((unsigned)d_ul, v_bfi12((unsigned)xg_u, (unsigned)yg_l));
+}
+__device__ __forceinline__ unsigned cell_c(const CellRegs& k, int d_ul, int v_u, int h_l, int t, int o,
+                                           int& d, int& v, int& h) {
+    const int cs = (t == o) ? k.cmat : k.cmis;
+    const int mr = (d_ul & k.clean) + cs;
+    const int xr = (v_u & k.clean) | kTagX;
+    const int yr = h_l & k.clean;
+    const int xg = xr + k.gox6;
+    const int yg = yr + k.goy6;
+    d = max(max(mr, xg), yg);
+    v = max(max(mr, xr), yg);
+    h = max(max(mr, xg), yr);
+    return v_bfi3((unsigned)d_ul, v_bfi12((unsigned)v_u, (unsigned)h_l));
+}
+
 // pack the low bytes of four values into one dword (3 v_perm_b32)
 __device__ __forceinline__ unsigned pack4(unsigned b0, unsigned b1, unsigned b2, unsigned b3) {
     const unsigned lo = __builtin_amdgcn_perm(b1, b0, 0x0C0C0400u);
@@ -152,7 +186,7 @@ __device__ __forceinline__ unsigned pack4(unsigned b0, unsigned b1, unsigned b2,
 // win: window of 16-byte pieces [(group - gw_lo) * 64 + lane]; x_lo: row index just above the
 // strip (cells with x > x_lo are in it); klow: smallest valid skewed step.  Returns the number
 // of ops appended to opsbuf; updates x, y, st.  The walk stops when it leaves the strip, the
-// valid steps, the table (x == 0 or y == 0) or after max_ops.
+// valid steps (klow, in steps), the table (x == 0 or y == 0) or after max_ops.
 //
 // TOP_PENDING (two-phase aligner): the window's first-row cells hold no PM / PX (the row above came
 // without winner tags).  A step that leaves a strip below the first one upwards is still taken,
@@ -165,21 +199,25 @@ __device__ __forceinline__ unsigned pack4(unsigned b0, unsigned b1, unsigned b2,
 // OPS_REV: opsbuf points at the slot of the FIRST column this call emits in the caller's
 // right-aligned output and columns go to descending addresses (opsbuf[-i]): the walk writes the
 // alignment straight to memory, no staging buffer.  Otherwise opsbuf[i], ascending (LDS staging).
-template <bool TOP_PENDING = false, int WL = 64, bool OPS_REV = false>
+// R: rows per lane of the strip layout the window is in (PtrLayout<R>: 16 / R steps per 16-byte piece).
+template <bool TOP_PENDING = false, int WL = 64, bool OPS_REV = false, int R = 4>
 __device__ __forceinline__ int walk_window_vec(const uint4* win, int gw_lo, int klow, int x_lo,
                                                int& x, int& y, int& st, uint8_t* opsbuf, int max_ops,
                                                int lane, long long* iterations = nullptr, int l_lo = 0) {
     const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
+    constexpr int SPG = 16 / R;                                   // steps per piece
+    constexpr int RSH = (R == 4) ? 2 : (R == 2 ? 1 : 0), SSH = (SPG == 4) ? 2 : (SPG == 8 ? 3 : 4);
+    static_assert(R == 1 || R == 2 || R == 4, "rows per lane");
     int cnt = 0;
     while (true) {
         if (iterations) ++*iterations;
         const int up = (st != 2), left = (st != 1);
         const int xi = x - lane * up, yi = y - lane * left;
-        const int li = (xi - 1 - x_lo) >> 2;
+        const int li = (xi - 1 - x_lo) >> RSH;
         const int ki = (yi - 1) + li;
         const bool valid = (xi > x_lo) & (yi > 0) & (ki >= klow) & (WL == 64 || li >= l_lo);
         unsigned b = 0;
-        if (valid) b = wb[((ki >> 2) - gw_lo) * (WL * 16) + (li - l_lo) * 16 + (ki & 3) * 4 + ((xi - 1) & 3)];
+        if (valid) b = wb[((ki >> SSH) - gw_lo) * (WL * 16) + (li - l_lo) * 16 + (ki & (SPG - 1)) * R + ((xi - 1) & (R - 1))];
         int nxt = 2 - (int)((b >> (2 * st)) & 3u);
         if (TOP_PENDING && up && x_lo > 0 && xi == x_lo + 1) nxt = 3 + st;
         const unsigned long long vmask = __ballot(valid);

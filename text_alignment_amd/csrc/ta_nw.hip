@@ -19,6 +19,8 @@
 // caller's buffer.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <type_traits>
 
 #include "nw_cell.h"
 #include "nw_hw.h"
@@ -65,8 +67,10 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
     constexpr int SPG = L::SPG;
     // groups between two looks at the LDS progress word of the strip above: a strip follows the one
     // above at CHK + 17 groups (the wide launch exports to HBM every kCheck groups regardless)
-    constexpr int CHK = 4;
-    constexpr int DW = R / 4;                     // dwords of pointer bytes per step
+    constexpr int CHK = (R == 4) ? 4 : (R == 2 ? 2 : 1);   // ~16 .. 32 steps of look-ahead whatever the group length
+    // export grain of the wide launch (groups between two copies of the bottom row to HBM): ~64 steps
+    constexpr int XCHK = (R == 4) ? kCheck : (R == 2 ? 8 : 4);
+    static_assert(R == 1 || R == 2 || R == 4, "rows per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int p = WIDE ? (int)(blockIdx.x % a.wide_stride) : (int)blockIdx.x;
@@ -86,6 +90,13 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
     // keep the two select constants resident in VGPRs (hipcc otherwise re-materialises them with
     // two v_mov per step)
     asm volatile("" : "+v"(kr.cmis), "+v"(kr.cmat));
+    // Non-positive gap opens (every system of the reference's grid): the strip state and the hand-off
+    // rows are kept in CARRIED form, XG = V~ + gox and YG = H~ + goy, and the cell is
+    // cell_update_carried_tagged (nw_cell.h: 13 instructions instead of 16, same pointers); with equal
+    // gap opens one add fewer still.  Decided per problem (uniform in the workgroup).
+    const bool carried = opens_nonpositive(c.gox, c.goy);
+    const int form = carried ? (c.gox == c.goy ? 2 : 1) : 0;
+    const int xadj6 = carried ? c.gox6 : 0, yadj6 = carried ? c.goy6 : 0;
 
     const NwLds lds(m);
     int2* hvd = reinterpret_cast<int2*>(smem);
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
         const int src = j - kOPad;
         ocode[j] = (src >= 0 && src < m) ? (uint16_t)a.o_codes[o0 + src] : (uint16_t)0xFFFF;
     }
-    for (int j = tid; j <= m; j += W * 64) hvd[j] = make_int2(bnd_V_row0(c, j), bnd_D_row0(c, j));
+    for (int j = tid; j <= m; j += W * 64) hvd[j] = make_int2(bnd_V_row0(c, j) + xadj6, bnd_D_row0(c, j));
     if (tid < 16) prog[tid] = 0;
     __syncthreads();
 
@@ -114,6 +125,7 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
     int2* const xrows = reinterpret_cast<int2*>(ws_p + wl.rows_off);
     int* const gprog = reinterpret_cast<int*>(ws_p + wl.prog_off);
     int imp_hi = 0, exp_hi = 0;                   // hand-off columns imported / exported so far (WIDE)
+    int exp_pending = 0;                          // progress value of an export whose stores are still in flight (WIDE)
     const int prev_wave = (wave + W - 1) % W;
     // groups [g_lo, g_hi) are "steady": every lane is inside 1 <= j <= m on every step
     const int g_lo = (63 + SPG - 1) / SPG;
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
         for (int r = 0; r < R; ++r) {
             const int i = row0 + r + 1;
             D[r] = bnd_D_col0(c, i);
-            H[r] = bnd_H_col0(c, i);
+            H[r] = bnd_H_col0(c, i) + yadj6;
             V[r] = 0;
             tc[r] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
         }
@@ -152,7 +164,10 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
             const int need_groups = min(ngroups, (col + 62) / SPG + 1);
             if (WIDE && wave == 0) {
                 // the strip above belongs to the previous workgroup: wait for its progress word,
-                // then pull every newly final column from its HBM row into the LDS hand-off row
+                // then pull every newly final column from its HBM row into the LDS hand-off row.
+                // The row was stored write-through (sc1) and drained before the word was set, and it is
+                // read here with sc1 loads by the wave that polled, after its poll matched: no acquire
+                // fence (buffer_inv, ~1.7 us each, on the critical path of every workgroup's first strip).
                 if (imp_hi >= col) return;
                 const int row = s / W - 1;
                 int have;
@@ -160,42 +175,72 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
                     have = __builtin_amdgcn_readfirstlane(
                         __hip_atomic_load(&gprog[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                     if (have >= need_groups) break;
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // no instruction: keeps the loads below the poll
                 const int cfin = (have >= ngroups) ? m : min(m, have * SPG - 1 - 62);
-                const int2* src = xrows + (int64_t)row * wl.row_elems;
-                for (int j = imp_hi + 1 + lane; j <= cfin; j += 64) hvd[j] = src[j];
+                const unsigned long long* src = reinterpret_cast<const unsigned long long*>(xrows + (int64_t)row * wl.row_elems);
+                for (int j = imp_hi + 1 + lane; j <= cfin; j += 64) {
+                    const unsigned long long e = __hip_atomic_load(&src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hvd[j] = make_int2((int)(unsigned)e, (int)(unsigned)(e >> 32));
+                }
                 imp_hi = cfin;
                 return;
             }
+            // Strips of one workgroup hand their rows over in LDS, and the LDS executes a wave's operations
+            // in order: a relaxed read of the progress word, then the entries.
             const int need = prod_pass * ngroups + need_groups;
             while (true) {
-                const int have = __hip_atomic_load(&prog[prev_wave], __ATOMIC_ACQUIRE,
+                const int have = __hip_atomic_load(&prog[prev_wave], __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (__builtin_amdgcn_readfirstlane(have) >= need) break;
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
         // progress is published after groups 0, CHK, 2 CHK, ...: the consumer's needs are 1 mod CHK
         auto publish = [&](int g) {
             if (WIDE && wave == W - 1) {
-                if (((g % kCheck) == 0 || g == ngroups - 1) && s + 1 < nstrips) {
+                if (((g % XCHK) == 0 || g == ngroups - 1) && s + 1 < nstrips) {
+                    // Export: the newly final columns of this strip's bottom row go to the row in HBM with
+                    // WRITE-THROUGH stores (8-byte sc1: no release fence, whose L2 write-back stalled this
+                    // wave ~2 us per export).  The progress word may only follow stores that have completed;
+                    // instead of draining the queue here (the group's pointer-byte store has just been
+                    // issued), the word of the PREVIOUS export is set now: XCHK groups -- one vector-memory
+                    // operation each -- have been issued since its stores, so once all but the XCHK / 2
+                    // youngest operations are done, they are.  The last export of a strip drains.
+                    int* const word = &gprog[s / W];
+                    if (exp_pending > 0 && g != ngroups - 1) {    // (the last export may follow the one before closely: it drains)
+                        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(XCHK / 2) : "memory");
+                        if (lane == 0) __hip_atomic_store(word, exp_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     // lane 63 has finished columns <= k - 62 of this strip's bottom row
                     const int cfin = (g == ngroups - 1) ? m : min(m, (g + 1) * SPG - 1 - 62);
-                    int2* dst = xrows + (int64_t)(s / W) * wl.row_elems;
-                    for (int j = exp_hi + 1 + lane; j <= cfin; j += 64) dst[j] = hvd[j];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // lane 63's entries are in LDS
+                    unsigned long long* dst = reinterpret_cast<unsigned long long*>(xrows + (int64_t)(s / W) * wl.row_elems);
+                    for (int j = exp_hi + 1 + lane; j <= cfin; j += 64) {
+                        const int2 e = hvd[j];
+                        __hip_atomic_store(&dst[j], ((unsigned long long)(unsigned)e.y << 32) | (unsigned)e.x,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     exp_hi = max(exp_hi, cfin);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    if (lane == 0)
-                        __hip_atomic_store(&gprog[s / W], g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    exp_pending = g + 1;
+                    if (g == ngroups - 1) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) __hip_atomic_store(word, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        exp_pending = 0;
+                    }
                 }
                 return;
             }
             if (W == 1) return;
             if ((g % CHK) == 0 || g == ngroups - 1) {
+                // lane 63's hand-off entries and the progress word are LDS writes of one wave: in order.
+                // (An atomic RELEASE store would also drain this wave's pointer-byte stores -- a round trip
+                // to HBM per publish, which a lone wave on its SIMD has nothing to hide behind.)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 63)
-                    __hip_atomic_store(&prog[wave], pass * ngroups + g + 1, __ATOMIC_RELEASE,
+                    __hip_atomic_store(&prog[wave], pass * ngroups + g + 1, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         };
@@ -216,6 +261,20 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
                 load_group(g + 1);
             }
         };
+        // the strip's groups with the cell in the problem's form (FORM: 0 general, 1 carried, 2 carried
+        // with one gap open)
+        auto run = [&](auto form_tag) {
+        constexpr int FORM = decltype(form_tag)::value;
+        auto cell = [&](int d_ul, int x_u, int y_l, int t, int o, int& d, int& x, int& y) -> unsigned {
+            if constexpr (FORM == 0) return cell_c(kr, d_ul, x_u, y_l, t, o, d, x, y);
+            else return cell_carried_tagged_c<FORM == 2>(kr, d_ul, x_u, y_l, t, o, d, x, y);
+        };
+        // 16 pointer bytes of a group (byte q * R + r: step q, row r) -> one 16-byte piece
+        auto store_piece = [&](int gg, const unsigned (&bb)[16]) {
+            *reinterpret_cast<uint4*>(out + (int64_t)gg * 1024) =
+                make_uint4(pack4(bb[0], bb[1], bb[2], bb[3]), pack4(bb[4], bb[5], bb[6], bb[7]),
+                           pack4(bb[8], bb[9], bb[10], bb[11]), pack4(bb[12], bb[13], bb[14], bb[15]));
+        };
         // one group with per-lane activity tests (ramp-up, ramp-down, short rows)
         auto group_edge = [&](int g) {
             int oc[SPG];
@@ -223,7 +282,9 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
 #pragma unroll
             for (int q = 0; q < SPG; ++q) { oc[q] = oc_next[q]; hd[q] = hd_next[q]; }
             prefetch(g);
-            unsigned acc[4] = {0u, 0u, 0u, 0u};
+            unsigned bb[16];
+#pragma unroll
+            for (int x = 0; x < 16; ++x) bb[x] = 0u;
 #pragma unroll
             for (int q = 0; q < SPG; ++q) {
                 const int k = g * SPG + q;
@@ -234,22 +295,18 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
                 wave_shr1_pair<4>(v_up, V[R - 1], d_next, D[R - 1]);
                 if (active) {
                     int d_ul = dsave, v_u = v_up;
-                    unsigned b[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int d_old = D[r];
-                        b[r] = cell_hw(kr, d_ul, v_u, H[r], tc[r], oc[q], D[r], V[r], H[r]);
+                        bb[q * R + r] = cell(d_ul, v_u, H[r], tc[r], oc[q], D[r], V[r], H[r]);
                         d_ul = d_old;
                         v_u = V[r];
                     }
-#pragma unroll
-                    for (int x = 0; x < DW; ++x)
-                        acc[q * DW + x] = pack4(b[4 * x], b[4 * x + 1], b[4 * x + 2], b[4 * x + 3]);
                     dsave = d_next;
                     if (lane == 63) hvd[j] = make_int2(V[R - 1], D[R - 1]);
                 }
             }
-            *reinterpret_cast<uint4*>(out + (int64_t)g * 1024) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+            store_piece(g, bb);
             publish(g);
         };
 
@@ -284,30 +341,91 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
                 }
             };
             auto steady = [&](int gg, const int (&oc)[SPG], const int2 (&hd)[SPG]) {
-                unsigned acc[4];
+                unsigned bb[16];
 #pragma unroll
                 for (int q = 0; q < SPG; ++q) {
                     int v_up = hd[q].x, d_next = hd[q].y;
                     wave_shr1_pair<1>(v_up, V[R - 1], d_next, D[R - 1]);
                     int d_ul = dsave, v_u = v_up;
-                    unsigned b[R];
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int d_old = D[r];
-                        b[r] = cell_hw(kr, d_ul, v_u, H[r], tc[r], oc[q], D[r], V[r], H[r]);
+                        bb[q * R + r] = cell(d_ul, v_u, H[r], tc[r], oc[q], D[r], V[r], H[r]);
                         d_ul = d_old;
                         v_u = V[r];
                     }
-#pragma unroll
-                    for (int x = 0; x < DW; ++x)
-                        acc[q * DW + x] = pack4(b[4 * x], b[4 * x + 1], b[4 * x + 2], b[4 * x + 3]);
                     dsave = d_next;
                     wptr[q] = make_int2(V[R - 1], D[R - 1]);
                 }
                 wptr += winc;
-                *reinterpret_cast<uint4*>(out + (int64_t)gg * 1024) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+                store_piece(gg, bb);
                 publish(gg);
             };
+            // Blocks of CHK groups with running pointers: one progress wait and one publish per block at
+            // fixed places in straight-line code, no per-group conditions, clamps or index arithmetic.  A
+            // wave ALONE on its SIMD -- the latency-shaped launches, a few problems spread over the chip --
+            // issues one instruction of ANY kind per ~5.5 cycles (tools/ubench/lone_wave.hip), so the ~25
+            // scalar instructions per step that the per-group form spent on control were a quarter of
+            // such a launch's critical path.
+            if constexpr (CHK % 2 == 0) {
+                if ((g % CHK) == 0 && g + CHK < g_hi) {
+                    const uint16_t* ocp = ocode + (kOPad + (g + 1) * SPG - lane);   // codes of the next group to fetch
+                    const int2* hvp = hvd + ((g + 1) * SPG + 1);                    // its hand-off entries: all <= m here
+                    uint8_t* outp = out + (int64_t)g * 1024;
+                    int* const pw = (lane == 63) ? &prog[wave] : reinterpret_cast<int*>(dummy + lane);
+                    int pv = pass * ngroups + g + 1;
+                    auto fetch_fast = [&](int (&oc)[SPG], int2 (&hd)[SPG]) {
+#pragma unroll
+                        for (int q = 0; q < SPG; ++q) { oc[q] = ocp[q]; hd[q] = hvp[q]; }
+                        ocp += SPG; hvp += SPG;
+                    };
+                    auto steady_fast = [&](const int (&oc)[SPG], const int2 (&hd)[SPG]) {
+                        unsigned bb[16];
+#pragma unroll
+                        for (int q = 0; q < SPG; ++q) {
+                            int v_up = hd[q].x, d_next = hd[q].y;
+                            wave_shr1_pair_sched(v_up, V[R - 1], d_next, D[R - 1]);
+                            int d_ul = dsave, v_u = v_up;
+#pragma unroll
+                            for (int r = 0; r < R; ++r) {
+                                const int d_old = D[r];
+                                bb[q * R + r] = cell(d_ul, v_u, H[r], tc[r], oc[q], D[r], V[r], H[r]);
+                                d_ul = d_old;
+                                v_u = V[r];
+                            }
+                            dsave = d_next;
+                            wptr[q] = make_int2(V[R - 1], D[R - 1]);
+                        }
+                        wptr += winc;
+                        *reinterpret_cast<uint4*>(outp) =
+                            make_uint4(pack4(bb[0], bb[1], bb[2], bb[3]), pack4(bb[4], bb[5], bb[6], bb[7]),
+                                       pack4(bb[8], bb[9], bb[10], bb[11]), pack4(bb[12], bb[13], bb[14], bb[15]));
+                        outp += 1024;
+                    };
+                    while (g + CHK < g_hi) {
+                        wait_span(g);                       // covers the fetches of groups g + 1 .. g + CHK
+                        fetch_fast(ocB, hdB);
+                        steady_fast(ocA, hdA);
+                        // progress after the block's first group (g = 0 mod CHK): the consumer's needs are 1 mod CHK
+                        if (WIDE && wave == W - 1) publish(g);
+                        else if (W > 1) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __hip_atomic_store(pw, pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        pv += CHK;
+                        fetch_fast(ocA, hdA);
+                        steady_fast(ocB, hdB);
+#pragma unroll
+                        for (int b2 = 2; b2 < CHK; b2 += 2) {
+                            fetch_fast(ocB, hdB);
+                            steady_fast(ocA, hdA);
+                            fetch_fast(ocA, hdA);
+                            steady_fast(ocB, hdB);
+                        }
+                        g += CHK;
+                    }
+                }
+            }
             while (g + 1 < g_hi) {
                 fetch(g + 1, ocB, hdB);
                 steady(g, ocA, hdA);
@@ -327,6 +445,10 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
             }
         }
         for (; g < ngroups; ++g) group_edge(g);
+        };   // run
+        if (form == 2) run(std::integral_constant<int, 2>{});
+        else if (form == 1) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 0>{});
     }
 }
 
@@ -344,8 +466,8 @@ constexpr int kTbOps = 512;                   // alignment columns buffered per 
 
 template <int R>
 __global__ __launch_bounds__(64) void nw_traceback_kernel(NwArgs a) {
-    static_assert(R == 4, "window walk is written for 4 rows per lane");
     using L = PtrLayout<R>;
+    constexpr int SPG = L::SPG;
     __shared__ uint4 win[kTbGroups * 64];
     __shared__ uint8_t opsbuf[kTbOps];
     const int p = blockIdx.x, lane = threadIdx.x;
@@ -364,7 +486,7 @@ __global__ __launch_bounds__(64) void nw_traceback_kernel(NwArgs a) {
         int l = ((x - 1) % L::SR) / R;
         int r = (x - 1) % R;
         int k = (y - 1) + l;
-        const int g_hi = k >> 2;
+        const int g_hi = k / SPG;
         const int g_lo = max(0, g_hi - (kTbGroups - 1));
         {   // load the window: piece (g, lane) -> win[(g - g_lo) * 64 + lane]
             const uint8_t* base = ws_p + (int64_t)strip * strip_bytes + (int64_t)lane * 16;
@@ -375,11 +497,12 @@ __global__ __launch_bounds__(64) void nw_traceback_kernel(NwArgs a) {
         __syncthreads();
         const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
         if (first) {                                              // start state, textSeqCompare.py:102
-            st = ptr_pm(wb[(((k >> 2) - g_lo) * 64 + l) * 16 + (k & 3) * R + r]);
+            st = ptr_pm(wb[(((k / SPG) - g_lo) * 64 + l) * 16 + (k % SPG) * R + r]);
             first = false;
         }
         // walk while inside this window, a run at a time (nw_hw.h: walk_window_vec)
-        const int cnt = walk_window_vec(win, g_lo, g_lo * 4, strip * L::SR, x, y, st, opsbuf, kTbOps, lane);
+        const int cnt = walk_window_vec<false, 64, false, R>(win, g_lo, g_lo * SPG, strip * L::SR, x, y, st,
+                                                             opsbuf, kTbOps, lane);
         __syncthreads();
         for (int i = lane; i < cnt; i += 64) ops[cap - 1 - (len + i)] = opsbuf[i];
         len += cnt;
@@ -394,11 +517,26 @@ __global__ __launch_bounds__(64) void nw_traceback_kernel(NwArgs a) {
 
 using namespace ta;
 
-constexpr int kR = 4;          // rows per lane of the production kernel
+// Rows per lane.  R = 4 (256-row strips) is the throughput shape: two DPP shifts and one 16-byte store per
+// 16 cells.  A batch that cannot fill the chip with 256-row strips -- fewer than ~one strip per SIMD -- is
+// bound by the latency of its wavefronts instead (a strip's steps are issued by ONE wave, one instruction
+// per ~5.6 cycles, and a strip can start only ~86 steps behind the strip above): R = 2 (128-row strips)
+// halves the work of a step and doubles the strips in flight.  Chosen per launch from the batch size;
+// TA_NW_ROWS(r) in `flags` overrides (tests, timing).
+static int rows_per_lane(int nprob, int max_n, uint32_t flags) {
+    const int forced = (int)((flags >> TA_NW_ROWS_SHIFT) & 0x7u);
+    if (forced == 2 || forced == 4) return forced;
+    const int64_t strips4 = (int64_t)nprob * PtrLayout<4>::nstrips(max_n);
+    return strips4 < 1024 ? 2 : 4;                 // 1024 SIMDs
+}
+
+template <int R>
+static int64_t workspace_bytes_r(int n, int m) { return WideWs<R>(n, m).total; }
 
 extern "C" int64_t ta_nw_workspace_bytes(int32_t n, int32_t m) {
     if (n <= 0 || m <= 0) return 0;
-    return WideWs<kR>(n, m).total;
+    const int64_t a = workspace_bytes_r<4>(n, m), b = workspace_bytes_r<2>(n, m);
+    return a > b ? a : b;                          // whichever strip height the launch picks
 }
 
 extern "C" int32_t ta_nw_max_m(void) {
@@ -406,31 +544,55 @@ extern "C" int32_t ta_nw_max_m(void) {
     return 16000;
 }
 
-template <int W>
+// dynamic-LDS limit raise, once per kernel instantiation and device
+template <typename K>
+static hipError_t allow_full_lds(K kernel) {
+    constexpr int kMaxDev = 64;
+    static std::atomic<int> done[kMaxDev];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < kMaxDev && done[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && dev >= 0 && dev < kMaxDev) done[dev].store(1, std::memory_order_release);
+    return e;
+}
+
+template <int R, int W>
 static hipError_t launch_fill(const NwArgs& a, int max_m, hipStream_t st) {
     const size_t lds = NwLds(max_m).total;
-    // allow > 64 KiB of dynamic LDS: once per process, thread-safe (function-local static initialiser)
-    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&nw_fill_kernel<kR, W, false>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (once != hipSuccess) return once;
-    hipLaunchKernelGGL((nw_fill_kernel<kR, W, false>), dim3(a.nprob), dim3(W * 64), lds, st, a);
+    hipError_t e = allow_full_lds(&nw_fill_kernel<R, W, false>);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((nw_fill_kernel<R, W, false>), dim3(a.nprob), dim3(W * 64), lds, st, a);
     return hipGetLastError();
 }
 
 // few tall problems: spread each over ceil(nstrips / kWideW) workgroups so that every strip has a
 // SIMD of its own.  Block index = chunk * stride + p with stride a multiple of 8: workgroups are
 // dealt round-robin to the 8 XCDs, so all chunks of a problem share one L2 for the HBM hand-off rows.
+template <int R>
 static hipError_t launch_fill_wide(NwArgs a, int nstrips, int max_m, hipStream_t st) {
     const size_t lds = NwLds(max_m).total;
-    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&nw_fill_kernel<kR, kWideW, true>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (once != hipSuccess) return once;
+    hipError_t e = allow_full_lds(&nw_fill_kernel<R, kWideW, true>);
+    if (e != hipSuccess) return e;
     a.wide_stride = (a.nprob + 7) & ~7;
     const int chunks = (nstrips + kWideW - 1) / kWideW;
-    hipLaunchKernelGGL((nw_wide_init_kernel<kR>), dim3(a.nprob), dim3(64), 0, st, a);
-    hipLaunchKernelGGL((nw_fill_kernel<kR, kWideW, true>), dim3(a.wide_stride * chunks), dim3(kWideW * 64),
+    hipLaunchKernelGGL((nw_wide_init_kernel<R>), dim3(a.nprob), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((nw_fill_kernel<R, kWideW, true>), dim3(a.wide_stride * chunks), dim3(kWideW * 64),
                        lds, st, a);
     return hipGetLastError();
+}
+
+template <int R>
+static hipError_t launch_fill_r(const NwArgs& a, int max_n, int max_m, int nprob, uint32_t flags, hipStream_t st) {
+    const int nstrips = PtrLayout<R>::nstrips(max_n);
+    const bool wide = (flags & TA_NW_WIDE) ? true : (flags & TA_NW_NARROW) ? false
+                      : (nprob < 256 && nstrips > kWideW);
+    if (wide && nstrips > kWideW) return launch_fill_wide<R>(a, nstrips, max_m, st);
+    if (nstrips >= 8) return launch_fill<R, 8>(a, max_m, st);
+    if (nstrips >= 4) return launch_fill<R, 4>(a, max_m, st);
+    if (nstrips >= 2) return launch_fill<R, 2>(a, max_m, st);
+    return launch_fill<R, 1>(a, max_m, st);
 }
 
 extern "C" int ta_nw_batch(const int32_t* t_codes, const int64_t* t_off,
@@ -451,24 +613,21 @@ extern "C" int ta_nw_batch(const int32_t* t_codes, const int64_t* t_off,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     NwArgs a{t_codes, t_off, o_codes, o_off, params, params_stride, ws, ws_off,
              ops_out, ops_off, ops_len, nprob};
+    // fill and traceback of one batch must agree on the strip height: both derive it from the same
+    // (nprob, max_n, flags), so a caller that issues them as two calls passes the same three
+    const int rows = rows_per_lane(nprob, max_n, flags);
     if (flags & TA_NW_FILL) {
         if (max_n > 0 && max_m > 0) {
             if (!t_codes || !o_codes || !ws) return ta_fail(TA_EINVAL, "null code/workspace pointer");
-            const int nstrips = PtrLayout<kR>::nstrips(max_n);
-            hipError_t e;
-            const bool wide = (flags & TA_NW_WIDE) ? true : (flags & TA_NW_NARROW) ? false
-                              : (nprob < 256 && nstrips > kWideW);
-            if (wide && nstrips > kWideW) e = launch_fill_wide(a, nstrips, max_m, st);
-            else if (nstrips >= 8) e = launch_fill<8>(a, max_m, st);
-            else if (nstrips >= 4) e = launch_fill<4>(a, max_m, st);
-            else if (nstrips >= 2) e = launch_fill<2>(a, max_m, st);
-            else e = launch_fill<1>(a, max_m, st);
+            const hipError_t e = rows == 2 ? launch_fill_r<2>(a, max_n, max_m, nprob, flags, st)
+                                           : launch_fill_r<4>(a, max_n, max_m, nprob, flags, st);
             if (e != hipSuccess) return ta_fail_hip(e, "nw_fill_kernel launch");
         }
     }
     if (flags & TA_NW_TRACEBACK) {
         if (!ops_out && (max_n + max_m) > 0) return ta_fail(TA_EINVAL, "null ops_out");
-        hipLaunchKernelGGL((nw_traceback_kernel<kR>), dim3(nprob), dim3(64), 0, st, a);
+        if (rows == 2) hipLaunchKernelGGL((nw_traceback_kernel<2>), dim3(nprob), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((nw_traceback_kernel<4>), dim3(nprob), dim3(64), 0, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return ta_fail_hip(e, "nw_traceback_kernel launch");
     }

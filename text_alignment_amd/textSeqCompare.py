@@ -114,6 +114,8 @@ class NWBatch(object):
         # phase 1 with exactly this many waves per workgroup (None = the library's own choice)
         self.no_profile = False
         self.waves = None
+        # one-pass fill: rows per lane (2 or 4; None = the library's choice by batch size)
+        self.rows = None
         p = np.asarray(params, dtype=np.int64)
         if p.ndim == 1:
             p = p.reshape(1, 6)
@@ -180,6 +182,8 @@ class NWBatch(object):
             flags |= self.phase1_flags()
         if self.wide is not None and not self.two_phase:
             flags |= _native.TA_NW_WIDE if self.wide else _native.TA_NW_NARROW
+        if self.rows and not self.two_phase:
+            flags |= (int(self.rows) & 0x7) << _native.TA_NW_ROWS_SHIFT
         stream = torch.cuda.current_stream(self.device).cuda_stream
         entry = _native.lib.ta_nw2_batch if self.two_phase else _native.lib.ta_nw_batch
         rc = entry(
