@@ -489,6 +489,7 @@ __global__ __launch_bounds__(64) void nw_traceback_kernel(NwArgs a) {
         const int g_hi = k / SPG;
         const int g_lo = max(0, g_hi - (kTbGroups - 1));
         {   // load the window: piece (g, lane) -> win[(g - g_lo) * 64 + lane]
+            // (all 32 loads in flight at once through a register array was tried: 2x slower, the array spills)
             const uint8_t* base = ws_p + (int64_t)strip * strip_bytes + (int64_t)lane * 16;
 #pragma unroll 8
             for (int it = 0; it <= g_hi - g_lo; ++it)
