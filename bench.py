@@ -53,7 +53,7 @@ def measured_traffic(batch, n, m, kernel):
     profiles/ (WRITE_SIZE + 2 x FETCH_SIZE, MI355X_MICROARCH.md HBM section) -- a number read from
     that file, not measured in this run; (None, None) for configs that were not profiled."""
     stem = "nw2_hbm_traffic.json" if kernel == "nw_score_kernel" else "nw_hbm_traffic.json"
-    name, path = _profile_file("r02_" + stem, "r01_" + stem)
+    name, path = _profile_file("r03_" + stem, "r02_" + stem, "r01_" + stem)
     try:
         with open(path) as f:
             d = json.load(f)
@@ -69,7 +69,7 @@ def measured_traffic(batch, n, m, kernel):
 def measured_mfma_busy(kernel):
     """MFMA pipe utilisation of a recogniser kernel from the counter pass kept under profiles/
     (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD-cycles, 1920-line workload); (None, None) if absent."""
-    name, path = _profile_file("r02_ocr_pmc_mfma.json", "r01_ocr_pmc_mfma.json")
+    name, path = _profile_file("r03_ocr_pmc_mfma.json", "r02_ocr_pmc_mfma.json", "r01_ocr_pmc_mfma.json")
     try:
         with open(path) as f:
             for k, v in json.load(f)["kernels"].items():

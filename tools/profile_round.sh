@@ -10,7 +10,7 @@
 # 4. matrix-pipe counters of the recogniser kernels (1920 lines, both modes) -> <round>_ocr_pmc_mfma.json
 # then (where gpurun_out/ was merged back): python3 tools/profile_summarise.py <round> gpurun_out/prof_<round>
 set -eo pipefail
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$ROUND
 mkdir -p "$OUT"
@@ -19,7 +19,12 @@ cd /tmp
 NW="--steps 5 --warmup 2 --no-cpu-baseline --no-pipelined --no-configs --no-ocr --pages 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_nw" -o nw -- python3 "$REPO/bench.py" $NW > "$OUT/kt_nw.log" 2>&1
 echo "nw kernel trace done"
-for w in "1920 split" "1920 f32" "5760 split"; do
+for w in "1 4096 4096" "64 4096 4096" "1 8192 8192"; do
+  set -- $w
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_onepass_$1x$2" -o nw -- python3 "$REPO/tools/onepass_time.py" $1 $2 $3 > "$OUT/kt_onepass_$1x$2.log" 2>&1
+  echo "one-pass $1 x $2 kernel trace done"
+done
+for w in "1920 f32" "1920 split" "5760 f32"; do
   set -- $w
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_$1_$2" -o ocr -- python3 "$REPO/tools/ocr_only.py" $1 $2 > "$OUT/kt_ocr_$1_$2.log" 2>&1
   echo "ocr $1 $2 kernel trace done"
