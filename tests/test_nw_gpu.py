@@ -288,6 +288,32 @@ def test_fuzz_2000_problems_one_launch(tsc, two_phase):
     assert not bad, bad[:10]
 
 
+@pytest.mark.parametrize("wide", [None, True], ids=["auto", "wide"])
+def test_fuzz_tall_problems_every_one_pass_launch_shape(tsc, rows, wide):
+    """800 ragged problems up to 2600 x 2600 -- several strips per problem, strips handed from wave to wave
+    (progress words in LDS) and, in the wide launch, from workgroup to workgroup (write-through rows in
+    HBM) -- for both strip heights, twice over the same buffers.  This is the test that catches a missing
+    progress wait: round 3's first block loop fetched a hand-off group without one, which only a fuzz of
+    tall problems showed (1 problem in 800, not every run)."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(11)
+    special = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049]
+    t_list, o_list, prm = [], [], []
+    for k in range(800):
+        n = int(rng.choice(special)) if rng.random() < 0.4 else int(rng.integers(1, 2600))
+        m = int(rng.choice(special)) if rng.random() < 0.4 else int(rng.integers(1, 2600))
+        t, o = _random_problem(rng, n, m, [2, 3, 5, 27, 31][k % 5], rng.random() < 0.6)
+        t_list.append(t); o_list.append(o); prm.append(SYSTEMS[int(rng.integers(0, len(SYSTEMS)))])
+    batch = tsc.NWBatch(t_list, o_list, prm, two_phase=False, wide=wide)
+    batch.rows = rows
+    want = [nw_oracle.align_ids(t_list[k], o_list[k], prm[k]).tolist() for k in range(800)]
+    for rep in range(2):
+        batch.run()
+        res = batch.results()
+        bad = [k for k in range(800) if res[k].tolist() != want[k]]
+        assert not bad, (rep, [(k, len(t_list[k]), len(o_list[k]), prm[k]) for k in bad[:5]])
+
+
 def test_overflow_guard_routes_to_general_kernel(tsc):
     from oracle import nw_oracle
     t, o = list("abcabcabc"), list("abcbcaabc")

@@ -424,6 +424,9 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
                         }
                         g += CHK;
                     }
+                    // the per-group loop below waits when it FETCHES a group that is 0 mod CHK; group g was
+                    // fetched by the last block without that wait, so take it here (covers g + 1 .. g + CHK)
+                    wait_span(g);
                 }
             }
             while (g + 1 < g_hi) {

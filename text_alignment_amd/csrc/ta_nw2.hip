@@ -81,11 +81,13 @@ __device__ __forceinline__ void cell_raw_hw(const RawRegs& k, int d_ul, int v_u,
     h = v_max3(mr, xg, h_l);
 }
 
-// carried form (nw_cell.h: cell_update_carried), compare-select score
+// carried form (nw_cell.h: cell_update_carried), compare-select score.  Plain C: hipcc selects v_max3_i32
+// for the nested max itself and, unlike between asm statements, pads nothing (the predicated start-up
+// groups that run this form were twice as expensive per cell as the steady ones).
 __device__ __forceinline__ void cell_carried_hw(const RawRegs& k, int d_ul, int xg_u, int yg_l, int t, int o,
                                                 int& d, int& xg, int& yg) {
-    const int mr = d_ul + v_score(t, o, k.cmis, k.cmat);
-    d = v_max3(mr, xg_u, yg_l);
+    const int mr = d_ul + ((t == o) ? k.cmat : k.cmis);
+    d = c_max3(mr, xg_u, yg_l);
     xg = max(d + k.gox, xg_u);
     yg = max(d + k.goy, yg_l);
 }
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
                 const int j = k - lane + 1;
                 const bool active = (j >= 1) && (j <= m) && lane_has_rows;
                 int v_up = hd[q].x, d_next = hd[q].y;
-                wave_shr1_pair<4>(v_up, V[R - 1], d_next, D[R - 1]);
+                wave_shr1_pair_sched(v_up, V[R - 1], d_next, D[R - 1]);
                 if (active) {
                     int d_ul = dsave, v_u = v_up;
 #pragma unroll

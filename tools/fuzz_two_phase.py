@@ -1,6 +1,6 @@
-"""Ad-hoc fuzz of the two-phase aligner against the C oracle: random sizes around strip / block /
-checkpoint borders, every scoring system of the test suite, similar and unrelated sequences.
-    python tools/fuzz_two_phase.py [rounds] [seed]"""
+"""Ad-hoc fuzz of the aligner against the C oracle: random sizes around strip / block / checkpoint
+borders, every scoring system of the test suite, similar and unrelated sequences.
+    python tools/fuzz_two_phase.py [rounds] [seed] [two-phase | rows2 | rows4 | rows2-wide | rows4-wide]"""
 import os
 import sys
 
@@ -16,6 +16,7 @@ SYSTEMS = [[8, -4, -7, -7, -3, 0], [10, -5, -7, -7, -7, -7], [5, -10, -2, -7, 0,
            [2, -1, 1, -3, -1, 1], [0, 0, 0, 0, 0, 0], [4, -6, -9, -1, -2, -4], [7, 7, 3, 2, 1, 1]]
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+shape = sys.argv[3] if len(sys.argv) > 3 else "two-phase"
 special = [1, 2, 3, 4, 63, 64, 65, 255, 256, 257, 258, 511, 512, 513, 768, 769, 1023, 1024, 1025, 2047, 2048, 2049]
 bad = 0
 for rnd in range(rounds):
@@ -41,7 +42,11 @@ for rnd in range(rounds):
     same_sys = rnd % 2 == 1
     if same_sys:
         prm = SYSTEMS[rnd % len(SYSTEMS)]
-    batch = tsc.NWBatch(t_list, o_list, prm, two_phase=True)
+    if shape == "two-phase":
+        batch = tsc.NWBatch(t_list, o_list, prm, two_phase=True)
+    else:
+        batch = tsc.NWBatch(t_list, o_list, prm, two_phase=False, wide=True if shape.endswith("wide") else None)
+        batch.rows = 2 if shape.startswith("rows2") else 4
     batch.run()
     torch.cuda.synchronize()
     res = batch.results()
