@@ -208,7 +208,11 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
     // A chunk = the KCG groups between two state checkpoints.  The chunk the walk is in is re-filled
     // with the tagged cell from its checkpoint (in carried form when phase 1 used it); its first two
     // steps carry no valid tags, so when the walk gets there the chunk before is re-filled one group
-    // further (g_top = the first group of the chunk just left).  (GSPAN is unused by this data flow.)
+    // further (g_top = the first group of the chunk just left).  Of a chunk's pointer bytes only the lanes
+    // l_lo .. l_lo + WL - 1 are kept, l_lo = max(0, entry lane - WL + 1) (WL = GSPAN if 0 < GSPAN < 64, else all
+    // 64: nw_trace2_kernel's kWinLanes): a walk that needs a lane above l_lo stops, and the SAME chunk is
+    // re-filled up to the group the walk stands in with the window at its lane.  Bytes outside the window
+    // stay 0xEE here, so a walk that read one would fail with -7.
     (void)GSPAN;
     const int xadj6 = xadj * 64, yadj6 = yadj * 64;
     std::vector<uint8_t> rev;
@@ -265,6 +269,8 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
             }
             // tagged fill of groups g0..g_top into the chunk buffer; the tagged outputs of the strip's
             // bottom row are kept per step for a pending state
+            const int WL = (GSPAN > 0 && GSPAN < 64) ? GSPAN : 64;
+            const int l_lo = std::max(0, l - (WL - 1));
             std::vector<uint8_t> wbuf((size_t)(g_top - g0 + 1) * 1024, 0xEE);
             std::vector<int> capV((size_t)(g_top - g0 + 1) * SPG, 0), capD(capV.size(), 0);
             std::vector<char> capOk(capV.size(), 0);
@@ -306,7 +312,7 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
                         capV[kk - k0] = V[kLanes - 1][R - 1]; capD[kk - k0] = D[kLanes - 1][R - 1]; capOk[kk - k0] = 1;
                     }
                 }
-                for (int ll = 0; ll < kLanes; ++ll) memcpy(&wbuf[((size_t)(g - g0) * 64 + ll) * 16], acc[ll], 16);
+                for (int ll = l_lo; ll < std::min(kLanes, l_lo + WL); ++ll) memcpy(&wbuf[((size_t)(g - g0) * 64 + ll) * 16], acc[ll], 16);
             }
             auto byte_at = [&](int ll, int rr, int kk) -> unsigned {
                 return wbuf[((size_t)(kk / SPG - g0) * 64 + ll) * 16 + (kk % SPG) * R + rr];
@@ -325,7 +331,7 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
             }
             if (first && k >= kvalid) { st = ptr_pm(byte_at(l, r, k)); first = false; }   // start state, textSeqCompare.py:102
             int steps = 0;
-            while (x > 0 && y > 0 && l >= 0 && k >= kvalid) {
+            while (x > 0 && y > 0 && l >= l_lo && k >= kvalid) {
                 if (k / SPG > g_top) return -6;               // would read past what this chunk re-filled
                 const unsigned b = byte_at(l, r, k);
                 if (b == 0xEE) return -7;
@@ -340,7 +346,10 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
                 ++steps;
             }
             if (x <= 0 || y <= 0 || l < 0) in_strip = false;
-            else {
+            else if (k >= kvalid) {
+                if (steps == 0) return -12;                   // no progress: the entry lane is always in its window
+                g_top = k / SPG;                              // ran off the window's top lane: same chunk, window at l
+            } else {
                 g_top = g0;
                 ck -= 1;
                 if (ck < 0) return -5;

@@ -87,10 +87,13 @@ def test_sim_matches_oracle_synth(sim, R):
         assert got.tolist() == want.tolist(), (R, n, m, seed)
 
 
-@pytest.mark.parametrize("kcg,gspan", [(1, 1), (2, 3), (4, 8), (12, 12), (16, 16), (32, 96)])
+@pytest.mark.parametrize("kcg,gspan", [(1, 1), (2, 3), (4, 8), (12, 12), (16, 16), (16, 32), (32, 96)])
 def test_two_phase_sim_matches_oracle(sim, kcg, gspan):
-    """Checkpointed score-only fill + windowed tagged re-fill (the two-phase aligner's data flow):
-    tiny checkpoint periods and spans force many restarts, multi-window strips and halo steps."""
+    """Checkpointed score-only fill + chunked tagged re-fill (the two-phase aligner's data flow): tiny
+    checkpoint periods force many restarts and halo steps; `gspan` below 64 is the number of lanes of a
+    chunk whose pointer bytes are kept (nw_trace2_kernel keeps 32 at a checkpoint period of 16): windows
+    of 1 .. 16 lanes make the walk run off the window's top lane all the time, and the chunk is then
+    re-filled around the new position."""
     rng = np.random.default_rng(500 + kcg)
     for k in range(60):
         asz = [2, 4, 27][k % 3]
@@ -109,6 +112,14 @@ def test_two_phase_sim_matches_oracle(sim, kcg, gspan):
         t, o = synth_pair_ids(n, m, seed)
         want = nw_oracle.align_ids(t, o, SYSTEMS[0])
         assert _sim2_ops(sim, t, o, SYSTEMS[0], 4, kcg, gspan).tolist() == want.tolist()
+    # long runs of transcript-side gaps: the walk climbs many lanes inside one chunk
+    for runlen, at in [(150, 100), (400, 0), (300, 250)]:
+        base = rng.integers(0, 27, size=400)
+        junk = 27 + rng.integers(0, 3, size=runlen)
+        t = np.concatenate([base[:at], junk, base[at:]])
+        for sc in ([8, -4, -7, -7, 0, 0], SYSTEMS[0]):
+            want = nw_oracle.align_ids(t, base, sc)
+            assert _sim2_ops(sim, t, base, sc, 4, kcg, gspan).tolist() == want.tolist(), (runlen, at, sc, kcg, gspan)
     # walks that START in a strip's first row (n = 256 s + 1: the start state is a tag of the strip
     # above) and that cross strip borders in every state, under every scoring system
     for k, (n, m) in enumerate([(257, 300), (513, 1), (257, 1), (513, 2), (769, 640), (257, 64), (512, 300),

@@ -143,7 +143,7 @@ def run(npages, seed0=100):
     torch.cuda.synchronize()
     raw_dt = time.perf_counter() - t2
     # and from whole page images: preprocessing and line finding on the device as well
-    nimg = min(npages, 16)
+    nimg = min(npages, 32)
     ipages = [RawPage(make_page_image(seed0 + 9000 + k)) for k in range(nimg)]
     itrs = list(trs[:nimg])
     atocr.process_batch(ipages[:2], itrs[:2], rec, PARAMS)
