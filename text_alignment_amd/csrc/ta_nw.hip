@@ -491,12 +491,18 @@ __global__ __launch_bounds__(64) void nw_traceback_kernel(NwArgs a) {
         int k = (y - 1) + l;
         const int g_hi = k / SPG;
         const int g_lo = max(0, g_hi - (kTbGroups - 1));
-        {   // load the window: piece (g, lane) -> win[(g - g_lo) * 64 + lane]
-            // (all 32 loads in flight at once through a register array was tried: 2x slower, the array spills)
+        {   // load the window: piece (g, lane) -> win[(g - g_lo) * 64 + lane].  A group's 64 pieces are 1 KiB
+            // contiguous both in the workspace and in the window, which is exactly the shape of the
+            // direct-to-LDS load (wave-uniform LDS base + 16 B per lane): no registers in between, so every
+            // load of the window is in flight at once and the window costs ONE memory latency (batches of
+            // eight through registers cost four, ~6 us per window of a wave that has nothing to hide them
+            // behind; a 32-deep register array spilled).
             const uint8_t* base = ws_p + (int64_t)strip * strip_bytes + (int64_t)lane * 16;
-#pragma unroll 8
             for (int it = 0; it <= g_hi - g_lo; ++it)
-                win[it * 64 + lane] = *reinterpret_cast<const uint4*>(base + (int64_t)(g_lo + it) * 1024);
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(base + (int64_t)(g_lo + it) * 1024),
+                    (__attribute__((address_space(3))) void*)(win + it * 64), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
         const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
