@@ -51,8 +51,9 @@ extern "C" {
 /* ta_nw2_batch launch-shape overrides (tests, A/B timing): phase 1 without the score profile even where
  * the hints allow it; phase 1 with exactly w waves per workgroup (1, 2, 4 or 8; ignored when the tallest
  * problem has fewer strips or the LDS does not hold it; 0 = the library's own choice). */
-/* ta_nw_batch launch-shape override (tests, timing): rows per lane of the one-pass fill, 2 or 4 (0 = the
- * library's choice: 2 for batches too small to give every SIMD a 256-row strip).  Fill and traceback of
+/* ta_nw_batch launch-shape override (tests, timing): rows per lane of the one-pass fill, 1, 2 or 4 (0 = the
+ * library's choice: 2 for batches too small to give every SIMD a 256-row strip, else 4; 1 -- 64-row
+ * strips -- measured slower than 2 at every size tried and is never chosen).  Fill and traceback of
  * one batch must be given the same value (and the same nprob / max_n), also when issued as two calls. */
 #define TA_NW_ROWS_SHIFT 20
 #define TA_NW_ROWS(r) (((uint32_t)(r) & 0x7u) << TA_NW_ROWS_SHIFT)

@@ -24,9 +24,10 @@ def two_phase(request):
     return request.param
 
 
-@pytest.fixture(params=[4, 2], ids=["rows4", "rows2"])
+@pytest.fixture(params=[4, 2, 1], ids=["rows4", "rows2", "rows1"])
 def rows(request):
-    """rows per lane of the one-pass fill (256- / 128-row strips); ignored by the two-phase aligner"""
+    """rows per lane of the one-pass fill (256- / 128- / 64-row strips; the library picks 4 or 2, 1 is
+    reachable through TA_NW_ROWS only); ignored by the two-phase aligner"""
     return request.param
 
 

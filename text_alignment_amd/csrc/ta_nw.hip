@@ -19,6 +19,7 @@
 // caller's buffer.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <atomic>
 #include <type_traits>
 
@@ -67,9 +68,9 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
     constexpr int SPG = L::SPG;
     // groups between two looks at the LDS progress word of the strip above: a strip follows the one
     // above at CHK + 17 groups (the wide launch exports to HBM every kCheck groups regardless)
-    constexpr int CHK = (R == 4) ? 4 : (R == 2 ? 2 : 1);   // ~16 .. 32 steps of look-ahead whatever the group length
-    // export grain of the wide launch (groups between two copies of the bottom row to HBM): ~64 steps
-    constexpr int XCHK = (R == 4) ? kCheck : (R == 2 ? 8 : 4);
+    constexpr int CHK = (R == 4) ? 4 : 2;                  // 16 .. 32 steps of look-ahead (R = 4: 16, R = 2: 16, R = 1: 32)
+    // export grain of the wide launch (groups between two copies of the bottom row to HBM): 32 .. 64 steps
+    constexpr int XCHK = (R == 4) ? kCheck : (R == 2 ? 8 : 2);
     static_assert(R == 1 || R == 2 || R == 4, "rows per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -532,10 +533,12 @@ using namespace ta;
 // bound by the latency of its wavefronts instead (a strip's steps are issued by ONE wave, one instruction
 // per ~5.6 cycles, and a strip can start only ~86 steps behind the strip above): R = 2 (128-row strips)
 // halves the work of a step and doubles the strips in flight.  Chosen per launch from the batch size;
-// TA_NW_ROWS(r) in `flags` overrides (tests, timing).
+// TA_NW_ROWS(r) in `flags` overrides (tests, timing).  R = 1 (64-row strips) is instantiated and tested but
+// never chosen: one 4096^2 problem fills in 0.92 ms against 0.76 ms at R = 2 (the 62-step lag between
+// strips is paid 64 times, and a step still costs ~30 instructions).
 static int rows_per_lane(int nprob, int max_n, uint32_t flags) {
     const int forced = (int)((flags >> TA_NW_ROWS_SHIFT) & 0x7u);
-    if (forced == 2 || forced == 4) return forced;
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
     const int64_t strips4 = (int64_t)nprob * PtrLayout<4>::nstrips(max_n);
     return strips4 < 1024 ? 2 : 4;                 // 1024 SIMDs
 }
@@ -545,8 +548,8 @@ static int64_t workspace_bytes_r(int n, int m) { return WideWs<R>(n, m).total; }
 
 extern "C" int64_t ta_nw_workspace_bytes(int32_t n, int32_t m) {
     if (n <= 0 || m <= 0) return 0;
-    const int64_t a = workspace_bytes_r<4>(n, m), b = workspace_bytes_r<2>(n, m);
-    return a > b ? a : b;                          // whichever strip height the launch picks
+    const int64_t a = workspace_bytes_r<4>(n, m), b = workspace_bytes_r<2>(n, m), c = workspace_bytes_r<1>(n, m);
+    return std::max(a, std::max(b, c));            // whichever strip height the launch picks
 }
 
 extern "C" int32_t ta_nw_max_m(void) {
@@ -629,14 +632,16 @@ extern "C" int ta_nw_batch(const int32_t* t_codes, const int64_t* t_off,
     if (flags & TA_NW_FILL) {
         if (max_n > 0 && max_m > 0) {
             if (!t_codes || !o_codes || !ws) return ta_fail(TA_EINVAL, "null code/workspace pointer");
-            const hipError_t e = rows == 2 ? launch_fill_r<2>(a, max_n, max_m, nprob, flags, st)
+            const hipError_t e = rows == 1 ? launch_fill_r<1>(a, max_n, max_m, nprob, flags, st)
+                                 : rows == 2 ? launch_fill_r<2>(a, max_n, max_m, nprob, flags, st)
                                            : launch_fill_r<4>(a, max_n, max_m, nprob, flags, st);
             if (e != hipSuccess) return ta_fail_hip(e, "nw_fill_kernel launch");
         }
     }
     if (flags & TA_NW_TRACEBACK) {
         if (!ops_out && (max_n + max_m) > 0) return ta_fail(TA_EINVAL, "null ops_out");
-        if (rows == 2) hipLaunchKernelGGL((nw_traceback_kernel<2>), dim3(nprob), dim3(64), 0, st, a);
+        if (rows == 1) hipLaunchKernelGGL((nw_traceback_kernel<1>), dim3(nprob), dim3(64), 0, st, a);
+        else if (rows == 2) hipLaunchKernelGGL((nw_traceback_kernel<2>), dim3(nprob), dim3(64), 0, st, a);
         else hipLaunchKernelGGL((nw_traceback_kernel<4>), dim3(nprob), dim3(64), 0, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return ta_fail_hip(e, "nw_traceback_kernel launch");
