@@ -69,9 +69,9 @@ const char* ta_last_error(void);
  * (reference textSeqCompare.py:13-177; called from alignToOCR.py:273).
  *
  * ta_nw_workspace_bytes: bytes of pointer-matrix workspace one n x m problem needs
- * (1 byte per DP cell plus the skew padding of the strip layout -- 63 columns per 128- or 256-row strip,
- * whichever the launch picks -- plus one 8(m+2)-byte hand-off row per four strips for the wide launch;
- * multiple of 1024).
+ * (1 byte per DP cell plus the skew padding of the strip layout -- 63 columns per strip, sized for the
+ * finest strips TA_NW_ROWS can ask for -- plus one 8(m+2)-byte hand-off row per four strips for the wide
+ * launch; multiple of 1024).
  */
 int64_t ta_nw_workspace_bytes(int32_t n, int32_t m);
 
