@@ -268,7 +268,8 @@ int ta_linenorm_resample(const uint8_t* pix, const int64_t* pix_off, const int32
  *
  * ta_pp_label: 8-connected components; lab[p] = linear index of the component's first pixel in
  *   raster order, -1 on background; stats = int32[5][h*w] = area, x0, y0, x1, y1, indexed by that
- *   root; flag = one device int.  Synchronises the stream between passes.
+ *   root; flag = one device int (unused since round 3: tiles are stitched by one lock-free union-find
+ *   pass, nothing iterates and nothing waits for the stream).
  * ta_pp_components: up to cap records {root, area, x0, y0, x1, y1} (any order), *count = true number.
  * ta_pp_filter_components: clears components with area < min_area or more than max_height rows.
  * ta_pp_angle_histograms: hist[a][row] of the page decimated by `step` and rotated by angle a

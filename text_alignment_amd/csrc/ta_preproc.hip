@@ -90,25 +90,75 @@ __global__ __launch_bounds__(kTileH * kTileW) void pp_label_tile_kernel(const ui
     }
 }
 
-__global__ __launch_bounds__(kPpThreads) void pp_label_scan_kernel(int32_t* lab, int h, int w, int32_t* changed) {
+// Second stage: stitch the tile-local components across tile borders with a lock-free union-find on the
+// label array itself (a root is a pixel whose label is its own index; the smaller index always wins, so a
+// component's final root is its raster-first pixel whatever the order of the unions).  Only pixels on a
+// tile's left / right column or bottom row have neighbours in another tile; each unites itself with its
+// "forward" neighbours (right, down-left, down, down-right) that lie in another tile, which covers every
+// cross-tile pair once.  ONE pass, no convergence loop and no host round trip: the first form (every
+// pixel lowering its root towards its smallest neighbour, then a flatten, repeated until a pass changed
+// nothing -- ~4 scan / flatten pairs and 2 host waits per labelling) was half of a page's kernel time.
+__device__ __forceinline__ int32_t uf_find(int32_t* lab, int32_t a) {
+    // with path halving: a node is re-pointed to its grandparent on the way (atomicMin: parents only ever
+    // decrease, so this can only shorten chains) -- the page background, once the image is inverted, is one
+    // component across thousands of tiles, and without it every union walks an ever longer chain
+    while (true) {
+        const int32_t p = __hip_atomic_load(&lab[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == a) return a;
+        const int32_t gp = __hip_atomic_load(&lab[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gp == p) return p;
+        atomicMin(&lab[a], gp);
+        a = gp;
+    }
+}
+__device__ __forceinline__ void uf_unite(int32_t* lab, int32_t a, int32_t b) {
+    while (true) {
+        a = uf_find(lab, a);
+        b = uf_find(lab, b);
+        if (a == b) return;
+        if (a > b) { const int32_t t = a; a = b; b = t; }          // the larger root goes under the smaller
+        const int32_t old = atomicMin(&lab[b], a);
+        if (old == b) return;                                       // b was still a root: linked
+        b = old;                                                    // b had been linked elsewhere meanwhile: unite with that
+    }
+}
+__device__ __forceinline__ void uf_link(int32_t* lab, int64_t a, int64_t b) {
+    // cheap look first, through the (possibly stale) L1: parents only ever move to smaller ancestors, so two
+    // walks that meet in one node prove the pixels connected whatever else is going on
+    int32_t ra = (int32_t)a, rb = (int32_t)b;
+    while (lab[ra] != ra) ra = lab[ra];
+    while (lab[rb] != rb) rb = lab[rb];
+    if (ra != rb) uf_unite(lab, ra, rb);
+}
+__global__ __launch_bounds__(kPpThreads) void pp_label_merge_kernel(int32_t* lab, int h, int w) {
+    // Work items: the ink pixels of every tile's right column, bottom row and left column.  A link is made
+    // only where no other link implies it: the straight neighbour across the border if it is ink (its own
+    // in-tile or cross-tile neighbours then carry the diagonals), the diagonals only where the straight one is
+    // background; and of a run of border pixels that all face ink only the first links (the others join the
+    // same two tile components).
     const int64_t n = (int64_t)h * w;
     for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
-        const int32_t mine = lab[e];
-        if (mine < 0) continue;
         const int y = (int)(e / w), x = (int)(e % w);
-        int32_t m = mine;
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int yy = y + dy, xx = x + dx;
-                if ((dy | dx) == 0 || yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
-                const int32_t q = lab[(int64_t)yy * w + xx];
-                if (q >= 0 && q < m) m = q;
+        const int cx = x % kTileW, cy = y % kTileH;
+        if (cx != 0 && cx != kTileW - 1 && cy != kTileH - 1) continue;
+        if (lab[e] < 0) continue;
+        auto ink = [&](int yy, int xx) { return lab[(int64_t)yy * w + xx] >= 0; };
+        if (cx == kTileW - 1 && x + 1 < w) {                           // the tile to the right
+            if (ink(y, x + 1)) {
+                if (!(cy != 0 && ink(y - 1, x) && ink(y - 1, x + 1))) uf_link(lab, e, e + 1);
+            } else if (y + 1 < h && ink(y + 1, x + 1)) {
+                uf_link(lab, e, e + w + 1);
             }
-        if (m < mine) {
-            atomicMin(&lab[mine], m);              // lower the root this pixel currently points at
-            *changed = 1;
+        }
+        if (cy == kTileH - 1 && y + 1 < h) {                           // the tile below
+            if (ink(y + 1, x)) {
+                if (!(cx != 0 && ink(y, x - 1) && ink(y + 1, x - 1))) uf_link(lab, e, e + w);
+            } else {
+                if (x > 0 && ink(y + 1, x - 1)) uf_link(lab, e, e + w - 1);
+                if (x + 1 < w && ink(y + 1, x + 1)) uf_link(lab, e, e + w + 1);
+            }
+        } else if (cx == 0 && x > 0 && y + 1 < h && !ink(y + 1, x) && ink(y + 1, x - 1)) {
+            uf_link(lab, e, e + w - 1);                                // down-left into the tile to the left
         }
     }
 }
@@ -422,8 +472,7 @@ extern "C" int ta_pp_threshold(const uint8_t* img, int64_t n, int32_t thr, int32
 
 // 8-connected components of `ink` (h x w): lab[p] = linear index of the component's first pixel,
 // -1 on background.  stats: five int32 arrays of h*w entries (area, x0, y0, x1, y1; indexed by the
-// root).  flag: one device int.  Synchronises the stream between passes (the iteration count is
-// data-dependent).
+// root).  flag: one device int, unused (nothing iterates any more).  Asynchronous on `stream`.
 extern "C" int ta_pp_label(const uint8_t* ink, int32_t h, int32_t w, int32_t* lab, int32_t* stats,
                            int32_t* flag, void* stream) {
     if (h < 0 || w < 0) return ta_fail(TA_EINVAL, "negative size");
@@ -435,22 +484,10 @@ extern "C" int ta_pp_label(const uint8_t* ink, int32_t h, int32_t w, int32_t* la
     const int nb = pp_blocks(n);
     hipLaunchKernelGGL(pp_label_tile_kernel, dim3((w + kTileW - 1) / kTileW, (h + kTileH - 1) / kTileH),
                        dim3(kTileH * kTileW), 0, st, ink, h, w, lab);
-    // stitching across tiles.  The iteration count is data-dependent: rounds of two scan / flatten
-    // pairs between looks at the flag (a pass over a converged labelling changes nothing, so overshooting is harmless and
-    // the host waits for the stream half as often)
-    for (int round = 0; round < 100000; ++round) {
-        hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), st);
-        if (e != hipSuccess) return ta_fail_hip(e, "label flag memset");
-        for (int k = 0; k < 2; ++k) {
-            hipLaunchKernelGGL(pp_label_scan_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, h, w, flag);
-            hipLaunchKernelGGL(pp_label_flatten_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, n);
-        }
-        int32_t changed = 0;
-        e = hipMemcpyAsync(&changed, flag, sizeof(int32_t), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) return ta_fail_hip(e, "label iteration");
-        if (!changed) break;
-    }
+    // stitching across tiles (one union-find pass over the tile borders) and path compression
+    hipLaunchKernelGGL(pp_label_merge_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, h, w);
+    hipLaunchKernelGGL(pp_label_flatten_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, n);
+    (void)flag;
     int32_t* area = stats; int32_t* x0 = stats + n; int32_t* y0 = stats + 2 * n;
     int32_t* x1 = stats + 3 * n; int32_t* y1 = stats + 4 * n;
     hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, area, n, 0);
@@ -462,17 +499,13 @@ extern "C" int ta_pp_label(const uint8_t* ink, int32_t h, int32_t w, int32_t* la
 }
 
 // The same for `nimg` images at once: ink / lab / stats are HOST arrays of device pointers, h / w host
-// arrays, flags nimg device ints.  The data-dependent iteration is shared: every image that is still
-// changing gets a round of two scan / flatten pairs, then ONE copy of all flags and ONE wait for the
-// stream -- two to four waits per batch instead of per image (a page's preprocessing labels four
-// times, and the waits, not the kernels, are what a page costs).
+// arrays (flags: unused since the labelling needs no convergence loop; kept in the signature).
 extern "C" int ta_pp_label_batch(int32_t nimg, const uint8_t* const* ink, const int32_t* h, const int32_t* w,
                                  int32_t* const* lab, int32_t* const* stats, int32_t* flags, void* stream) {
     if (nimg < 0) return ta_fail(TA_EINVAL, "negative size");
     if (nimg == 0) return TA_OK;
     if (!ink || !h || !w || !lab || !stats || !flags) return ta_fail(TA_EINVAL, "null pointer argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    std::vector<int32_t> changed(nimg, 0);
     std::vector<char> active(nimg, 0);
     for (int i = 0; i < nimg; ++i) {
         if (h[i] < 0 || w[i] < 0) return ta_fail(TA_EINVAL, "negative size");
@@ -484,27 +517,14 @@ extern "C" int ta_pp_label_batch(int32_t nimg, const uint8_t* const* ink, const 
         hipLaunchKernelGGL(pp_label_tile_kernel, dim3((w[i] + kTileW - 1) / kTileW, (h[i] + kTileH - 1) / kTileH),
                            dim3(kTileH * kTileW), 0, st, ink[i], h[i], w[i], lab[i]);
     }
-    for (int round = 0; round < 100000; ++round) {
-        hipError_t e = hipMemsetAsync(flags, 0, sizeof(int32_t) * nimg, st);
-        if (e != hipSuccess) return ta_fail_hip(e, "label flag memset");
-        bool any = false;
-        for (int i = 0; i < nimg; ++i) {
-            if (!active[i]) continue;
-            any = true;
-            const int64_t n = (int64_t)h[i] * w[i];
-            const int nb = pp_blocks(n);
-            for (int k = 0; k < 2; ++k) {
-                hipLaunchKernelGGL(pp_label_scan_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab[i], h[i], w[i], flags + i);
-                hipLaunchKernelGGL(pp_label_flatten_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab[i], n);
-            }
-        }
-        if (!any) break;
-        e = hipMemcpyAsync(changed.data(), flags, sizeof(int32_t) * nimg, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) return ta_fail_hip(e, "label iteration");
-        for (int i = 0; i < nimg; ++i)
-            if (active[i] && !changed[i]) active[i] = 0;
+    for (int i = 0; i < nimg; ++i) {
+        if (!active[i]) continue;
+        const int64_t n = (int64_t)h[i] * w[i];
+        const int nb = pp_blocks(n);
+        hipLaunchKernelGGL(pp_label_merge_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab[i], h[i], w[i]);
+        hipLaunchKernelGGL(pp_label_flatten_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab[i], n);
     }
+    (void)flags;
     for (int i = 0; i < nimg; ++i) {
         const int64_t n = (int64_t)h[i] * w[i];
         if (n == 0) continue;
