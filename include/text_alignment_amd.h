@@ -299,6 +299,12 @@ int ta_pp_open_runs(const uint8_t* in, uint8_t* out, int32_t h, int32_t w, int32
                     void* stream);
 int ta_pp_row_sums(const uint8_t* ink, int32_t h, int32_t w, int32_t* sums, void* stream);
 int ta_pp_clear_rows(uint8_t* ink, int32_t w, const int32_t* rows, int32_t nrows, void* stream);
+/* The text-line strips of a page, cut from its ink plane (h x w, non-zero = ink) into one packed buffer as
+ * the greyscale images the reference writes for the recogniser (alignToOCR.py:131-132; ink 0 on 255).
+ * boxes (device): nstrips x {ulx, uly, lrx, lry, byte offset of the strip in out}, inclusive corners inside
+ * the plane (the caller's to guarantee); strip s is row-major (lry - uly + 1) x (lrx - ulx + 1) at out + offset. */
+int ta_pp_cut_strips(const uint8_t* ink, int32_t h, int32_t w, const int64_t* boxes, int32_t nstrips,
+                     uint8_t* out, void* stream);
 
 #ifdef __cplusplus
 }

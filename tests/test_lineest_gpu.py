@@ -59,6 +59,27 @@ def test_device_normaliser_rejects_what_the_checker_rejects():
     assert x.shape == (0, 48) and len(T) == 0
 
 
+def test_strips_already_on_the_device_are_normalised_where_they_are():
+    """The device preprocessing leaves its strips on the GPU (Strip.device_pixels): the normaliser takes
+    them there, alone or mixed with host strips, bit for bit as from host arrays; a constant one is
+    refused (after the measuring pass, which finds its minimum and maximum anyway); `.pixels` downloads."""
+    from text_alignment_amd import lineest_gpu, page as page_mod
+    rng = np.random.default_rng(21)
+    strips = [_strip(rng, h, w) for h, w in [(44, 600), (50, 420), (61, 800), (38, 256)]]
+    on_dev = [torch.from_numpy(s).cuda() for s in strips]
+    x0, T0, _ = lineest_gpu.normalize_strips(strips)
+    for mix in (on_dev, [on_dev[0], strips[1], on_dev[2], strips[3]]):
+        x1, T1, _ = lineest_gpu.normalize_strips(mix)
+        assert np.array_equal(T0, T1) and torch.equal(x0, x1)
+    with pytest.raises(ValueError, match="empty or constant"):
+        lineest_gpu.normalize_strips([on_dev[0], torch.full((30, 100), 255, dtype=torch.uint8, device="cuda")])
+    with pytest.raises(TypeError):
+        lineest_gpu.normalize_strips([on_dev[0].t()])                       # not contiguous
+    st = page_mod.Strip(3, 4, 44, device_pixels=on_dev[0])
+    assert st.width == 600 and page_mod.prepared_line(st)[0] is on_dev[0]
+    assert np.array_equal(st.pixels, strips[0])
+
+
 def test_recogniser_takes_raw_strips():
     """LineRecognizer.prepare: raw uint8 strips (device normaliser) mixed with host-prepared lines
     give the rows the checker's normaliser gives, and the same decoded characters."""

@@ -106,6 +106,15 @@ def test_prepared_lines_hand_raw_strips_to_the_device_normaliser():
     assert got[2][0].dtype == np.uint8 and np.array_equal(got[2][0], raw.pixels)
     with pytest.raises(ValueError, match="empty or constant"):
         page_mod.prepared_lines([page_mod.Strip(0, 0, 40, pixels=np.full((40, 100), 255, np.uint8))])
+    # a strip whose pixels live in a tensor (on the GPU, after the device preprocessing): handed on as it is,
+    # `.pixels` reads it back once; assigning pixels drops the tensor
+    import torch
+    t = torch.from_numpy(np.where(ink, 0, 255).astype(np.uint8))
+    lazy = page_mod.Strip(1, 2, 50, device_pixels=t)
+    assert lazy.width == 300 and page_mod.prepared_lines([lazy])[0][0] is t
+    assert np.array_equal(lazy.pixels, raw.pixels) and lazy.pixels is lazy.pixels
+    lazy.pixels = raw.pixels
+    assert lazy.device_pixels is None and page_mod.prepared_lines([lazy])[0][0] is raw.pixels
     with pytest.raises(TypeError):
         page_mod.prepared_lines([page_mod.Strip(0, 0, 40, pixels=np.zeros((40, 100), np.float32))])
     with pytest.raises(TypeError):

@@ -429,6 +429,20 @@ __global__ __launch_bounds__(kPpThreads) void pp_row_sums_kernel(const uint8_t* 
     if (threadIdx.x == 0) sums[y] = sh[0];
 }
 
+// the text-line strips of a page, cut out of its ink plane into one packed buffer as the greyscale images the
+// reference saves for the recogniser (ink black on white): boxes[s] = {ulx, uly, lrx, lry, offset into out}
+__global__ __launch_bounds__(kPpThreads) void pp_cut_strips_kernel(const uint8_t* __restrict__ ink, int w,
+                                                                   const int64_t* __restrict__ boxes,
+                                                                   uint8_t* __restrict__ out) {
+    const int64_t* b = boxes + 5 * (int64_t)blockIdx.y;
+    const int ulx = (int)b[0], uly = (int)b[1], sw = (int)(b[2] - b[0]) + 1, sh = (int)(b[3] - b[1]) + 1;
+    uint8_t* o = out + b[4];
+    for (int y = blockIdx.x; y < sh; y += gridDim.x) {
+        const uint8_t* src = ink + (int64_t)(uly + y) * w + ulx;
+        for (int x = threadIdx.x; x < sw; x += kPpThreads) o[(int64_t)y * sw + x] = src[x] ? 0 : 255;
+    }
+}
+
 __global__ __launch_bounds__(kPpThreads) void pp_clear_rows_kernel(uint8_t* ink, int w, const int32_t* rows, int nrows) {
     const int r = rows[blockIdx.x];
     for (int x = threadIdx.x; x < w; x += kPpThreads) ink[(int64_t)r * w + x] = 0;
@@ -629,6 +643,17 @@ extern "C" int ta_pp_row_sums(const uint8_t* ink, int32_t h, int32_t w, int32_t*
     if (h) hipLaunchKernelGGL(pp_row_sums_kernel, dim3(h), dim3(kPpThreads), 0,
                               reinterpret_cast<hipStream_t>(stream), ink, h, w, sums);
     PP_LAUNCH_CHECK("pp_row_sums_kernel");
+    return TA_OK;
+}
+
+extern "C" int ta_pp_cut_strips(const uint8_t* ink, int32_t h, int32_t w, const int64_t* boxes, int32_t nstrips,
+                                uint8_t* out, void* stream) {
+    if (h < 0 || w < 0 || nstrips < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (nstrips == 0) return TA_OK;
+    if (!ink || !boxes || !out) return ta_fail(TA_EINVAL, "null pointer argument");
+    hipLaunchKernelGGL(pp_cut_strips_kernel, dim3(64, nstrips), dim3(kPpThreads), 0,
+                       reinterpret_cast<hipStream_t>(stream), ink, w, boxes, out);
+    PP_LAUNCH_CHECK("pp_cut_strips_kernel");
     return TA_OK;
 }
 

@@ -30,7 +30,8 @@ def _line_kernels(h):
 
 
 def normalize_strips(strips, device="cuda", want_debug=False):
-    """strips: list of 2-D uint8 arrays (white background).  Returns (x, T, debug): x = float32
+    """strips: list of 2-D uint8 images (white background), each a host array or a tensor already on
+    the device.  Returns (x, T, debug): x = float32
     device tensor [sum T, 48] (line b owns rows sum(T[:b]) .. + T[b]), T = int64 array of
     timesteps (normalised width + 32)."""
     dev = torch.device(device)
@@ -39,16 +40,23 @@ def normalize_strips(strips, device="cuda", want_debug=False):
     if n == 0:
         return torch.zeros((0, TARGET_HEIGHT), dtype=torch.float32, device=dev), np.zeros(0, np.int64), {}
     hh = np.zeros(n, np.int32); ww = np.zeros(n, np.int32)
+    on_device = [isinstance(s, torch.Tensor) for s in strips]
     for k, s in enumerate(strips):
-        s = np.asarray(s)
-        if s.ndim != 2 or s.dtype != np.uint8:
-            raise TypeError("the device normaliser takes 2-D uint8 strips")
-        if s.size == 0 or s.max() == s.min():
-            raise ValueError("empty or constant text-line image")
+        if on_device[k]:
+            if (s.dim() != 2 or s.dtype != torch.uint8 or not s.is_contiguous() or s.device.type != "cuda" or
+                    s.device.index != (torch.cuda.current_device() if dev.index is None else dev.index)):
+                raise TypeError("a device strip is a contiguous 2-D uint8 tensor on %s" % dev)
+            if s.numel() == 0:
+                raise ValueError("empty or constant text-line image")
+        else:
+            s = np.asarray(s)
+            if s.ndim != 2 or s.dtype != np.uint8:
+                raise TypeError("the device normaliser takes 2-D uint8 strips")
+            if s.size == 0 or s.max() == s.min():
+                raise ValueError("empty or constant text-line image")
         hh[k], ww[k] = s.shape
     pix_off = np.zeros(n + 1, np.int64); np.cumsum(hh.astype(np.int64) * ww, out=pix_off[1:])
     col_off = np.zeros(n + 1, np.int64); np.cumsum(ww, out=col_off[1:])
-    pix = np.concatenate([np.ascontiguousarray(s).ravel() for s in strips])
     # gaussian kernels: one set per distinct strip height, offsets point at the centre taps
     gw_parts, gw_off, gr, where, pos = [], np.zeros((n, 3), np.int64), np.zeros((n, 3), np.int32), {}, 0
     for k in range(n):
@@ -64,7 +72,11 @@ def normalize_strips(strips, device="cuda", want_debug=False):
 
     def up(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    d_pix, d_pix_off, d_hh, d_ww = up(pix), up(pix_off[:-1].copy()), up(hh), up(ww)
+    if not any(on_device):
+        d_pix = up(np.concatenate([np.ascontiguousarray(s).ravel() for s in strips]))
+    else:
+        d_pix = torch.cat([s.reshape(-1) if on_device[k] else up(np.asarray(s).ravel()) for k, s in enumerate(strips)])
+    d_pix_off, d_hh, d_ww = up(pix_off[:-1].copy()), up(hh), up(ww)
     d_gw, d_gw_off, d_gr, d_col_off = up(gw), up(gw_off), up(gr), up(col_off[:-1].copy())
     d_ws_off = up(3 * pix_off[:-1])
     ws = torch.empty(3 * int(pix_off[-1]), dtype=torch.float64, device=dev)
@@ -79,7 +91,10 @@ def normalize_strips(strips, device="cuda", want_debug=False):
         d_gw.data_ptr(), d_gw_off.data_ptr(), d_gr.data_ptr(), ws.data_ptr(), d_ws_off.data_ptr(),
         arg.data_ptr(), center.data_ptr(), d_col_off.data_ptr(), minmax.data_ptr(),
         r.data_ptr(), wout.data_ptr(), stream), "ta_linenorm_measure")
-    wo = wout.cpu().numpy().astype(np.int64)              # output sizes are data-dependent: one small sync
+    sized = torch.cat([wout, minmax]).cpu().numpy()       # output sizes are data-dependent: one small sync
+    wo = sized[:n].astype(np.int64)
+    if any(on_device) and bool((sized[n::2] == sized[n + 1::2]).any()):      # host strips were checked above
+        raise ValueError("empty or constant text-line image")
     del ws
     T = wo + 2 * PAD
     row_off = np.zeros(n + 1, np.int64); np.cumsum(T, out=row_off[1:])

@@ -169,6 +169,12 @@ def _copy_pool():
     return _pool
 
 
+def _is_raw_strip(ln):
+    """a raw greyscale strip: uint8, numpy on the host or torch on the device"""
+    dt = getattr(ln, "dtype", None)
+    return dt is torch.uint8 or (dt is not None and not isinstance(dt, torch.dtype) and dt == np.uint8)
+
+
 class LineRecognizer(object):
     """precision:
     "f32" (the default) runs the recurrence as an exact f32-input MFMA chain -- bit for bit a k-ordered
@@ -235,12 +241,13 @@ class LineRecognizer(object):
     # ---- batched device pass -------------------------------------------------------------
     def prepare(self, lines):
         """Upload lines and allocate outputs.  A line is either a prepared (T, 48) float array
-        (ink = 1, padded) or a raw 2-D uint8 strip (white background), which is normalised on the
-        device (lineest_gpu, csrc/ta_lineest.hip) without a host round trip."""
+        (ink = 1, padded) or a raw 2-D uint8 strip (white background; a host array or a tensor already
+        on the device), which is normalised on the device (lineest_gpu, csrc/ta_lineest.hip) without a
+        host round trip."""
         done = getattr(self, "_stage_done", None)
         if done is not None:
             done.synchronize()
-        raw = [k for k, ln in enumerate(lines) if getattr(ln, "dtype", None) == np.uint8]
+        raw = [k for k, ln in enumerate(lines) if _is_raw_strip(ln)]
         T = np.zeros(len(lines), dtype=np.int64)
         x_raw, T_raw = None, None
         if raw:
@@ -248,7 +255,7 @@ class LineRecognizer(object):
             x_raw, T_raw, _ = lineest_gpu.normalize_strips([lines[k] for k in raw], device=self.device)
             T[raw] = T_raw
         for k, ln in enumerate(lines):
-            if getattr(ln, "dtype", None) == np.uint8:
+            if _is_raw_strip(ln):
                 continue
             if ln.ndim != 2 or ln.shape[1] != NI:
                 raise ValueError("a prepared line must have shape (T, 48)")

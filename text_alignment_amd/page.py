@@ -28,20 +28,37 @@ class Strip(object):
     offset_x, offset_y, height: as the reference reads them (alignToOCR.py:160-162).
     prepared: (T, 48) float array, ink = 1, normalised to height 48 and padded by 16 columns on
         each side (what ocropus-rpred feeds its network); or
-    pixels: raw (H, W) uint8 strip with white background, normalised on the device (lineest_gpu).
+    pixels: raw (H, W) uint8 strip with white background, normalised on the device (lineest_gpu); or
+    device_pixels: the same strip as a 2-D uint8 tensor that already lives on the GPU (what the device
+        preprocessing cuts, preproc_gpu.identify_text_lines_batch) -- `.pixels` then downloads it on
+        first use, the recogniser takes it where it is.
     width: raw strip width in pixels (sets the scale of the reported character positions).
     """
 
-    def __init__(self, offset_x, offset_y, height, width=None, prepared=None, pixels=None):
+    def __init__(self, offset_x, offset_y, height, width=None, prepared=None, pixels=None, device_pixels=None):
         self.offset_x, self.offset_y, self.height = int(offset_x), int(offset_y), int(height)
         self.prepared = None if prepared is None else np.asarray(prepared)
-        self.pixels = None if pixels is None else np.asarray(pixels)
+        self._pixels = None if pixels is None else np.asarray(pixels)
+        self.device_pixels = device_pixels
         if width is None:
-            if self.pixels is not None:
-                width = self.pixels.shape[1]
+            if self._pixels is not None:
+                width = self._pixels.shape[1]
+            elif device_pixels is not None:
+                width = device_pixels.shape[1]
             elif self.prepared is not None:
                 width = self.prepared.shape[0] - 32
         self.width = int(width)
+
+    @property
+    def pixels(self):
+        if self._pixels is None and self.device_pixels is not None:
+            self._pixels = self.device_pixels.cpu().numpy()
+        return self._pixels
+
+    @pixels.setter
+    def pixels(self, value):
+        self._pixels = None if value is None else np.asarray(value)
+        self.device_pixels = None
 
 
 class PreparedPage(object):
@@ -88,11 +105,14 @@ def raw_strip_pixels(strip):
 
 def prepared_line(strip):
     """(line, raw_width): what LineRecognizer.prepare takes for a strip -- its (T, 48) network input
-    if the strip carries one, else its raw uint8 pixels (normalised on the device,
-    csrc/ta_lineest.hip) -- and its raw pixel width."""
+    if the strip carries one, else its raw uint8 pixels (host array or device tensor; normalised on the
+    device, csrc/ta_lineest.hip) -- and its raw pixel width."""
     if getattr(strip, "prepared", None) is not None:
         xs = np.asarray(strip.prepared)
         return xs, int(getattr(strip, "width", xs.shape[0] - 32))
+    dp = getattr(strip, "device_pixels", None)
+    if dp is not None:                  # cut on the GPU: stays there (an empty or constant one is refused by
+        return dp, int(dp.shape[1])     # the normaliser, which measures it anyway)
     px = raw_strip_pixels(strip)
     return px, int(px.shape[1])
 

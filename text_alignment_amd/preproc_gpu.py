@@ -310,7 +310,7 @@ def identify_text_lines_batch(d, planes):
                           "ta_pp_clear_rows")
         smoothed_all.append(smoothed); peaks_all.append(peaks); works.append(work)
     recs_all = d.components_many(d.label_many(works))
-    boxes_all, pieces = [], []
+    boxes_all, total = [], 0
     for (ink, eroded), peaks, recs in zip(planes, peaks_all, recs_all):
         boxes = []
         big = recs[recs[:, 1] > host.noise_area_thresh]
@@ -324,22 +324,28 @@ def identify_text_lines_batch(d, planes):
                 hit = comps[host.coincide_mask(loc, comps[:, 1], comps[:, 3] - comps[:, 1] + 1, cc_median_height)]
                 if not len(hit):
                     continue
-                boxes.append((int(hit[:, 0].min()), int(hit[:, 1].min()), int(hit[:, 2].max()), int(hit[:, 3].max())))
+                ulx, uly, lrx, lry = int(hit[:, 0].min()), int(hit[:, 1].min()), int(hit[:, 2].max()), int(hit[:, 3].max())
+                boxes.append((ulx, uly, lrx, lry, total))
+                total += (lry - uly + 1) * (lrx - ulx + 1)
         boxes_all.append(boxes)
+    # cut the strips on the device (ink black on white, as the reference saves them) into one packed buffer
+    # and leave them there: the recogniser's normaliser reads them where they are, `strip.pixels` downloads
+    packed = torch.empty(max(total, 1), dtype=torch.uint8, device=d.dev)
+    keep = []
+    for (ink, eroded), boxes in zip(planes, boxes_all):
         if boxes:
-            # cut the strips on the device (ink black on white, as the reference saves them) and bring
-            # only those over: the page itself stays where it is
-            white = (1 - ink) * 255
-            pieces += [white[uly:lry + 1, ulx:lrx + 1].reshape(-1) for ulx, uly, lrx, lry in boxes]
-    packed = torch.cat(pieces).cpu().numpy() if pieces else np.zeros(0, np.uint8)
-    out, pos = [], 0
+            h, w = ink.shape
+            d_boxes = torch.tensor(boxes, dtype=torch.int64).to(d.dev)
+            keep.append(d_boxes)
+            _native.check(d.lib.ta_pp_cut_strips(ink.data_ptr(), h, w, d_boxes.data_ptr(), len(boxes),
+                                                 packed.data_ptr(), d.stream), "ta_pp_cut_strips")
+    out = []
     for boxes, peaks, smoothed in zip(boxes_all, peaks_all, smoothed_all):
         strips = []
-        for ulx, uly, lrx, lry in boxes:
+        for ulx, uly, lrx, lry, off in boxes:
             hh, ww = lry - uly + 1, lrx - ulx + 1
-            pixels = packed[pos:pos + hh * ww].reshape(hh, ww)
-            pos += hh * ww
-            strips.append(page_mod.Strip(ulx, uly, hh, width=ww, pixels=pixels))
+            strips.append(page_mod.Strip(ulx, uly, hh, width=ww,
+                                         device_pixels=packed[off:off + hh * ww].view(hh, ww)))
         out.append((strips, peaks, smoothed))
     return out
 

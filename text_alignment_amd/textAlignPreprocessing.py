@@ -96,7 +96,8 @@ def find_peak_locations(data, tol=prominence_tolerance, ranked=False):
         mid, left, right = d[1:-1], d[:-2], d[2:]
         cand[1:-1] = ~((left > mid) | (right > mid) | ((left == mid) & (right == mid)))
     idx = np.flatnonzero(cand).tolist()
-    vals = [calculate_peak_prominence(d, i, data_max) for i in idx]
+    vals = _candidate_prominences(d, idx, data_max) if isinstance(data, np.ndarray) and d.ndim == 1 \
+        else [calculate_peak_prominence(d, i, data_max) for i in idx]
     top = max(vals + [0])             # rows that are no candidates score 0 (the first and the last row always do)
     if top == 0:
         return []
@@ -109,6 +110,36 @@ def find_peak_locations(data, tol=prominence_tolerance, ranked=False):
         peaks.sort(key=lambda p: p[1] * -1)
         return peaks
     return [p[0] for p in peaks]
+
+
+def _candidate_prominences(d, idx, data_max):
+    """[calculate_peak_prominence(d, i, data_max) for i in idx] for rows that passed its local-maximum
+    test, all at once: the nearest higher sample to either side from one comparison table, the key
+    column from one pass of minimum.reduceat; the logarithms are still taken one scalar at a time, as
+    the per-row form takes them"""
+    if not idx:
+        return []
+    n, ix = len(d), np.asarray(idx)
+    here = d[ix]
+    higher = d[None, :] > here[:, None]
+    cols = np.arange(n)[None, :]
+    right = higher & (cols > ix[:, None])
+    left = higher & (cols < ix[:, None])
+    has_r, has_l = right.any(axis=1), left.any(axis=1)
+    nr = right.argmax(axis=1)                                   # first higher sample to the right
+    nl = n - 1 - left[:, ::-1].argmax(axis=1)                   # last one to the left
+    dist_r = np.where(has_r, nr - ix, np.inf)
+    dist_l = np.where(has_l, ix - nl, np.inf)
+    go_left = dist_r > dist_l
+    lo = np.where(go_left, nl, ix)
+    hi = np.where(go_left, ix, nr)
+    top = here == data_max                                      # nothing is higher: scored by its height
+    lo[top], hi[top] = 0, 1
+    bounds = np.empty(2 * len(ix), dtype=np.intp)
+    bounds[0::2], bounds[1::2] = lo, hi
+    key = np.minimum.reduceat(d, bounds)[0::2]
+    arg = np.where(top, here, here - key + 1)
+    return [np.log(v) for v in arg]
 
 
 def _find_peak_locations_all_rows(data, tol, ranked):
