@@ -5,6 +5,8 @@
 #    per-kernel averages are not mixed with other shapes       -> <round>_kernel_stats_nw_headline.csv
 # 2. kernel trace + stats of the line recogniser alone, per workload and mode
 #                                                              -> <round>_kernel_stats_ocr_<lines>_<mode>.csv
+# 2b. kernel trace + stats of process_batch on 32 whole page images (one page thread)
+#                                                              -> <round>_kernel_stats_pages_images.csv
 # 3. WRITE_SIZE and FETCH_SIZE counter passes (separate runs, counters only, no trace flags) of the
 #    two-phase and the one-pass aligner                        -> <round>_nw2_hbm_traffic.json, <round>_nw_hbm_traffic.json
 # 4. matrix-pipe counters of the recogniser kernels (1920 lines, both modes) -> <round>_ocr_pmc_mfma.json
@@ -29,6 +31,8 @@ for w in "1920 f32" "1920 split" "5760 f32"; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_$1_$2" -o ocr -- python3 "$REPO/tools/ocr_only.py" $1 $2 > "$OUT/kt_ocr_$1_$2.log" 2>&1
   echo "ocr $1 $2 kernel trace done"
 done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_pages_images" -o pg -- python3 "$REPO/tools/pages_img_time.py" 32 8 1 > "$OUT/kt_pages_images.log" 2>&1
+echo "page images kernel trace done"
 for mode in two one; do
   flag=""; [ $mode = one ] && flag="--one-pass"
   for ctr in WRITE_SIZE FETCH_SIZE; do
