@@ -268,7 +268,7 @@ int ta_linenorm_resample(const uint8_t* pix, const int64_t* pix_off, const int32
  *
  * ta_pp_label: 8-connected components; lab[p] = linear index of the component's first pixel in
  *   raster order, -1 on background; stats = int32[5][h*w] = area, x0, y0, x1, y1, indexed by that
- *   root; flag = one device int (unused since round 3: tiles are stitched by one lock-free union-find
+ *   root (only the entries of roots are written; the others keep whatever the buffer held); flag = one device int (unused since round 3: tiles are stitched by one lock-free union-find
  *   pass, nothing iterates and nothing waits for the stream).
  * ta_pp_components: up to cap records {root, area, x0, y0, x1, y1} (any order), *count = true number.
  * ta_pp_filter_components: clears components with area < min_area or more than max_height rows.
@@ -299,6 +299,12 @@ int ta_pp_open_runs(const uint8_t* in, uint8_t* out, int32_t h, int32_t w, int32
                     void* stream);
 int ta_pp_row_sums(const uint8_t* ink, int32_t h, int32_t w, int32_t* sums, void* stream);
 int ta_pp_clear_rows(uint8_t* ink, int32_t w, const int32_t* rows, int32_t nrows, void* stream);
+/* Host arithmetic, no device work: for the candidate rows idx[0..k) (local maxima) of a row projection
+ * d[0..n), the arguments of the logarithms of calculate_peak_prominence (textAlignPreprocessing.py:59-110):
+ * arg[c] = d[i] where d[i] == data_max, else d[i] - min(d[lo:hi]) + 1 over the reference's slice between i
+ * and the nearest strictly higher sample.  All pointers [host]. */
+int ta_pp_peak_prominence_args(const double* d, int32_t n, const int32_t* idx, int32_t k, double data_max,
+                               double* arg);
 /* The text-line strips of a page, cut from its ink plane (h x w, non-zero = ink) into one packed buffer as
  * the greyscale images the reference writes for the recogniser (alignToOCR.py:131-132; ink 0 on 255).
  * boxes (device): nstrips x {ulx, uly, lrx, lry, byte offset of the strip in out}, inclusive corners inside

@@ -16,6 +16,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _library_is_built():
+    """the package's host modules call into libta_hip.so (C ABI; loads without a GPU): build it once if a
+    fresh checkout has none (hipcc cross-compiles gfx950 here)"""
+    if not os.path.exists(os.path.join(REPO, "text_alignment_amd", "libta_hip.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+@pytest.fixture(scope="session")
+def native(_library_is_built):
+    from text_alignment_amd import _native
+    return _native
+
+
 def load_golden(name):
     with open(os.path.join(GOLDEN, name), encoding="utf-8") as f:
         return json.load(f)

@@ -8,15 +8,6 @@ import pytest
 from conftest import REPO
 
 
-@pytest.fixture(scope="module")
-def native():
-    if not os.path.exists(os.path.join(REPO, "text_alignment_amd", "libta_hip.so")):
-        import __graft_entry__
-        __graft_entry__.build()
-    from text_alignment_amd import _native
-    return _native
-
-
 def _declared_symbols():
     hdr = open(os.path.join(REPO, "include", "text_alignment_amd.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)

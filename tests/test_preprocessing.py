@@ -68,6 +68,26 @@ def test_product_peak_finder_equals_the_reference_loop():
             fn(np.zeros(0))
 
 
+def test_candidate_prominences_three_ways(native):
+    """float64 projections take the library's host loops (ta_pp_peak_prominence_args), other dtypes the
+    array form; both give, value for value, what calculate_peak_prominence gives row by row"""
+    from text_alignment_amd import textAlignPreprocessing as pp
+    rng = np.random.default_rng(8)
+    for k in range(120):
+        n = int(rng.integers(3, 500))
+        d = [rng.integers(0, 9, n).astype(np.float64), rng.random(n) * 300,
+             pp.moving_avg_filter(rng.integers(0, 1400, n + 40))][k % 3]
+        top = d.max()
+        cand = [i for i in range(1, n - 1)
+                if not (d[i - 1] > d[i] or d[i + 1] > d[i] or (d[i - 1] == d[i] and d[i + 1] == d[i]))]
+        want = [float(pp.calculate_peak_prominence(d, i, top)) for i in cand]
+        assert [float(v) for v in pp._candidate_prominences_native(d, cand, top)] == want, k
+        assert [float(v) for v in pp._candidate_prominences(d, cand, top)] == want, k
+    assert pp._candidate_prominences_native(np.zeros(5), [], 0.0) == []
+    with pytest.raises(ValueError):
+        pp._candidate_prominences_native(np.zeros(5), [7], 0.0)
+
+
 def _synthetic_page(nlines=6, angle=0.0, seed=0):
     """White page with `nlines` rows of word-like ink blobs (ink density bell-shaped across each
     line, like text); returns (uint8 image, line centres)."""

@@ -163,12 +163,19 @@ __global__ __launch_bounds__(kPpThreads) void pp_label_merge_kernel(int32_t* lab
     }
 }
 
-__global__ __launch_bounds__(kPpThreads) void pp_label_flatten_kernel(int32_t* lab, int64_t n) {
+// (and the statistics entries of the roots -- the only ones ever read -- start from their neutral values here:
+// filling all five planes, 20 bytes per pixel, was a sixth of a labelling call)
+__global__ __launch_bounds__(kPpThreads) void pp_label_flatten_kernel(int32_t* lab, int64_t n, int32_t* stats) {
     for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
         int32_t r = lab[e];
         if (r < 0) continue;
         while (lab[r] != r) r = lab[r];
         lab[e] = r;
+        if (r == e && stats) {
+            stats[e] = 0;
+            stats[n + e] = 0x7fffffff; stats[2 * n + e] = 0x7fffffff;
+            stats[3 * n + e] = -1; stats[4 * n + e] = -1;
+        }
     }
 }
 
@@ -500,13 +507,10 @@ extern "C" int ta_pp_label(const uint8_t* ink, int32_t h, int32_t w, int32_t* la
                        dim3(kTileH * kTileW), 0, st, ink, h, w, lab);
     // stitching across tiles (one union-find pass over the tile borders) and path compression
     hipLaunchKernelGGL(pp_label_merge_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, h, w);
-    hipLaunchKernelGGL(pp_label_flatten_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, n);
+    hipLaunchKernelGGL(pp_label_flatten_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab, n, stats);
     (void)flag;
     int32_t* area = stats; int32_t* x0 = stats + n; int32_t* y0 = stats + 2 * n;
     int32_t* x1 = stats + 3 * n; int32_t* y1 = stats + 4 * n;
-    hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, area, n, 0);
-    hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, x0, 2 * n, 0x7fffffff);
-    hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, x1, 2 * n, -1);
     hipLaunchKernelGGL(pp_stats_kernel, dim3(nb > kStatBlocks ? kStatBlocks : nb), dim3(kPpThreads), 0, st, lab, h, w, area, x0, y0, x1, y1);
     PP_LAUNCH_CHECK("pp_label kernels");
     return TA_OK;
@@ -536,7 +540,7 @@ extern "C" int ta_pp_label_batch(int32_t nimg, const uint8_t* const* ink, const 
         const int64_t n = (int64_t)h[i] * w[i];
         const int nb = pp_blocks(n);
         hipLaunchKernelGGL(pp_label_merge_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab[i], h[i], w[i]);
-        hipLaunchKernelGGL(pp_label_flatten_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab[i], n);
+        hipLaunchKernelGGL(pp_label_flatten_kernel, dim3(nb), dim3(kPpThreads), 0, st, lab[i], n, stats[i]);
     }
     (void)flags;
     for (int i = 0; i < nimg; ++i) {
@@ -545,9 +549,6 @@ extern "C" int ta_pp_label_batch(int32_t nimg, const uint8_t* const* ink, const 
         const int nb = pp_blocks(n);
         int32_t* area = stats[i]; int32_t* x0 = area + n; int32_t* y0 = area + 2 * n;
         int32_t* x1 = area + 3 * n; int32_t* y1 = area + 4 * n;
-        hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, area, n, 0);
-        hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, x0, 2 * n, 0x7fffffff);
-        hipLaunchKernelGGL(pp_fill_kernel, dim3(nb), dim3(kPpThreads), 0, st, x1, 2 * n, -1);
         hipLaunchKernelGGL(pp_stats_kernel, dim3(nb > kStatBlocks ? kStatBlocks : nb), dim3(kPpThreads), 0, st, lab[i], h[i], w[i], area, x0, y0, x1, y1);
     }
     PP_LAUNCH_CHECK("pp_label_batch kernels");
@@ -643,6 +644,35 @@ extern "C" int ta_pp_row_sums(const uint8_t* ink, int32_t h, int32_t w, int32_t*
     if (h) hipLaunchKernelGGL(pp_row_sums_kernel, dim3(h), dim3(kPpThreads), 0,
                               reinterpret_cast<hipStream_t>(stream), ink, h, w, sums);
     PP_LAUNCH_CHECK("pp_row_sums_kernel");
+    return TA_OK;
+}
+
+// Host arithmetic (no device work): the arguments of the logarithms in calculate_peak_prominence
+// (reference textAlignPreprocessing.py:59-110) for the candidate rows idx[0..k) of a projection d[0..n) --
+// rows that passed its local-maximum test.  arg[c] = d[i] where d[i] is the maximum, else
+// d[i] - min(d[lo:hi]) + 1 with [lo, hi) running from the nearest strictly higher sample (the left one
+// only if it is strictly nearer) to i, as the reference slices it.  Plain float64, evaluated left to right.
+extern "C" int ta_pp_peak_prominence_args(const double* d, int32_t n, const int32_t* idx, int32_t k,
+                                          double data_max, double* arg) {
+    if (n < 0 || k < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (k == 0) return TA_OK;
+    if (!d || !idx || !arg) return ta_fail(TA_EINVAL, "null pointer argument");
+    for (int c = 0; c < k; ++c) {
+        const int i = idx[c];
+        if (i < 0 || i >= n) return ta_fail(TA_EINVAL, "candidate row outside the projection");
+        const double here = d[i];
+        if (here == data_max) { arg[c] = here; continue; }
+        int nr = i + 1, nl = i - 1;
+        while (nr < n && !(d[nr] > here)) ++nr;
+        while (nl >= 0 && !(d[nl] > here)) --nl;
+        const bool has_r = nr < n, has_l = nl >= 0;
+        if (!has_r && !has_l) { arg[c] = here; continue; }           // (data_max was not the maximum: as if it were)
+        const bool go_left = has_l && (!has_r || (nr - i) > (i - nl));
+        const int lo = go_left ? nl : i, hi = go_left ? i : nr;
+        double key = d[lo];
+        for (int j = lo + 1; j < hi; ++j) key = d[j] < key ? d[j] : key;
+        arg[c] = here - key + 1.0;
+    }
     return TA_OK;
 }
 

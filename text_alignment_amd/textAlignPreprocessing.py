@@ -96,8 +96,10 @@ def find_peak_locations(data, tol=prominence_tolerance, ranked=False):
         mid, left, right = d[1:-1], d[:-2], d[2:]
         cand[1:-1] = ~((left > mid) | (right > mid) | ((left == mid) & (right == mid)))
     idx = np.flatnonzero(cand).tolist()
-    vals = _candidate_prominences(d, idx, data_max) if isinstance(data, np.ndarray) and d.ndim == 1 \
-        else [calculate_peak_prominence(d, i, data_max) for i in idx]
+    if isinstance(data, np.ndarray) and d.ndim == 1:
+        vals = (_candidate_prominences_native if d.dtype == np.float64 else _candidate_prominences)(d, idx, data_max)
+    else:
+        vals = [calculate_peak_prominence(d, i, data_max) for i in idx]
     top = max(vals + [0])             # rows that are no candidates score 0 (the first and the last row always do)
     if top == 0:
         return []
@@ -110,6 +112,23 @@ def find_peak_locations(data, tol=prominence_tolerance, ranked=False):
         peaks.sort(key=lambda p: p[1] * -1)
         return peaks
     return [p[0] for p in peaks]
+
+
+def _candidate_prominences_native(d, idx, data_max):
+    """the same for a float64 projection with the scans in the library's host code
+    (ta_pp_peak_prominence_args: plain float64 loops, no device work) -- a page's ~60 candidates over its
+    ~4 000 rows are a quarter-million comparisons either way, but there they neither build tables nor hold
+    the interpreter lock; the logarithms stay here, one numpy scalar at a time"""
+    if not idx:
+        return []
+    from . import _native
+    dd = np.ascontiguousarray(d)
+    ix = np.asarray(idx, dtype=np.int32)
+    arg = np.empty(len(ix), dtype=np.float64)
+    _native.check(_native.lib.ta_pp_peak_prominence_args(dd.ctypes.data, len(dd), ix.ctypes.data, len(ix),
+                                                         float(data_max), arg.ctypes.data),
+                  "ta_pp_peak_prominence_args")
+    return [np.log(v) for v in arg]
 
 
 def _candidate_prominences(d, idx, data_max):
