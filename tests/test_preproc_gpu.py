@@ -55,6 +55,73 @@ def test_labels_match_scipy():
         assert sorted(map(tuple, recs[:, 2:6].tolist())) == boxes
 
 
+def test_labels_across_tile_borders():
+    """The stitching pass links a border pixel only where no other link implies the connection (straight
+    neighbour first, diagonals only beside background, first pixel of a run only): patterns whose components
+    touch ONLY through tile corners / diagonals / long runs along tile borders (tiles are 16 x 64), and pages
+    that are nearly all ink (one component across hundreds of tiles), against scipy's partition."""
+    from scipy import ndimage
+    from text_alignment_amd import preproc_gpu as G
+    rng = np.random.default_rng(12)
+    d = G._Dev()
+    yy, xx = np.mgrid[0:130, 0:260]
+    pats = [(yy + xx) % 2 == 0,                                   # checkerboard: diagonal links only
+            (yy - xx) % 7 == 0, (yy + xx) % 5 == 0,               # diagonal stripes, both directions
+            (yy % 16 == 15) | (xx % 64 == 63),                    # the tile borders themselves (one side)
+            (yy % 16 == 0) | (xx % 64 == 0),                      # ... the other side
+            ((yy % 16 == 15) & (xx % 3 == 0)) | ((yy % 16 == 0) & (xx % 3 == 1)),   # only diagonal contacts across rows 15/16
+            ((xx % 64 == 63) & (yy % 2 == 0)) | ((xx % 64 == 0) & (yy % 2 == 1)),   # ... across columns 63/64
+            rng.random((130, 260)) < 0.92, rng.random((130, 260)) < 0.08]
+    pats += [rng.random((530, 700)) < q for q in (0.97, 0.55, 0.4)]
+    for a in pats:
+        ink = torch.from_numpy(np.ascontiguousarray(a).astype(np.uint8)).cuda()
+        lab = d.label(ink)[0].cpu().numpy()
+        want, n = ndimage.label(a, structure=np.ones((3, 3), bool))
+        assert ((lab >= 0) == a).all()
+        flat = want.ravel()
+        first = np.full(n + 1, flat.size, np.int64)
+        np.minimum.at(first, flat, np.arange(flat.size))
+        assert np.array_equal(lab.ravel()[flat > 0], first[flat[flat > 0]])
+
+
+def test_strip_cutter():
+    """ta_pp_cut_strips: boxes (inclusive corners, touching the page edges too) out of an ink plane into one
+    packed buffer, ink 0 on 255"""
+    import ctypes
+    from text_alignment_amd import _native
+    rng = np.random.default_rng(4)
+    ink = (rng.random((300, 500)) < 0.4).astype(np.uint8)
+    boxes, total = [], 0
+    for ulx, uly, lrx, lry in [(0, 0, 499, 0), (0, 0, 0, 299), (10, 20, 400, 90), (499, 299, 499, 299), (3, 250, 77, 299)]:
+        boxes.append((ulx, uly, lrx, lry, total))
+        total += (lry - uly + 1) * (lrx - ulx + 1)
+    d_ink = torch.from_numpy(ink).cuda()
+    d_boxes = torch.tensor(boxes, dtype=torch.int64).cuda()
+    out = torch.zeros(total, dtype=torch.uint8, device="cuda")
+    _native.check(_native.lib.ta_pp_cut_strips(d_ink.data_ptr(), 300, 500, d_boxes.data_ptr(), len(boxes),
+                                               out.data_ptr(), None), "ta_pp_cut_strips")
+    got = out.cpu().numpy()
+    for ulx, uly, lrx, lry, off in boxes:
+        want = np.where(ink[uly:lry + 1, ulx:lrx + 1] > 0, 0, 255).astype(np.uint8)
+        assert np.array_equal(got[off:off + want.size].reshape(want.shape), want)
+    assert _native.lib.ta_pp_cut_strips(d_ink.data_ptr(), 300, 500, None, 0, None, None) == 0     # nothing to cut
+
+
+def test_pages_without_lines_in_a_batch():
+    """a blank page and a page of specks between two text pages: no strips, no peaks, and the text pages'
+    results are what they are alone"""
+    from text_alignment_amd import preproc_gpu as G
+    a, b = _noisy_page(2), _noisy_page(9)
+    blank = np.full_like(a, 255)
+    specks = blank.copy()
+    specks[::97, ::89] = 0
+    got = G.find_lines_batch([a, blank, specks, b])
+    assert [len(g[3]) for g in got[1:3]] == [0, 0]
+    for alone, both in ((G.find_lines(a), got[0]), (G.find_lines(b), got[3])):
+        assert alone[2] == both[2] and list(alone[4]) == list(both[4]) and len(alone[3]) == len(both[3]) >= 4
+        assert all(np.array_equal(x.pixels, y.pixels) for x, y in zip(alone[3], both[3]))
+
+
 @pytest.mark.parametrize("seed,angle", [(0, 0.0), (3, 2.0), (5, -3.3)])
 def test_preprocess_and_lines_match_host(seed, angle):
     from oracle import preproc_ref as H
