@@ -13,6 +13,47 @@ TARGET_HEIGHT = 48          # CenterNormalizer target_height (SURVEY.md Appendix
 PAD = 16                    # prepare_line pad (Appendix B.2)
 
 _kernels = {}
+_stage = {}                 # pinned staging buffer for host strips + the event of its last transfer
+_stage_lock = None
+_pool = None
+
+
+def _upload_host_strips(strips, pix_off, dev):
+    """host strips -> one packed uint8 device tensor: copied into a pinned staging buffer by a few threads
+    (numpy releases the GIL for the copies; 64 pages of strips are 160 MB, a single memcpy stream and a
+    pageable transfer were a third of such a batch) and sent in one asynchronous transfer"""
+    global _stage_lock, _pool
+    import threading
+    if _stage_lock is None:
+        _stage_lock = threading.Lock()
+    total = int(pix_off[-1])
+    with _stage_lock:
+        st = _stage.get("buf")
+        if _stage.get("done") is not None:
+            _stage["done"].synchronize()                 # the previous batch's transfer still reads the buffer
+        if st is None or st.numel() < total:
+            st = _stage["buf"] = torch.empty(int(total * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+        view = st.numpy()
+
+        def copy(span):
+            for k in range(*span):
+                view[pix_off[k]:pix_off[k + 1]] = np.asarray(strips[k]).reshape(-1)
+        n = len(strips)
+        nthreads = min(8, max(1, total >> 22))           # ~4 MB per thread at least
+        if nthreads == 1:
+            copy((0, n))
+        else:
+            if _pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                _pool = ThreadPoolExecutor(8, thread_name_prefix="ta-strips")
+            cuts = np.searchsorted(pix_off, np.linspace(0, total, nthreads + 1)).tolist()
+            cuts[0], cuts[-1] = 0, n
+            list(_pool.map(copy, [(cuts[i], cuts[i + 1]) for i in range(nthreads)]))
+        d_pix = torch.empty(total, dtype=torch.uint8, device=dev)
+        d_pix.copy_(st[:total], non_blocking=True)
+        _stage["done"] = torch.cuda.Event()
+        _stage["done"].record()
+    return d_pix
 
 
 def _gauss_weights(sigma):
@@ -52,7 +93,7 @@ def normalize_strips(strips, device="cuda", want_debug=False):
             s = np.asarray(s)
             if s.ndim != 2 or s.dtype != np.uint8:
                 raise TypeError("the device normaliser takes 2-D uint8 strips")
-            if s.size == 0 or s.max() == s.min():
+            if s.size == 0:
                 raise ValueError("empty or constant text-line image")
         hh[k], ww[k] = s.shape
     pix_off = np.zeros(n + 1, np.int64); np.cumsum(hh.astype(np.int64) * ww, out=pix_off[1:])
@@ -73,7 +114,7 @@ def normalize_strips(strips, device="cuda", want_debug=False):
     def up(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     if not any(on_device):
-        d_pix = up(np.concatenate([np.ascontiguousarray(s).ravel() for s in strips]))
+        d_pix = _upload_host_strips(strips, pix_off, dev)
     else:
         d_pix = torch.cat([s.reshape(-1) if on_device[k] else up(np.asarray(s).ravel()) for k, s in enumerate(strips)])
     d_pix_off, d_hh, d_ww = up(pix_off[:-1].copy()), up(hh), up(ww)
@@ -93,7 +134,7 @@ def normalize_strips(strips, device="cuda", want_debug=False):
         r.data_ptr(), wout.data_ptr(), stream), "ta_linenorm_measure")
     sized = torch.cat([wout, minmax]).cpu().numpy()       # output sizes are data-dependent: one small sync
     wo = sized[:n].astype(np.int64)
-    if any(on_device) and bool((sized[n::2] == sized[n + 1::2]).any()):      # host strips were checked above
+    if bool((sized[n::2] == sized[n + 1::2]).any()):      # the measuring pass found a strip's minimum = its maximum
         raise ValueError("empty or constant text-line image")
     del ws
     T = wo + 2 * PAD
