@@ -352,7 +352,7 @@ def identify_text_lines_batch(d, planes):
 
 def identify_text_lines(image_bin, image_eroded):
     """(line strips, peak locations, smoothed projection) of one preprocessed page"""
-    d = image_bin.dev or _Dev(image_bin.plane.device)
+    d = _Dev(image_bin.plane.device)          # a handle of this call: it launches on the stream current HERE
     return identify_text_lines_batch(d, [(image_bin.plane, image_eroded.plane)])[0]
 
 
