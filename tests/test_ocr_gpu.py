@@ -103,7 +103,7 @@ def _segmented_states(rec, st, om, lines, seg):
         r_h, r_c = R.lstm_forward(om.rev, xs[::-1], return_cell=True)      # index = reversed time
         for a in range(0, Tl, seg):
             e = min(a + seg, Tl)
-            row_off.append(int(st["row_off_host"][b]) + a)
+            row_off.append(int(st["row_start_host"][b]) + a)
             T.append(e - a)
             zero = np.zeros(100)
             done_rev = Tl - e                                  # reversed steps before this segment
@@ -152,7 +152,7 @@ def test_spec_model_benchmark_widths_per_segment(seed, no, precision):
     worst = 0.0
     for k, xs in enumerate(lines):
         ref = R.recognise(om, xs)
-        sl = slice(int(st["row_off_host"][k]), int(st["row_off_host"][k + 1]))
+        sl = slice(int(st["row_start_host"][k]), int(st["row_start_host"][k] + st["T_host"][k]))
         e_h = float(np.abs(states[sl] - ref["states"]).max())
         e_z = float(np.abs(logits[sl] - ref["logits"]).max())
         e_p = float(np.abs(probs[sl] - ref["probs"]).max())
@@ -224,6 +224,40 @@ def test_group_boundaries_and_order():
         dec = rec.recognise(base[:cnt])
         assert dec == ref[:cnt], cnt
     assert rec.recognise([]) == []
+
+
+@pytest.mark.parametrize("precision", ["f32", "split"])
+def test_class_split_launches_equal_single_launches(precision):
+    """run(): the recurrence and the output layer per length class on side streams (large batches) against
+    one launch each -- same kernels on the same rows, so states, summaries, probabilities and decode are
+    bit for bit the same; rows are laid out by groups (longest lines first), every line at row_start ..
+    + T, whatever the order the lines came in; and the one-off timing check leaves a verdict behind."""
+    R, ocr, om, pm = _models(7001, 96)
+    rec = ocr.LineRecognizer(pm, precision=precision)
+    rng = np.random.default_rng(3)
+    lines = [R.synthetic_line(9500 + k, width=int(w)) for k, w in enumerate(rng.integers(20, 200, size=16 * 26 + 5))]
+    st = rec.prepare(lines)
+    assert st["ngroups"] == 27
+    T, start = st["T_host"], st["row_start_host"]
+    order = np.argsort(-T, kind="stable")
+    assert np.array_equal(start[order], np.cumsum(T[order]) - T[order])           # sorted layout, no holes
+    assert np.array_equal(st["group_row_host"][:-1], start[order[::16]]) and st["group_row_host"][-1] == T.sum()
+    out = {}
+    for split in (False, True):
+        for key in ("hout", "summary", "dec_t", "dec_c", "dec_n"):
+            st[key].fill_(0)
+        rec.run(st, want_logits=True, class_split=split)
+        torch.cuda.synchronize()
+        out[split] = {k: st[k].clone() for k in ("hout", "summary", "probs", "logits", "dec_t", "dec_c", "dec_n")}
+    for k, v in out[False].items():
+        assert torch.equal(v, out[True][k]), k
+    dec = rec.decoded(st)
+    few = [0, 5, 77, 300, len(lines) - 1]
+    alone = rec.recognise([lines[k] for k in few])
+    assert [dec[k] for k in few] == alone
+    rec.run(st)                                               # the default path: checks itself once, then decides
+    assert ocr._split_state["ok"] in (True, False) and set(ocr._split_state["times_ms"]) == {True, False}
+    print("class split timing check:", ocr._split_state["times_ms"], "->", ocr._split_state["ok"])
 
 
 def test_input_too_large():

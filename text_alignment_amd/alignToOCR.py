@@ -376,7 +376,7 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     x_min = np.array([s.offset_x for s in all_strips], dtype=np.int64)
     y_min = np.array([s.offset_y for s in all_strips], dtype=np.int64)
     y_max = y_min + np.array([s.height for s in all_strips], dtype=np.int64)
-    line, cp, boxes = pb.chars_of_batch(dec_t, dec_c, dec_n, st["row_off_host"][:-1], st["T_host"],
+    line, cp, boxes = pb.chars_of_batch(dec_t, dec_c, dec_n, st["row_start_host"], st["T_host"],
                                         np.asarray(widths, dtype=np.int64), x_min, y_min, y_max, cps, ocr_pad())
     first_line = np.zeros(len(pages) + 1, dtype=np.int64)
     np.cumsum([len(s) for s in strips_per_page], out=first_line[1:])

@@ -70,11 +70,12 @@ def _line_kernels(h):
     return _kernels[h]
 
 
-def normalize_strips(strips, device="cuda", want_debug=False):
+def normalize_strips(strips, device="cuda", want_debug=False, layout=None):
     """strips: list of 2-D uint8 images (white background), each a host array or a tensor already on
     the device.  Returns (x, T, debug): x = float32
-    device tensor [sum T, 48] (line b owns rows sum(T[:b]) .. + T[b]), T = int64 array of
-    timesteps (normalised width + 32)."""
+    device tensor [sum T, 48] (line b owns rows sum(T[:b]) .. + T[b]; or, with `layout`, rows
+    layout(T)[b] .. + T[b] -- a permutation of those ranges, for a caller that wants the lines in an order of
+    its own: the output widths are only known in here), T = int64 array of timesteps (normalised width + 32)."""
     dev = torch.device(device)
     lib = _native.lib
     n = len(strips)
@@ -139,11 +140,12 @@ def normalize_strips(strips, device="cuda", want_debug=False):
     del ws
     T = wo + 2 * PAD
     row_off = np.zeros(n + 1, np.int64); np.cumsum(T, out=row_off[1:])
+    row_start = row_off[:-1].copy() if layout is None else np.ascontiguousarray(layout(T), dtype=np.int64)
     tmp_off = np.zeros(n + 1, np.int64); np.cumsum(wo * TARGET_HEIGHT, out=tmp_off[1:])
     tmp = torch.empty(max(int(tmp_off[-1]), 1), dtype=torch.float32, device=dev)
     omax = torch.empty(n, dtype=torch.int32, device=dev)
     x = torch.empty((int(row_off[-1]), TARGET_HEIGHT), dtype=torch.float32, device=dev)
-    d_tmp_off, d_row_off = up(tmp_off[:-1].copy()), up(row_off[:-1].copy())     # named: they must outlive the launch
+    d_tmp_off, d_row_off = up(tmp_off[:-1].copy()), up(row_start)     # named: they must outlive the launch
     _native.check(lib.ta_linenorm_resample(
         d_pix.data_ptr(), d_pix_off.data_ptr(), d_hh.data_ptr(), d_ww.data_ptr(), n,
         center.data_ptr(), d_col_off.data_ptr(), minmax.data_ptr(), r.data_ptr(), wout.data_ptr(),

@@ -9,6 +9,8 @@ lines are sorted by length, grouped 16 to a workgroup, and run through K3 (BiLST
 (output layer + softmax) and K5 (decode) behind the C ABI (`ta_lstm_forward`,
 `ta_lstm_output` / `ta_lstm_output_split`, `ta_decode`).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -169,6 +171,45 @@ def _copy_pool():
     return _pool
 
 
+CLASS_SPLIT_MIN_GROUPS = 24     # below this (a few pages) the recurrence's tail has nothing worth hiding
+_split_state = {"streams": {}, "ok": None}
+
+
+def _class_streams(device):
+    """Three HIGH-priority side streams per device.  HIP spreads the streams of one priority over a few
+    hardware queues in creation order, and two class streams that land on one queue run their classes one
+    after the other (20 ms per 1 920 lines instead of 10.7); torch's high-priority pool is a queue set of its
+    own, whose first three streams are neighbours -- measured independent of whatever normal-priority streams
+    the process has made (tools/ocr_overlap_probe.py)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _split_state["streams"]:
+        _split_state["streams"][key] = [torch.cuda.Stream(device=device, priority=-1) for _ in range(3)]
+    return _split_state["streams"][key]
+
+
+def _class_split_wanted(rec, st):
+    """TA_OCR_CLASS_SPLIT=0 / 1 decides; otherwise batches of CLASS_SPLIT_MIN_GROUPS groups or more take the
+    class split unless the one-off check below found it SLOWER in this process (another user of the
+    high-priority queues): the first eligible batch is run both ways once, timed with events."""
+    env = os.environ.get("TA_OCR_CLASS_SPLIT")
+    if env in ("0", "1"):
+        return env == "1"
+    if st["ngroups"] < CLASS_SPLIT_MIN_GROUPS or st.get("continuation"):
+        return False
+    if _split_state["ok"] is None:
+        times = {}
+        for split in (True, False, True, False):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rec.run(st, decode=False, class_split=split)
+            e1.record()
+            e1.synchronize()
+            times[split] = min(times.get(split, 1e30), e0.elapsed_time(e1))
+        _split_state["ok"] = times[True] <= 1.02 * times[False]
+        _split_state["times_ms"] = times
+    return _split_state["ok"]
+
+
 def _is_raw_strip(ln):
     """a raw greyscale strip: uint8, numpy on the host or torch on the device"""
     dt = getattr(ln, "dtype", None)
@@ -209,8 +250,8 @@ class LineRecognizer(object):
             self.w2bias = torch.from_numpy(bias).to(self.device)
 
     # ---- host -> device ------------------------------------------------------------------
-    def _upload_rows(self, lines, row_off, rows):
-        """All prepared lines as one [rows, 48] float32 device tensor.  The lines are copied (and, if
+    def _upload_rows(self, lines, row_start, rows):
+        """All prepared lines as one [rows, 48] float32 device tensor (line k at rows row_start[k] ...).  The lines are copied (and, if
         need be, converted) straight into a pinned staging buffer by a few threads -- numpy releases
         the GIL for these copies, and at ~275 KB per line a page is 8 MB, so one thread's memcpy
         rate would bound the whole pipeline -- and go over PCIe in one asynchronous transfer."""
@@ -223,12 +264,13 @@ class LineRecognizer(object):
 
         def copy(span):
             for k in range(*span):
-                view[row_off[k]:row_off[k + 1]] = lines[k]
+                view[row_start[k]:row_start[k] + lines[k].shape[0]] = lines[k]
         nthreads = min(8, max(1, len(lines) // 64))
         if nthreads == 1:
             copy((0, len(lines)))
         else:
-            cuts = np.searchsorted(row_off, np.linspace(0, rows, nthreads + 1)).tolist()
+            done_rows = np.cumsum([ln.shape[0] for ln in lines])
+            cuts = np.searchsorted(done_rows, np.linspace(0, rows, nthreads + 1)).tolist()
             cuts[0], cuts[-1] = 0, len(lines)
             list(_copy_pool().map(copy, [(cuts[i], cuts[i + 1]) for i in range(nthreads)]))
         x_dev = torch.empty((rows, NI), dtype=torch.float32, device=self.device)
@@ -248,11 +290,21 @@ class LineRecognizer(object):
         if done is not None:
             done.synchronize()
         raw = [k for k, ln in enumerate(lines) if _is_raw_strip(ln)]
-        T = np.zeros(len(lines), dtype=np.int64)
+        n = len(lines)
+        T = np.zeros(n, dtype=np.int64)
+
+        def layout(Tl):
+            """first row of every line: lines sorted by length (longest first, the order the groups of 16 take
+            them in), so that the rows of any run of groups are one contiguous range of x / hout / summary"""
+            order_ = np.argsort(-Tl, kind="stable")
+            start = np.empty(len(Tl), dtype=np.int64)
+            start[order_] = np.cumsum(Tl[order_]) - Tl[order_]
+            return start
         x_raw, T_raw = None, None
         if raw:
             from . import lineest_gpu
-            x_raw, T_raw, _ = lineest_gpu.normalize_strips([lines[k] for k in raw], device=self.device)
+            x_raw, T_raw, _ = lineest_gpu.normalize_strips([lines[k] for k in raw], device=self.device,
+                                                           layout=layout if len(raw) == n else None)
             T[raw] = T_raw
         for k, ln in enumerate(lines):
             if _is_raw_strip(ln):
@@ -260,36 +312,41 @@ class LineRecognizer(object):
             if ln.ndim != 2 or ln.shape[1] != NI:
                 raise ValueError("a prepared line must have shape (T, 48)")
             T[k] = ln.shape[0]
-        if len(lines) and T.max() > MAX_T:
+        if n and T.max() > MAX_T:
             raise RecognitionError("input too large for LSTM model")
         order = np.argsort(-T, kind="stable")
-        ngroups = (len(lines) + 15) // 16
+        ngroups = (n + 15) // 16
         group_lines = np.full((max(ngroups, 1), 16), -1, dtype=np.int32)
-        group_lines.reshape(-1)[:len(lines)] = order
-        row_off = np.zeros(len(lines) + 1, dtype=np.int64)
-        np.cumsum(T, out=row_off[1:])
-        rows = int(row_off[-1])
+        group_lines.reshape(-1)[:n] = order
+        row_start = layout(T) if n else np.zeros(0, dtype=np.int64)
+        rows = int(T.sum())
         raw_set = set(raw)
-        host = [k for k in range(len(lines)) if k not in raw_set]
+        host = [k for k in range(n) if k not in raw_set]
         if not raw:
-            x_dev = self._upload_rows(lines, row_off, rows)
+            x_dev = self._upload_rows(lines, row_start, rows)
         elif not host:
-            x_dev = x_raw
-        else:                                   # mixed batch: stitch the two sources together in line order
+            x_dev = x_raw                           # the normaliser wrote its rows in this layout
+        else:                                   # mixed batch: stitch the two sources together
             x_dev = torch.empty((rows, NI), dtype=torch.float32, device=self.device)
             xh = torch.from_numpy(np.ascontiguousarray(
                 np.concatenate([lines[k] for k in host], axis=0).astype(np.float32))).to(self.device)
             ph = pr = 0
-            for k in range(len(lines)):
+            for k in range(n):
                 t = int(T[k])
                 if k in raw_set:
-                    x_dev[row_off[k]:row_off[k] + t] = x_raw[pr:pr + t]; pr += t
+                    x_dev[row_start[k]:row_start[k] + t] = x_raw[pr:pr + t]; pr += t
                 else:
-                    x_dev[row_off[k]:row_off[k] + t] = xh[ph:ph + t]; ph += t
-        st = {"n": len(lines), "rows": rows, "T_host": T, "row_off_host": row_off, "ngroups": ngroups}
+                    x_dev[row_start[k]:row_start[k] + t] = xh[ph:ph + t]; ph += t
+        # first row of every group (+ the end): group g owns rows group_row[g] .. group_row[g + 1]
+        group_row = np.zeros(max(ngroups, 1) + 1, dtype=np.int64)
+        if n:
+            group_row[:ngroups] = row_start[order[::16]]
+        group_row[ngroups:] = rows
+        st = {"n": n, "rows": rows, "T_host": T, "row_start_host": row_start, "ngroups": ngroups,
+              "group_row_host": group_row}
         dev = self.device
         st["x"] = x_dev
-        st["row_off"] = torch.from_numpy(row_off[:-1].copy() if len(lines) else row_off).to(dev)
+        st["row_off"] = torch.from_numpy(row_start if n else np.zeros(1, np.int64)).to(dev)
         st["T"] = torch.from_numpy(T.astype(np.int32) if len(lines) else np.zeros(1, np.int32)).to(dev)
         st["group_lines"] = torch.from_numpy(group_lines).to(dev)
         st["hout"] = torch.empty((max(rows, 1), 2 * NS), dtype=torch.float32, device=dev)
@@ -301,39 +358,69 @@ class LineRecognizer(object):
         st["dec_n"] = torch.zeros(max(len(lines), 1), dtype=torch.int32, device=dev)
         return st
 
-    def run(self, st, want_logits=False, lstm=True, output=True, decode=True, from_probs=False):
-        """Enqueue K3, K4, K5 on torch's current stream.  By default K4 emits only the 16-byte
+    def run(self, st, want_logits=False, lstm=True, output=True, decode=True, from_probs=False, class_split=None):
+        """Enqueue K3, K4, K5 behind torch's current stream.  By default K4 emits only the 16-byte
         per-timestep summaries and K5 decodes from them; want_logits / from_probs also
-        materialise the (rows, No) probabilities (and logits) and decode from those."""
+        materialise the (rows, No) probabilities (and logits) and decode from those.
+
+        A batch of at least CLASS_SPLIT_MIN_GROUPS groups runs K3 and K4 per length CLASS (the longest tenth
+        of the groups, the next fifth, the rest; rows are laid out in group order, so a class is one
+        row range) on three side streams: the recurrence is a chain of T dependent steps per group, the
+        longest group sets its time and the CUs of the short groups idle towards the end -- the output
+        layer of the classes that are done runs there instead of behind the whole recurrence (11.9 ->
+        10.7 ms per 1 920 lines, against 10.2 for the recurrence alone).  Same kernels on the same rows:
+        results are bit for bit those of the single launches.  class_split = True / False forces the choice
+        (tests, timing); None leaves it to _class_split_wanted."""
         if st["n"] == 0:
             return
         lib = _native.lib
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        if lstm:
-            cont = st.get("continuation")          # (h0, c0, tstart) device tensors, or None: fresh lines
-            _native.check(lib.ta_lstm_forward(
-                st["x"].data_ptr(), st["row_off"].data_ptr(), st["T"].data_ptr(),
-                st["group_lines"].data_ptr(), st["ngroups"], self.wp.data_ptr(),
-                self.peep.data_ptr(), st["hout"].data_ptr(), self.mode,
-                cont[0].data_ptr() if cont else None, cont[1].data_ptr() if cont else None,
-                cont[2].data_ptr() if cont else None, stream), "ta_lstm_forward")
+        cs = torch.cuda.current_stream(self.device)
+        stream = cs.cuda_stream
+        cont = st.get("continuation")          # (h0, c0, tstart) device tensors, or None: fresh lines
         full = want_logits or from_probs
         if full and st["probs"] is None:
             shape = (max(st["rows"], 1), self.model.no)
             st["probs"] = torch.empty(shape, dtype=torch.float32, device=self.device)
             st["logits"] = torch.empty(shape, dtype=torch.float32, device=self.device)
-        if output and self.mode == 1:
-            _native.check(lib.ta_lstm_output_split(
-                st["hout"].data_ptr(), st["rows"], self.w2s.data_ptr(), self.w2bias.data_ptr(), self.model.no,
-                st["probs"].data_ptr() if full else None,
-                st["logits"].data_ptr() if full else None,
-                st["summary"].data_ptr(), stream), "ta_lstm_output_split")
-        elif output:
-            _native.check(lib.ta_lstm_output(
-                st["hout"].data_ptr(), st["rows"], self.w2p.data_ptr(), self.model.no,
-                st["probs"].data_ptr() if full else None,
-                st["logits"].data_ptr() if full else None,
-                st["summary"].data_ptr(), stream), "ta_lstm_output")
+
+        def forward(g0, g1, stream_):
+            _native.check(lib.ta_lstm_forward(
+                st["x"].data_ptr(), st["row_off"].data_ptr(), st["T"].data_ptr(),
+                st["group_lines"].data_ptr() + 64 * g0, g1 - g0, self.wp.data_ptr(),
+                self.peep.data_ptr(), st["hout"].data_ptr(), self.mode,
+                cont[0].data_ptr() if cont else None, cont[1].data_ptr() if cont else None,
+                cont[2].data_ptr() if cont else None, stream_), "ta_lstm_forward")
+
+        def outputs(r0, r1, stream_):
+            no = self.model.no
+            probs = st["probs"].data_ptr() + 4 * no * r0 if full else None
+            logits = st["logits"].data_ptr() + 4 * no * r0 if full else None
+            hout, summary = st["hout"].data_ptr() + 4 * 2 * NS * r0, st["summary"].data_ptr() + 16 * r0
+            if self.mode == 1:
+                _native.check(lib.ta_lstm_output_split(hout, r1 - r0, self.w2s.data_ptr(), self.w2bias.data_ptr(), no,
+                                                       probs, logits, summary, stream_), "ta_lstm_output_split")
+            else:
+                _native.check(lib.ta_lstm_output(hout, r1 - r0, self.w2p.data_ptr(), no, probs, logits, summary,
+                                                 stream_), "ta_lstm_output")
+        ng = st["ngroups"]
+        if class_split is None:
+            class_split = lstm and output and _class_split_wanted(self, st)
+        if class_split and lstm and output and ng >= 3:
+            cuts = [0, max(1, int(round(0.1 * ng))), max(2, int(round(0.3 * ng))), ng]
+            side = _class_streams(self.device)
+            for c in range(3):
+                side[c].wait_stream(cs)
+                forward(cuts[c], cuts[c + 1], side[c].cuda_stream)
+                r0, r1 = int(st["group_row_host"][cuts[c]]), int(st["group_row_host"][cuts[c + 1]])
+                if r1 > r0:
+                    outputs(r0, r1, side[c].cuda_stream)
+            for c in range(3):
+                cs.wait_stream(side[c])
+        else:
+            if lstm:
+                forward(0, ng, stream)
+            if output:
+                outputs(0, st["rows"], stream)
         if decode and from_probs:
             _native.check(lib.ta_decode(
                 st["probs"].data_ptr(), st["row_off"].data_ptr(), st["T"].data_ptr(), st["n"],
@@ -354,7 +441,7 @@ class LineRecognizer(object):
         dn = st["dec_n"].cpu().numpy()
         out = []
         for b in range(st["n"]):
-            o = int(st["row_off_host"][b])
+            o = int(st["row_start_host"][b])
             k = int(dn[b])
             out.append(list(zip(dt[o:o + k].tolist(), dc[o:o + k].tolist())))
         return out
@@ -369,7 +456,7 @@ class LineRecognizer(object):
         probs = st["probs"].cpu().numpy()
         logits = st["logits"].cpu().numpy()
         states = st["hout"].cpu().numpy()
-        sl = [slice(int(st["row_off_host"][b]), int(st["row_off_host"][b + 1])) for b in range(st["n"])]
+        sl = [slice(int(st["row_start_host"][b]), int(st["row_start_host"][b] + st["T_host"][b])) for b in range(st["n"])]
         return dec, [probs[s] for s in sl], [logits[s] for s in sl], [states[s] for s in sl]
 
     # ---- wire format ------------------------------------------------------------------------

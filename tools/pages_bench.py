@@ -100,8 +100,9 @@ def setup_sharded(pages_per_rank, rank, world, seed0=100):
     job = {"pages": [make_page(seed0 + k)[0] for k in mine], "transcripts": [transcripts[k] for k in mine],
            "ids": mine, "models": [recs[k % 2] for k in mine], "capacity": capacity,
            "all_transcripts": transcripts, "total_pages": total}
-    sharding.process_shard(job["pages"], job["transcripts"], mine, job["models"],
-                           capacity, PARAMS)                       # warm-up at full size (collective: every rank)
+    for _ in range(3):                    # warm-up at full size (collective: every rank); the first calls of a process
+        sharding.process_shard(job["pages"], job["transcripts"], mine, job["models"],      # pay for stream / queue
+                               capacity, PARAMS)                                           # creation and allocator growth
     torch.cuda.synchronize()
     return job
 
@@ -119,12 +120,20 @@ def run(npages, seed0=100):
     from text_alignment_amd import alignToOCR as atocr
     rec = make_recognizer()
     pages, trs = zip(*[make_page(seed0 + k) for k in range(npages)])
-    atocr.process_batch(list(pages), list(trs), rec, PARAMS)                  # warm-up at full size (staging buffer)
+    def best_of(n, pages_, trs_):
+        """shortest of n passes (the host side of a pass -- numpy, uploads from pageable memory -- varies by
+        +-20 % from call to call on a shared box; the device work does not)"""
+        best, out = 1e30, None
+        for _ in range(n):
+            t0 = time.perf_counter()
+            out = atocr.process_batch(pages_, trs_, rec, PARAMS)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        return best, out
+    for _ in range(3):                       # warm-up at full size (staging buffers, streams, allocator)
+        atocr.process_batch(list(pages), list(trs), rec, PARAMS)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res = atocr.process_batch(list(pages), list(trs), rec, PARAMS)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, res = best_of(3, list(pages), list(trs))
     # BASELINE configs[2]: one page end to end (30 strips + one NW problem), latency of a lone call
     import gc
     gc.collect()                               # a generation-2 collection in mid-call costs ~20 ms
@@ -136,24 +145,17 @@ def run(npages, seed0=100):
         lat.append(time.perf_counter() - t1)
     # the same from raw strips: line normaliser on the device in front of the recogniser
     rpages, rtrs = zip(*[make_page(seed0 + 5000 + k, raw=True) for k in range(npages)])
-    atocr.process_batch(list(rpages), list(rtrs), rec, PARAMS)
+    for _ in range(2):
+        atocr.process_batch(list(rpages), list(rtrs), rec, PARAMS)
     torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    atocr.process_batch(list(rpages), list(rtrs), rec, PARAMS)
-    torch.cuda.synchronize()
-    raw_dt = time.perf_counter() - t2
+    raw_dt, _ = best_of(3, list(rpages), list(rtrs))
     # and from whole page images: preprocessing and line finding on the device as well
     nimg = npages
     ipages = [RawPage(make_page_image(seed0 + 9000 + k)) for k in range(nimg)]
     itrs = list(trs[:nimg])
     atocr.process_batch(ipages, itrs, rec, PARAMS)         # warm: the page planes come out of torch's caching allocator
     torch.cuda.synchronize()
-    img_dt = 1e9
-    for _ in range(2):
-        t3 = time.perf_counter()
-        atocr.process_batch(ipages, itrs, rec, PARAMS)
-        torch.cuda.synchronize()
-        img_dt = min(img_dt, time.perf_counter() - t3)
+    img_dt, _ = best_of(3, ipages, itrs)
     return {"pages": npages, "seconds": dt, "pages_per_s": npages / dt, "lines_per_s": npages * 30 / dt,
             "single_page_ms": 1e3 * sorted(lat)[2],
             "page_images": {"pages": nimg, "pages_per_s": nimg / img_dt, "seconds": img_dt,
@@ -161,6 +163,7 @@ def run(npages, seed0=100):
             "raw_strips": {"pages_per_s": npages / raw_dt, "seconds": raw_dt,
                            "note": "strips as 60-row uint8 images, normalised by csrc/ta_lineest.hip"},
             "syllable_boxes": sum(len(r[0]) for r in res),
+            "timing": "shortest of 3 passes after warm-up, each a whole process_batch call incl. the final synchronize",
             "note": "process_batch end to end: host upload + K3/K4/K5 + NW + host glue (numpy arrays, page_batch.py)"}
 
 
