@@ -26,11 +26,17 @@ for w in "1 4096 4096" "64 4096 4096" "1 8192 8192"; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_onepass_$1x$2" -o nw -- python3 "$REPO/tools/onepass_time.py" $1 $2 $3 > "$OUT/kt_onepass_$1x$2.log" 2>&1
   echo "one-pass $1 x $2 kernel trace done"
 done
+# per-kernel traces: one launch per kernel (the product splits large batches into length classes on side
+# streams, ocr.LineRecognizer.run; its own trace follows)
+export TA_OCR_CLASS_SPLIT=0
 for w in "1920 f32" "1920 split" "5760 f32"; do
   set -- $w
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_$1_$2" -o ocr -- python3 "$REPO/tools/ocr_only.py" $1 $2 > "$OUT/kt_ocr_$1_$2.log" 2>&1
   echo "ocr $1 $2 kernel trace done"
 done
+unset TA_OCR_CLASS_SPLIT
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_1920_f32_classes" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f32 > "$OUT/kt_ocr_1920_f32_classes.log" 2>&1
+echo "ocr 1920 f32 (length classes) kernel trace done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_pages_images" -o pg -- python3 "$REPO/tools/pages_img_time.py" 32 8 1 > "$OUT/kt_pages_images.log" 2>&1
 echo "page images kernel trace done"
 for mode in two one; do
@@ -40,6 +46,7 @@ for mode in two one; do
     echo "$mode $ctr done"
   done
 done
+export TA_OCR_CLASS_SPLIT=0
 for prec in split f32; do
   timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_$prec" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 $prec > "$OUT/ocr_pmc_$prec.log" 2>&1
   echo "ocr pmc $prec done"
