@@ -263,11 +263,14 @@ def bench_ocr(args, rank, precision=None, nlines=None):
         # exact f32 arithmetic of this recurrence is bounded by the f32-input MFMA rate; algorithmic
         # flops per timestep: 2 dirs x 4 gates x 100 units x 149 inputs x 2
         tf = tsteps * 238400.0 / (lstm_ms * 1e-3) / 1e12
-        busy, busy_src = measured_mfma_busy("lstm_seq_kernel") if nlines == 1920 else (None, None)
+        busy, busy_src = (measured_mfma_busy("lstm_seq_kernel") if nlines == 1920 and st["group_size"] == 16
+                          else (None, None))
         roof = {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": tf / F32_MFMA_PEAK_TF, "traffic": None, "kernel": "lstm_seq_kernel",
+                "frac": tf / F32_MFMA_PEAK_TF, "traffic": None,
+                "kernel": "lstm_seq4_kernel" if st["group_size"] == 4 else "lstm_seq_kernel",
                 "flops": "algorithmic: 238400 per timestep (the kernel executes 14 % more on padded tiles)",
-                "peak_is": "f32-input MFMA (v_mfma_f32_16x16x4_f32), the instruction the kernel issues",
+                "peak_is": "f32-input MFMA (v_mfma_f32_4x4x1_16B_f32 for groups of 4 lines, v_mfma_f32_16x16x4_f32 for "
+                           "groups of 16: the same 256 flop per cycle and CU), the instruction the kernel issues",
                 "mfma_pipe_busy_rocprof": busy, "mfma_pipe_busy_source": busy_src}
     else:
         # what the 16-bit matrix pipe executes in this mode: 4 products per k-step on 16x16x32 tiles over
@@ -283,7 +286,8 @@ def bench_ocr(args, rank, precision=None, nlines=None):
             "dtype": "f32" if f32 else "split 16-bit operands (W: bf16 + fp16, a: 3 x bf16 + fp16), f32 accumulate",
             "ms": {"lstm": lstm_ms, "output_softmax": out_ms, "decode": dec_ms, "pass": 1e3 * dt,
                    "note": "lstm / output_softmax / decode: each kernel launched alone; pass: one run() of all three"},
-            "class_split": bool(ocr._split_state.get("ok")) and st["ngroups"] >= ocr.CLASS_SPLIT_MIN_GROUPS,
+            "class_split": bool(ocr._split_state.get("ok")) and st["n"] >= ocr.CLASS_SPLIT_MIN_LINES,
+            "lines_per_workgroup": st["group_size"],
             "roofline": roof}
 
 

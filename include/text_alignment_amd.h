@@ -179,8 +179,8 @@ int ta_nw_general_batch(const int32_t* t_codes, const int64_t* t_off,
  *   hout  [rows][200]  BiLSTM outputs [forward 100 | reversed LSTM flipped back 100]
  *   probs [rows][no]   softmax outputs;  logits [rows][no] optional (NULL to skip)
  *
- * ta_lstm_forward: group_lines = int32[ngroups][16] line ids (-1 = empty slot); one workgroup
- *   runs the 16 lines of a group in lockstep, so groups should hold lines of similar length.
+ * ta_lstm_forward: group_lines = int32[ngroups][16] line ids (-1 = empty slot; [ngroups][4] in mode 2); one
+ *   workgroup runs the lines of a group in lockstep, so groups should hold lines of similar length.
  *   mode 0: exact f32 MFMA chain.  wp = ta_lstm_packed_weight_floats(0) floats: B fragments
  *          [dir 2][wave 7][gate GI,GF,GO,CI][k-step 38][lane 64] =
  *          W_gate[unit 16*wave + lane%16][kp 4*kstep + lane/16], kp: 0 bias, 1..48 x,
@@ -191,6 +191,11 @@ int ta_nw_general_batch(const int32_t* t_codes, const int64_t* t_off,
  *          [dir 2][wave 7][plane hi,r][gate 4][k-step 5][lane 64][8] =
  *          plane of W_gate[unit 16*wave + lane%16][kp 32*kstep + 8*(lane/16) + j], kp as above
  *          padded with zeros to 160.
+ *   mode 2: mode 0's arithmetic, bit for bit, on groups of FOUR lines (group_lines = int32[ngroups][4]):
+ *          v_mfma_f32_4x4x1_16B_f32, one k per instruction -- a step costs a quarter of mode 0's, for the
+ *          batches (a page, a few hundred lines) whose time is their longest line's.  wp =
+ *          ta_lstm_packed_weight_floats(2) floats [dir 2][wave 7][k 152][lane 64] =
+ *          W_gate(lane % 4)[unit 16*wave + lane/4][kp k], kp and padding as in mode 0.
  *   peep = float[2][3][112]: WIP, WFP, WOP per direction, units >= 100 zero.
  *   h0, c0, tstart (all NULL for fresh lines, or all given): a "line" may be the continuation of a
  *          sequence run elsewhere -- float h0[lines][2][100] / c0[lines][2][100] are the LSTM output

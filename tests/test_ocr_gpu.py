@@ -87,7 +87,7 @@ def test_split_mode():
     _check_lines(R, ocr, R.synthetic_model(7001, no=96), [1, 17, 40, 64, 100], TOL, precision="split")
 
 
-def _segmented_states(rec, st, om, lines, seg):
+def _segmented_states(rec, st, om, lines, seg, group=16):
     """Re-run K3 over `st` (a prepared batch of `lines`) in segments of `seg` timesteps, every
     segment restarted from the float64 oracle's LSTM state at its boundary: the kernel's own drift
     is then bounded by what `seg` steps can accumulate, however chaotic the model is.  The segments
@@ -112,8 +112,8 @@ def _segmented_states(rec, st, om, lines, seg):
             ts.append([a, done_rev])
     nseg = len(T)
     order = np.argsort(-np.asarray(T), kind="stable")
-    ngroups = (nseg + 15) // 16
-    group_lines = np.full((ngroups, 16), -1, dtype=np.int32)
+    ngroups = (nseg + group - 1) // group
+    group_lines = np.full((ngroups, group), -1, dtype=np.int32)
     group_lines.reshape(-1)[:nseg] = order
 
     def d(a, dt):
@@ -121,8 +121,9 @@ def _segmented_states(rec, st, om, lines, seg):
     args = (d(row_off, np.int64), d(T, np.int32), d(group_lines, np.int32),
             d(h0, np.float32), d(c0, np.float32), d(ts, np.int32))
     rc = _native.lib.ta_lstm_forward(st["x"].data_ptr(), args[0].data_ptr(), args[1].data_ptr(),
-                                     args[2].data_ptr(), ngroups, rec.wp.data_ptr(), rec.peep.data_ptr(),
-                                     st["hout"].data_ptr(), rec.mode, args[3].data_ptr(), args[4].data_ptr(),
+                                     args[2].data_ptr(), ngroups, (rec.wp4 if group == 4 else rec.wp).data_ptr(),
+                                     rec.peep.data_ptr(), st["hout"].data_ptr(), 2 if group == 4 else rec.mode,
+                                     args[3].data_ptr(), args[4].data_ptr(),
                                      args[5].data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     _native.check(rc, "ta_lstm_forward")
     torch.cuda.synchronize()
@@ -237,11 +238,12 @@ def test_class_split_launches_equal_single_launches(precision):
     rng = np.random.default_rng(3)
     lines = [R.synthetic_line(9500 + k, width=int(w)) for k, w in enumerate(rng.integers(20, 200, size=16 * 26 + 5))]
     st = rec.prepare(lines)
-    assert st["ngroups"] == 27
+    G = st["group_size"]
+    assert G == (4 if precision == "f32" else 16) and st["ngroups"] == (len(lines) + G - 1) // G
     T, start = st["T_host"], st["row_start_host"]
     order = np.argsort(-T, kind="stable")
     assert np.array_equal(start[order], np.cumsum(T[order]) - T[order])           # sorted layout, no holes
-    assert np.array_equal(st["group_row_host"][:-1], start[order[::16]]) and st["group_row_host"][-1] == T.sum()
+    assert np.array_equal(st["group_row_host"][:-1], start[order[::G]]) and st["group_row_host"][-1] == T.sum()
     out = {}
     for split in (False, True):
         for key in ("hout", "summary", "dec_t", "dec_c", "dec_n"):
@@ -258,6 +260,42 @@ def test_class_split_launches_equal_single_launches(precision):
     rec.run(st)                                               # the default path: checks itself once, then decides
     assert ocr._split_state["ok"] in (True, False) and set(ocr._split_state["times_ms"]) == {True, False}
     print("class split timing check:", ocr._split_state["times_ms"], "->", ocr._split_state["ok"])
+
+
+def test_four_line_groups_equal_sixteen_line_groups(monkeypatch):
+    """Exact-f32 mode has two recurrence kernels: groups of 16 lines on v_mfma_f32_16x16x4_f32 and groups of 4
+    on v_mfma_f32_4x4x1_16B_f32 (small and medium batches).  One k per instruction in ascending order is the
+    fmaf chain the 16 x 16 x 4 form computes too and the gate arithmetic is the same code, so the LSTM outputs
+    are equal to the BIT -- which kernel a batch takes never shows in a result.  Ragged lengths, 1 .. 21
+    lines (every fill of the last group), both directions, and a continued sequence (h0 / c0 / tstart)."""
+    R, ocr, om, pm = _models(7002, 64)
+    rec = ocr.LineRecognizer(pm)
+    rng = np.random.default_rng(17)
+    pool = [R.synthetic_line(9900 + k, width=int(w)) for k, w in enumerate(rng.integers(1, 260, size=21))]
+    for cnt in (1, 2, 3, 4, 5, 7, 8, 16, 17, 21):
+        got = {}
+        for G in ("4", "16"):
+            monkeypatch.setenv("TA_OCR_GROUP", G)
+            st = rec.prepare(pool[:cnt])
+            assert st["group_size"] == int(G)
+            rec.run(st, want_logits=True)
+            torch.cuda.synchronize()
+            # rows are laid out by groups of G: compare line by line
+            got[G] = [(st["hout"][int(s):int(s + t)].clone(), st["logits"][int(s):int(s + t)].clone())
+                      for s, t in zip(st["row_start_host"], st["T_host"])] + [rec.decoded(st)]
+        for a, b in zip(got["4"][:-1], got["16"][:-1]):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), cnt
+        assert got["4"][-1] == got["16"][-1]
+    # continued sequences (h0 / c0 / tstart): segments of 37 steps restarted from the float64 states, both kernels
+    monkeypatch.delenv("TA_OCR_GROUP")
+    lines = [ln for ln in pool if ln.shape[0] >= 60][:7]
+    st = rec.prepare(lines)
+    seg = {}
+    for G in (4, 16):
+        st["hout"].zero_()
+        _segmented_states(rec, st, om, lines, 37, group=G)
+        seg[G] = st["hout"].clone()
+    assert torch.equal(seg[4], seg[16])
 
 
 def test_input_too_large():

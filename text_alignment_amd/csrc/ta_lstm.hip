@@ -76,6 +76,24 @@ __device__ __forceinline__ float tanh_min(float x) {
     return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.8853900432586669921875f)), -1.0f);
 }
 
+// One LSTM cell update from the four pre-activations of a (line, unit) pair, shared by
+// both exact-f32 recurrence kernels so that they round alike: every multiply-add is spelled as the fmaf it is
+// meant to be, which leaves the compiler nothing to contract (which of `ci * gi + gf * c`'s two products is
+// fused was its choice before, and it chose differently in the two kernels).  past0: not the first step of the
+// whole sequence -- the peepholes on the old cell state and the output peephole are skipped at t = 0.
+__device__ __forceinline__ float lstm_cell_f32(float gi, float gf, float go, float ci_pre, float& c, bool past0,
+                                               float wip, float wfp, float wop) {
+    const float ci = tanh_min(ci_pre);
+    if (past0) { gi = fmaf(wip, c, gi); gf = fmaf(wfp, c, gf); }
+    gi = sigmoid_min(gi);
+    gf = sigmoid_min(gf);
+    const float cn = past0 ? fmaf(ci, gi, gf * c) : ci * gi;       // (the product with the old state is the rounded one)
+    if (past0) go = fmaf(wop, cn, go);
+    go = sigmoid_min(go);
+    c = cn;
+    return tanh_min(cn) * go;
+}
+
 // Seven waves own 16 units each (4 gates x 38 k-steps = 152 MFMAs per timestep); on four SIMDs that
 // is 2, 2, 2, 1 waves and the SIMDs with two waves set the pace.  An eighth wave takes the CI gate of
 // waves 4, 5 and 6 (3 x 38 = 114 MFMAs, the same operands in the same order, so the sums are
@@ -234,17 +252,21 @@ __global__ __launch_bounds__(kSeqWaves * 64) void lstm_seq_kernel(LstmArgs a) {
         // gates: acc[0..3] = WGI, WGF, WGO, WCI . src
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            const bool past0 = (t > 0) | (ts[r] > 0);             // not the first step of the whole sequence
+#ifdef TA_OLD_GATES
             float gi = acc[0][r], gf = acc[1][r], go = acc[2][r];
             const float ci = tanh_min(acc[3][r]);
-            const bool past0 = (t > 0) | (ts[r] > 0);             // not the first step of the whole sequence
             if (past0) { gi += wip * c[r]; gf += wfp * c[r]; }
             gi = sigmoid_min(gi);
             gf = sigmoid_min(gf);
             float cn = ci * gi;
-            if (past0) { cn += gf * c[r]; go += wop * cn; }      // output peephole skipped at t = 0
+            if (past0) { cn += gf * c[r]; go += wop * cn; }
             go = sigmoid_min(go);
             const float h = tanh_min(cn) * go;
             c[r] = cn;
+#else
+            const float h = lstm_cell_f32(acc[0][r], acc[1][r], acc[2][r], acc[3][r], c[r], past0, wip, wfp, wop);
+#endif
             if (unit < kNs) {
                 const int slot = (lane >> 4) * 4 + r;
                 const int kp = kXK + unit;
@@ -257,6 +279,239 @@ __global__ __launch_bounds__(kSeqWaves * 64) void lstm_seq_kernel(LstmArgs a) {
         }
         __syncthreads();
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3 for SMALL batches: the same recurrence, bit for bit, on groups of FOUR lines.
+//
+// The recurrence is a chain of T dependent steps per group, and a step of the 16-line kernel above costs
+// what its 16 x 16 x 4 MFMA tiles cost however many of the 16 rows are lines: a page of 30 lines is two
+// groups, and even 1 920 lines are only 240 workgroups on 256 CUs -- the longest group sets the time and
+// most CUs idle for part of it.  v_mfma_f32_4x4x1_16B_f32 computes sixteen 4 x 4 outer products per
+// instruction (one k per instruction, 8 cycles instead of 32): with A broadcast from one block (cbsz = 4:
+// the four LINES' inputs at step k) and B holding the weights of 16 units x 4 gates at that k, a wave
+// advances four lines at a quarter of the cost -- four times as many, four times shorter workgroups, which
+// pack onto the CUs (and a lone page finishes in a quarter of the time).  One k per instruction in
+// ascending order is the fmaf chain the 16 x 16 x 4 form computes as well (tools/ubench/mfma4x4.hip: all
+// 256 outputs of a 152-term product identical to the host's fmaf chain in both forms), the gate functions
+// are the same instructions, so the outputs are the 16-line kernel's to the bit
+// (tests/test_ocr_gpu.py::test_four_line_groups_equal_sixteen_line_groups).
+//
+// Layout.  A wave owns 16 units; lane = 4 * b + j holds, of the B operand, the weight of (unit 16w + b,
+// gate j) -- blocks are units, the 4 columns of a block the 4 gates -- so the accumulator register r of lane
+// (b, j) is the pre-activation of gate j, unit b, LINE r.  A 4 x 4 transpose inside each quad of lanes (two
+// rounds of DPP quad permutes) turns that into: lane (b, j) holds all four gates of unit b for line j, and
+// does the gate math of that one (line, unit) pair.  The A operand of 16 consecutive k is ONE register
+// (lane = 4 * (k % 16) + line; `abid` = k % 16 selects the block to broadcast): ten LDS reads per step.
+constexpr int kG4 = 4;              // lines per workgroup
+constexpr int kKC4 = (kKP + 15) / 16;   // 10 A registers of 16 k each
+
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+__global__ __launch_bounds__(kWaves * 64) void lstm_seq4_kernel(LstmArgs a) {
+    // A tile in LDS, [k][line]: the x rows (k < 52: 1, x_t, zeros) three deep, the h rows (k >= 52) two deep
+    __shared__ __attribute__((aligned(16))) float xs[3][256];              // 52 x 4 used; a 64-lane read of chunk 3 stays inside
+    __shared__ __attribute__((aligned(16))) float hs[2][448];              // 112 units x 4 lines
+    __shared__ int s_line[kG4];
+    __shared__ int s_T[kG4];
+    __shared__ long long s_row[kG4];
+
+    const int grp = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < kG4) {
+        const int id = a.group_lines[grp * kG4 + tid];
+        s_line[tid] = id;
+        s_T[tid] = id >= 0 ? a.T[id] : 0;
+        s_row[tid] = id >= 0 ? a.row_off[id] : 0;
+    }
+    for (int e = tid; e < 3 * 256; e += kWaves * 64) (&xs[0][0])[e] = 0.0f;
+    for (int e = tid; e < 2 * 448; e += kWaves * 64) (&hs[0][0])[e] = 0.0f;
+    __syncthreads();
+    int Tmax = 0;
+#pragma unroll
+    for (int s = 0; s < kG4; ++s) Tmax = max(Tmax, s_T[s]);
+
+    // weights: Bf[k][lane] = W_gate(lane % 4)[unit 16 * wave + lane / 4][k]
+    float Bf[kKP];
+    {
+        const float* wp = a.wp + ((size_t)(dir * kWaves + wave) * kKP) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < kKP; ++k) Bf[k] = wp[(size_t)k * 64];
+    }
+    const int unit = wave * 16 + (lane >> 2), slot = lane & 3;      // this lane's (unit, line) after the transpose
+    const float wip = a.peep[(dir * 3 + 0) * 112 + unit];
+    const float wfp = a.peep[(dir * 3 + 1) * 112 + unit];
+    const float wop = a.peep[(dir * 3 + 2) * 112 + unit];
+    const int myT = s_T[slot];
+    const long long myrow = s_row[slot];
+    float c = 0.f;
+    int ts = 0;
+    {
+        const int id = s_line[slot];
+        if (id >= 0) {
+            if (a.c0 && unit < kNs) c = a.c0[((size_t)id * 2 + dir) * kNs + unit];
+            if (a.tstart) ts = a.tstart[(size_t)id * 2 + dir];
+        }
+    }
+    if (a.h0) {                                            // h_{-1} of continued sequences into the first A tile
+        for (int e = tid; e < kG4 * kNs; e += kWaves * 64) {
+            const int sl = e / kNs, u = e % kNs;
+            const int id = s_line[sl];
+            if (id >= 0) hs[0][u * kG4 + sl] = a.h0[((size_t)id * 2 + dir) * kNs + u];
+        }
+    }
+    // loader role: thread e < 4 * 48 -> (line e / 48, input row e % 48); the constant row k = 0 is set once
+    if (tid < 3 * kG4) xs[tid / kG4][tid % kG4] = 1.0f;
+    // loader role: wave 3 -- alone on its SIMD (waves w and w + 4 share one), so the wait for its loads costs
+    // nobody else's issue slots -- lane l takes elements l, l + 64, l + 128 of the 4 x 48 inputs of a step:
+    // element e -> (line e / 48, input row e % 48)
+    const bool loader = wave == 3;
+    auto x_value = [&](int i, int t) -> float {
+        const int e = lane + 64 * i, sl = e / kNi;
+        const int Tl = s_T[sl];
+        if (Tl <= 0) return 0.0f;
+        int tt = t < Tl ? t : Tl - 1;
+        if (dir) tt = Tl - 1 - tt;                          // Reversed(LSTM): run on xs[::-1]
+        return a.x[(s_row[sl] + tt) * kNi + e % kNi];
+    };
+    auto x_store = [&](int buf, int i, float v) {
+        const int e = lane + 64 * i;
+        xs[buf][(1 + e % kNi) * kG4 + e / kNi] = v;
+    };
+    if (loader) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            x_store(0, i, x_value(i, 0));
+            if (Tmax > 1) x_store(1, i, x_value(i, 1));
+        }
+    }
+    __syncthreads();
+
+    // A step's products come in two parts: k < 49 over [1, x_t] (k = 49 .. 51 are zero padding of both operands:
+    // adding +0 to an accumulator that is never -0 changes nothing, so those three are not issued) and k >= 52 over
+    // h_{t-1}; only the second waits for the previous step.  A wave's accumulator is ONE dependent chain of MFMAs
+    // (12.6 cycles each when the wave is alone on the pipe, 8 when something fills the gaps), so the x part of step
+    // t + 1 -- a second, independent accumulator -- is issued INTERLEAVED with the h part of step t, two h products
+    // to one x product: x_{t+1} sits in LDS one step early for that (xs is three deep: x_t is gone, x_{t+1} is being
+    // multiplied, x_{t+2} is being stored) and the row prefetched from HBM is x_{t+2}.  Either accumulator takes
+    // its x part first (into zeros), then its h part, k ascending -- the order of the 16-line kernel: same bits.
+#define TA_M4(ac, q, kk) ac = __builtin_amdgcn_mfma_f32_4x4x1f32(A[q], Bf[16 * (q) + (kk)], ac, 4, kk, 0);
+    static_assert(kXK == 52 && kKP == 152 && kNi == 48, "the spelled-out k ranges below");
+    f32x4 accn = {0.f, 0.f, 0.f, 0.f};
+    {                                                         // x part of step 0
+        float A[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) A[q] = xs[0][64 * q + lane];
+        f32x4 ac = accn;
+        TA_M4(ac, 0, 0) TA_M4(ac, 0, 1) TA_M4(ac, 0, 2) TA_M4(ac, 0, 3)
+        TA_M4(ac, 0, 4) TA_M4(ac, 0, 5) TA_M4(ac, 0, 6) TA_M4(ac, 0, 7)
+        TA_M4(ac, 0, 8) TA_M4(ac, 0, 9) TA_M4(ac, 0, 10) TA_M4(ac, 0, 11)
+        TA_M4(ac, 0, 12) TA_M4(ac, 0, 13) TA_M4(ac, 0, 14) TA_M4(ac, 0, 15)
+        TA_M4(ac, 1, 0) TA_M4(ac, 1, 1) TA_M4(ac, 1, 2) TA_M4(ac, 1, 3)
+        TA_M4(ac, 1, 4) TA_M4(ac, 1, 5) TA_M4(ac, 1, 6) TA_M4(ac, 1, 7)
+        TA_M4(ac, 1, 8) TA_M4(ac, 1, 9) TA_M4(ac, 1, 10) TA_M4(ac, 1, 11)
+        TA_M4(ac, 1, 12) TA_M4(ac, 1, 13) TA_M4(ac, 1, 14) TA_M4(ac, 1, 15)
+        TA_M4(ac, 2, 0) TA_M4(ac, 2, 1) TA_M4(ac, 2, 2) TA_M4(ac, 2, 3)
+        TA_M4(ac, 2, 4) TA_M4(ac, 2, 5) TA_M4(ac, 2, 6) TA_M4(ac, 2, 7)
+        TA_M4(ac, 2, 8) TA_M4(ac, 2, 9) TA_M4(ac, 2, 10) TA_M4(ac, 2, 11)
+        TA_M4(ac, 2, 12) TA_M4(ac, 2, 13) TA_M4(ac, 2, 14) TA_M4(ac, 2, 15)
+        TA_M4(ac, 3, 0)
+        accn = ac;
+    }
+    int b1 = 1, b2 = 2, b3 = 0;                               // xs buffers of x_{t+1}, x_{t+2} and the one after
+
+    for (int t = 0; t < Tmax; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        float xn[3] = {0.f, 0.f, 0.f};
+        if (loader && t + 2 < Tmax) {                         // flies under the MFMAs
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xn[i] = x_value(i, t + 2);
+        }
+        f32x4 acc = accn;
+        accn = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            float A[kKC4];                                    // chunks 0 .. 3 (lanes < 16 of chunk 3): x rows; 3 .. 9: h rows
+#pragma unroll
+            for (int q = 0; q < 3; ++q) A[q] = xs[b1][64 * q + lane];
+            // chunk 3 = k 48 .. 63: lanes < 16 are x rows (k 48 .. 51), lanes >= 16 h rows 0 .. 11
+            A[3] = lane < 16 ? xs[b1][192 + lane] : hs[cur][max(lane - 16, 0)];
+#pragma unroll
+            for (int q = 4; q < kKC4; ++q) A[q] = hs[cur][64 * q - 4 * kXK + lane];
+            TA_M4(acc, 3, 4) TA_M4(acc, 3, 5) TA_M4(accn, 0, 0) TA_M4(acc, 3, 6)
+            TA_M4(acc, 3, 7) TA_M4(accn, 0, 1) TA_M4(acc, 3, 8) TA_M4(acc, 3, 9)
+            TA_M4(accn, 0, 2) TA_M4(acc, 3, 10) TA_M4(acc, 3, 11) TA_M4(accn, 0, 3)
+            TA_M4(acc, 3, 12) TA_M4(acc, 3, 13) TA_M4(accn, 0, 4) TA_M4(acc, 3, 14)
+            TA_M4(acc, 3, 15) TA_M4(accn, 0, 5) TA_M4(acc, 4, 0) TA_M4(acc, 4, 1)
+            TA_M4(accn, 0, 6) TA_M4(acc, 4, 2) TA_M4(acc, 4, 3) TA_M4(accn, 0, 7)
+            TA_M4(acc, 4, 4) TA_M4(acc, 4, 5) TA_M4(accn, 0, 8) TA_M4(acc, 4, 6)
+            TA_M4(acc, 4, 7) TA_M4(accn, 0, 9) TA_M4(acc, 4, 8) TA_M4(acc, 4, 9)
+            TA_M4(accn, 0, 10) TA_M4(acc, 4, 10) TA_M4(acc, 4, 11) TA_M4(accn, 0, 11)
+            TA_M4(acc, 4, 12) TA_M4(acc, 4, 13) TA_M4(accn, 0, 12) TA_M4(acc, 4, 14)
+            TA_M4(acc, 4, 15) TA_M4(accn, 0, 13) TA_M4(acc, 5, 0) TA_M4(acc, 5, 1)
+            TA_M4(accn, 0, 14) TA_M4(acc, 5, 2) TA_M4(acc, 5, 3) TA_M4(accn, 0, 15)
+            TA_M4(acc, 5, 4) TA_M4(acc, 5, 5) TA_M4(accn, 1, 0) TA_M4(acc, 5, 6)
+            TA_M4(acc, 5, 7) TA_M4(accn, 1, 1) TA_M4(acc, 5, 8) TA_M4(acc, 5, 9)
+            TA_M4(accn, 1, 2) TA_M4(acc, 5, 10) TA_M4(acc, 5, 11) TA_M4(accn, 1, 3)
+            TA_M4(acc, 5, 12) TA_M4(acc, 5, 13) TA_M4(accn, 1, 4) TA_M4(acc, 5, 14)
+            TA_M4(acc, 5, 15) TA_M4(accn, 1, 5) TA_M4(acc, 6, 0) TA_M4(acc, 6, 1)
+            TA_M4(accn, 1, 6) TA_M4(acc, 6, 2) TA_M4(acc, 6, 3) TA_M4(accn, 1, 7)
+            TA_M4(acc, 6, 4) TA_M4(acc, 6, 5) TA_M4(accn, 1, 8) TA_M4(acc, 6, 6)
+            TA_M4(acc, 6, 7) TA_M4(accn, 1, 9) TA_M4(acc, 6, 8) TA_M4(acc, 6, 9)
+            TA_M4(accn, 1, 10) TA_M4(acc, 6, 10) TA_M4(acc, 6, 11) TA_M4(accn, 1, 11)
+            TA_M4(acc, 6, 12) TA_M4(acc, 6, 13) TA_M4(accn, 1, 12) TA_M4(acc, 6, 14)
+            TA_M4(acc, 6, 15) TA_M4(accn, 1, 13) TA_M4(acc, 7, 0) TA_M4(acc, 7, 1)
+            TA_M4(accn, 1, 14) TA_M4(acc, 7, 2) TA_M4(acc, 7, 3) TA_M4(accn, 1, 15)
+            TA_M4(acc, 7, 4) TA_M4(acc, 7, 5) TA_M4(accn, 2, 0) TA_M4(acc, 7, 6)
+            TA_M4(acc, 7, 7) TA_M4(accn, 2, 1) TA_M4(acc, 7, 8) TA_M4(acc, 7, 9)
+            TA_M4(accn, 2, 2) TA_M4(acc, 7, 10) TA_M4(acc, 7, 11) TA_M4(accn, 2, 3)
+            TA_M4(acc, 7, 12) TA_M4(acc, 7, 13) TA_M4(accn, 2, 4) TA_M4(acc, 7, 14)
+            TA_M4(acc, 7, 15) TA_M4(accn, 2, 5) TA_M4(acc, 8, 0) TA_M4(acc, 8, 1)
+            TA_M4(accn, 2, 6) TA_M4(acc, 8, 2) TA_M4(acc, 8, 3) TA_M4(accn, 2, 7)
+            TA_M4(acc, 8, 4) TA_M4(acc, 8, 5) TA_M4(accn, 2, 8) TA_M4(acc, 8, 6)
+            TA_M4(acc, 8, 7) TA_M4(accn, 2, 9) TA_M4(acc, 8, 8) TA_M4(acc, 8, 9)
+            TA_M4(accn, 2, 10) TA_M4(acc, 8, 10) TA_M4(acc, 8, 11) TA_M4(accn, 2, 11)
+            TA_M4(acc, 8, 12) TA_M4(acc, 8, 13) TA_M4(accn, 2, 12) TA_M4(acc, 8, 14)
+            TA_M4(acc, 8, 15) TA_M4(accn, 2, 13) TA_M4(acc, 9, 0) TA_M4(acc, 9, 1)
+            TA_M4(accn, 2, 14) TA_M4(acc, 9, 2) TA_M4(acc, 9, 3) TA_M4(accn, 2, 15)
+            TA_M4(acc, 9, 4) TA_M4(acc, 9, 5) TA_M4(accn, 3, 0) TA_M4(acc, 9, 6)
+            TA_M4(acc, 9, 7)
+        }
+        // before this step's output stores are issued: the wait for the prefetched load would otherwise also wait
+        // for those stores (vmcnt counts both)
+        if (loader && t + 2 < Tmax) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) x_store(b2, i, xn[i]);
+        }
+        // transpose inside the quad: acc[r] of lane j = (gate j, line r)  ->  g[q] of lane j = (gate q, line j)
+        float g0 = acc[0], g1 = acc[1], g2 = acc[2], g3 = acc[3];
+        {
+            const bool odd = lane & 1, hi = lane & 2;
+            float s, r;
+            s = odd ? g0 : g1; r = quad_perm<0xB1>(s); if (odd) g0 = r; else g1 = r;      // lanes j ^ 1, registers 0 <-> 1
+            s = odd ? g2 : g3; r = quad_perm<0xB1>(s); if (odd) g2 = r; else g3 = r;      //             registers 2 <-> 3
+            s = hi ? g0 : g2; r = quad_perm<0x4E>(s); if (hi) g0 = r; else g2 = r;        // lanes j ^ 2, registers 0 <-> 2
+            s = hi ? g1 : g3; r = quad_perm<0x4E>(s); if (hi) g1 = r; else g3 = r;        //             registers 1 <-> 3
+        }
+        // gates, the 16-line kernel's arithmetic: g0..g3 = WGI, WGF, WGO, WCI . src
+        {
+            const bool past0 = (t > 0) | (ts > 0);                  // not the first step of the whole sequence
+            const float h = lstm_cell_f32(g0, g1, g2, g3, c, past0, wip, wfp, wop);
+            if (unit < kNs) {
+                hs[nxt][unit * kG4 + slot] = h;
+                if (t < myT) {
+                    const int tt = dir ? myT - 1 - t : t;
+                    a.hout[(myrow + tt) * (2 * kNs) + dir * kNs + unit] = h;
+                }
+            }
+        }
+        __syncthreads();
+        const int bt = b1; b1 = b2; b2 = b3; b3 = bt;
+    }
+#undef TA_M4
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -856,7 +1111,9 @@ __global__ __launch_bounds__(64) void decode_summary_kernel(DecSumArgs a) {
 using namespace ta;
 
 extern "C" int32_t ta_lstm_packed_weight_floats(int32_t mode) {
-    // mode 0: f32 fragments [2][7][4][38][64]; mode 1: 16-bit planes [2][7][2][4][5][64][8] (as 4-byte units)
+    // mode 0: f32 fragments [2][7][4][38][64]; mode 1: 16-bit planes [2][7][2][4][5][64][8] (as 4-byte units);
+    // mode 2: f32, one k per instruction [2][7][152][64]
+    if (mode == 2) return 2 * kWaves * kKP * 64;
     return mode == 0 ? 2 * kWaves * 4 * kKS * 64 : 2 * kWaves * 2 * 4 * kKS2 * 64 * 4;
 }
 
@@ -869,12 +1126,16 @@ extern "C" int ta_lstm_forward(const float* x, const int64_t* row_off, const int
     if (ngroups == 0) return TA_OK;
     if (!x || !row_off || !T || !group_lines || !wp || !peep || !hout)
         return ta_fail(TA_EINVAL, "null pointer argument");
-    if (mode != 0 && mode != 1) return ta_fail(TA_EINVAL, "mode must be 0 (f32 MFMA) or 1 (split 16-bit operands)");
+    if (mode != 0 && mode != 1 && mode != 2)
+        return ta_fail(TA_EINVAL, "mode must be 0 (f32 MFMA), 1 (split 16-bit operands) or 2 (f32 MFMA, groups of four lines)");
     if ((h0 != nullptr) != (c0 != nullptr) || (h0 != nullptr) != (tstart != nullptr))
         return ta_fail(TA_EINVAL, "h0, c0 and tstart go together (all null, or all given)");
     LstmArgs a{x, row_off, T, group_lines, wp, peep, hout, h0, c0, tstart};
     if (mode == 1)
         hipLaunchKernelGGL(lstm_seq_split_kernel, dim3(2 * ngroups), dim3(kWaves * 64), 0,
+                           reinterpret_cast<hipStream_t>(stream), a);
+    else if (mode == 2)
+        hipLaunchKernelGGL(lstm_seq4_kernel, dim3(2 * ngroups), dim3(kWaves * 64), 0,
                            reinterpret_cast<hipStream_t>(stream), a);
     else
         hipLaunchKernelGGL(lstm_seq_kernel, dim3(2 * ngroups), dim3(kSeqWaves * 64), 0,

@@ -160,6 +160,23 @@ def _pack_lstm(model):
     return wp, peep, w2p
 
 
+def _pack_lstm4(model):
+    """weights of the four-lines-per-workgroup recurrence kernel (ta_lstm_forward mode 2): one k per MFMA,
+    [dir 2][wave 7][k 152][lane 64] = W_gate(lane % 4)[unit 16 * wave + lane // 4][k], k as in mode 0"""
+    wp = np.zeros((2, 7, 152, 64), dtype=np.float32)
+    assert wp.size == _native.lib.ta_lstm_packed_weight_floats(2)
+    lane = np.arange(64)
+    for d, w in enumerate((model.fwd, model.rev)):
+        Wp = np.zeros((4, 112, 152), dtype=np.float64)
+        for g, name in enumerate(("WGI", "WGF", "WGO", "WCI")):
+            W = np.asarray(w[name], dtype=np.float64)
+            Wp[g, :NS, 0:1 + NI] = W[:, 0:1 + NI]            # bias + x
+            Wp[g, :NS, 52:152] = W[:, 1 + NI:]               # h
+        for wv in range(7):
+            wp[d, wv] = Wp[lane % 4, 16 * wv + lane // 4, :].T
+    return wp
+
+
 _pool = None
 
 
@@ -171,7 +188,8 @@ def _copy_pool():
     return _pool
 
 
-CLASS_SPLIT_MIN_GROUPS = 24     # below this (a few pages) the recurrence's tail has nothing worth hiding
+CLASS_SPLIT_MIN_LINES = 384     # below this (a few pages) the recurrence's tail has nothing worth hiding
+GROUP4_MAX_LINES = 2048         # exact-f32 mode: batches up to this size run in groups of 4 lines (see prepare)
 _split_state = {"streams": {}, "ok": None}
 
 
@@ -188,13 +206,13 @@ def _class_streams(device):
 
 
 def _class_split_wanted(rec, st):
-    """TA_OCR_CLASS_SPLIT=0 / 1 decides; otherwise batches of CLASS_SPLIT_MIN_GROUPS groups or more take the
+    """TA_OCR_CLASS_SPLIT=0 / 1 decides; otherwise batches of CLASS_SPLIT_MIN_LINES lines or more take the
     class split unless the one-off check below found it SLOWER in this process (another user of the
     high-priority queues): the first eligible batch is run both ways once, timed with events."""
     env = os.environ.get("TA_OCR_CLASS_SPLIT")
     if env in ("0", "1"):
         return env == "1"
-    if st["ngroups"] < CLASS_SPLIT_MIN_GROUPS or st.get("continuation"):
+    if st["n"] < CLASS_SPLIT_MIN_LINES or st["ngroups"] < 3 or st.get("continuation"):
         return False
     if _split_state["ok"] is None:
         times = {}
@@ -242,6 +260,7 @@ class LineRecognizer(object):
         if self.mode == 1:
             wp = _pack_lstm_split(model)
         self.wp = torch.from_numpy(wp).to(self.device)
+        self.wp4 = torch.from_numpy(_pack_lstm4(model)).to(self.device) if self.mode == 0 else None
         self.peep = torch.from_numpy(peep).to(self.device)
         self.w2p = torch.from_numpy(w2p).to(self.device)
         if self.mode == 1:
@@ -315,8 +334,19 @@ class LineRecognizer(object):
         if n and T.max() > MAX_T:
             raise RecognitionError("input too large for LSTM model")
         order = np.argsort(-T, kind="stable")
-        ngroups = (n + 15) // 16
-        group_lines = np.full((max(ngroups, 1), 16), -1, dtype=np.int32)
+        # Lines per workgroup of the recurrence.  Exact-f32 mode has two kernels that compute the same bits:
+        # groups of 16 (v_mfma_f32_16x16x4) and groups of 4 (v_mfma_f32_4x4x1, a quarter of the cost per step).
+        # A step costs the same however few of a group's rows are lines and a batch takes as long as its
+        # longest group, so small and medium batches take the small groups (a page: 3.1 instead of 10 ms;
+        # 1 920 lines: 960 short workgroups pack onto the CUs instead of 240 long ones idling for the
+        # longest, 8.7 instead of 10.0 ms); large batches keep the 16-line kernel, whose step has less
+        # overhead per line (2 560 lines: 12.7 against 13.5 ms for the whole pass).
+        G = 4 if (self.mode == 0 and n <= GROUP4_MAX_LINES) else 16
+        forced = os.environ.get("TA_OCR_GROUP")
+        if forced in ("4", "16") and self.mode == 0:
+            G = int(forced)
+        ngroups = (n + G - 1) // G
+        group_lines = np.full((max(ngroups, 1), G), -1, dtype=np.int32)
         group_lines.reshape(-1)[:n] = order
         row_start = layout(T) if n else np.zeros(0, dtype=np.int64)
         rows = int(T.sum())
@@ -340,10 +370,10 @@ class LineRecognizer(object):
         # first row of every group (+ the end): group g owns rows group_row[g] .. group_row[g + 1]
         group_row = np.zeros(max(ngroups, 1) + 1, dtype=np.int64)
         if n:
-            group_row[:ngroups] = row_start[order[::16]]
+            group_row[:ngroups] = row_start[order[::G]]
         group_row[ngroups:] = rows
         st = {"n": n, "rows": rows, "T_host": T, "row_start_host": row_start, "ngroups": ngroups,
-              "group_row_host": group_row}
+              "group_row_host": group_row, "group_size": G}
         dev = self.device
         st["x"] = x_dev
         st["row_off"] = torch.from_numpy(row_start if n else np.zeros(1, np.int64)).to(dev)
@@ -363,7 +393,7 @@ class LineRecognizer(object):
         per-timestep summaries and K5 decodes from them; want_logits / from_probs also
         materialise the (rows, No) probabilities (and logits) and decode from those.
 
-        A batch of at least CLASS_SPLIT_MIN_GROUPS groups runs K3 and K4 per length CLASS (the longest tenth
+        A batch of at least CLASS_SPLIT_MIN_LINES lines runs K3 and K4 per length CLASS (the longest tenth
         of the groups, the next fifth, the rest; rows are laid out in group order, so a class is one
         row range) on three side streams: the recurrence is a chain of T dependent steps per group, the
         longest group sets its time and the CUs of the short groups idle towards the end -- the output
@@ -383,11 +413,13 @@ class LineRecognizer(object):
             st["probs"] = torch.empty(shape, dtype=torch.float32, device=self.device)
             st["logits"] = torch.empty(shape, dtype=torch.float32, device=self.device)
 
+        ng, G = st["ngroups"], st["group_size"]
+
         def forward(g0, g1, stream_):
             _native.check(lib.ta_lstm_forward(
                 st["x"].data_ptr(), st["row_off"].data_ptr(), st["T"].data_ptr(),
-                st["group_lines"].data_ptr() + 64 * g0, g1 - g0, self.wp.data_ptr(),
-                self.peep.data_ptr(), st["hout"].data_ptr(), self.mode,
+                st["group_lines"].data_ptr() + 4 * G * g0, g1 - g0, (self.wp4 if G == 4 else self.wp).data_ptr(),
+                self.peep.data_ptr(), st["hout"].data_ptr(), 2 if G == 4 else self.mode,
                 cont[0].data_ptr() if cont else None, cont[1].data_ptr() if cont else None,
                 cont[2].data_ptr() if cont else None, stream_), "ta_lstm_forward")
 
@@ -402,7 +434,6 @@ class LineRecognizer(object):
             else:
                 _native.check(lib.ta_lstm_output(hout, r1 - r0, self.w2p.data_ptr(), no, probs, logits, summary,
                                                  stream_), "ta_lstm_output")
-        ng = st["ngroups"]
         if class_split is None:
             class_split = lstm and output and _class_split_wanted(self, st)
         if class_split and lstm and output and ng >= 3:
