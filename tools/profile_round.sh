@@ -29,14 +29,22 @@ done
 # per-kernel traces: one launch per kernel (the product splits large batches into length classes on side
 # streams, ocr.LineRecognizer.run; its own trace follows)
 export TA_OCR_CLASS_SPLIT=0
+export TA_OCR_GROUP=16            # the 16-line recurrence kernel (the product's choice above 2 048 lines)
 for w in "1920 f32" "1920 split" "5760 f32"; do
   set -- $w
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_$1_$2" -o ocr -- python3 "$REPO/tools/ocr_only.py" $1 $2 > "$OUT/kt_ocr_$1_$2.log" 2>&1
   echo "ocr $1 $2 kernel trace done"
 done
+export TA_OCR_GROUP=4             # the 4-line kernel (the product's choice up to 2 048 lines)
+for n in 30 1920; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_${n}_f32_g4" -o ocr -- python3 "$REPO/tools/ocr_only.py" $n f32 > "$OUT/kt_ocr_${n}_f32_g4.log" 2>&1
+  echo "ocr $n f32 (groups of 4) kernel trace done"
+done
 unset TA_OCR_CLASS_SPLIT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_1920_f32_classes" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f32 > "$OUT/kt_ocr_1920_f32_classes.log" 2>&1
-echo "ocr 1920 f32 (length classes) kernel trace done"
+export TA_OCR_GROUP=16
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_5760_f32_classes" -o ocr -- python3 "$REPO/tools/ocr_only.py" 5760 f32 > "$OUT/kt_ocr_5760_f32_classes.log" 2>&1
+echo "ocr 5760 f32 (length classes) kernel trace done"
+unset TA_OCR_GROUP
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_pages_images" -o pg -- python3 "$REPO/tools/pages_img_time.py" 32 8 1 > "$OUT/kt_pages_images.log" 2>&1
 echo "page images kernel trace done"
 for mode in two one; do
@@ -47,8 +55,13 @@ for mode in two one; do
   done
 done
 export TA_OCR_CLASS_SPLIT=0
+export TA_OCR_GROUP=16
 for prec in split f32; do
   timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_$prec" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 $prec > "$OUT/ocr_pmc_$prec.log" 2>&1
   echo "ocr pmc $prec done"
 done
+export TA_OCR_GROUP=4
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_f32g4" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f32 > "$OUT/ocr_pmc_f32g4.log" 2>&1
+echo "ocr pmc f32 groups of 4 done"
+unset TA_OCR_GROUP
 echo "now run: python3 tools/profile_summarise.py $ROUND gpurun_out/prof_$ROUND"

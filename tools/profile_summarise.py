@@ -57,8 +57,10 @@ def main():
             json.dump(doc, fh, indent=1)
     # matrix-pipe counters of the recogniser kernels
     kernels = {}
-    for prec in ("split", "f32"):
+    for prec in ("split", "f32", "f32g4"):
         path = os.path.join(out, "ocr_pmc_" + prec)
+        if not os.path.isdir(path):
+            continue
         names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES",
                  "GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU"]
         per = {}
@@ -74,7 +76,8 @@ def main():
         with open(os.path.join(prof, "%s_ocr_pmc_mfma.json" % rnd), "w") as fh:
             json.dump({"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU "
                                   "SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -- python3 "
-                                  "tools/ocr_only.py 1920 <split|f32>   (counter pass only)",
+                                  "tools/ocr_only.py 1920 <split|f32>   (counter pass only; TA_OCR_CLASS_SPLIT=0, TA_OCR_GROUP=16, "
+                                  "and =4 for the f32g4 entry: the 4-line recurrence kernel)",
                        "reading": "GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES"
                                   " / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
                        "kernels": kernels}, fh, indent=1)
