@@ -227,8 +227,8 @@ def test_group_boundaries_and_order():
     assert rec.recognise([]) == []
 
 
-@pytest.mark.parametrize("precision", ["f32", "split"])
-def test_class_split_launches_equal_single_launches(precision):
+@pytest.mark.parametrize("precision,group", [("f32", None), ("f32", "16"), ("split", None)])
+def test_class_split_launches_equal_single_launches(precision, group, monkeypatch):
     """run(): the recurrence and the output layer per length class on side streams (large batches) against
     one launch each -- same kernels on the same rows, so states, summaries, probabilities and decode are
     bit for bit the same; rows are laid out by groups (longest lines first), every line at row_start ..
@@ -237,9 +237,11 @@ def test_class_split_launches_equal_single_launches(precision):
     rec = ocr.LineRecognizer(pm, precision=precision)
     rng = np.random.default_rng(3)
     lines = [R.synthetic_line(9500 + k, width=int(w)) for k, w in enumerate(rng.integers(20, 200, size=16 * 26 + 5))]
+    if group:
+        monkeypatch.setenv("TA_OCR_GROUP", group)             # the kernel large batches take, on a batch a test can afford
     st = rec.prepare(lines)
     G = st["group_size"]
-    assert G == (4 if precision == "f32" else 16) and st["ngroups"] == (len(lines) + G - 1) // G
+    assert G == (4 if precision == "f32" and not group else 16) and st["ngroups"] == (len(lines) + G - 1) // G
     T, start = st["T_host"], st["row_start_host"]
     order = np.argsort(-T, kind="stable")
     assert np.array_equal(start[order], np.cumsum(T[order]) - T[order])           # sorted layout, no holes
