@@ -238,7 +238,7 @@ def test_class_split_launches_equal_single_launches(precision, group, monkeypatc
     rng = np.random.default_rng(3)
     lines = [R.synthetic_line(9500 + k, width=int(w)) for k, w in enumerate(rng.integers(20, 200, size=16 * 26 + 5))]
     if group:
-        monkeypatch.setenv("TA_OCR_GROUP", group)             # the kernel large batches take, on a batch a test can afford
+        monkeypatch.setattr(ocr, "FORCE_GROUP", int(group))   # the kernel large batches take, on a batch a test can afford
     st = rec.prepare(lines)
     G = st["group_size"]
     assert G == (4 if precision == "f32" and not group else 16) and st["ngroups"] == (len(lines) + G - 1) // G
@@ -277,7 +277,7 @@ def test_four_line_groups_equal_sixteen_line_groups(monkeypatch):
     for cnt in (1, 2, 3, 4, 5, 7, 8, 16, 17, 21):
         got = {}
         for G in ("4", "16"):
-            monkeypatch.setenv("TA_OCR_GROUP", G)
+            monkeypatch.setattr(ocr, "FORCE_GROUP", int(G))
             st = rec.prepare(pool[:cnt])
             assert st["group_size"] == int(G)
             rec.run(st, want_logits=True)
@@ -289,7 +289,7 @@ def test_four_line_groups_equal_sixteen_line_groups(monkeypatch):
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), cnt
         assert got["4"][-1] == got["16"][-1]
     # continued sequences (h0 / c0 / tstart): segments of 37 steps restarted from the float64 states, both kernels
-    monkeypatch.delenv("TA_OCR_GROUP")
+    monkeypatch.setattr(ocr, "FORCE_GROUP", None)
     lines = [ln for ln in pool if ln.shape[0] >= 60][:7]
     st = rec.prepare(lines)
     seg = {}

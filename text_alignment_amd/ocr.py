@@ -188,6 +188,10 @@ def _copy_pool():
     return _pool
 
 
+# Overrides for tests and timing tools, read ONCE at import (TA_OCR_GROUP=4|16, TA_OCR_CLASS_SPLIT=0|1); the tests
+# patch the attributes.  None = the product's own choice.
+FORCE_GROUP = int(os.environ["TA_OCR_GROUP"]) if os.environ.get("TA_OCR_GROUP") in ("4", "16") else None
+FORCE_CLASS_SPLIT = (os.environ["TA_OCR_CLASS_SPLIT"] == "1") if os.environ.get("TA_OCR_CLASS_SPLIT") in ("0", "1") else None
 CLASS_SPLIT_MIN_LINES = 384     # below this (a few pages) the recurrence's tail has nothing worth hiding
 GROUP4_MAX_LINES = 2048         # exact-f32 mode: batches up to this size run in groups of 4 lines (see prepare)
 _split_state = {"streams": {}, "ok": None}
@@ -206,12 +210,11 @@ def _class_streams(device):
 
 
 def _class_split_wanted(rec, st):
-    """TA_OCR_CLASS_SPLIT=0 / 1 decides; otherwise batches of CLASS_SPLIT_MIN_LINES lines or more take the
+    """FORCE_CLASS_SPLIT (TA_OCR_CLASS_SPLIT=0 / 1 at import) decides; otherwise batches of CLASS_SPLIT_MIN_LINES lines or more take the
     class split unless the one-off check below found it SLOWER in this process (another user of the
     high-priority queues): the first eligible batch is run both ways once, timed with events."""
-    env = os.environ.get("TA_OCR_CLASS_SPLIT")
-    if env in ("0", "1"):
-        return env == "1"
+    if FORCE_CLASS_SPLIT is not None:
+        return FORCE_CLASS_SPLIT
     if st["n"] < CLASS_SPLIT_MIN_LINES or st["ngroups"] < 3 or st.get("continuation"):
         return False
     if _split_state["ok"] is None:
@@ -342,9 +345,8 @@ class LineRecognizer(object):
         # longest, 8.7 instead of 10.0 ms); large batches keep the 16-line kernel, whose step has less
         # overhead per line (2 560 lines: 12.7 against 13.5 ms for the whole pass).
         G = 4 if (self.mode == 0 and n <= GROUP4_MAX_LINES) else 16
-        forced = os.environ.get("TA_OCR_GROUP")
-        if forced in ("4", "16") and self.mode == 0:
-            G = int(forced)
+        if FORCE_GROUP is not None and self.mode == 0:
+            G = FORCE_GROUP
         ngroups = (n + G - 1) // G
         group_lines = np.full((max(ngroups, 1), G), -1, dtype=np.int32)
         group_lines.reshape(-1)[:n] = order
