@@ -772,50 +772,58 @@ __device__ __forceinline__ unsigned long long row16_max_u64(unsigned long long k
 struct OutSinks { int64_t rows; int no; float* probs; float* logits; float4* summary; };
 template <int NCT>
 __device__ __forceinline__ void softmax_tile(f32x4 (&acc)[NCT], int64_t r0, const OutSinks& a, int lane) {
+    // Only the LAST class tile can hold classes >= no, and whether a lane's class there exists is one bit per
+    // lane: it is applied with selects (a masked class enters the maximum as -3e38, the sum and the arg-max as
+    // nothing), so the arithmetic below is straight-line code -- the first form tested `cls < no` around every
+    // use and compiled to some seventy exec-masked branch regions per tile, as long as the tile's MFMAs.
     const int rr = lane & 15;
+    const bool lastv = (NCT - 1) * 16 + rr < a.no;
+    const bool want_logits = a.logits != nullptr, want_probs = a.probs != nullptr;      // wave-uniform
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t row = r0 + (lane >> 4) * 4 + r;
+        const bool row_ok = row < a.rows;
+        if (want_logits && row_ok) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                if (ct < NCT - 1 || lastv) a.logits[row * a.no + ct * 16 + rr] = acc[ct][r];
+        }
         float zmax = -3.0e38f;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            const int cls = ct * 16 + rr;
-            if (cls < a.no) {
-                if (a.logits && row < a.rows) a.logits[row * a.no + cls] = acc[ct][r];
-                const float z = fminf(fmaxf(acc[ct][r], -100.f), 100.f);
-                acc[ct][r] = z;
-                zmax = fmaxf(zmax, z);
-            }
+            float z = fminf(fmaxf(acc[ct][r], -100.f), 100.f);
+            if (ct == NCT - 1) z = lastv ? z : -3.0e38f;
+            acc[ct][r] = z;
+            zmax = fmaxf(zmax, z);
         }
         zmax = row16_max(zmax);
         float sum = 0.f;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            const int cls = ct * 16 + rr;
-            if (cls < a.no) {
-                const float e = exp_fast(fmaxf(acc[ct][r] - zmax, -87.0f));
-                acc[ct][r] = e;
-                sum += e;
-            }
+            float e = exp_fast(fmaxf(acc[ct][r] - zmax, -87.0f));
+            if (ct == NCT - 1) e = lastv ? e : 0.0f;
+            acc[ct][r] = e;
+            sum += e;
         }
         sum = row16_sum(sum);
         const float inv = 1.0f / sum;
         unsigned long long key = 0ull;           // larger P wins, then the smaller class
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-            const int cls = ct * 16 + rr;
-            if (cls < a.no) {
-                const float pr = acc[ct][r] * inv;
-                if (a.probs && row < a.rows) a.probs[row * a.no + cls] = pr;
-                const unsigned long long k =
-                    ((unsigned long long)__float_as_uint(pr) << 32) | (unsigned)(0xFFFFFFFFu - cls);
-                key = k > key ? k : key;
-                if (ct == 0) acc[0][r] = pr;     // lane rr == 0 keeps P(class 0)
-            }
+            const float pr = acc[ct][r] * inv;
+            acc[ct][r] = pr;
+            unsigned long long k = ((unsigned long long)__float_as_uint(pr) << 32) | (unsigned)(0xFFFFFFFFu - (ct * 16 + rr));
+            if (ct == NCT - 1) k = lastv ? k : 0ull;
+            key = k > key ? k : key;
+        }
+        if (want_probs && row_ok) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+                if (ct < NCT - 1 || lastv) a.probs[row * a.no + ct * 16 + rr] = acc[ct][r];
         }
         if (a.summary) {
             key = row16_max_u64(key);
-            if (rr == 0 && row < a.rows) {
+            if (rr == 0 && row_ok) {             // lane rr == 0 holds P(class 0) in acc[0]
                 const unsigned cls = 0xFFFFFFFFu - (unsigned)key;
                 a.summary[row] = make_float4(acc[0][r], __uint_as_float((unsigned)(key >> 32)),
                                              __uint_as_float(cls), 0.f);
@@ -823,7 +831,6 @@ __device__ __forceinline__ void softmax_tile(f32x4 (&acc)[NCT], int64_t r0, cons
         }
     }
 }
-
 template <int NCT>
 __global__ __launch_bounds__(kOWaves * 64) void lstm_output_kernel(OutArgs a) {
     extern __shared__ __attribute__((aligned(16))) float osm[];
