@@ -217,6 +217,8 @@ def _class_split_wanted(rec, st):
         return FORCE_CLASS_SPLIT
     if st["n"] < CLASS_SPLIT_MIN_LINES or st["ngroups"] < 3 or st.get("continuation"):
         return False
+    if st["group_size"] != 16:        # groups of four lines pack onto the CUs: no idle tail to hide anything under
+        return False
     if _split_state["ok"] is None:
         times = {}
         for split in (True, False, True, False):
@@ -395,7 +397,7 @@ class LineRecognizer(object):
         per-timestep summaries and K5 decodes from them; want_logits / from_probs also
         materialise the (rows, No) probabilities (and logits) and decode from those.
 
-        A batch of at least CLASS_SPLIT_MIN_LINES lines runs K3 and K4 per length CLASS (the longest tenth
+        A batch of at least CLASS_SPLIT_MIN_LINES lines in groups of 16 runs K3 and K4 per length CLASS (the longest tenth
         of the groups, the next fifth, the rest; rows are laid out in group order, so a class is one
         row range) on three side streams: the recurrence is a chain of T dependent steps per group, the
         longest group sets its time and the CUs of the short groups idle towards the end -- the output
