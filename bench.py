@@ -286,8 +286,7 @@ def bench_ocr(args, rank, precision=None, nlines=None):
             "dtype": "f32" if f32 else "split 16-bit operands (W: bf16 + fp16, a: 3 x bf16 + fp16), f32 accumulate",
             "ms": {"lstm": lstm_ms, "output_softmax": out_ms, "decode": dec_ms, "pass": 1e3 * dt,
                    "note": "lstm / output_softmax / decode: each kernel launched alone; pass: one run() of all three"},
-            "class_split": bool(ocr._split_state.get("ok")) and st["n"] >= ocr.CLASS_SPLIT_MIN_LINES
-            and st["group_size"] == 16,
+            "class_split": bool(ocr._split_state.get("ok")) and st["n"] >= ocr.CLASS_SPLIT_MIN_LINES and rec.mode == 1,
             "lines_per_workgroup": st["group_size"],
             "roofline": roof}
 

@@ -259,8 +259,8 @@ def test_class_split_launches_equal_single_launches(precision, group, monkeypatc
     few = [0, 5, 77, 300, len(lines) - 1]
     alone = rec.recognise([lines[k] for k in few])
     assert [dec[k] for k in few] == alone
-    rec.run(st)                                               # the default path: groups of 16 check themselves once, then decide
-    if G == 16:
+    rec.run(st)                                               # the default path: split mode checks itself once, then decides
+    if precision == "split":
         assert ocr._split_state["ok"] in (True, False) and set(ocr._split_state["times_ms"]) == {True, False}
         print("class split timing check:", ocr._split_state["times_ms"], "->", ocr._split_state["ok"])
 

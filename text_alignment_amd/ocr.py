@@ -217,7 +217,10 @@ def _class_split_wanted(rec, st):
         return FORCE_CLASS_SPLIT
     if st["n"] < CLASS_SPLIT_MIN_LINES or st["ngroups"] < 3 or st.get("continuation"):
         return False
-    if st["group_size"] != 16:        # groups of four lines pack onto the CUs: no idle tail to hide anything under
+    if rec.mode != 1:
+        # exact-f32 mode: up to GROUP4_MAX_LINES its groups of four lines pack onto the CUs and leave no idle tail
+        # to hide anything under; above that the output layer is a small share of the pass and the split
+        # measured no gain (5 760 lines: 25.6 ms one launch each, 25.9 per class)
         return False
     if _split_state["ok"] is None:
         times = {}
@@ -397,12 +400,12 @@ class LineRecognizer(object):
         per-timestep summaries and K5 decodes from them; want_logits / from_probs also
         materialise the (rows, No) probabilities (and logits) and decode from those.
 
-        A batch of at least CLASS_SPLIT_MIN_LINES lines in groups of 16 runs K3 and K4 per length CLASS (the longest tenth
+        In split-operand mode a batch of at least CLASS_SPLIT_MIN_LINES lines runs K3 and K4 per length CLASS (the longest tenth
         of the groups, the next fifth, the rest; rows are laid out in group order, so a class is one
         row range) on three side streams: the recurrence is a chain of T dependent steps per group, the
         longest group sets its time and the CUs of the short groups idle towards the end -- the output
-        layer of the classes that are done runs there instead of behind the whole recurrence (11.9 ->
-        10.7 ms per 1 920 lines, against 10.2 for the recurrence alone).  Same kernels on the same rows:
+        layer of the classes that are done runs there instead of behind the whole recurrence (split mode:
+        5.85 -> 5.2 ms per 1 920 lines, against 4.7 for the recurrence alone).  Same kernels on the same rows:
         results are bit for bit those of the single launches.  class_split = True / False forces the choice
         (tests, timing); None leaves it to _class_split_wanted."""
         if st["n"] == 0:
