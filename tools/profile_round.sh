@@ -41,10 +41,9 @@ for n in 30 1920; do
   echo "ocr $n f32 (groups of 4) kernel trace done"
 done
 unset TA_OCR_CLASS_SPLIT
-export TA_OCR_GROUP=16
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_5760_f32_classes" -o ocr -- python3 "$REPO/tools/ocr_only.py" 5760 f32 > "$OUT/kt_ocr_5760_f32_classes.log" 2>&1
-echo "ocr 5760 f32 (length classes) kernel trace done"
 unset TA_OCR_GROUP
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_1920_split_classes" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 split > "$OUT/kt_ocr_1920_split_classes.log" 2>&1
+echo "ocr 1920 split (length classes) kernel trace done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_pages_images" -o pg -- python3 "$REPO/tools/pages_img_time.py" 32 8 1 > "$OUT/kt_pages_images.log" 2>&1
 echo "page images kernel trace done"
 for mode in two one; do
