@@ -83,13 +83,13 @@ __device__ __forceinline__ float tanh_min(float x) {
 // whole sequence -- the peepholes on the old cell state and the output peephole are skipped at t = 0.
 __device__ __forceinline__ float lstm_cell_f32(float gi, float gf, float go, float ci_pre, float& c, bool past0,
                                                float wip, float wfp, float wop) {
+    // (the "[t > 0]" rules as selects on the operands: fmaf(w, 0, g) is g, so the arithmetic is straight-line)
     const float ci = tanh_min(ci_pre);
-    if (past0) { gi = fmaf(wip, c, gi); gf = fmaf(wfp, c, gf); }
-    gi = sigmoid_min(gi);
-    gf = sigmoid_min(gf);
-    const float cn = past0 ? fmaf(ci, gi, gf * c) : ci * gi;       // (the product with the old state is the rounded one)
-    if (past0) go = fmaf(wop, cn, go);
-    go = sigmoid_min(go);
+    const float cp = past0 ? c : 0.0f;
+    gi = sigmoid_min(fmaf(wip, cp, gi));
+    gf = sigmoid_min(fmaf(wfp, cp, gf));
+    const float cn = fmaf(ci, gi, gf * cp);                       // (the product with the old state is the rounded one)
+    go = sigmoid_min(fmaf(past0 ? wop : 0.0f, cn, go));
     c = cn;
     return tanh_min(cn) * go;
 }
