@@ -253,20 +253,7 @@ __global__ __launch_bounds__(kSeqWaves * 64) void lstm_seq_kernel(LstmArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool past0 = (t > 0) | (ts[r] > 0);             // not the first step of the whole sequence
-#ifdef TA_OLD_GATES
-            float gi = acc[0][r], gf = acc[1][r], go = acc[2][r];
-            const float ci = tanh_min(acc[3][r]);
-            if (past0) { gi += wip * c[r]; gf += wfp * c[r]; }
-            gi = sigmoid_min(gi);
-            gf = sigmoid_min(gf);
-            float cn = ci * gi;
-            if (past0) { cn += gf * c[r]; go += wop * cn; }
-            go = sigmoid_min(go);
-            const float h = tanh_min(cn) * go;
-            c[r] = cn;
-#else
             const float h = lstm_cell_f32(acc[0][r], acc[1][r], acc[2][r], acc[3][r], c[r], past0, wip, wfp, wop);
-#endif
             if (unit < kNs) {
                 const int slot = (lane >> 4) * 4 + r;
                 const int kp = kXK + unit;
@@ -1091,15 +1078,25 @@ __global__ __launch_bounds__(64) void decode_summary_kernel(DecSumArgs a) {
         const unsigned long long key =
             ((unsigned long long)__float_as_uint(v.y) << 32) | (0xFFFFFFFFu - __float_as_uint(v.z));
         const unsigned long long below = __ballot(v.x < a.threshold);
-        const int cnt = min(64, T - t0);
-        for (int q = 0; q < cnt; ++q) {                        // uniform scan of the 64 entries
-            const unsigned klo = __builtin_amdgcn_readlane((unsigned)key, q);
-            const unsigned khi = __builtin_amdgcn_readlane((unsigned)(key >> 32), q);
-            const unsigned long long kq = ((unsigned long long)khi << 32) | klo;
-            if ((below >> q) & 1ull) {
-                if (!in_run) { in_run = true; best = 0ull; best_t = t0 + q; }
+        // wave-uniform scan of the chunk, run by run: only the entries inside runs are visited (entries beyond T
+        // read as "not below", so a run that reaches T ends there)
+        int q = 0;
+        while (q < 64) {
+            if (!in_run) {
+                const unsigned long long rest = below >> q;
+                if (rest == 0ull) break;
+                q += (int)__builtin_ctzll(rest);               // first entry of the next run
+                in_run = true; best = 0ull; best_t = t0 + q;
+            }
+            const unsigned long long inv = ~(below >> q);       // (bits shifted in from above read as "not below")
+            const int stop = inv == 0ull ? 64 : min(q + (int)__builtin_ctzll(inv), 64);   // end of the run of ones at q
+            for (; q < stop; ++q) {
+                const unsigned klo = __builtin_amdgcn_readlane((unsigned)key, q);
+                const unsigned khi = __builtin_amdgcn_readlane((unsigned)(key >> 32), q);
+                const unsigned long long kq = ((unsigned long long)khi << 32) | klo;
                 if (kq > best) { best = kq; best_t = t0 + q; }
-            } else if (in_run) {
+            }
+            if (q < 64) {                                       // the entry at q is not below: the run is over
                 if (lane == 0) { out_t[n] = best_t; out_c[n] = (int)(0xFFFFFFFFu - (unsigned)best); }
                 ++n;
                 in_run = false;

@@ -10,6 +10,7 @@ Usage: python tools/ocr_mode_agreement.py [lines per model] [out.json]
 import json
 import os
 import sys
+import zlib
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,7 +33,7 @@ def measure(nlines=24, modes=None):
     modes = modes or list(ocr.PRECISIONS)
     out = {}
     for name, om in _models():
-        rng = np.random.default_rng(abs(hash(name)) % 1000)
+        rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000)        # (hash() of a str changes from run to run)
         widths = [800, 2000] + [int(w) for w in rng.integers(800, 2001, size=nlines - 2)]
         lines = [R.synthetic_line(8000 + k, width=w) for k, w in enumerate(widths)]
         t0 = time.time()
