@@ -54,7 +54,15 @@ __global__ __launch_bounds__(kTileH * kTileW) void pp_label_tile_kernel(const ui
     const bool inside = x < w && y < h;
     const int me = threadIdx.x;
     const bool on = inside && ink[(int64_t)y * w + x];
-    loc[me] = on ? me : -1;
+    // a tile row is one wave: every ink pixel starts at the FIRST pixel of its horizontal run (the highest
+    // background bit below it in the row's ballot, plus one), so the rounds below only have to join runs
+    // of neighbouring rows -- a fully inked tile (the page background once the image is inverted) needs
+    // log2(16) rounds instead of one per pixel of width
+    static_assert(kTileW == 64, "a tile row is a wave");
+    const unsigned long long rowmask = __ballot(on);
+    const unsigned long long gaps_below = ~rowmask & ((1ull << tx) - 1ull);
+    const int run0 = gaps_below ? 64 - (int)__builtin_clzll(gaps_below) : 0;
+    loc[me] = on ? ty * kTileW + run0 : -1;
     __syncthreads();
     while (true) {
         int changed = 0;

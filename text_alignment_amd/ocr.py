@@ -252,8 +252,8 @@ class LineRecognizer(object):
     Both hold the 1e-3 logit parity of the spec model per 128-step segment; FREE-RUNNING on that
     (chaotic) model at 800 .. 2000 columns, against the float64 restatement (96 lines per model,
     tools/ocr_mode_agreement.py, profiles/r03_ocr_mode_agreement.json): f32 median logit error
-    1.3e-4 / 2.4e-5 (models 7001 / 7002), 89 / 94 of 96 lines within 1e-3; split 3.5e-4 / 3.4e-5,
-    72 / 92 of 96; decoded characters identical in both modes on all 19 697 characters of the sample.
+    9.1e-5 / 2.7e-5 (models 7001 / 7002), 88 / 94 of 96 lines within 1e-3; split 3.3e-4 / 3.5e-5,
+    78 / 91 of 96; decoded characters: f32 identical on all 19 614 of the sample, split one different.
     ("bf16x3", the name of the split mode's first form, is accepted.)"""
 
     def __init__(self, model, device="cuda", precision=DEFAULT_PRECISION):
