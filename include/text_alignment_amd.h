@@ -298,6 +298,15 @@ int ta_pp_filter_components(uint8_t* ink, const int32_t* lab, const int32_t* sta
 int ta_pp_invert(uint8_t* ink, int64_t n, void* stream);
 int ta_pp_angle_histograms(const uint8_t* ink, int32_t h, int32_t w, int32_t step, const double* cos_sin,
                            int32_t nang, uint32_t* hist, void* stream);
+/* The skew search from a list of the page's ink pixels, made once for every angle of both sweeps:
+ * ta_pp_ink_points: points[i] = (row << 16) | column on the grid decimated by `step` (room for
+ * ceil(h/step) * ceil(w/step) entries; at most 65535 rows / columns), in no particular order; *count [dev].
+ * ta_pp_angle_histograms_points(points, count, hs = ceil(h/step), ws = ceil(w/step), ...): the histograms of
+ * ta_pp_angle_histograms, count for count. */
+int ta_pp_ink_points(const uint8_t* ink, int32_t h, int32_t w, int32_t step, uint32_t* points, uint32_t* count,
+                     void* stream);
+int ta_pp_angle_histograms_points(const uint32_t* points, const uint32_t* count, int32_t hs, int32_t ws,
+                                  const double* cos_sin, int32_t nang, uint32_t* hist, void* stream);
 int ta_pp_rotate(const uint8_t* ink, int32_t h, int32_t w, uint8_t* out, int32_t oh, int32_t ow,
                  const double* mo, void* stream);
 int ta_pp_open_runs(const uint8_t* in, uint8_t* out, int32_t h, int32_t w, int32_t len, int32_t axis,

@@ -84,6 +84,30 @@ def test_labels_across_tile_borders():
         assert np.array_equal(lab.ravel()[flat > 0], first[flat[flat > 0]])
 
 
+def test_angle_histograms_from_the_point_list_equal_those_from_the_page():
+    """ta_pp_ink_points + ta_pp_angle_histograms_points against ta_pp_angle_histograms (which walks the whole
+    decimated page per angle): same counts for every angle and row, decimated and not, and an empty page"""
+    from text_alignment_amd import _native
+    rng = np.random.default_rng(6)
+    lib = _native.lib
+    for (h, w), step, dens in [((700, 1100), 1, 0.1), ((2400, 1500), 2, 0.07), ((300, 200), 3, 0.5), ((64, 64), 1, 0.0)]:
+        ink = torch.from_numpy((rng.random((h, w)) < dens).astype(np.uint8)).cuda()
+        hs, ws = (h + step - 1) // step, (w + step - 1) // step
+        ang = np.deg2rad(np.arange(-6, 6.01, 0.75))
+        cs = np.empty(2 * len(ang)); cs[0::2], cs[1::2] = np.cos(ang), np.sin(ang)
+        d_cs = torch.from_numpy(cs).cuda()
+        a = torch.empty((len(ang), hs), dtype=torch.int32, device="cuda")
+        b = torch.empty_like(a)
+        pts = torch.empty(hs * ws, dtype=torch.int32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _native.check(lib.ta_pp_angle_histograms(ink.data_ptr(), h, w, step, d_cs.data_ptr(), len(ang), a.data_ptr(), None), "a")
+        _native.check(lib.ta_pp_ink_points(ink.data_ptr(), h, w, step, pts.data_ptr(), cnt.data_ptr(), None), "p")
+        _native.check(lib.ta_pp_angle_histograms_points(pts.data_ptr(), cnt.data_ptr(), hs, ws, d_cs.data_ptr(), len(ang),
+                                                        b.data_ptr(), None), "b")
+        assert int(cnt.item()) == int(ink[::step, ::step].sum().item())
+        assert torch.equal(a, b), ((h, w), step)
+
+
 def test_strip_cutter():
     """ta_pp_cut_strips: boxes (inclusive corners, touching the page edges too) out of an ink plane into one
     packed buffer, ink 0 on 255"""

@@ -92,7 +92,9 @@ def _load():
           "ta_pp_rotate": [vp, i32, i32, vp, i32, i32, vp, vp], "ta_pp_open_runs": [vp, vp, i32, i32, i32, i32, vp],
           "ta_pp_row_sums": [vp, i32, i32, vp, vp], "ta_pp_clear_rows": [vp, i32, vp, i32, vp],
           "ta_pp_cut_strips": [vp, i32, i32, vp, i32, vp, vp],
-          "ta_pp_peak_prominence_args": [vp, i32, vp, i32, ctypes.c_double, vp]}
+          "ta_pp_peak_prominence_args": [vp, i32, vp, i32, ctypes.c_double, vp],
+          "ta_pp_ink_points": [vp, i32, i32, i32, vp, vp, vp],
+          "ta_pp_angle_histograms_points": [vp, vp, i32, i32, vp, i32, vp, vp]}
     for name, args in pp.items():
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = args
@@ -107,7 +109,8 @@ EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m"
            "ta_decode_summary", "ta_linenorm_measure", "ta_linenorm_resample",
            "ta_pp_histogram", "ta_pp_threshold", "ta_pp_label", "ta_pp_label_batch", "ta_pp_components", "ta_pp_filter_components",
            "ta_pp_invert", "ta_pp_angle_histograms", "ta_pp_rotate", "ta_pp_open_runs", "ta_pp_row_sums",
-           "ta_pp_clear_rows", "ta_pp_cut_strips", "ta_pp_peak_prominence_args"]
+           "ta_pp_clear_rows", "ta_pp_cut_strips", "ta_pp_peak_prominence_args", "ta_pp_ink_points",
+           "ta_pp_angle_histograms_points"]
 
 
 def check(rc, what):

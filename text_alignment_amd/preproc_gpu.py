@@ -165,19 +165,29 @@ def rotation_angles_device(d, inks, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
     n = len(inks)
     steps = [max(1, int(max(k.shape) / 1200)) for k in inks]
     hs = [(int(k.shape[0]) + st - 1) // st for k, st in zip(inks, steps)]
+    ws = [(int(k.shape[1]) + st - 1) // st for k, st in zip(inks, steps)]
+    # the ink pixels of every decimated page, listed once for all angles of both sweeps (ta_pp_ink_points)
+    points, counts = [], torch.zeros(max(n, 1), dtype=torch.int32, device=d.dev)
+    for k, ink in enumerate(inks):
+        pts = torch.empty(max(hs[k] * ws[k], 1), dtype=torch.int32, device=d.dev)
+        h, w = ink.shape
+        _native.check(d.lib.ta_pp_ink_points(ink.data_ptr(), h, w, steps[k], pts.data_ptr(), counts[k:].data_ptr(),
+                                             d.stream), "ta_pp_ink_points")
+        points.append(pts)
 
     def sweep(grids):
-        parts = []
+        parts, keep = [], []
         for k, ink in enumerate(inks):
             g = grids[k]
             cs = np.empty(2 * len(g), np.float64)
             rad = np.deg2rad(g)
             cs[0::2], cs[1::2] = np.cos(rad), np.sin(rad)
             d_cs = torch.from_numpy(cs).to(d.dev)
+            keep.append(d_cs)
             hist = torch.empty((len(g), hs[k]), dtype=torch.int32, device=d.dev)
-            h, w = ink.shape
-            _native.check(d.lib.ta_pp_angle_histograms(ink.data_ptr(), h, w, steps[k], d_cs.data_ptr(), len(g),
-                                                       hist.data_ptr(), d.stream), "ta_pp_angle_histograms")
+            _native.check(d.lib.ta_pp_angle_histograms_points(points[k].data_ptr(), counts[k:].data_ptr(), hs[k], ws[k],
+                                                              d_cs.data_ptr(), len(g), hist.data_ptr(), d.stream),
+                          "ta_pp_angle_histograms_points")
             parts.append(hist.reshape(-1))
         flat = torch.cat(parts).cpu().numpy()
         out, pos = [], 0
