@@ -491,11 +491,14 @@ def main():
     if args.pages > 0 and not args.no_ocr:
         from tools import pages_bench
         job = pages_bench.setup_sharded(args.pages, rank, world, seed0=100)
-        barrier()
-        t1 = time.perf_counter()
-        allrec = pages_bench.run_sharded(job)
-        barrier()
-        sh_dt = reduce_max(time.perf_counter() - t1)
+        sh_dt = None
+        for _ in range(3):          # shortest of three passes (each a barrier-to-barrier pass of every rank incl. the gather):
+            barrier()               # the host side of a pass varies by +-20 % from call to call on a shared box
+            t1 = time.perf_counter()
+            allrec = pages_bench.run_sharded(job)
+            barrier()
+            dt1 = reduce_max(time.perf_counter() - t1)
+            sh_dt = dt1 if sh_dt is None else min(sh_dt, dt1)
         if rank == 0:
             heads = allrec[allrec[:, 1] == sharding.HEADER]
             boxes = int((allrec[:, 1] != sharding.HEADER).sum())
@@ -508,6 +511,7 @@ def main():
                        "gather_capacity_records_per_rank": job["capacity"],
                        "gather_ok": bool(sorted(int(v) for v in heads[:, 0]) == list(range(job["total_pages"]))
                                          and int(heads[:, 4].sum()) == boxes),
+                       "timing": "shortest of 3 barrier-to-barrier passes (max over ranks each)",
                        "note": "sharding.process_shard: process_batch per model on this rank's pages + ONE "
                                "gather of [page, syllable, ulx, uly, lrx, lry] records to rank 0"}
         del job
