@@ -543,7 +543,7 @@ template <bool CARRIED, bool SAMEGO>
 __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], int (&V)[4], int (&H)[4], int& dsave,
                                              const int (&tc)[4], const int2* hvt, const uint16_t* ow,
                                              uint4* win, int2* hvb, int g0, int g_top, int m, int lane,
-                                             bool lane_has_rows, int l_lo) {
+                                             bool lane_has_rows, int l_lo, int top_steps) {
     constexpr int R = 4, SPG = 4;
     const int k0 = g0 * SPG;
     int oc_next[SPG];
@@ -566,20 +566,43 @@ __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], in
     // unpredicated groups: from the one in which the last lane has started on (a lane past its last column
     // goes on over pad codes; what it computes reaches only lanes that are past theirs, pointer bytes
     // and captured bottom-row entries of columns > m, none of which is ever read -- as in phase 1)
-    const int gs_lo = (63 + SPG - 1) / SPG, gs_hi = 0x7FFFFFFF;
-    for (int g = g0; g <= g_top; ++g) {
-        int oc[SPG];
-        int2 hd[SPG];
+    const int gs_lo = (63 + SPG - 1) / SPG;
+    // one unpredicated group of NQ <= 4 steps (the steps behind the walk's entry point are nobody's: the walk only
+    // moves to smaller k, and the lane state is dropped after the chunk)
+    auto steady_group = [&](int g, const int (&oc)[SPG], const int2 (&hd)[SPG], unsigned (&acc)[4], auto nq_c) {
+        constexpr int NQ = decltype(nq_c)::value;
+        int2 cap[NQ];
 #pragma unroll
-        for (int q = 0; q < SPG; ++q) { oc[q] = oc_next[q]; hd[q] = hd_next[q]; }
-        if (g < g_top) load_group(g + 1);
-        unsigned acc[4] = {0u, 0u, 0u, 0u};
-        if (g >= gs_lo && g < gs_hi) {
-            int2 cap[SPG];
+        for (int q = 0; q < NQ; ++q) {
+            int v_up = hd[q].x, d_next = hd[q].y;
+            wave_shr1_pair_sched(v_up, V[R - 1], d_next, D[R - 1]);
+            int d_ul = dsave, v_u = v_up;
+            unsigned b[R];
 #pragma unroll
-            for (int q = 0; q < SPG; ++q) {
-                int v_up = hd[q].x, d_next = hd[q].y;
-                wave_shr1_pair_sched(v_up, V[R - 1], d_next, D[R - 1]);
+            for (int rr = 0; rr < R; ++rr) {
+                const int d_old = D[rr];
+                b[rr] = cell(d_ul, v_u, H[rr], tc[rr], oc[q], D[rr], V[rr], H[rr]);
+                d_ul = d_old;
+                v_u = V[rr];
+            }
+            acc[q] = pack4(b[0], b[1], b[2], b[3]);
+            dsave = d_next;
+            cap[q] = make_int2(V[R - 1], D[R - 1]);
+        }
+        if (lane == 63) {                               // its bottom-row outputs of the steps
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) hvb[g * SPG - k0 + q] = cap[q];
+        }
+    };
+    auto edge_group = [&](int g, const int (&oc)[SPG], const int2 (&hd)[SPG], unsigned (&acc)[4]) {
+#pragma unroll
+        for (int q = 0; q < SPG; ++q) {
+            const int kk = g * SPG + q;
+            const int j = kk - lane + 1;
+            const bool active = (j >= 1) && (j <= m) && lane_has_rows;
+            int v_up = hd[q].x, d_next = hd[q].y;
+            wave_shr1_pair<4>(v_up, V[R - 1], d_next, D[R - 1]);
+            if (active) {
                 int d_ul = dsave, v_u = v_up;
                 unsigned b[R];
 #pragma unroll
@@ -591,35 +614,26 @@ __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], in
                 }
                 acc[q] = pack4(b[0], b[1], b[2], b[3]);
                 dsave = d_next;
-                cap[q] = make_int2(V[R - 1], D[R - 1]);
+                if (lane == 63) hvb[kk - k0] = make_int2(V[R - 1], D[R - 1]);
             }
-            if (lane == 63) {                               // its bottom-row outputs of the four steps
+        }
+    };
+    for (int g = g0; g <= g_top; ++g) {
+        int oc[SPG];
+        int2 hd[SPG];
 #pragma unroll
-                for (int q = 0; q < SPG; ++q) hvb[g * SPG - k0 + q] = cap[q];
-            }
+        for (int q = 0; q < SPG; ++q) { oc[q] = oc_next[q]; hd[q] = hd_next[q]; }
+        unsigned acc[4] = {0u, 0u, 0u, 0u};
+        if (g < g_top) {
+            load_group(g + 1);
+            if (g >= gs_lo) steady_group(g, oc, hd, acc, std::integral_constant<int, SPG>{});
+            else edge_group(g, oc, hd, acc);
+        } else if (g >= gs_lo) {
+            // the group the walk enters the chunk in: only its steps up to the entry point (top_steps of them)
+            if (top_steps <= 2) steady_group(g, oc, hd, acc, std::integral_constant<int, 2>{});
+            else steady_group(g, oc, hd, acc, std::integral_constant<int, SPG>{});
         } else {
-#pragma unroll
-            for (int q = 0; q < SPG; ++q) {
-                const int kk = g * SPG + q;
-                const int j = kk - lane + 1;
-                const bool active = (j >= 1) && (j <= m) && lane_has_rows;
-                int v_up = hd[q].x, d_next = hd[q].y;
-                wave_shr1_pair<4>(v_up, V[R - 1], d_next, D[R - 1]);
-                if (active) {
-                    int d_ul = dsave, v_u = v_up;
-                    unsigned b[R];
-#pragma unroll
-                    for (int rr = 0; rr < R; ++rr) {
-                        const int d_old = D[rr];
-                        b[rr] = cell(d_ul, v_u, H[rr], tc[rr], oc[q], D[rr], V[rr], H[rr]);
-                        d_ul = d_old;
-                        v_u = V[rr];
-                    }
-                    acc[q] = pack4(b[0], b[1], b[2], b[3]);
-                    dsave = d_next;
-                    if (lane == 63) hvb[kk - k0] = make_int2(V[R - 1], D[R - 1]);
-                }
-            }
+            edge_group(g, oc, hd, acc);
         }
         if (kWinLanes == 64 || in_win) win[(g - g0) * kWinLanes + (lane - l_lo)] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
     }
@@ -773,11 +787,12 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
             __syncthreads();
             PC_LAP(pc_setup)
 
-            // (d) tagged re-fill of groups g0 .. g_top into LDS
+            // (d) tagged re-fill of groups g0 .. g_top into LDS; of group g_top only the steps up to the walk's (k & 3)
             {
-                if (carried && c.gox == c.goy) refill_chunk<true, true>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows, l_lo);
-                else if (carried) refill_chunk<true, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows, l_lo);
-                else refill_chunk<false, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows, l_lo);
+                const int top_steps = ((k >> 2) == g_top) ? (k & 3) + 1 : SPG;
+                if (carried && c.gox == c.goy) refill_chunk<true, true>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows, l_lo, top_steps);
+                else if (carried) refill_chunk<true, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows, l_lo, top_steps);
+                else refill_chunk<false, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows, l_lo, top_steps);
             }
             __syncthreads();
             PC_LAP(pc_fill)
