@@ -389,9 +389,13 @@ __global__ __launch_bounds__(kPpThreads) void pp_ink_points_kernel(const uint8_t
                                                                    uint32_t* points, uint32_t* count) {
     const int hs = (h + step - 1) / step, wsm = (w + step - 1) / step;
     const int64_t n = (int64_t)hs * wsm;
-    const int lane = threadIdx.x & 63;
+    // one append per WORKGROUP and pass (a wave's ballot gives its count, the waves' counts meet in LDS): one
+    // atomic on the single counter per 64 pixels was most of this kernel's time
+    __shared__ uint32_t wcnt[kPpThreads / 64];
+    __shared__ uint32_t wbase;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t span = (int64_t)gridDim.x * kPpThreads;
-    for (int64_t base = (int64_t)blockIdx.x * kPpThreads; base < n; base += span) {     // uniform trip count per wave
+    for (int64_t base = (int64_t)blockIdx.x * kPpThreads; base < n; base += span) {     // uniform trip count per workgroup
         const int64_t e = base + threadIdx.x;
         int ys = 0, xs = 0;
         bool on = false;
@@ -400,11 +404,19 @@ __global__ __launch_bounds__(kPpThreads) void pp_ink_points_kernel(const uint8_t
             on = ink[(int64_t)ys * step * w + (int64_t)xs * step] != 0;
         }
         const unsigned long long m = __ballot(on);
-        if (m == 0ull) continue;
-        uint32_t at = 0;
-        if (lane == 0) at = atomicAdd(count, (uint32_t)__builtin_popcountll(m));
-        at = __shfl(at, 0, 64);
+        if (lane == 0) wcnt[wave] = (uint32_t)__builtin_popcountll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int k = 0; k < kPpThreads / 64; ++k) tot += wcnt[k];
+            wbase = tot ? atomicAdd(count, tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t at = wbase;
+        for (int k = 0; k < wave; ++k) at += wcnt[k];
         if (on) points[at + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = ((uint32_t)ys << 16) | (uint32_t)xs;
+        __syncthreads();                                   // wcnt / wbase are rewritten by the next pass
     }
 }
 
