@@ -106,6 +106,10 @@ def test_angle_histograms_from_the_point_list_equal_those_from_the_page():
                                                         b.data_ptr(), None), "b")
         assert int(cnt.item()) == int(ink[::step, ::step].sum().item())
         assert torch.equal(a, b), ((h, w), step)
+    # a decimated grid that does not fit 16-bit point coordinates is refused, not wrapped
+    tall = torch.zeros((70000, 2), dtype=torch.uint8, device="cuda")
+    rc = lib.ta_pp_ink_points(tall.data_ptr(), 70000, 2, 1, pts.data_ptr(), cnt.data_ptr(), None)
+    assert rc == _native.TA_ELIMIT and b"16-bit" in lib.ta_last_error()
 
 
 def test_strip_cutter():
