@@ -22,6 +22,9 @@
 namespace ta {
 
 constexpr int kLnThreads = 256;
+#ifndef TA_LN_ROW_NO
+#define TA_LN_ROW_NO 8      // adjacent outputs per thread of the row gaussian (4: 4.3 ms per 960 strips, 8: see DESIGN)
+#endif
 constexpr int kLnTarget = 48;      // target height
 constexpr int kLnPad = 16;         // prepare_line pad
 
@@ -97,13 +100,13 @@ __global__ __launch_bounds__(kLnThreads) void ln_gauss_kernel(LnArgs a) {
     }
 }
 
-// The same correlation along a row (the expensive one: up to 8 h + 1 taps), four adjacent outputs
+// The same correlation along a row (the expensive one: up to 8 h + 1 taps), NO adjacent outputs
 // per thread: the two tap windows x[j + jj .. j + jj + 3] and x[j - jj .. j - jj + 3] slide by one
-// element per tap pair, so each pair costs two new loads for four outputs.  Every output still sums
+// element per tap pair, so each pair costs two new loads for NO outputs.  Every output still sums
 // its own products in scipy's order.
 template <int SRC, int DST, int WSEL>
 __global__ __launch_bounds__(kLnThreads) void ln_gauss_row_kernel(LnArgs a) {
-    constexpr int NO = 4;
+    constexpr int NO = TA_LN_ROW_NO;
     const int line = blockIdx.x;
     const int h = a.hh[line], w = a.ww[line];
     const int64_t n = (int64_t)h * w;
@@ -126,20 +129,74 @@ __global__ __launch_bounds__(kLnThreads) void ln_gauss_row_kernel(LnArgs a) {
             lo[q] = X(j0 - reach + q);
             hi[q] = X(j0 + reach + q);
         }
-        for (int jj = -reach; jj < 0; ++jj) {
-            const double wj = wc[jj];
+        // the windows are RINGS: at the u-th tap of a round of NO, element q of the low window sits in
+        // lo[(q + u) % NO] and of the high window in hi[(q - u) mod NO] -- a slide costs one load each and no
+        // register moves (shifting 2 x NO doubles per tap pair cost as much as the arithmetic)
+        for (int jb = -reach; jb < 0; jb += NO) {
 #pragma unroll
-            for (int q = 0; q < NO; ++q) t[q] = dadd(t[q], dmul(dadd(lo[q], hi[q]), wj));
+            for (int u = 0; u < NO; ++u) {
+                const int jj = jb + u;
+                if (jj < 0) {
+                    const double wj = wc[jj];
 #pragma unroll
-            for (int q = 0; q < NO - 1; ++q) lo[q] = lo[q + 1];
-            lo[NO - 1] = X(j0 + jj + NO);                      // window of tap jj + 1: x[j0 + jj + 1 + q]
-#pragma unroll
-            for (int q = NO - 1; q > 0; --q) hi[q] = hi[q - 1];
-            hi[0] = X(j0 - jj - 1);                            // window of tap jj + 1: x[j0 - jj - 1 + q]
+                    for (int q = 0; q < NO; ++q)
+                        t[q] = dadd(t[q], dmul(dadd(lo[(q + u) % NO], hi[(q - u + NO) % NO]), wj));
+                    lo[u % NO] = X(j0 + jj + NO);                  // enters as element NO - 1 of tap jj + 1's window
+                    hi[(NO - 1 - u) % NO] = X(j0 - jj - 1);        // enters as element 0
+                }
+            }
         }
 #pragma unroll
         for (int q = 0; q < NO; ++q)
             if (j0 + q < w) D[(int64_t)i * w + j0 + q] = t[q];
+    }
+}
+
+// The correlation down the columns (AXIS 0 of ln_gauss_kernel; reach = h - 1: every row of the strip), four
+// vertically adjacent outputs per thread with the same sliding tap windows -- a thread's loads per tap pair go
+// from eight to two, and the threads of a wave sit on neighbouring columns, so every load is one coalesced row
+// segment.  Every output sums its own products in scipy's order.
+template <int SRC, int DST, int WSEL>
+__global__ __launch_bounds__(kLnThreads) void ln_gauss_col_kernel(LnArgs a) {
+    constexpr int NO = 4;
+    const int line = blockIdx.x;
+    const int h = a.hh[line], w = a.ww[line];
+    const int64_t n = (int64_t)h * w;
+    const double* S = a.ws + a.ws_off[line] + (int64_t)SRC * n;
+    double* D = a.ws + a.ws_off[line] + (int64_t)DST * n;
+    const double* wc = a.gw + a.gw_off[3 * line + WSEL];
+    const int rad = a.gr[3 * line + WSEL];
+    const int reach = min(rad, h - 1);
+    const int64_t ngroups = (int64_t)((h + NO - 1) / NO) * w;
+    for (int64_t gidx = (int64_t)blockIdx.y * kLnThreads + threadIdx.x; gidx < ngroups;
+         gidx += (int64_t)gridDim.y * kLnThreads) {
+        const int j = (int)(gidx % w), i0 = (int)(gidx / w) * NO;
+        const double* col = S + j;
+        auto X = [&](int k) -> double { return (k >= 0 && k < h) ? col[(int64_t)k * w] : 0.0; };
+        double t[NO], lo[NO], hi[NO];
+#pragma unroll
+        for (int q = 0; q < NO; ++q) {
+            t[q] = dmul(X(i0 + q), wc[0]);
+            lo[q] = X(i0 - reach + q);
+            hi[q] = X(i0 + reach + q);
+        }
+        for (int jb = -reach; jb < 0; jb += NO) {              // ring windows, as in the row kernel above
+#pragma unroll
+            for (int u = 0; u < NO; ++u) {
+                const int jj = jb + u;
+                if (jj < 0) {
+                    const double wj = wc[jj];
+#pragma unroll
+                    for (int q = 0; q < NO; ++q)
+                        t[q] = dadd(t[q], dmul(dadd(lo[(q + u) % NO], hi[(q - u + NO) % NO]), wj));
+                    lo[u % NO] = X(i0 + jj + NO);
+                    hi[(NO - 1 - u) % NO] = X(i0 - jj - 1);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NO; ++q)
+            if (i0 + q < h) D[(int64_t)(i0 + q) * w + j] = t[q];
     }
 }
 
@@ -353,7 +410,7 @@ extern "C" int ta_linenorm_measure(const uint8_t* pix, const int64_t* pix_off, c
     const dim3 one(nlines), wide(nlines, 32), cols(nlines, 8);
     hipLaunchKernelGGL(ln_minmax_kernel, one, dim3(kLnThreads), 0, st, a);
     hipLaunchKernelGGL(ln_temp_kernel, wide, dim3(kLnThreads), 0, st, a);
-    hipLaunchKernelGGL((ln_gauss_kernel<0, 0, 1, 0>), wide, dim3(kLnThreads), 0, st, a);      // plane 0 -> 1
+    hipLaunchKernelGGL((ln_gauss_col_kernel<0, 1, 0>), wide, dim3(kLnThreads), 0, st, a);     // plane 0 -> 1
     hipLaunchKernelGGL((ln_gauss_row_kernel<1, 2, 1>), wide, dim3(kLnThreads), 0, st, a);     // plane 1 -> 2
     hipLaunchKernelGGL((ln_uniform_kernel<0, 2, 0>), cols, dim3(kLnThreads), 0, st, a);       // plane 2 -> 0
     hipLaunchKernelGGL((ln_uniform_kernel<1, 0, 1>), one, dim3(kLnThreads), 0, st, a);        // plane 0 -> 1
