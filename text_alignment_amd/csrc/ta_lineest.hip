@@ -225,12 +225,32 @@ __global__ __launch_bounds__(kLnThreads) void ln_uniform_kernel(LnArgs a) {
             const int src = k - size1;
             return (src >= 0 && src < len) ? s[(int64_t)src * stride] : 0.0;
         };
+        // the running sum is one dependent chain per line (scipy's order); its INPUTS are not: eight steps'
+        // worth are loaded first, so the chain waits for one memory latency per eight steps, not per step
+        constexpr int kU = 8;
         double tmp = 0.0;
-        for (int ll = 0; ll < size; ++ll) tmp = dadd(tmp, ext(ll));
+        for (int l0 = 0; l0 < size; l0 += kU) {
+            double in[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) in[u] = (l0 + u < size) ? ext(l0 + u) : 0.0;
+#pragma unroll
+            for (int u = 0; u < kU; ++u) if (l0 + u < size) tmp = dadd(tmp, in[u]);
+        }
         d[0] = tmp / (double)size;
-        for (int ll = 1; ll < len; ++ll) {
-            tmp = dadd(tmp, dadd(ext(ll + size - 1), -ext(ll - 1)));
-            d[(int64_t)ll * stride] = tmp / (double)size;
+        for (int l0 = 1; l0 < len; l0 += kU) {
+            double in[kU], out[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                in[u] = (l0 + u < len) ? ext(l0 + u + size - 1) : 0.0;
+                out[u] = (l0 + u < len) ? ext(l0 + u - 1) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                if (l0 + u < len) {
+                    tmp = dadd(tmp, dadd(in[u], -out[u]));
+                    d[(int64_t)(l0 + u) * stride] = tmp / (double)size;
+                }
+            }
         }
     }
 }
