@@ -144,11 +144,25 @@ __global__ __launch_bounds__(kPpThreads) void pp_label_merge_kernel(int32_t* lab
     // in-tile or cross-tile neighbours then carry the diagonals), the diagonals only where the straight one is
     // background; and of a run of border pixels that all face ink only the first links (the others join the
     // same two tile components).
-    const int64_t n = (int64_t)h * w;
-    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
-        const int y = (int)(e / w), x = (int)(e % w);
+    // Only those pixels are enumerated (a tenth of the page): first the bottom rows of the tile rows, whole; then
+    // the left and right columns of the tile columns, without the pixels the bottom rows already had.
+    const int ntx = (w + kTileW - 1) / kTileW;
+    const int64_t nrow_items = (int64_t)(h / kTileH) * w;                   // rows y = 16 k + 15 < h
+    const int64_t ncol_items = (int64_t)h * 2 * ntx;
+    const int64_t nitems = nrow_items + ncol_items;
+    for (int64_t it = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; it < nitems; it += (int64_t)gridDim.x * kPpThreads) {
+        int y, x;
+        if (it < nrow_items) {
+            y = (int)(it / w) * kTileH + kTileH - 1; x = (int)(it % w);
+        } else {
+            const int64_t b = it - nrow_items;
+            y = (int)(b / (2 * ntx));
+            const int t = (int)(b % (2 * ntx));
+            x = (t >> 1) * kTileW + ((t & 1) ? kTileW - 1 : 0);
+            if (x >= w || (y % kTileH) == kTileH - 1) continue;
+        }
+        const int64_t e = (int64_t)y * w + x;
         const int cx = x % kTileW, cy = y % kTileH;
-        if (cx != 0 && cx != kTileW - 1 && cy != kTileH - 1) continue;
         if (lab[e] < 0) continue;
         auto ink = [&](int yy, int xx) { return lab[(int64_t)yy * w + xx] >= 0; };
         if (cx == kTileW - 1 && x + 1 < w) {                           // the tile to the right
