@@ -64,30 +64,37 @@ __global__ __launch_bounds__(kTileH * kTileW) void pp_label_tile_kernel(const ui
     const int run0 = gaps_below ? 64 - (int)__builtin_clzll(gaps_below) : 0;
     loc[me] = on ? ty * kTileW + run0 : -1;
     __syncthreads();
-    while (true) {
-        int changed = 0;
-        if (on) {
-            const int mine = loc[me];
-            int m = mine;
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int yy = ty + dy, xx = tx + dx;
-                    if ((dy | dx) == 0 || yy < 0 || yy >= kTileH || xx < 0 || xx >= kTileW) continue;
-                    const int q = loc[yy * kTileW + xx];
-                    if (q >= 0 && q < m) m = q;
-                }
-            if (m < mine) { atomicMin(&loc[mine], m); changed = 1; }
+    // join the runs of neighbouring rows: one lock-free union-find pass over LDS (a root is an entry that points
+    // to itself; the smaller index wins, so a component's root ends up its raster-first pixel).  A pixel links to
+    // the row above only where no neighbour's link implies it: to the pixel straight above if that is ink (the
+    // diagonals are then in the same upper run or background), else to either diagonal that is; and not at all
+    // if its left neighbour is ink and sees ink straight above too (same two runs).
+    auto find = [&](int a) { while (true) { const int p = loc[a]; if (p == a) return a; a = p; } };
+    auto unite = [&](int a, int b) {
+        while (true) {
+            a = find(a); b = find(b);
+            if (a == b) return;
+            if (a > b) { const int t = a; a = b; b = t; }
+            const int old = atomicMin(&loc[b], a);
+            if (old == b) return;
+            b = old;
         }
-        if (!__syncthreads_or(changed)) break;
-        if (on) {
-            int r = loc[me];
-            while (loc[r] != r) r = loc[r];
-            loc[me] = r;
+    };
+    if (on && ty > 0) {
+        const int up = me - kTileW;
+        const bool u = loc[up] >= 0;
+        const bool ul = tx > 0 && loc[up - 1] >= 0, ur = tx + 1 < kTileW && loc[up + 1] >= 0;
+        if (u) {
+            const bool left_same = tx > 0 && loc[me - 1] >= 0 && ul;
+            if (!left_same) unite(me, up);
+        } else {
+            if (ul && !(tx > 0 && loc[me - 1] >= 0)) unite(me, up - 1);     // (a left neighbour has it straight above)
+            if (ur) unite(me, up + 1);
         }
-        __syncthreads();
     }
+    __syncthreads();
+    if (on) loc[me] = find(me);
+    __syncthreads();
     if (inside) {
         int32_t out = -1;
         if (on) {
