@@ -245,15 +245,26 @@ __global__ __launch_bounds__(kPpThreads) void pp_stats_kernel(const int32_t* lab
     for (int64_t base = (int64_t)blockIdx.x * kPpThreads; base < n; base += span) {     // uniform trip count per wave
         const int64_t e = base + threadIdx.x;
         int32_t r = (e < n) ? lab[e] : -1;
-        const int y = (e < n) ? (int)(e / w) : 0, x = (e < n) ? (int)(e % w) : 0;
         unsigned long long todo = __ballot(r >= 0);
+        if (todo == 0ull) continue;                           // a wave of background (most of a text page): no coordinates needed
+        const uint32_t e32 = (uint32_t)(e < n ? e : n - 1);   // n < 2^31 (checked by the callers)
+        const int y = (int)(e32 / (uint32_t)w), x = (int)(e32 - (uint32_t)y * (uint32_t)w);
+        // the 64 pixels are neighbours in one row unless the wave wraps a row end
+        const bool one_row = __builtin_amdgcn_readlane(y, 0) == __builtin_amdgcn_readlane(y, 63);
         while (todo) {
             const int leader = __builtin_ctzll(todo);
             const int32_t root = __shfl(r, leader, 64);
             const bool same = (r == root);
             const unsigned long long grp = __ballot(same);
-            const int mnx = wave_min(same ? x : 0x7fffffff), mny = wave_min(same ? y : 0x7fffffff);
-            const int mxx = wave_max(same ? x : -1), mxy = wave_max(same ? y : -1);
+            int mnx, mny, mxx, mxy;
+            if (one_row) {                                    // x grows with the lane: the group's ends are its first and last lane
+                mnx = __shfl(x, leader, 64);
+                mxx = __shfl(x, 63 - (int)__builtin_clzll(grp), 64);
+                mny = mxy = __builtin_amdgcn_readlane(y, 0);
+            } else {
+                mnx = wave_min(same ? x : 0x7fffffff); mny = wave_min(same ? y : 0x7fffffff);
+                mxx = wave_max(same ? x : -1); mxy = wave_max(same ? y : -1);
+            }
             if (lane == leader) {
                 const int cnt = (int)__popcll(grp);
                 unsigned slot = ((unsigned)root * 2654435761u) >> 24;            // 8 bits: kStatSlots = 256
