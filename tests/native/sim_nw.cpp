@@ -277,7 +277,10 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
             for (int g = g0; g <= g_top; ++g) {
                 uint8_t acc[kLanes][16];
                 memset(acc, 0xEE, sizeof(acc));
-                for (int q = 0; q < SPG; ++q) {
+                // of the group the walk enters the chunk in only the steps up to the entry point are re-filled (two
+                // of four when it stands in the group's first half, as the kernel does): the rest stays poisoned
+                const int nq = (g == g_top && k / SPG == g_top && (k % SPG) + 1 <= 2) ? 2 : SPG;
+                for (int q = 0; q < nq; ++q) {
                     const int kk = g * SPG + q;
                     int vup[kLanes], dnext[kLanes];
                     for (int ll = 0; ll < kLanes; ++ll) {
