@@ -83,6 +83,77 @@ def test_charbox_and_helpers(tmp_path):
     assert atocr.parallel == 2 and atocr.median_line_mult == 2
 
 
+def _py2_style_box_pickle(module, boxes):
+    """Bytes of `pickle.dump(list_of_CharBox, f, -1)` as PYTHON 2 writes it for the reference's class (alignToOCR.py:35-58,
+    dumped at :435-436 and evaluate_text_alignment.py:170-171): protocol 2, the class by GLOBAL + NEWOBJ, the default
+    state of a __slots__ class -- the pair (None, {slot: value}) -- str values as SHORT_BINSTRING (Python 2 str = bytes)."""
+    def s(b):
+        return b"U" + bytes([len(b)]) + b
+    def i(v):
+        return b"K" + bytes([v]) if 0 <= v < 256 else b"M" + int(v).to_bytes(2, "little")
+    out = b"\x80\x02]("
+    for ch, ul, lr in boxes:
+        out += b"c" + module.encode() + b"\nCharBox\n)\x81N}("
+        out += s(b"char") + s(ch)
+        if ul is None:
+            out += s(b"ul") + b"N" + s(b"lr") + b"N"
+        else:
+            out += s(b"ul") + i(ul[0]) + i(ul[1]) + b"\x86" + s(b"lr") + i(lr[0]) + i(lr[1]) + b"\x86"
+            for name, v in (("ulx", ul[0]), ("uly", ul[1]), ("lrx", lr[0]), ("lry", lr[1]),
+                            ("width", lr[0] - ul[0]), ("height", lr[1] - ul[1])):
+                out += s(name.encode()) + i(v)
+        out += b"u\x86b"
+    return out + b"e."
+
+
+def test_ocr_cache_files_written_by_the_reference_load(tmp_path):
+    """existing_ocr_pickle (alignToOCR.py:225-233): the grid search's cache (evaluate_text_alignment.py:159-171).  A
+    file the reference wrote names `alignToOCR.CharBox` (or `__main__.CharBox` when it ran as a script), carries
+    Python 2 byte strings and the default __slots__ state; it loads into this package's CharBox through an
+    unpickler that resolves nothing else."""
+    import sys, types
+    from text_alignment_amd import alignToOCR as atocr
+    boxes = [(b"a", (1, 2), (4, 8)), (b"\xc5\xab", (300, 7), (1000, 47)), (b"_", None, None)]
+    for module in ("alignToOCR", "__main__"):
+        raw = _py2_style_box_pickle(module, boxes)
+        # the bytes are what a class of that shape pickles to: a stand-in module under the reference's name reads them
+        fake = types.ModuleType("alignToOCR")
+        class CharBox(object):
+            __slots__ = ['char', 'ul', 'lr', 'ulx', 'lrx', 'uly', 'lry', 'width', 'height']
+        CharBox.__module__, fake.CharBox = "alignToOCR", CharBox
+        if module == "alignToOCR":
+            sys.modules["alignToOCR"] = fake
+            try:
+                probe = pickle.loads(raw, encoding="latin1")
+            finally:
+                del sys.modules["alignToOCR"]
+            assert probe[0].lr == (4, 8) and probe[2].ul is None and not hasattr(probe[2], "ulx")
+        f = tmp_path / ("%s.pickle" % module.strip("_"))
+        f.write_bytes(raw)
+        got = atocr.load_ocr_pickle(str(f))
+        assert [type(b) for b in got] == [atocr.CharBox] * 3
+        assert (got[0].char, got[0].ul, got[0].lr, got[0].width, got[0].height) == ("a", (1, 2), (4, 8), 3, 6)
+        assert got[1].char == "\xc5\xab" and got[1].lrx == 1000          # Python 2 bytes read as latin-1, as pickle.load(encoding='latin1')
+        assert got[2].ul is None and got[2].lr is None and not hasattr(got[2], "ulx")
+    # this package's own files (the output of process(), numpy int16 corners after rotate_bbox)
+    own = [atocr.CharBox('x', (np.int16(3), np.int16(4)), (np.int16(30), np.int16(40))), atocr.CharBox('_')]
+    f = tmp_path / "own.pickle"
+    f.write_bytes(pickle.dumps(own, -1))
+    got = atocr.load_ocr_pickle(str(f))
+    assert got[0].lr == (30, 40) and got[1].ul is None
+    # nothing else resolves: a cache file cannot run code, and it holds a list of CharBox
+    f.write_bytes(b"cos\nsystem\n(S'true'\ntR.")
+    with pytest.raises(pickle.UnpicklingError):
+        atocr.load_ocr_pickle(str(f))
+    f.write_bytes(pickle.dumps({"a": 1}, 2))
+    with pytest.raises(pickle.UnpicklingError):
+        atocr.load_ocr_pickle(str(f))
+    bad = _py2_style_box_pickle("alignToOCR", [(b"a", (1, 2), (4, 8))]).replace(b"U\x05width", b"U\x05wedth")
+    f.write_bytes(bad)
+    with pytest.raises(pickle.UnpicklingError):
+        atocr.load_ocr_pickle(str(f))
+
+
 def test_chars_from_llocs_half_to_even_and_rejects():
     from text_alignment_amd import alignToOCR as atocr
     out = []

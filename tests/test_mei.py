@@ -63,3 +63,59 @@ def test_rodan_wrapper_imports_without_rodan():
     from text_alignment_amd import textAlignment as ta
     assert ta.RodanTask is None or hasattr(ta, "textAlignment")
     assert callable(ta.run_alignment)
+
+
+def test_rodan_task_runs_under_a_stand_in_rodan(tmp_path, monkeypatch):
+    """The RodanTask subclass (reference textAlignment.py:7-63) is only defined where `rodan` imports.  With a
+    ten-line stand-in for `rodan.jobs.base` the class is defined and `run_my_task` is EXECUTED: ports resolved as
+    Rodan passes them (reference textAlignment.py:51-63), transcript read with read_file, the text layer loaded,
+    `process` called with the reference's arguments, and the 4-tuple written as the syl_boxes JSON.  (`process`
+    itself -- the GPU path -- is replaced by a recorder here; tests/test_page_gpu.py covers it.)"""
+    import importlib, json, sys, types
+    from PIL import Image
+    base = types.ModuleType("rodan.jobs.base")
+
+    class RodanTask(object):
+        def run(self, inputs, settings, outputs):
+            return self.run_my_task(inputs, settings, outputs)
+    base.RodanTask = RodanTask
+    for name, mod in (("rodan", types.ModuleType("rodan")), ("rodan.jobs", types.ModuleType("rodan.jobs")),
+                      ("rodan.jobs.base", base)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    from text_alignment_amd import textAlignment as ta, alignToOCR as atocr
+    ta = importlib.reload(ta)
+    try:
+        assert ta.RodanTask is RodanTask and issubclass(ta.textAlignment, RodanTask)
+        task = ta.textAlignment()
+        assert task.name == 'Text Alignment' and task.settings['required'] == ['MEI Version']
+        assert [p['name'] for p in task.input_port_types] == ['Text Layer', 'Transcript']
+        assert task.output_port_types[0]['resource_types'] == ['application/JSON']
+        img = tmp_path / "layer.png"
+        Image.fromarray(np.full((40, 60), 255, dtype=np.uint8)).save(str(img))
+        txt = tmp_path / "t.txt"
+        txt.write_text("# header\ndominus dixit | \nad me\n")
+        out = tmp_path / "out.json"
+        seen = {}
+
+        def fake_process(raw_image, transcript, model, seq_align_params=None, wkdir_name=None, verbose=True, **kw):
+            seen.update(shape=raw_image.shape, dtype=raw_image.dtype, transcript=transcript, model=model, wkdir=wkdir_name)
+            if transcript.startswith("fail"):
+                return None
+            boxes = [atocr.CharBox('do', (5, 6), (20, 30)), atocr.CharBox('mi', (22, 6), (40, 30))]
+            return boxes, object(), [100, 220, 340, 470], []
+        monkeypatch.setattr(atocr, "process", fake_process)
+        ports = lambda p: [{'resource_path': str(p)}]
+        ok = task.run({'Text Layer': ports(img), 'Transcript': ports(txt)}, {'MEI Version': '3.9.9'}, {'JSON': ports(out)})
+        assert ok is True
+        assert seen == dict(shape=(40, 60), dtype=np.uint8, transcript="dominus dixit  ad me", model=ta.DEFAULT_MODEL, wkdir='test')
+        assert json.loads(out.read_text()) == {
+            'median_line_spacing': 125.0,
+            'syl_boxes': [{'syl': 'do', 'ul': [5, 6], 'lr': [20, 30]}, {'syl': 'mi', 'ul': [22, 6], 'lr': [40, 30]}]}
+        # OCR failure: process returns None (reference alignToOCR.py:241-243), the task reports it and writes nothing
+        txt.write_text("fail here\n")
+        out.unlink()
+        assert task.run({'Text Layer': ports(img), 'Transcript': ports(txt)}, {}, {'JSON': ports(out)}) is False
+        assert not out.exists()
+    finally:
+        monkeypatch.undo()
+        importlib.reload(ta)

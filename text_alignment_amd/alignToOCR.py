@@ -57,8 +57,50 @@ class CharBox(object):
         return {k: getattr(self, k) for k in self.__slots__ if hasattr(self, k)}
 
     def __setstate__(self, state):
+        # a pickle the reference wrote (alignToOCR.py:435-436: its CharBox has no __getstate__) carries the
+        # default state of a __slots__ class, the pair (None, {slot: value})
+        if isinstance(state, tuple) and len(state) == 2:
+            state = dict(state[0] or {}, **(state[1] or {}))
         for k, v in state.items():
+            if k not in self.__slots__:
+                raise pickle.UnpicklingError("CharBox has no slot %r" % (k,))
             setattr(self, k, v)
+
+
+class _BoxUnpickler(pickle.Unpickler):
+    """Loader of the OCR cache files of alignToOCR.py:225-233 (written at :435-436 and by
+    evaluate_text_alignment.py:170-171 with protocol 2): a list of CharBox and nothing else.  The class may be
+    named after the reference's module (`alignToOCR`, or `__main__` when the reference ran as a script) or
+    after this one; coordinates may be numpy scalars (rotate_bbox's int16).  No other global resolves, so a
+    cache file cannot run code -- the same rule as the model loader's (model_io.RestrictedUnpickler)."""
+    _BOX_MODULES = ('alignToOCR', '__main__', 'text_alignment_amd.alignToOCR')
+
+    def find_class(self, module, name):
+        if name == 'CharBox' and module in self._BOX_MODULES:
+            return CharBox
+        if module in ('numpy.core.multiarray', 'numpy._core.multiarray') and name == 'scalar':
+            import numpy.core.multiarray as ma
+            return ma.scalar
+        if module == 'numpy' and name == 'dtype':
+            return np.dtype
+        if (module, name) in (('copy_reg', '_reconstructor'), ('copyreg', '_reconstructor')):
+            import copyreg
+            return copyreg._reconstructor
+        if (module, name) in (('__builtin__', 'object'), ('builtins', 'object')):
+            return object
+        if (module, name) == ('_codecs', 'encode'):       # how Python 3 writes bytes at protocol 2
+            import _codecs
+            return _codecs.encode
+        raise pickle.UnpicklingError('global %s.%s is not allowed in an OCR cache file' % (module, name))
+
+
+def load_ocr_pickle(path):
+    """list[CharBox] from a cache file this package or the reference (Python 2, latin-1 strings) wrote"""
+    with open(path, 'rb') as f:
+        chars = _BoxUnpickler(f, encoding='latin1').load()
+    if not isinstance(chars, list) or not all(isinstance(c, CharBox) for c in chars):
+        raise pickle.UnpicklingError('an OCR cache file holds a list of CharBox')
+    return chars
 
 
 def clean_special_chars(inp):
@@ -458,8 +500,7 @@ def process(raw_image,
     all_chars = []
     if existing_ocr_pickle:
         try:
-            with open(existing_ocr_pickle, 'rb') as f:
-                all_chars = pickle.load(f)
+            all_chars = load_ocr_pickle(existing_ocr_pickle)
             print('using pickled ocr results in {}...'.format(existing_ocr_pickle))
         except IOError:
             print('Pickle file {} not found - performing ocr instead'.format(existing_ocr_pickle))

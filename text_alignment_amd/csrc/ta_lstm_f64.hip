@@ -1,0 +1,383 @@
+// ta_lstm_f64.hip -- the line recogniser's recurrence in FLOAT64 on the f64 matrix cores of MI355X (gfx950).
+//
+// Why: the reference's recogniser (`ocropus-rpred`, reference alignToOCR.py:142-147; arithmetic of the
+// third-party ocropy 1.3.3) computes in float64 numpy.  The random-weight model of
+// SURVEY.md section 8(d) is chaotic: a float32 rounding difference grows up to ten-thousandfold over a line of
+// 800 .. 2000 columns, so no float32 recurrence (ta_lstm.hip, either mode) holds "logits within 1e-3" free-running
+// on every line.  This mode accumulates, carries state and evaluates the gate functions in float64.
+//
+// One direction's float64 weights (4 gates x 100 units x 149 inputs = 477 KB) do not fit a CU, so the product is
+// split where the recurrence allows it:
+//
+//  Kx lstm_xproj_f64_kernel   Gx[dir][row][4 unit + gate] = W[:, :49] . [1; x_row] for EVERY row of the batch at
+//                             once (no dependence between timesteps): a weight-stationary f64 GEMM on
+//                             v_mfma_f64_16x16x4_f64, rows x 52 x 400 per direction.
+//  Kr lstm_seq_f64_kernel     one workgroup of FOUR waves (one per SIMD, 512 registers each) per (16 lines,
+//                             direction).  The recurrent weights W[:, 49:] (4 x 100 x 100 float64 = 320 KB) live in
+//                             the CU's registers as B fragments for the whole kernel; h_{t-1} of the 16 lines is the A
+//                             operand in LDS (float64); per step the accumulators start from Gx (the loads are issued
+//                             a step ahead) and take 25 k-steps of v_mfma_f64_16x16x4_f64; cell state and gate
+//                             functions in float64 (own exp: range reduction + degree-11 polynomial, 1e-15).
+//
+// Tiling of the 400 pre-activations of a step: 25 column tiles of 16 = (4 units) x (4 gates), gate fastest.  The
+// f64 MFMA returns D[i][j] in lane j + 16 (i mod 4), register i / 4 (tools/ubench/mfma_f64.hip): the four gates of
+// a unit sit in the four lanes of a quad, for the same four lines -- a 4 x 4 transpose inside the quad (DPP quad
+// permutes) gives every lane all four gates of ONE (line, unit) pair, whose cell update it computes.  No padding:
+// 25 tiles x 25 k-steps are exactly 400 x 100.  Waves take 7, 6, 6, 6 tiles.
+//
+// Measured (tools/ubench/mfma_f64.hip, profiles/r04_mfma_f64.txt): 64 cycles per MFMA per SIMD (= the 78.6 TF
+// float64 peak), the same for one dependent accumulator chain; a wave's v_fma_f64 beside another wave's f64 MFMAs
+// on the same SIMD gets one issue per 69 cycles -- the matrix instruction runs on the vector f64 units, so the gate
+// math cannot hide under it and a step costs MFMA time + gate time.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ta_common.h"
+
+namespace ta64 {
+
+constexpr int kNi = 48;
+constexpr int kNs = 100;
+constexpr int kLines = 16;          // lines per workgroup (MFMA M)
+constexpr int kCols = 4 * kNs;      // 400 pre-activations per step, column = 4 * unit + gate
+constexpr int kTiles = kCols / 16;  // 25 column tiles
+constexpr int kKH = kNs / 4;        // 25 k-steps over h
+constexpr int kXK = 52;             // [1, x(48), 3 zeros]
+constexpr int kKX = kXK / 4;        // 13 k-steps over [1, x]
+constexpr int kW = 4;               // waves per workgroup
+constexpr int kMaxNT = 7;           // tiles of wave 0; waves 1..3 take 6
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int tile0_of(int wave) { return wave == 0 ? 0 : 1 + 6 * wave; }   // 0, 7, 13, 19
+__host__ __device__ constexpr int ntiles_of(int wave) { return wave == 0 ? 7 : 6; }
+
+// ---------------------------------------------------------------------------------------------
+// float64 gate functions.  exp: x = n ln2 + r, |r| <= ln2 / 2; e^r by its Taylor polynomial of degree 11
+// (remainder r^12 / 12! < 7e-15 relative), scaled by 2^n with v_ldexp_f64.  Valid for |x| < 700.
+__device__ __forceinline__ double exp_f64(double x) {
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);          // ln2 split as in fdlibm: hi has 32 bits
+    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 39916800.0;
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)n);
+}
+// 1 / d for d in [1, 1 + e^20]: the hardware reciprocal refined by two Newton steps (quadratic: whatever the
+// seed's accuracy above 2^-14, the result is within an ulp or two)
+__device__ __forceinline__ double rcp_f64(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+// ocropy's sigmoid: 1 / (1 + exp(clip(-x, -20, 20)))   -- in float64 the clip is visible
+// (sigma(-25) = 2.06e-9 with it, 1.4e-11 without), so it is kept
+__device__ __forceinline__ double sigmoid_f64(double x) {
+    const double z = __builtin_fmin(__builtin_fmax(-x, -20.0), 20.0);
+    return rcp_f64(1.0 + exp_f64(z));
+}
+// tanh(x) = (1 - e) / (1 + e), e = exp(-2x); |x| clamped to 20 (tanh(20) = 1 - 8e-18 rounds to 1)
+__device__ __forceinline__ double tanh_f64(double x) {
+    const double z = __builtin_fmin(__builtin_fmax(x, -20.0), 20.0);
+    const double e = exp_f64(-2.0 * z);
+    return (1.0 - e) * rcp_f64(1.0 + e);
+}
+
+// One LSTM cell update (`forward_py`) from the four pre-activations of a (line, unit) pair.
+// past0: not the first step of the whole sequence (the peepholes on the old cell state and the output peephole are
+// skipped at t = 0).
+__device__ __forceinline__ double lstm_cell_f64(double gi, double gf, double go, double ci_pre, double& c, bool past0,
+                                                double wip, double wfp, double wop) {
+    const double ci = tanh_f64(ci_pre);
+    const double cp = past0 ? c : 0.0;
+    gi = sigmoid_f64(__builtin_fma(wip, cp, gi));
+    gf = sigmoid_f64(__builtin_fma(wfp, cp, gf));
+    const double cn = __builtin_fma(ci, gi, gf * cp);
+    go = sigmoid_f64(__builtin_fma(past0 ? wop : 0.0, cn, go));
+    c = cn;
+    return tanh_f64(cn) * go;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double quad_perm_f64(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kx: Gx[dir][row][col] = sum_kp Wx[dir][col][kp] * [1, x_row, 0, 0, 0][kp]     (kp < 52, float64)
+struct XprojArgs {
+    const float* x;        // [rows][48], the rows of this call
+    int64_t rows;
+    const double* wx;      // [dir 2][tile 25][k-step 13][lane 64]: W_gate(j % 4)[unit 4 tile + j / 4][kp 4 kstep + lane / 16], j = lane % 16
+    double* gx;            // [dir 2][rows][400]
+};
+
+template <int NT>
+__device__ __forceinline__ void xproj_body(const XprojArgs& a, int dir, int wave, int lane) {
+    const int tile0 = tile0_of(wave);
+    double Bx[NT][kKX];
+    {
+        const double* wp = a.wx + ((size_t)(dir * kTiles + tile0) * kKX) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < NT; ++s)
+#pragma unroll
+            for (int kk = 0; kk < kKX; ++kk) Bx[s][kk] = wp[((size_t)s * kKX + kk) * 64];
+    }
+    const int64_t ntiles = (a.rows + 15) / 16;
+    const int li = lane & 15, kq = lane >> 4;
+    double* gxd = a.gx + (size_t)dir * a.rows * kCols;
+    // this lane's A values of a row tile: [1, x, 0 0 0][4 kk + kq] of row tile * 16 + li (rows past the end: clamped)
+    auto load_tile = [&](int64_t tile, float (&dst)[kKX]) {
+        const int64_t row = min(min(tile, ntiles - 1) * 16 + li, a.rows - 1);
+        const float* xr = a.x + row * kNi;
+#pragma unroll
+        for (int kk = 0; kk < kKX; ++kk) {
+            const int kp = 4 * kk + kq;                        // kp = 0: the constant 1; 49 .. 51: zero padding
+            dst[kk] = (kp >= 1 && kp <= kNi) ? xr[kp - 1] : (kp == 0 ? 1.0f : 0.0f);
+        }
+    };
+    float A[kKX], An[kKX];
+    load_tile(blockIdx.x, A);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        load_tile(tile + gridDim.x, An);                       // flies under this tile's MFMAs
+        f64x4 acc[NT];
+#pragma unroll
+        for (int s = 0; s < NT; ++s) acc[s] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < kKX; ++kk) {
+            const double av = (double)A[kk];
+#pragma unroll
+            for (int s = 0; s < NT; ++s) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bx[s][kk], acc[s], 0, 0, 0);
+        }
+        // D[i][j]: lane j + 16 (i % 4), register i / 4
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = tile * 16 + 4 * r + kq;
+            if (row < a.rows) {
+                double* o = gxd + row * kCols + 16 * tile0 + li;
+#pragma unroll
+                for (int s = 0; s < NT; ++s) o[16 * s] = acc[s][r];
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < kKX; ++kk) A[kk] = An[kk];
+    }
+}
+
+__global__ __launch_bounds__(kW * 64) void lstm_xproj_f64_kernel(XprojArgs a) {
+    const int dir = blockIdx.y, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0) xproj_body<7>(a, dir, wave, lane);
+    else xproj_body<6>(a, dir, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kr: the recurrence
+struct Seq64Args {
+    const double* gx;          // [dir 2][gx_rows][400], row r of it = absolute row gx_row0 + r
+    int64_t gx_row0, gx_rows;
+    const int64_t* row_off;    // per line: first (absolute) row
+    const int32_t* T;          // per line: timesteps
+    const int32_t* group_lines;// [ngroups][16] line ids, -1 = empty slot
+    const double* wh;          // [dir 2][wave 4][slot 7][k-step 25][lane 64]: W_gate(j % 4)[unit 4 (tile0(wave) + slot) + j / 4][49 + 4 kstep + lane / 16]
+    const double* peep;        // [dir 2][3: WIP, WFP, WOP][100]
+    float* hout;               // [rows][200] (absolute rows)
+    const double* h0;          // optional [lines][2][100]: outputs before the first step
+    const double* c0;          // optional [lines][2][100]: cell states before the first step
+    const int32_t* tstart;     // optional [lines][2]: steps of the sequence already done
+};
+
+template <int NT>
+__device__ __forceinline__ void seq_f64_body(const Seq64Args& a, double (&hs)[2][kNs][kLines], const double (&peep_s)[3][kNs],
+                                             const int (&s_line)[kLines], const int (&s_T)[kLines],
+                                             const long long (&s_row)[kLines], int dir, int wave, int lane, int Tmax) {
+    const int tile0 = tile0_of(wave);
+    // recurrent weights of this wave's tiles: B fragments, constant over time (NT * 25 * 2 registers)
+    double Bw[NT][kKH];
+    {
+        const double* wp = a.wh + ((size_t)(dir * kW + wave) * kMaxNT * kKH) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < NT; ++s)
+#pragma unroll
+            for (int kk = 0; kk < kKH; ++kk) Bw[s][kk] = wp[((size_t)s * kKH + kk) * 64];
+    }
+    const int li = lane & 15, kq = lane >> 4;
+    // accumulator rows of this lane (for the Gx loads): line slot 4 r + kq, r = 0 .. 3
+    const double* gxd = a.gx + (size_t)dir * a.gx_rows * kCols + 16 * tile0 + li;
+    int accT[4];
+    long long accrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        accT[r] = s_T[4 * r + kq];
+        accrow[r] = s_row[4 * r + kq] - a.gx_row0;
+    }
+    auto gx_row = [&](int r, int t) -> const double* {
+        const int Tl = accT[r];
+        int tt = t < Tl ? t : Tl - 1;
+        if (dir) tt = Tl - 1 - tt;                              // Reversed(LSTM): run on xs[::-1]
+        const long long row = Tl > 0 ? accrow[r] + tt : 0;     // an empty slot reads row 0 of the buffer (never used)
+        return gxd + row * kCols;
+    };
+    // the (line, unit) pairs whose cell this lane updates after the quad transpose: line slot 4 (lane % 4) + kq,
+    // unit 4 (tile0 + s) + li / 4
+    const int cslot = 4 * (lane & 3) + kq;
+    const int cT = s_T[cslot];
+    const long long crow = s_row[cslot];
+    const int cid = s_line[cslot];
+    const int ubase = 4 * tile0 + (li >> 2);
+    double c[NT];
+    int ts = 0;
+#pragma unroll
+    for (int s = 0; s < NT; ++s) c[s] = 0.0;
+    if (cid >= 0) {
+        if (a.c0) {
+#pragma unroll
+            for (int s = 0; s < NT; ++s) c[s] = a.c0[((size_t)cid * 2 + dir) * kNs + ubase + 4 * s];
+        }
+        if (a.tstart) ts = a.tstart[(size_t)cid * 2 + dir];
+    }
+    float* houtp = a.hout + dir * kNs + ubase;
+
+    f64x4 acc[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[s][r] = gx_row(r, 0)[16 * s];
+
+    for (int t = 0; t < Tmax; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        // h part: A[i][k] = h_{t-1}[unit k] of line i, lane i + 16 (k % 4)
+#pragma unroll
+        for (int kk = 0; kk < kKH; ++kk) {
+            const double av = hs[cur][4 * kk + kq][li];
+#pragma unroll
+            for (int s = 0; s < NT; ++s) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bw[s][kk], acc[s], 0, 0, 0);
+        }
+        const bool past0 = (t > 0) | (ts > 0);
+        const bool more = t + 1 < Tmax;
+        const double* gnext[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gnext[r] = gx_row(r, t + 1);
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            // transpose inside the quad: acc[r] of quad lane q = (gate q, line slot 4 r + kq) -> g[q'] of quad
+            // lane q = (gate q', line slot 4 q + kq)
+            double g0 = acc[s][0], g1 = acc[s][1], g2 = acc[s][2], g3 = acc[s][3];
+            {
+                const bool odd = lane & 1, hi = lane & 2;
+                double v, w;
+                v = odd ? g0 : g1; w = quad_perm_f64<0xB1>(v); if (odd) g0 = w; else g1 = w;
+                v = odd ? g2 : g3; w = quad_perm_f64<0xB1>(v); if (odd) g2 = w; else g3 = w;
+                v = hi ? g0 : g2; w = quad_perm_f64<0x4E>(v); if (hi) g0 = w; else g2 = w;
+                v = hi ? g1 : g3; w = quad_perm_f64<0x4E>(v); if (hi) g1 = w; else g3 = w;
+            }
+            const int unit = ubase + 4 * s;
+            const double h = lstm_cell_f64(g0, g1, g2, g3, c[s], past0, peep_s[0][unit], peep_s[1][unit], peep_s[2][unit]);
+            hs[nxt][unit][cslot] = h;
+            if (t < cT) {
+                const int tt = dir ? cT - 1 - t : t;
+                houtp[(crow + tt) * (2 * kNs) + 4 * s] = (float)h;
+            }
+            // the tile's accumulators are free: next step's x part starts to arrive
+            if (more) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[s][r] = gnext[r][16 * s];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kW * 64) void lstm_seq_f64_kernel(Seq64Args a) {
+    __shared__ __attribute__((aligned(16))) double hs[2][kNs][kLines];       // h of the 16 lines, [unit][line]
+    __shared__ double peep_s[3][kNs];
+    __shared__ int s_line[kLines];
+    __shared__ int s_T[kLines];
+    __shared__ long long s_row[kLines];
+
+    const int grp = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < kLines) {
+        const int id = a.group_lines[grp * kLines + tid];
+        s_line[tid] = id;
+        s_T[tid] = id >= 0 ? a.T[id] : 0;
+        s_row[tid] = id >= 0 ? a.row_off[id] : 0;
+    }
+    for (int e = tid; e < 2 * kNs * kLines; e += kW * 64) (&hs[0][0][0])[e] = 0.0;
+    for (int e = tid; e < 3 * kNs; e += kW * 64) (&peep_s[0][0])[e] = a.peep[(size_t)dir * 3 * kNs + e];
+    __syncthreads();
+    int Tmax = 0;
+#pragma unroll
+    for (int s = 0; s < kLines; ++s) Tmax = max(Tmax, s_T[s]);
+    if (a.h0) {                                            // h_{-1} of continued sequences
+        for (int e = tid; e < kLines * kNs; e += kW * 64) {
+            const int slot = e / kNs, u = e % kNs;
+            const int id = s_line[slot];
+            if (id >= 0) hs[0][u][slot] = a.h0[((size_t)id * 2 + dir) * kNs + u];
+        }
+    }
+    __syncthreads();
+    if (wave == 0) seq_f64_body<7>(a, hs, peep_s, s_line, s_T, s_row, dir, wave, lane, Tmax);
+    else seq_f64_body<6>(a, hs, peep_s, s_line, s_T, s_row, dir, wave, lane, Tmax);
+}
+
+}  // namespace ta64
+
+using namespace ta64;
+
+extern "C" int64_t ta_lstm_f64_weight_doubles(int32_t which) {
+    // 0: wh [2][4][7][25][64]; 1: wx [2][25][13][64]; 2: peep [2][3][100]
+    if (which == 0) return (int64_t)2 * kW * kMaxNT * kKH * 64;
+    if (which == 1) return (int64_t)2 * kTiles * kKX * 64;
+    if (which == 2) return (int64_t)2 * 3 * kNs;
+    return 0;
+}
+
+extern "C" int64_t ta_lstm_f64_gx_bytes(int64_t rows) { return rows < 0 ? 0 : (int64_t)2 * rows * kCols * 8; }
+
+extern "C" int ta_lstm_xproj_f64(const float* x, int64_t rows, const double* wx, double* gx, void* stream) {
+    if (rows < 0) return ta_fail(TA_EINVAL, "negative row count");
+    if (rows == 0) return TA_OK;
+    if (!x || !wx || !gx) return ta_fail(TA_EINVAL, "null pointer argument");
+    XprojArgs a{x, rows, wx, gx};
+    const int64_t ntiles = (rows + 15) / 16;
+    const dim3 grid((unsigned)(ntiles < 1024 ? ntiles : 1024), 2);
+    hipLaunchKernelGGL(lstm_xproj_f64_kernel, grid, dim3(kW * 64), 0, reinterpret_cast<hipStream_t>(stream), a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ta_fail_hip(e, "lstm_xproj_f64_kernel launch");
+    return TA_OK;
+}
+
+extern "C" int ta_lstm_forward_f64(const double* gx, int64_t gx_row0, int64_t gx_rows, const int64_t* row_off,
+                                   const int32_t* T, const int32_t* group_lines, int32_t ngroups, const double* wh,
+                                   const double* peep, float* hout, const double* h0, const double* c0,
+                                   const int32_t* tstart, void* stream) {
+    if (ngroups < 0 || gx_rows < 0 || gx_row0 < 0) return ta_fail(TA_EINVAL, "negative count");
+    if (ngroups == 0) return TA_OK;
+    if (!gx || !row_off || !T || !group_lines || !wh || !peep || !hout)
+        return ta_fail(TA_EINVAL, "null pointer argument");
+    if ((h0 != nullptr) != (c0 != nullptr) || (h0 != nullptr) != (tstart != nullptr))
+        return ta_fail(TA_EINVAL, "h0, c0 and tstart go together (all null, or all given)");
+    Seq64Args a{gx, gx_row0, gx_rows, row_off, T, group_lines, wh, peep, hout, h0, c0, tstart};
+    hipLaunchKernelGGL(lstm_seq_f64_kernel, dim3(2 * ngroups), dim3(kW * 64), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ta_fail_hip(e, "lstm_seq_f64_kernel launch");
+    return TA_OK;
+}

@@ -28,7 +28,7 @@ class RecognitionError(Exception):
 
 
 MAX_CLASSES = 128        # csrc/ta_lstm.hip: kMaxCT = 8 class tiles of 16
-PRECISIONS = ("f32", "split")
+PRECISIONS = ("f32", "split", "f64")
 DEFAULT_PRECISION = "f32"
 
 
@@ -177,6 +177,39 @@ def _pack_lstm4(model):
     return wp
 
 
+def _pack_lstm_f64(model):
+    """weights of the float64 recurrence (csrc/ta_lstm_f64.hip).  The 400 pre-activations of a step are tiled as
+    25 column tiles of 16 = (4 units) x (4 gates), gate fastest; waves take tiles 0..6, 7..12, 13..18, 19..24.
+    wh [dir 2][wave 4][slot 7][k-step 25][lane 64] = W_gate(j % 4)[unit 4 (tile0(wave) + slot) + j // 4][49 + 4 kstep + lane // 16]
+    wx [dir 2][tile 25][k-step 13][lane 64]        = W_gate(j % 4)[unit 4 tile + j // 4][kp = 4 kstep + lane // 16]  (kp <= 48)
+    with j = lane % 16; peep [dir 2][WIP, WFP, WOP][100]."""
+    wh = np.zeros((2, 4, 7, 25, 64), dtype=np.float64)
+    wx = np.zeros((2, 25, 13, 64), dtype=np.float64)
+    peep = np.zeros((2, 3, NS), dtype=np.float64)
+    lane = np.arange(64)
+    j, kq = lane % 16, lane // 16
+    for d, w in enumerate((model.fwd, model.rev)):
+        Wg = np.stack([np.asarray(w[name], dtype=np.float64) for name in ("WGI", "WGF", "WGO", "WCI")])   # [gate][unit][149]
+        Wx = np.zeros((4, NS, 52), dtype=np.float64)
+        Wx[:, :, :1 + NI] = Wg[:, :, :1 + NI]
+        Wh = Wg[:, :, 1 + NI:]                                                                                  # [gate][unit][100]
+        for tile in range(25):
+            units = 4 * tile + j // 4
+            for kk in range(13):
+                wx[d, tile, kk] = Wx[j % 4, units, 4 * kk + kq]
+        for wv in range(4):
+            tile0 = 0 if wv == 0 else 1 + 6 * wv
+            for s in range(7 if wv == 0 else 6):
+                units = 4 * (tile0 + s) + j // 4
+                for kk in range(25):
+                    wh[d, wv, s, kk] = Wh[j % 4, units, 4 * kk + kq]
+        for q, name in enumerate(("WIP", "WFP", "WOP")):
+            peep[d, q] = np.asarray(w[name], dtype=np.float64)
+    lib = _native.lib
+    assert (wh.size, wx.size, peep.size) == tuple(lib.ta_lstm_f64_weight_doubles(k) for k in range(3))
+    return wh, wx, peep
+
+
 _pool = None
 
 
@@ -194,6 +227,7 @@ FORCE_GROUP = int(os.environ["TA_OCR_GROUP"]) if os.environ.get("TA_OCR_GROUP") 
 FORCE_CLASS_SPLIT = (os.environ["TA_OCR_CLASS_SPLIT"] == "1") if os.environ.get("TA_OCR_CLASS_SPLIT") in ("0", "1") else None
 CLASS_SPLIT_MIN_LINES = 384     # below this (a few pages) the recurrence's tail has nothing worth hiding
 GROUP4_MAX_LINES = 2048         # exact-f32 mode: batches up to this size run in groups of 4 lines (see prepare)
+F64_GX_MAX_ROWS = 3200000       # float64 mode: rows whose hoisted input projection (6 400 B per row) is held at once: 20 GB
 _split_state = {"streams": {}, "ok": None}
 
 
@@ -259,11 +293,11 @@ class LineRecognizer(object):
     def __init__(self, model, device="cuda", precision=DEFAULT_PRECISION):
         if not torch.cuda.is_available():
             raise RuntimeError("text_alignment_amd needs an AMD GPU (MI355X); there is no CPU fallback")
-        if precision not in ("split", "bf16x3", "f32"):
-            raise ValueError("precision must be 'f32' or 'split'")
+        if precision not in ("split", "bf16x3", "f32", "f64"):
+            raise ValueError("precision must be 'f32', 'split' or 'f64'")
         self.model = model
         self.device = torch.device(device)
-        self.mode = 0 if precision == "f32" else 1
+        self.mode = {"f32": 0, "f64": 3}.get(precision, 1)
         wp, peep, w2p = _pack_lstm(model)
         if self.mode == 1:
             wp = _pack_lstm_split(model)
@@ -275,6 +309,9 @@ class LineRecognizer(object):
             w2s, bias = _pack_output_split(model)
             self.w2s = torch.from_numpy(w2s).to(self.device)
             self.w2bias = torch.from_numpy(bias).to(self.device)
+        if self.mode == 3:
+            self.wh64, self.wx64, self.peep64 = (torch.from_numpy(w).to(self.device) for w in _pack_lstm_f64(model))
+            self._gx = None
 
     # ---- host -> device ------------------------------------------------------------------
     def _upload_rows(self, lines, row_start, rows):
@@ -422,7 +459,33 @@ class LineRecognizer(object):
 
         ng, G = st["ngroups"], st["group_size"]
 
+        def forward_f64(g0, g1, stream_):
+            """float64 mode: the input projection of every row of a run of groups in one GEMM (Gx, 6 400 bytes per row,
+            held for at most F64_GX_MAX_ROWS rows at a time -- runs of groups are contiguous row ranges), then the
+            recurrence over those groups; both on stream_, which also orders the reuse of the buffer."""
+            grow = st["group_row_host"]
+            a = g0
+            while a < g1:
+                b = a + 1
+                while b < g1 and int(grow[b + 1] - grow[a]) <= F64_GX_MAX_ROWS:
+                    b += 1
+                r0, r1 = int(grow[a]), int(grow[b])
+                need = lib.ta_lstm_f64_gx_bytes(r1 - r0)
+                if self._gx is None or self._gx.numel() * 8 < need:
+                    self._gx = None                                  # (free the old one first)
+                    self._gx = torch.empty(max(need // 8, 1), dtype=torch.float64, device=self.device)
+                _native.check(lib.ta_lstm_xproj_f64(st["x"].data_ptr() + 4 * NI * r0, r1 - r0, self.wx64.data_ptr(),
+                                                    self._gx.data_ptr(), stream_), "ta_lstm_xproj_f64")
+                _native.check(lib.ta_lstm_forward_f64(
+                    self._gx.data_ptr(), r0, r1 - r0, st["row_off"].data_ptr(), st["T"].data_ptr(),
+                    st["group_lines"].data_ptr() + 4 * G * a, b - a, self.wh64.data_ptr(), self.peep64.data_ptr(),
+                    st["hout"].data_ptr(), cont[0].data_ptr() if cont else None, cont[1].data_ptr() if cont else None,
+                    cont[2].data_ptr() if cont else None, stream_), "ta_lstm_forward_f64")
+                a = b
+
         def forward(g0, g1, stream_):
+            if self.mode == 3:
+                return forward_f64(g0, g1, stream_)
             _native.check(lib.ta_lstm_forward(
                 st["x"].data_ptr(), st["row_off"].data_ptr(), st["T"].data_ptr(),
                 st["group_lines"].data_ptr() + 4 * G * g0, g1 - g0, (self.wp4 if G == 4 else self.wp).data_ptr(),
