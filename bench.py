@@ -35,6 +35,8 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 F32_MFMA_PEAK_TF = 157.3       # MI355X_MICROARCH.md: f32-input MFMA peak (spec)
 BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (spec)
+F64_MFMA_PEAK_TF = 78.6        # f64 matrix peak (spec); measured: v_mfma_f64_16x16x4_f64 at 64 cycles per SIMD = 78.6 TF
+                               # at 2.4 GHz (tools/ubench/mfma_f64.hip, profiles/r04_mfma_f64.txt)
 DEFAULT_SYS = [8, -4, -7, -7, -3, 0]
 P1_VALU_PER_BLOCK = 382        # nw_score_kernel, score profile + one gap open: VALU instructions per 64 cells of a lane
 P1_NS_PER_VALU = 1.72          # measured issue interval of that instruction mix (profiles/r02_valu_issue_rates.txt)
@@ -53,7 +55,7 @@ def measured_traffic(batch, n, m, kernel):
     profiles/ (WRITE_SIZE + 2 x FETCH_SIZE, MI355X_MICROARCH.md HBM section) -- a number read from
     that file, not measured in this run; (None, None) for configs that were not profiled."""
     stem = "nw2_hbm_traffic.json" if kernel == "nw_score_kernel" else "nw_hbm_traffic.json"
-    name, path = _profile_file("r03_" + stem, "r02_" + stem, "r01_" + stem)
+    name, path = _profile_file("r04_" + stem, "r03_" + stem, "r02_" + stem, "r01_" + stem)
     try:
         with open(path) as f:
             d = json.load(f)
@@ -69,11 +71,12 @@ def measured_traffic(batch, n, m, kernel):
 def measured_mfma_busy(kernel):
     """MFMA pipe utilisation of a recogniser kernel from the counter pass kept under profiles/
     (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD-cycles, 1920-line workload); (None, None) if absent."""
-    name, path = _profile_file("r03_ocr_pmc_mfma.json", "r02_ocr_pmc_mfma.json", "r01_ocr_pmc_mfma.json")
+    name, path = _profile_file("r04_ocr_pmc_mfma.json", "r03_ocr_pmc_mfma.json", "r02_ocr_pmc_mfma.json",
+                               "r01_ocr_pmc_mfma.json")
     try:
         with open(path) as f:
             for k, v in json.load(f)["kernels"].items():
-                if kernel in k:
+                if (kernel + "(") in k or k.endswith(kernel):
                     return v["mfma_pipe_utilisation"], "profiles/" + name
     except (OSError, KeyError, ValueError, TypeError):
         pass
@@ -113,9 +116,18 @@ def cpu_baseline(seconds=12.0):
         dt = time.perf_counter() - t0
         if dt > seconds or done >= 64:
             break
+    # SURVEY 8(d)'s second single-process point: ONE 2048 x 2048 problem (six float64 matrices of 2049^2: 200 MB)
+    t2, o2 = synth_pair(2048, 2048, 1234)
+    t1 = time.perf_counter()
+    a2 = nw_ref_py.perform_alignment(t2, o2)
+    dt2 = time.perf_counter() - t1
+    big = {"value": 2048 * 2048 / dt2, "unit": "cells/s", "cores": 1, "seconds": dt2,
+           "sample": "one problem of 2048x2048 (the shape of BASELINE configs[1]) through oracle/nw_ref_py.py",
+           "alignment_columns": len(a2[0])}
     out = {"value": done * n * m / dt, "unit": "cells/s", "cores": 1, "kind": "port",
            "sample": "%d problems of %dx%d (BASELINE configs[0] shape) through oracle/nw_ref_py.py, "
                      "%.1f s" % (done, n, m, dt),
+           "at_2048x2048": big,
            "c_restatement_cells_per_s": nw_oracle.fill_only_rate(*synth_pair_ids(2048, 2048, 1234)),
            "cpu_model": _cpu_model()}
     # the same port on every host core this process may use: one plain child interpreter per core
@@ -168,6 +180,8 @@ def _cpu_model():
 
 
 def ocr_cpu_baseline(model_seed, no, seconds=8.0):
+    """oracle/ocr_ref_f64.py on one host core, and on TWO processes -- the reference runs `ocropus-rpred -Q 2`
+    (alignToOCR.py:24, :142-143): two worker processes, one line each at a time."""
     from oracle import ocr_ref_f64 as R
     om = R.synthetic_model(model_seed, no=no)
     done, steps, t0 = 0, 0, time.perf_counter()
@@ -179,49 +193,27 @@ def ocr_cpu_baseline(model_seed, no, seconds=8.0):
         dt = time.perf_counter() - t0
         if dt > seconds:
             break
-    return {"value": done / dt, "unit": "lines/s", "cores": 1, "kind": "port",
-            "sample": "%d lines of width 1000 (T = 1032) through oracle/ocr_ref_f64.py, %.1f s" % (done, dt)}
-
-
-def bench_pipelined(tsc, args, first):
-    """The same steps with two batches in flight on two streams: the traceback of one batch runs
-    beside the fill of the next (phase 2 keeps one wave per problem and leaves issue slots free).
-    Reported next to the headline, which times each kernel alone; per-kernel durations are not
-    meaningful here, so only the step rate is."""
-    second, _ = make_nw_batch(tsc, args.batch, args.n, args.m, 77, two_phase=True)
-    pair = [first, second]
-    s_fill, s_tb = torch.cuda.Stream(), torch.cuda.Stream()
-    fill_done = [torch.cuda.Event(), torch.cuda.Event()]
-    tb_done = [torch.cuda.Event(), torch.cuda.Event()]
-
-    def run(nsteps):
-        for k in range(nsteps):
-            b = k % 2
-            with torch.cuda.stream(s_fill):
-                if k >= 2:
-                    s_fill.wait_event(tb_done[b])          # the workspace of batch b is free again
-                pair[b].run(fill=True, traceback=False)
-                fill_done[b].record(s_fill)
-            with torch.cuda.stream(s_tb):
-                s_tb.wait_event(fill_done[b])
-                pair[b].run(fill=False, traceback=True)
-                tb_done[b].record(s_tb)
-        s_fill.synchronize()
-        s_tb.synchronize()
-    torch.cuda.synchronize()
-    run(2)
+    out = {"value": done / dt, "unit": "lines/s", "cores": 1, "kind": "port",
+           "sample": "%d lines of width 1000 (T = 1032) through oracle/ocr_ref_f64.py, %.1f s" % (done, dt)}
+    import subprocess
+    per = max(2, done // 2)
+    code = ("import sys, os; sys.path.insert(0, %r); os.environ.setdefault('OMP_NUM_THREADS', '1'); "
+            "from oracle import ocr_ref_f64 as R; om = R.synthetic_model(%d, no=%d); s0 = int(sys.argv[1]); "
+            "[R.recognise(om, R.synthetic_line(s0 + k, width=1000)) for k in range(%d)]" % (REPO, model_seed, no, per))
     t0 = time.perf_counter()
-    run(args.steps)
-    dt = time.perf_counter() - t0
-    from oracle import nw_oracle
-    from tools.synth import synth_pair_ids
-    t, o = synth_pair_ids(args.n, args.m, 77)
-    ok = second.results()[0].tolist() == nw_oracle.align_ids(t, o, DEFAULT_SYS).tolist()
-    del second
-    torch.cuda.empty_cache()
-    return {"value": first.cells * args.steps / dt, "unit": "cells/s", "ms_per_step": dt / args.steps * 1e3,
-            "bit_exact_vs_oracle": ok,
-            "note": "two batches in flight, fill and traceback on separate streams"}
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(8100 + per * k)]) for k in range(2)]
+    ok = True
+    for pr in procs:
+        try:
+            ok = (pr.wait(timeout=max(1.0, 90.0 - (time.perf_counter() - t0))) == 0) and ok
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            ok = False
+    dt2 = time.perf_counter() - t0
+    out["two_processes"] = ({"value": 2 * per / dt2, "unit": "lines/s", "cores": 2,
+                             "sample": "2 processes x %d lines of width 1000 (the reference's -Q 2), %.1f s incl. "
+                                       "interpreter start" % (per, dt2)} if ok else {"error": "a worker failed or timed out"})
+    return out
 
 
 def bench_ocr(args, rank, precision=None, nlines=None):
@@ -259,12 +251,21 @@ def bench_ocr(args, rank, precision=None, nlines=None):
     out_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     dec_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev]))
     f32 = precision == "f32"
-    if f32:
+    if precision == "f64":
+        # float64 mode: hoisted input projection (a f64 GEMM) + the recurrence on v_mfma_f64_16x16x4_f64 (timed
+        # together as "lstm": one run() issues both per run of groups); algorithmic flops per timestep as in f32 mode
+        tf = tsteps * 238400.0 / (lstm_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": tf / F64_MFMA_PEAK_TF, "traffic": None,
+                "kernel": "lstm_seq_f64_kernel (+ lstm_xproj_f64_kernel)",
+                "flops": "algorithmic: 238400 per timestep, all of them float64 (no padding: 25 x 25 tiles are exactly 400 x 100; the x part pads 49 -> 52)",
+                "peak_is": "f64 matrix peak: v_mfma_f64_16x16x4_f64 at 64 cycles per SIMD (measured, profiles/r04_mfma_f64.txt)"}
+    elif f32:
         # exact f32 arithmetic of this recurrence is bounded by the f32-input MFMA rate; algorithmic
         # flops per timestep: 2 dirs x 4 gates x 100 units x 149 inputs x 2
         tf = tsteps * 238400.0 / (lstm_ms * 1e-3) / 1e12
-        busy, busy_src = (measured_mfma_busy("lstm_seq_kernel") if nlines == 1920 and st["group_size"] == 16
-                          else (None, None))
+        kern = "lstm_seq4_kernel" if st["group_size"] == 4 else "lstm_seq_kernel"
+        busy, busy_src = measured_mfma_busy(kern) if nlines == 1920 else (None, None)
         roof = {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tf / F32_MFMA_PEAK_TF, "traffic": None,
                 "kernel": "lstm_seq4_kernel" if st["group_size"] == 4 else "lstm_seq_kernel",
@@ -283,18 +284,20 @@ def bench_ocr(args, rank, precision=None, nlines=None):
                 "peak_is": "dense bf16 / fp16 MFMA (v_mfma_f32_16x16x32_bf16 / _f16), the instructions the kernel issues"}
     return {"lines_per_s": nlines / dt, "timesteps_per_s": tsteps / dt, "lines": nlines,
             "timesteps": tsteps, "classes": no, "precision": precision,
-            "dtype": "f32" if f32 else "split 16-bit operands (W: bf16 + fp16, a: 3 x bf16 + fp16), f32 accumulate",
+            "dtype": {"f32": "f32", "f64": "f64 recurrence (state, accumulation, gate functions), f32 output layer"}.get(
+                precision, "split 16-bit operands (W: bf16 + fp16, a: 3 x bf16 + fp16), f32 accumulate"),
             "ms": {"lstm": lstm_ms, "output_softmax": out_ms, "decode": dec_ms, "pass": 1e3 * dt,
                    "note": "lstm / output_softmax / decode: each kernel launched alone; pass: one run() of all three"},
-            "class_split": bool(ocr._split_state.get("ok")) and st["n"] >= ocr.CLASS_SPLIT_MIN_LINES and rec.mode == 1,
+            "class_split": bool(ocr._split_state["ok"].get(ocr._device_key(rec.device) + (rec.mode,))) and
+                           st["n"] >= ocr.CLASS_SPLIT_MIN_LINES and rec.mode == 1,
             "lines_per_workgroup": st["group_size"],
             "roofline": roof}
 
 
 def ocr_mode_agreement():
-    """Free-running agreement of both recogniser modes with oracle/ocr_ref_f64.py, as measured by
+    """Free-running agreement of the recogniser's modes (f32, split, f64) with oracle/ocr_ref_f64.py, as measured by
     tools/ocr_mode_agreement.py on the GPU box and kept under profiles/ (read, not measured here)."""
-    name, path = _profile_file("r03_ocr_mode_agreement.json")
+    name, path = _profile_file("r04_ocr_mode_agreement.json", "r03_ocr_mode_agreement.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -380,6 +383,38 @@ def nw_configs(tsc, torch):
     return rows
 
 
+def nw_grid_search(tsc, torch):
+    """SURVEY.md 8(d)'s secondary run / row N2: the reference's grid search (evaluate_text_alignment.py:134-198) is
+    2 187 page-sized alignments -- 3 pages x the 729 scoring systems of :181-188 -- one `perform_alignment` call each
+    (:163 via process, ~4 s per call on a CPU core).  Here: ONE launch with a scoring system per problem
+    (params_stride = 6).  Device time median of 10 after 3 warm-ups; a sample of problems spread over the grid
+    (every 27th, all three pages) checked bit-exact against the C oracle."""
+    from oracle import nw_oracle
+    from tools.nw_configs import grid_systems, time_batch
+    from tools.synth import synth_pair_ids
+    grid = grid_systems()
+    n, m = 800, 900
+    pages = [synth_pair_ids(n, m, 4400 + k) for k in range(3)]
+    params = np.array(grid * 3, dtype=np.int64)
+    nprob = len(params)
+    batch = tsc.NWBatch([pages[k // len(grid)][0] for k in range(nprob)],
+                        [pages[k // len(grid)][1] for k in range(nprob)], params)
+    total, fill, tb = time_batch(torch, batch)
+    res = batch.results()
+    sample = list(range(0, nprob, 27))
+    ok = all(res[k].tolist() == nw_oracle.align_ids(pages[k // len(grid)][0], pages[k // len(grid)][1],
+                                                     [int(v) for v in params[k]]).tolist() for k in sample)
+    out = {"problems": nprob, "n": n, "m": m, "scoring_systems": len(grid), "pages": 3,
+           "mode": "two-phase" if batch.two_phase else "one-pass", "launches": 1,
+           "ms": total, "fill_ms": fill, "traceback_ms": tb, "cells_per_s": batch.cells / (total * 1e-3),
+           "frac": batch.cells / (total * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "bit_exact": bool(ok), "problems_checked": len(sample),
+           "reference": "evaluate_text_alignment.py:181-198: one perform_alignment call per (page, system)"}
+    del batch
+    torch.cuda.empty_cache()
+    return out
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks as a fresh child (one process
     per GPU over RCCL) BEFORE this process has made any GPU call, and hand back its exit code."""
@@ -408,7 +443,8 @@ def main():
     ap.add_argument("--ocr-lines-large", type=int, default=5760,
                     help="second OCR measurement with more lines than CUs x 16 (0 = skip)")
     ap.add_argument("--no-pipelined", dest="pipelined", action="store_false",
-                    help="skip the extra two-stream measurement (N = 1 only)")
+                    help="accepted and ignored (the two-stream leg of rounds 2-3 is gone: fill and traceback are both "
+                         "bound by VALU issue, so running them side by side only ever lost, 14.5 against 14.3 ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ocr", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the SURVEY 8(d) NW shapes (N = 1 only)")
@@ -488,37 +524,37 @@ def main():
 
     # ---- BASELINE configs[4]: pages sharded over the ranks, one gather of syllable-box records ----
     sharded = None
-    if args.pages > 0 and not args.no_ocr:
+    if args.pages > 0:
         from tools import pages_bench
         job = pages_bench.setup_sharded(args.pages, rank, world, seed0=100)
-        sh_dt = None
-        for _ in range(3):          # shortest of three passes (each a barrier-to-barrier pass of every rank incl. the gather):
-            barrier()               # the host side of a pass varies by +-20 % from call to call on a shared box
+        sh_all = []
+        for _ in range(10):         # median of ten passes, each barrier to barrier over every rank incl. the gather
+            barrier()
             t1 = time.perf_counter()
             allrec = pages_bench.run_sharded(job)
             barrier()
-            dt1 = reduce_max(time.perf_counter() - t1)
-            sh_dt = dt1 if sh_dt is None else min(sh_dt, dt1)
+            sh_all.append(reduce_max(time.perf_counter() - t1))
+        sh_dt = float(np.median(sh_all))
         if rank == 0:
+            import hashlib
             heads = allrec[allrec[:, 1] == sharding.HEADER]
             boxes = int((allrec[:, 1] != sharding.HEADER).sum())
+            canon = allrec[np.lexsort(allrec.T[::-1])]          # rank order does not matter: sorted by (page, syllable, ...)
             sharded = {"pages": job["total_pages"], "pages_per_gpu": args.pages, "ranks": world,
                        "backend": (args.backend if dist is not None else "none (single process)"),
                        "seconds": sh_dt, "pages_per_s": job["total_pages"] / sh_dt,
                        "lines_per_s": job["total_pages"] * 30 / sh_dt,
                        "models": "half the pages 96 classes (Salzinnes-shaped), half 64 (St-Gall-shaped)",
                        "gathered_records": int(allrec.shape[0]), "syllable_boxes": boxes,
+                       "records_sha16": hashlib.sha256(np.ascontiguousarray(canon, dtype=np.int32).tobytes()).hexdigest()[:16],
                        "gather_capacity_records_per_rank": job["capacity"],
                        "gather_ok": bool(sorted(int(v) for v in heads[:, 0]) == list(range(job["total_pages"]))
                                          and int(heads[:, 4].sum()) == boxes),
-                       "timing": "shortest of 3 barrier-to-barrier passes (max over ranks each)",
+                       "timing": "median of 10 barrier-to-barrier passes (max over ranks each); shortest %.4f s, longest %.4f s"
+                                 % (min(sh_all), max(sh_all)),
                        "note": "sharding.process_shard: process_batch per model on this rank's pages + ONE "
                                "gather of [page, syllable, ulx, uly, lrx, lry] records to rank 0"}
         del job
-
-    pipelined = None
-    if world == 1 and args.pipelined and batch.two_phase:
-        pipelined = bench_pipelined(tsc, args, batch)
 
     ocr_res = None
     if not args.no_ocr:
@@ -529,6 +565,12 @@ def main():
             "lines_per_s": alt["lines_per_s"], "ms": alt["ms"], "roofline": alt["roofline"], "dtype": alt["dtype"],
             "note": "opt-in: LineRecognizer(model, precision=%r); agreement of both modes with the float64 "
                     "restatement under `agreement`" % other}
+        f64 = bench_ocr(args, rank, precision="f64")
+        ocr_res["f64_mode"] = {
+            "lines_per_s": f64["lines_per_s"], "ms": f64["ms"], "roofline": f64["roofline"], "dtype": f64["dtype"],
+            "note": "opt-in: LineRecognizer(model, precision='f64') -- the mode in which the north_star's 1e-3 logit "
+                    "tolerance holds FREE-RUNNING on every line of this (chaotic, random-weight) model: "
+                    "tests/test_ocr_gpu.py::test_spec_model_benchmark_widths_free_running_f64, and `agreement` below"}
         if args.ocr_lines_large > args.ocr_lines:
             # 240 workgroups on 256 CUs leave the longest line group in charge of the time; with
             # several workgroups per CU (longest first) the same kernels fill the chip
@@ -546,9 +588,10 @@ def main():
         from tools import pages_bench
         pages_res = pages_bench.run(args.pages, seed0=100)
 
-    configs = None
+    configs = grid = None
     if world == 1 and not args.no_configs and not args.one_pass:
         configs = nw_configs(tsc, torch)
+        grid = nw_grid_search(tsc, torch)
 
     if rank == 0:
         # bit-exact check of the timed output against the oracle (checker only): every distinct
@@ -580,8 +623,8 @@ def main():
             out["pages_sharded"] = sharded
         if configs is not None:
             out["configs"] = configs
-        if pipelined is not None:
-            out["pipelined_two_streams"] = pipelined
+        if grid is not None:
+            out["grid_search"] = grid
         if ocr_res is not None:
             out["ocr"] = ocr_res
         if pages_res is not None:

@@ -225,14 +225,15 @@ int ta_lstm_forward(const float* x, const int64_t* row_off, const int32_t* T,
  * The recurrence in FLOAT64 (csrc/ta_lstm_f64.hip) -- the arithmetic type of the reference's recogniser (ocropy
  * computes in float64 numpy; call site alignToOCR.py:142-147).  Two calls per run of groups:
  *
- * ta_lstm_xproj_f64: the input projection of every row at once, gx[dir][r][4 unit + gate] =
+ * ta_lstm_xproj_f64: the input projection of every row at once, gx[dir][r][16 (unit / 4) + 8 (gate / 2) + 2 (unit % 4) + gate % 2] =
  *   W_gate[unit][0 .. 48] . [1; x[r]] in float64 for the `rows` rows at x; gx = ta_lstm_f64_gx_bytes(rows) bytes
- *   ([2][rows][400] doubles).  wx = ta_lstm_f64_weight_doubles(1) doubles [dir 2][tile 25][k-step 13][lane 64] =
- *   W_gate(j % 4)[unit 4 tile + j / 4][kp 4 kstep + lane / 16], j = lane % 16, kp: 0 bias, 1..48 x, 49..51 zero.
+ *   ([2][rows][400] doubles; the buffer is private to the pair of calls, its layout is the recurrence kernel's).  wx = ta_lstm_f64_weight_doubles(1) doubles [dir 2][tile 25][k-step 13][lane 64] =
+ *   W_gate(2 (i / 8) + i % 2)[unit 4 tile + (i % 8) / 2][kp 4 kstep + lane / 16], i = lane % 16, kp: 0 bias, 1..48 x,
+ *   49..51 zero (B fragments of v_mfma_f64_16x16x4_f64: column i of a tile = its position in a row of gx).
  * ta_lstm_forward_f64: the recurrence over `ngroups` groups of 16 lines (group_lines = int32[ngroups][16], -1 =
  *   empty slot) whose rows lie in [gx_row0, gx_row0 + gx_rows) -- row_off / hout use ABSOLUTE rows, gx holds the
  *   projection of rows gx_row0 .. only.  wh = ta_lstm_f64_weight_doubles(0) doubles
- *   [dir 2][wave 4][slot 7][k-step 25][lane 64] = W_gate(j % 4)[unit 4 (tile0(wave) + slot) + j / 4][49 + 4 kstep + lane / 16],
+ *   [dir 2][wave 4][slot 7][k-step 25][lane 64] = W_gate(i / 4)[unit 4 (tile0(wave) + slot) + i % 4][49 + 4 kstep + lane / 16],
  *   tile0 = 0, 7, 13, 19 (slot 6 of waves 1..3 unused); peep = double[2][3][100]: WIP, WFP, WOP per direction.
  *   hout [rows][200] float (the float64 outputs rounded once).  h0 / c0 (double[lines][2][100]) / tstart as in
  *   ta_lstm_forward.

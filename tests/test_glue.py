@@ -90,7 +90,12 @@ def _py2_style_box_pickle(module, boxes):
     def s(b):
         return b"U" + bytes([len(b)]) + b
     def i(v):
-        return b"K" + bytes([v]) if 0 <= v < 256 else b"M" + int(v).to_bytes(2, "little")
+        v = int(v)
+        if 0 <= v < 256:
+            return b"K" + bytes([v])                                  # BININT1
+        if 0 <= v < 65536:
+            return b"M" + v.to_bytes(2, "little")                     # BININT2
+        return b"J" + v.to_bytes(4, "little", signed=True)            # BININT (a box whose lr lies left of its ul: negative width)
     out = b"\x80\x02]("
     for ch, ul, lr in boxes:
         out += b"c" + module.encode() + b"\nCharBox\n)\x81N}("

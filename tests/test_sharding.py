@@ -91,6 +91,8 @@ def _fake_process_batch(pages, transcripts, model, seq_align_params=None, indice
     for pg, tr in zip(pages, transcripts):
         if pg.get("bad"):                      # e.g. page.prepared_lines' 'empty or constant text-line image'
             raise ValueError("empty or constant text-line image")
+        if pg.get("fatal"):                    # e.g. _native.check after a kernel fault
+            raise RuntimeError("ta_nw2_batch failed (-3): hipErrorLaunchFailure")
         syls = [s for s in latsyl.syllabify_text(tr) if len(s) >= 1]
         boxes, idx = [], []
         for k, s in enumerate(syls):
@@ -108,7 +110,7 @@ _TEXTS = ["dominus dixit ad me", "filius meus es tu alleluia", "gloria patri et 
           "laudate eum omnes gentes", "quoniam confirmata est super nos misericordia eius", "et"]
 
 
-def _pages_worker(rank, world, port, q, bad_page=None, capacity_bug=False):
+def _pages_worker(rank, world, port, q, bad_page=None, capacity_bug=False, fatal_page=None):
     import warnings
     import torch.distributed as dist
     from text_alignment_amd import alignToOCR as atocr, sharding
@@ -118,8 +120,8 @@ def _pages_worker(rank, world, port, q, bad_page=None, capacity_bug=False):
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
     atocr.process_batch = _fake_process_batch
     sharding.estimate_cost = lambda pg, tr: float(len(tr))
-    pages = [{"seed": k, "empty": k == 3, "peaks": [100, 220 + k, 340, 470 + 3 * k], "bad": k == bad_page}
-             for k in range(len(_TEXTS))]
+    pages = [{"seed": k, "empty": k == 3, "peaks": [100, 220 + k, 340, 470 + 3 * k], "bad": k == bad_page,
+              "fatal": k == fatal_page} for k in range(len(_TEXTS))]
     if capacity_bug:                           # a capacity that one rank's records exceed
         sharding.record_capacity = lambda tr: 2
     warnings.simplefilter("ignore")
@@ -129,6 +131,8 @@ def _pages_worker(rank, world, port, q, bad_page=None, capacity_bug=False):
         out = sharding.process_pages(pages, _TEXTS, models, None)
     except ValueError as exc:                  # raised AFTER the collective: no rank is left waiting in it
         out = "ValueError: %s" % exc
+    except RuntimeError as exc:                # a failed native call: re-raised AFTER the collective
+        out = "RuntimeError: %s" % exc
     q.put((rank, out))
     if world > 1:
         dist.destroy_process_group()
@@ -191,6 +195,33 @@ def test_bad_page_on_one_rank_is_skipped_and_nobody_hangs():
             assert got[1] is None
 
 
+def test_a_failed_native_call_is_not_a_skipped_page():
+    """What is NOT a page to skip (the reference skips only on the OCR step's own failure,
+    alignToOCR.py:240-243): a RuntimeError out of a native call -- a kernel fault, a sticky HIP error -- on a
+    rank.  That rank must not report 'skipped pages' and return normally: it remembers the error, reports the
+    pages it did not finish as failed, still enters the one gather (nobody hangs) and re-raises afterwards.  The
+    other rank's pages arrive as usual."""
+    from text_alignment_amd import sharding
+    costs = [float(len(t)) for t in _TEXTS]
+    shards, _ = sharding.shard_plan(costs, _TEXTS, 2)
+    fatal = shards[1][0]                                   # a page of rank 1
+    good = _run_pages(1)[0]
+    got = _run_pages(2, fatal_page=fatal)
+    assert isinstance(got[1], str) and got[1].startswith("RuntimeError") and "hipErrorLaunchFailure" in got[1]
+    out = got[0]                                           # rank 0 finished: its own pages, and None for rank 1's unfinished ones
+    assert sorted(out) == list(range(len(_TEXTS)))
+    assert out[fatal] is None
+    assert all(out[k] == good[k] for k in shards[0])
+    assert all(out[k] is None or out[k] == good[k] for k in shards[1])
+    # alone (one process): the error reaches the caller
+    got = _run_pages(1, fatal_page=fatal)
+    assert isinstance(got[0], str) and got[0].startswith("RuntimeError")
+    # and a bad ARGUMENT to the library (a programming error) is not a page error either
+    from text_alignment_amd import _native
+    assert issubclass(_native.NativeArgumentError, ValueError)
+    assert not any(issubclass(_native.NativeArgumentError, e) and e is not ValueError for e in sharding._page_errors())
+
+
 def test_capacity_overflow_raises_after_the_collective_on_every_rank_involved():
     """Records beyond the agreed capacity (a capacity bug): the offending rank still enters the
     gather -- with a buffer that says how many records it had -- and raises afterwards; rank 0
@@ -217,3 +248,35 @@ def test_capacity_is_an_upper_bound_and_plan_is_deterministic():
     assert cap == max(sum(sharding.record_capacity(_TEXTS[k]) for k in sh) for sh in shards)
     with pytest.raises(ValueError):
         sharding.pack_records_device(np.zeros((5, 6), np.int32), 4, torch.device("cpu"))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """The multi-GPU path of bench.py rehearsed by a test, not by hand (the pool offers one GPU per box and the
+    driver's 8-GPU run is the only place the RCCL path runs): `python bench.py --gpus 2 --backend gloo ...` as a fresh
+    child -- it starts its own `torch.distributed.run` before touching the GPU; both ranks share device 0 -- times the
+    NW step per rank and runs BASELINE configs[4]'s leg, sharding.process_shard with its ONE gather.  Asserted: two
+    ranks, every page's header gathered, and the gathered records equal to a single process's over the same pages
+    (the loop being sharded: alignToOCR.py:407-438)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--batch", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-configs", "--no-ocr"]
+    lines = {}
+    for name, extra in (("two", ["--gpus", "2", "--backend", "gloo", "--pages", "4"]),
+                        ("one", ["--gpus", "1", "--pages", "8"])):
+        r = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + extra + common, cwd=repo,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        last = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        lines[name] = json.loads(last)
+    two, one = lines["two"], lines["one"]
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["bit_exact_vs_oracle"] and one["config"]["bit_exact_vs_oracle"]
+    assert two["value"] > 0 and two["config"]["cells_per_step"] == 2 * one["config"]["cells_per_step"]
+    ps2, ps1 = two["pages_sharded"], one["pages_sharded"]
+    assert ps2["ranks"] == 2 and ps2["backend"] == "gloo" and ps2["pages"] == 8 and ps1["pages"] == 8
+    assert ps2["gather_ok"] and ps1["gather_ok"]
+    assert ps2["syllable_boxes"] == ps1["syllable_boxes"] > 0
+    assert ps2["records_sha16"] == ps1["records_sha16"]

@@ -121,11 +121,16 @@ EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m"
            "ta_pp_angle_histograms_points"]
 
 
+class NativeArgumentError(ValueError):
+    """TA_EINVAL from the library: the CALLER passed a bad argument -- a programming error, not a property of
+    a page's data (sharding.process_shard tells the two apart)"""
+
+
 def check(rc, what):
     if rc != TA_OK:
         msg = lib.ta_last_error().decode("utf-8", "replace")
         if rc == TA_EINVAL:
-            raise ValueError("%s: %s" % (what, msg))
+            raise NativeArgumentError("%s: %s" % (what, msg))
         if rc == TA_ERANGE:
             raise OverflowError("%s: %s" % (what, msg))
         raise RuntimeError("%s failed (%d): %s" % (what, rc, msg))

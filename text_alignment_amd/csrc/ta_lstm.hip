@@ -1151,10 +1151,9 @@ extern "C" int ta_lstm_forward(const float* x, const int64_t* row_off, const int
 
 template <int NCT>
 static hipError_t launch_output(const OutArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    if (lds > 64 * 1024) {          // above the default dynamic-LDS limit: raise it once (thread-safe)
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_output_kernel<NCT>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (once != hipSuccess) return once;
+    if (lds > 64 * 1024) {          // above the default dynamic-LDS limit: raise it (once per device, ta_common.h)
+        const hipError_t e = allow_full_lds(&lstm_output_kernel<NCT>);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(lstm_output_kernel<NCT>, grid, dim3(kOWaves * 64), lds, st, a);
     return hipSuccess;
@@ -1191,9 +1190,8 @@ extern "C" int ta_lstm_output(const float* y, int64_t rows, const float* w2p, in
 
 template <int NCT>
 static hipError_t launch_output_split(const Out2Args& a, dim3 grid, size_t lds, hipStream_t st) {
-    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_output_split_kernel<NCT>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (once != hipSuccess) return once;
+    const hipError_t e = allow_full_lds(&lstm_output_split_kernel<NCT>);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(lstm_output_split_kernel<NCT>, grid, dim3(kO2Waves * 64), lds, st, a);
     return hipSuccess;
 }

@@ -9,7 +9,7 @@
 // One direction's float64 weights (4 gates x 100 units x 149 inputs = 477 KB) do not fit a CU, so the product is
 // split where the recurrence allows it:
 //
-//  Kx lstm_xproj_f64_kernel   Gx[dir][row][4 unit + gate] = W[:, :49] . [1; x_row] for EVERY row of the batch at
+//  Kx lstm_xproj_f64_kernel   Gx[dir][row][gx_index(unit, gate)] = W[:, :49] . [1; x_row] for EVERY row of the batch at
 //                             once (no dependence between timesteps): a weight-stationary f64 GEMM on
 //                             v_mfma_f64_16x16x4_f64, rows x 52 x 400 per direction.
 //  Kr lstm_seq_f64_kernel     one workgroup of FOUR waves (one per SIMD, 512 registers each) per (16 lines,
@@ -19,11 +19,12 @@
 //                             a step ahead) and take 25 k-steps of v_mfma_f64_16x16x4_f64; cell state and gate
 //                             functions in float64 (own exp: range reduction + degree-11 polynomial, 1e-15).
 //
-// Tiling of the 400 pre-activations of a step: 25 column tiles of 16 = (4 units) x (4 gates), gate fastest.  The
-// f64 MFMA returns D[i][j] in lane j + 16 (i mod 4), register i / 4 (tools/ubench/mfma_f64.hip): the four gates of
-// a unit sit in the four lanes of a quad, for the same four lines -- a 4 x 4 transpose inside the quad (DPP quad
-// permutes) gives every lane all four gates of ONE (line, unit) pair, whose cell update it computes.  No padding:
-// 25 tiles x 25 k-steps are exactly 400 x 100.  Waves take 7, 6, 6, 6 tiles.
+// Tiling of the 400 pre-activations of a step: 25 tiles of 16 = (4 units) x (4 gates).  The WEIGHTS are the A operand
+// (M = 16 tile rows, row i = 4 * gate + unit-in-tile), the 16 lines the B operand's columns.  The f64 MFMA returns
+// D[i][j] in lane j + 16 (i mod 4), register i / 4 (tools/ubench/mfma_f64.hip): lane (j, q) therefore holds, in its
+// four accumulator registers, the four GATES of (line j, unit 4 tile + q) -- the cell update needs no exchange between
+// lanes, and the four values are 32 contiguous bytes of Gx (two 16-byte loads / stores).  No padding: 25 tiles x 25
+// k-steps are exactly 400 x 100.  Waves take 7, 6, 6, 6 tiles.
 //
 // Measured (tools/ubench/mfma_f64.hip, profiles/r04_mfma_f64.txt): 64 cycles per MFMA per SIMD (= the 78.6 TF
 // float64 peak), the same for one dependent accumulator chain; a wave's v_fma_f64 beside another wave's f64 MFMAs
@@ -49,18 +50,25 @@ constexpr int kMaxNT = 7;           // tiles of wave 0; waves 1..3 take 6
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
+// Gx layout inside a row (400 doubles): per tile of 4 units 16 doubles = [gate pair 2][unit-in-tile 4][2]: a lane owns
+// the four gates of one (row, unit) and moves them with two 16-byte accesses; the four lanes of a row's tile make each
+// access a contiguous 64-byte piece.
+__host__ __device__ constexpr int gx_index(int unit, int gate) { return 16 * (unit / 4) + 8 * (gate / 2) + 2 * (unit % 4) + (gate % 2); }
 __host__ __device__ constexpr int tile0_of(int wave) { return wave == 0 ? 0 : 1 + 6 * wave; }   // 0, 7, 13, 19
 __host__ __device__ constexpr int ntiles_of(int wave) { return wave == 0 ? 7 : 6; }
 
 // ---------------------------------------------------------------------------------------------
-// float64 gate functions.  exp: x = n ln2 + r, |r| <= ln2 / 2; e^r by its Taylor polynomial of degree 11
-// (remainder r^12 / 12! < 7e-15 relative), scaled by 2^n with v_ldexp_f64.  Valid for |x| < 700.
+// float64 gate functions.  exp: x = n ln2 + r, |r| <= ln2 / 2; e^r by its Taylor polynomial of degree 10
+// (remainder < 3e-13 relative: four orders below what the chaotic spec model needs), scaled by 2^n with
+// v_ldexp_f64.  Valid for |x| < 700.
 __device__ __forceinline__ double exp_f64(double x) {
-    const double n = __builtin_rint(x * 1.4426950408889634074);
+    // n = rint(x log2 e) by the magic-number add: the integer lands in the low mantissa bits of t (|n| < 2^31 here)
+    const double kMagic = 6755399441055744.0;                             // 1.5 * 2^52
+    const double t = __builtin_fma(x, 1.4426950408889634074, kMagic);
+    const double n = t - kMagic;
     double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);          // ln2 split as in fdlibm: hi has 32 bits
     r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
-    double p = 1.0 / 39916800.0;
-    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    double p = 1.0 / 3628800.0;                                           // degree 10: remainder r^11 / 11! < 3e-13 relative
     p = __builtin_fma(p, r, 1.0 / 362880.0);
     p = __builtin_fma(p, r, 1.0 / 40320.0);
     p = __builtin_fma(p, r, 1.0 / 5040.0);
@@ -71,7 +79,7 @@ __device__ __forceinline__ double exp_f64(double x) {
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
-    return __builtin_ldexp(p, (int)n);
+    return __builtin_ldexp(p, (int)__builtin_bit_cast(long long, t));     // low dword of t = n (two's complement)
 }
 // 1 / d for d in [1, 1 + e^20]: the hardware reciprocal refined by two Newton steps (quadratic: whatever the
 // seed's accuracy above 2^-14, the result is within an ulp or two)
@@ -82,51 +90,45 @@ __device__ __forceinline__ double rcp_f64(double d) {
     e = __builtin_fma(-d, y, 1.0);
     return __builtin_fma(y, e, y);
 }
-// ocropy's sigmoid: 1 / (1 + exp(clip(-x, -20, 20)))   -- in float64 the clip is visible
-// (sigma(-25) = 2.06e-9 with it, 1.4e-11 without), so it is kept
-__device__ __forceinline__ double sigmoid_f64(double x) {
-    const double z = __builtin_fmin(__builtin_fmax(-x, -20.0), 20.0);
-    return rcp_f64(1.0 + exp_f64(z));
-}
-// tanh(x) = (1 - e) / (1 + e), e = exp(-2x); |x| clamped to 20 (tanh(20) = 1 - 8e-18 rounds to 1)
-__device__ __forceinline__ double tanh_f64(double x) {
-    const double z = __builtin_fmin(__builtin_fmax(x, -20.0), 20.0);
-    const double e = exp_f64(-2.0 * z);
-    return (1.0 - e) * rcp_f64(1.0 + e);
-}
+// ocropy's sigmoid is 1 / (1 + exp(clip(-x, -20, 20)))   -- in float64 the clip is visible
+// (sigma(-25) = 2.06e-9 with it, 1.4e-11 without), so it is kept; tanh(x) = (1 - e) / (1 + e) with e = exp(-2x), |x|
+// clamped to 20 (tanh(20) = 1 - 8e-18 rounds to 1).
 
 // One LSTM cell update (`forward_py`) from the four pre-activations of a (line, unit) pair.
 // past0: not the first step of the whole sequence (the peepholes on the old cell state and the output peephole are
 // skipped at t = 0).
 __device__ __forceinline__ double lstm_cell_f64(double gi, double gf, double go, double ci_pre, double& c, bool past0,
                                                 double wip, double wfp, double wop) {
-    const double ci = tanh_f64(ci_pre);
+    // every gate is a ratio with denominator 1 + e^z; the three of the cell-state update share ONE reciprocal
+    // (of the product of their denominators, at most (1 + e^20)^3 ~ 1e26), the two of the output another
     const double cp = past0 ? c : 0.0;
-    gi = sigmoid_f64(__builtin_fma(wip, cp, gi));
-    gf = sigmoid_f64(__builtin_fma(wfp, cp, gf));
-    const double cn = __builtin_fma(ci, gi, gf * cp);
-    go = sigmoid_f64(__builtin_fma(past0 ? wop : 0.0, cn, go));
+    const double ea = exp_f64(-2.0 * __builtin_fmin(__builtin_fmax(ci_pre, -20.0), 20.0));               // tanh(ci_pre) = (1 - ea) / (1 + ea)
+    const double eb = exp_f64(__builtin_fmin(__builtin_fmax(-__builtin_fma(wip, cp, gi), -20.0), 20.0)); // sigma = 1 / (1 + eb), ocropy's clip
+    const double ef = exp_f64(__builtin_fmin(__builtin_fmax(-__builtin_fma(wfp, cp, gf), -20.0), 20.0));
+    const double pa = (1.0 + ea) * (1.0 + eb), pf = 1.0 + ef;
+    const double r3 = rcp_f64(pa * pf);
+    const double cn = __builtin_fma((1.0 - ea) * pf, r3, (pa * r3) * cp);      // ci * gi + gf * c
+    const double ec = exp_f64(-2.0 * __builtin_fmin(__builtin_fmax(cn, -20.0), 20.0));
+    const double eo = exp_f64(__builtin_fmin(__builtin_fmax(-__builtin_fma(past0 ? wop : 0.0, cn, go), -20.0), 20.0));
     c = cn;
-    return tanh_f64(cn) * go;
-}
-
-template <int CTRL>
-__device__ __forceinline__ double quad_perm_f64(double v) {
-    const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_mov_dpp((int)b, CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+    return (1.0 - ec) * rcp_f64((1.0 + ec) * (1.0 + eo));                       // tanh(c) * go
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kx: Gx[dir][row][col] = sum_kp Wx[dir][col][kp] * [1, x_row, 0, 0, 0][kp]     (kp < 52, float64)
+// Kx: Gx[dir][row][4 unit + gate] = sum_kp W_gate[unit][kp] * [1, x_row, 0, 0, 0][kp]     (kp < 52, float64)
 struct XprojArgs {
     const float* x;        // [rows][48], the rows of this call
     int64_t rows;
-    const double* wx;      // [dir 2][tile 25][k-step 13][lane 64]: W_gate(j % 4)[unit 4 tile + j / 4][kp 4 kstep + lane / 16], j = lane % 16
-    double* gx;            // [dir 2][rows][400]
+    const double* wx;      // [dir 2][tile 25][k-step 13][lane 64]: B fragments, column j = lane % 16 of the tile = the (unit, gate) whose
+                           // gx_index is 16 tile + j: W_gate(2 (j / 8) + j % 2)[unit 4 tile + (j % 8) / 2][kp 4 kstep + lane / 16]
+    double* gx;            // [dir 2][rows][400], gx_index(unit, gate) inside a row
 };
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+// Here the ROWS are the A operand and the weights the B operand: D[i][j] = (row i, column j) sits in lane j + 16 (i % 4),
+// register i / 4, so one store instruction writes, for four rows, the 16 doubles of a tile row -- 128 contiguous bytes
+// each (with the weights as A, as in the recurrence, a lane would own 32 bytes of a row and every store instruction
+// would write half lines: measured 6.5 against 5.4 ms per 2.76 M rows).
 template <int NT>
 __device__ __forceinline__ void xproj_body(const XprojArgs& a, int dir, int wave, int lane) {
     const int tile0 = tile0_of(wave);
@@ -164,7 +166,6 @@ __device__ __forceinline__ void xproj_body(const XprojArgs& a, int dir, int wave
 #pragma unroll
             for (int s = 0; s < NT; ++s) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bx[s][kk], acc[s], 0, 0, 0);
         }
-        // D[i][j]: lane j + 16 (i % 4), register i / 4
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t row = tile * 16 + 4 * r + kq;
@@ -194,7 +195,7 @@ struct Seq64Args {
     const int64_t* row_off;    // per line: first (absolute) row
     const int32_t* T;          // per line: timesteps
     const int32_t* group_lines;// [ngroups][16] line ids, -1 = empty slot
-    const double* wh;          // [dir 2][wave 4][slot 7][k-step 25][lane 64]: W_gate(j % 4)[unit 4 (tile0(wave) + slot) + j / 4][49 + 4 kstep + lane / 16]
+    const double* wh;          // [dir 2][wave 4][slot 7][k-step 25][lane 64]: A fragments, W_gate(i / 4)[unit 4 (tile0(wave) + slot) + i % 4][49 + 4 kstep + lane / 16], i = lane % 16
     const double* peep;        // [dir 2][3: WIP, WFP, WOP][100]
     float* hout;               // [rows][200] (absolute rows)
     const double* h0;          // optional [lines][2][100]: outputs before the first step
@@ -207,97 +208,77 @@ __device__ __forceinline__ void seq_f64_body(const Seq64Args& a, double (&hs)[2]
                                              const int (&s_line)[kLines], const int (&s_T)[kLines],
                                              const long long (&s_row)[kLines], int dir, int wave, int lane, int Tmax) {
     const int tile0 = tile0_of(wave);
-    // recurrent weights of this wave's tiles: B fragments, constant over time (NT * 25 * 2 registers)
-    double Bw[NT][kKH];
+    // recurrent weights of this wave's tiles: A fragments, constant over time (NT * 25 * 2 registers)
+    double Aw[NT][kKH];
     {
         const double* wp = a.wh + ((size_t)(dir * kW + wave) * kMaxNT * kKH) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < NT; ++s)
 #pragma unroll
-            for (int kk = 0; kk < kKH; ++kk) Bw[s][kk] = wp[((size_t)s * kKH + kk) * 64];
+            for (int kk = 0; kk < kKH; ++kk) Aw[s][kk] = wp[((size_t)s * kKH + kk) * 64];
     }
+    // this lane's accumulators: the four gates of (line slot li, unit 4 (tile0 + s) + kq), s < NT
     const int li = lane & 15, kq = lane >> 4;
-    // accumulator rows of this lane (for the Gx loads): line slot 4 r + kq, r = 0 .. 3
-    const double* gxd = a.gx + (size_t)dir * a.gx_rows * kCols + 16 * tile0 + li;
-    int accT[4];
-    long long accrow[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        accT[r] = s_T[4 * r + kq];
-        accrow[r] = s_row[4 * r + kq] - a.gx_row0;
-    }
-    auto gx_row = [&](int r, int t) -> const double* {
-        const int Tl = accT[r];
-        int tt = t < Tl ? t : Tl - 1;
-        if (dir) tt = Tl - 1 - tt;                              // Reversed(LSTM): run on xs[::-1]
-        const long long row = Tl > 0 ? accrow[r] + tt : 0;     // an empty slot reads row 0 of the buffer (never used)
+    const int myT = s_T[li];
+    const long long myrow = s_row[li];
+    const int myid = s_line[li];
+    const int ubase = 4 * tile0 + kq;
+    const double* gxd = a.gx + (size_t)dir * a.gx_rows * kCols + 16 * tile0 + 2 * kq;
+    auto gx_row = [&](int t) -> const double* {
+        int tt = t < myT ? t : myT - 1;
+        if (dir) tt = myT - 1 - tt;                            // Reversed(LSTM): run on xs[::-1]
+        const long long row = myT > 0 ? myrow - a.gx_row0 + tt : 0;     // an empty slot reads row 0 of the buffer (never used)
         return gxd + row * kCols;
     };
-    // the (line, unit) pairs whose cell this lane updates after the quad transpose: line slot 4 (lane % 4) + kq,
-    // unit 4 (tile0 + s) + li / 4
-    const int cslot = 4 * (lane & 3) + kq;
-    const int cT = s_T[cslot];
-    const long long crow = s_row[cslot];
-    const int cid = s_line[cslot];
-    const int ubase = 4 * tile0 + (li >> 2);
     double c[NT];
     int ts = 0;
 #pragma unroll
     for (int s = 0; s < NT; ++s) c[s] = 0.0;
-    if (cid >= 0) {
+    if (myid >= 0) {
         if (a.c0) {
 #pragma unroll
-            for (int s = 0; s < NT; ++s) c[s] = a.c0[((size_t)cid * 2 + dir) * kNs + ubase + 4 * s];
+            for (int s = 0; s < NT; ++s) c[s] = a.c0[((size_t)myid * 2 + dir) * kNs + ubase + 4 * s];
         }
-        if (a.tstart) ts = a.tstart[(size_t)cid * 2 + dir];
+        if (a.tstart) ts = a.tstart[(size_t)myid * 2 + dir];
     }
     float* houtp = a.hout + dir * kNs + ubase;
 
+    auto load_acc = [&](f64x4 (&acc)[NT], int s, const double* g) {
+        const f64x2 lo = *reinterpret_cast<const f64x2*>(g + 16 * s);
+        const f64x2 hi = *reinterpret_cast<const f64x2*>(g + 16 * s + 8);
+        acc[s] = (f64x4){lo[0], lo[1], hi[0], hi[1]};
+    };
     f64x4 acc[NT];
+    {
+        const double* g = gx_row(0);
 #pragma unroll
-    for (int s = 0; s < NT; ++s)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[s][r] = gx_row(r, 0)[16 * s];
+        for (int s = 0; s < NT; ++s) load_acc(acc, s, g);
+    }
 
     for (int t = 0; t < Tmax; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
-        // h part: A[i][k] = h_{t-1}[unit k] of line i, lane i + 16 (k % 4)
-#pragma unroll
-        for (int kk = 0; kk < kKH; ++kk) {
-            const double av = hs[cur][4 * kk + kq][li];
-#pragma unroll
-            for (int s = 0; s < NT; ++s) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bw[s][kk], acc[s], 0, 0, 0);
-        }
         const bool past0 = (t > 0) | (ts > 0);
         const bool more = t + 1 < Tmax;
-        const double* gnext[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gnext[r] = gx_row(r, t + 1);
+        const double* gnext = gx_row(t + 1);
+        // Tile by tile: the 25 k-steps of a tile (one dependent accumulator chain: 64 cycles per MFMA either way),
+        // its cell update, then the loads of ITS accumulators for the next step.  With the k-steps outermost the
+        // first MFMA of a step needs every tile's x part at once, the last of which was requested moments before
+        // (a memory latency exposed per step); in this order a tile's loads have most of a step to arrive.  The B
+        // operand (h_{t-1}: B[k][j] = unit k of line j, lane j + 16 (k % 4)) is re-read from LDS per tile.
 #pragma unroll
         for (int s = 0; s < NT; ++s) {
-            // transpose inside the quad: acc[r] of quad lane q = (gate q, line slot 4 r + kq) -> g[q'] of quad
-            // lane q = (gate q', line slot 4 q + kq)
-            double g0 = acc[s][0], g1 = acc[s][1], g2 = acc[s][2], g3 = acc[s][3];
-            {
-                const bool odd = lane & 1, hi = lane & 2;
-                double v, w;
-                v = odd ? g0 : g1; w = quad_perm_f64<0xB1>(v); if (odd) g0 = w; else g1 = w;
-                v = odd ? g2 : g3; w = quad_perm_f64<0xB1>(v); if (odd) g2 = w; else g3 = w;
-                v = hi ? g0 : g2; w = quad_perm_f64<0x4E>(v); if (hi) g0 = w; else g2 = w;
-                v = hi ? g1 : g3; w = quad_perm_f64<0x4E>(v); if (hi) g1 = w; else g3 = w;
-            }
-            const int unit = ubase + 4 * s;
-            const double h = lstm_cell_f64(g0, g1, g2, g3, c[s], past0, peep_s[0][unit], peep_s[1][unit], peep_s[2][unit]);
-            hs[nxt][unit][cslot] = h;
-            if (t < cT) {
-                const int tt = dir ? cT - 1 - t : t;
-                houtp[(crow + tt) * (2 * kNs) + 4 * s] = (float)h;
-            }
-            // the tile's accumulators are free: next step's x part starts to arrive
-            if (more) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[s][r] = gnext[r][16 * s];
+            for (int kk = 0; kk < kKH; ++kk)
+                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aw[s][kk], hs[cur][4 * kk + kq][li], acc[s], 0, 0, 0);
+            const int unit = ubase + 4 * s;
+            const double h = lstm_cell_f64(acc[s][0], acc[s][1], acc[s][2], acc[s][3], c[s], past0,
+                                           peep_s[0][unit], peep_s[1][unit], peep_s[2][unit]);
+            hs[nxt][unit][li] = h;
+            if (t < myT) {
+                const int tt = dir ? myT - 1 - t : t;
+                houtp[(myrow + tt) * (2 * kNs) + 4 * s] = (float)h;
             }
+            if (more) load_acc(acc, s, gnext);
         }
         __syncthreads();
     }

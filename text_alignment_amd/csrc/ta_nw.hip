@@ -557,20 +557,6 @@ extern "C" int32_t ta_nw_max_m(void) {
     return 16000;
 }
 
-// dynamic-LDS limit raise, once per kernel instantiation and device
-template <typename K>
-static hipError_t allow_full_lds(K kernel) {
-    constexpr int kMaxDev = 64;
-    static std::atomic<int> done[kMaxDev];
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < kMaxDev && done[dev].load(std::memory_order_acquire)) return hipSuccess;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess && dev >= 0 && dev < kMaxDev) done[dev].store(1, std::memory_order_release);
-    return e;
-}
-
 template <int R, int W>
 static hipError_t launch_fill(const NwArgs& a, int max_m, hipStream_t st) {
     const size_t lds = NwLds(max_m).total;

@@ -871,22 +871,6 @@ extern "C" int64_t ta_nw2_workspace_bytes(int32_t n, int32_t m) {
     return (Ws2(n, m).total + 15) & ~(int64_t)15;
 }
 
-// raise of a kernel's dynamic LDS limit, once per instantiation AND device (the attribute belongs to the
-// device's copy of the code object; a process that drives several GPUs needs it on each)
-template <typename K>
-static hipError_t allow_full_lds(K kernel) {
-    constexpr int kMaxDev = 64;
-    static std::atomic<int> done[kMaxDev];
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < kMaxDev && done[dev].load(std::memory_order_acquire)) return hipSuccess;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess && dev >= 0 && dev < kMaxDev) done[dev].store(1, std::memory_order_release);
-    return e;
-}
-
 template <int W, int MODE, bool SAMEGO, typename OC>
 static hipError_t launch_score_k(const NwArgs& a, size_t lds, hipStream_t st) {
     hipError_t e = allow_full_lds(&nw_score_kernel<W, MODE, SAMEGO, OC>);

@@ -178,31 +178,33 @@ def _pack_lstm4(model):
 
 
 def _pack_lstm_f64(model):
-    """weights of the float64 recurrence (csrc/ta_lstm_f64.hip).  The 400 pre-activations of a step are tiled as
-    25 column tiles of 16 = (4 units) x (4 gates), gate fastest; waves take tiles 0..6, 7..12, 13..18, 19..24.
-    wh [dir 2][wave 4][slot 7][k-step 25][lane 64] = W_gate(j % 4)[unit 4 (tile0(wave) + slot) + j // 4][49 + 4 kstep + lane // 16]
-    wx [dir 2][tile 25][k-step 13][lane 64]        = W_gate(j % 4)[unit 4 tile + j // 4][kp = 4 kstep + lane // 16]  (kp <= 48)
-    with j = lane % 16; peep [dir 2][WIP, WFP, WOP][100]."""
+    """weights of the float64 recurrence (csrc/ta_lstm_f64.hip): A fragments of v_mfma_f64_16x16x4_f64.  The 400
+    pre-activations of a step are tiled as 25 tiles of 16 rows = (4 gates) x (4 units), row i = 4 gate + unit-in-tile;
+    waves take tiles 0..6, 7..12, 13..18, 19..24.
+    wh [dir 2][wave 4][slot 7][k-step 25][lane 64] = W_gate(i // 4)[unit 4 (tile0(wave) + slot) + i % 4][49 + 4 kstep + lane // 16]
+    wx [dir 2][tile 25][k-step 13][lane 64]        = W_gate(2 (i // 8) + i % 2)[unit 4 tile + (i % 8) // 2][kp = 4 kstep + lane // 16]
+                                                     (kp <= 48; B fragments, column i of a tile = position i of the tile in a row of Gx)
+    with i = lane % 16; peep [dir 2][WIP, WFP, WOP][100]."""
     wh = np.zeros((2, 4, 7, 25, 64), dtype=np.float64)
     wx = np.zeros((2, 25, 13, 64), dtype=np.float64)
     peep = np.zeros((2, 3, NS), dtype=np.float64)
     lane = np.arange(64)
-    j, kq = lane % 16, lane // 16
+    i, kq = lane % 16, lane // 16
     for d, w in enumerate((model.fwd, model.rev)):
         Wg = np.stack([np.asarray(w[name], dtype=np.float64) for name in ("WGI", "WGF", "WGO", "WCI")])   # [gate][unit][149]
         Wx = np.zeros((4, NS, 52), dtype=np.float64)
         Wx[:, :, :1 + NI] = Wg[:, :, :1 + NI]
         Wh = Wg[:, :, 1 + NI:]                                                                                  # [gate][unit][100]
-        for tile in range(25):
-            units = 4 * tile + j // 4
+        for tile in range(25):                      # B fragments: column j = lane % 16 is the (unit, gate) at in-row index 16 tile + j
+            units, gates = 4 * tile + (i % 8) // 2, 2 * (i // 8) + i % 2
             for kk in range(13):
-                wx[d, tile, kk] = Wx[j % 4, units, 4 * kk + kq]
+                wx[d, tile, kk] = Wx[gates, units, 4 * kk + kq]
         for wv in range(4):
             tile0 = 0 if wv == 0 else 1 + 6 * wv
             for s in range(7 if wv == 0 else 6):
-                units = 4 * (tile0 + s) + j // 4
+                units = 4 * (tile0 + s) + i % 4
                 for kk in range(25):
-                    wh[d, wv, s, kk] = Wh[j % 4, units, 4 * kk + kq]
+                    wh[d, wv, s, kk] = Wh[i // 4, units, 4 * kk + kq]
         for q, name in enumerate(("WIP", "WFP", "WOP")):
             peep[d, q] = np.asarray(w[name], dtype=np.float64)
     lib = _native.lib
@@ -228,7 +230,14 @@ FORCE_CLASS_SPLIT = (os.environ["TA_OCR_CLASS_SPLIT"] == "1") if os.environ.get(
 CLASS_SPLIT_MIN_LINES = 384     # below this (a few pages) the recurrence's tail has nothing worth hiding
 GROUP4_MAX_LINES = 2048         # exact-f32 mode: batches up to this size run in groups of 4 lines (see prepare)
 F64_GX_MAX_ROWS = 3200000       # float64 mode: rows whose hoisted input projection (6 400 B per row) is held at once: 20 GB
-_split_state = {"streams": {}, "ok": None}
+# class-split state: the side streams per device, and the verdict of the one-off timing check per (device, mode)
+# (a recogniser on another GPU or in another mode is timed for itself); guarded by a lock -- page threads share it
+_split_state = {"streams": {}, "ok": {}, "times_ms": {}}
+_split_lock = __import__("threading").Lock()
+
+
+def _device_key(device):
+    return (device.type, device.index if device.index is not None else torch.cuda.current_device())
 
 
 def _class_streams(device):
@@ -237,10 +246,11 @@ def _class_streams(device):
     after the other (20 ms per 1 920 lines instead of 10.7); torch's high-priority pool is a queue set of its
     own, whose first three streams are neighbours -- measured independent of whatever normal-priority streams
     the process has made (tools/ocr_overlap_probe.py)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    if key not in _split_state["streams"]:
-        _split_state["streams"][key] = [torch.cuda.Stream(device=device, priority=-1) for _ in range(3)]
-    return _split_state["streams"][key]
+    key = _device_key(device)
+    with _split_lock:
+        if key not in _split_state["streams"]:
+            _split_state["streams"][key] = [torch.cuda.Stream(device=device, priority=-1) for _ in range(3)]
+        return _split_state["streams"][key]
 
 
 def _class_split_wanted(rec, st):
@@ -256,7 +266,10 @@ def _class_split_wanted(rec, st):
         # to hide anything under; above that the output layer is a small share of the pass and the split
         # measured no gain (5 760 lines: 25.6 ms one launch each, 25.9 per class)
         return False
-    if _split_state["ok"] is None:
+    key = _device_key(rec.device) + (rec.mode,)
+    with _split_lock:
+        verdict = _split_state["ok"].get(key)
+    if verdict is None:
         times = {}
         for split in (True, False, True, False):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -265,9 +278,11 @@ def _class_split_wanted(rec, st):
             e1.record()
             e1.synchronize()
             times[split] = min(times.get(split, 1e30), e0.elapsed_time(e1))
-        _split_state["ok"] = times[True] <= 1.02 * times[False]
-        _split_state["times_ms"] = times
-    return _split_state["ok"]
+        verdict = times[True] <= 1.02 * times[False]
+        with _split_lock:
+            _split_state["ok"][key] = verdict
+            _split_state["times_ms"][key] = times
+    return verdict
 
 
 def _is_raw_strip(ln):
@@ -483,6 +498,8 @@ class LineRecognizer(object):
                     cont[2].data_ptr() if cont else None, stream_), "ta_lstm_forward_f64")
                 a = b
 
+        # (h0 / c0 / tstart of a continuation are indexed by LINE id, not by position in the launch: a launch over
+        # groups g0 .. g1 passes the whole arrays, un-offset, whichever run of groups it covers)
         def forward(g0, g1, stream_):
             if self.mode == 3:
                 return forward_f64(g0, g1, stream_)

@@ -202,6 +202,15 @@ def shard_plan(costs, transcripts, world):
     return shards, capacity
 
 
+def _page_errors():
+    """What a page's DATA can raise in alignToOCR.process_batch: a text line too long for the recogniser
+    (ocr.RecognitionError, the reference's 'OCRopus failed'), an empty / constant / mistyped strip (ValueError,
+    TypeError: page.raw_strip_pixels, lineest_gpu), a transcript / OCR length mismatch (the reference's assert,
+    alignToOCR.py:291) and a syllable the search cannot place (AttributeError, alignToOCR.py:307)."""
+    from . import ocr
+    return (ocr.RecognitionError, ValueError, TypeError, AssertionError, AttributeError)
+
+
 def process_shard(my_pages, my_transcripts, my_ids, my_models, capacity, seq_align_params=None,
                   group=None, dst=0, device=None):
     """This rank's pages (global indices `my_ids`) through alignToOCR.process_batch, one batch per
@@ -234,26 +243,51 @@ def process_shard(my_pages, my_transcripts, my_ids, my_models, capacity, seq_ali
         return out
 
     # Whatever happens on this rank, it must reach the collective: the other ranks are (or will be)
-    # waiting in it.  A batch that fails is retried page by page, and a page that still fails is
-    # reported by a status record instead of boxes -- one bad page (a blank strip, an over-long line,
-    # a syllable the search cannot place) costs that page, as in the reference's loop
+    # waiting in it.  A batch that fails ON ITS DATA is retried page by page, and a page that still
+    # fails is reported by a status record instead of boxes -- one bad page (a blank strip, an over-long
+    # line, a syllable the search cannot place) costs that page, as in the reference's loop
     # (alignToOCR.py:240-243: 'OCRopus failed! Skipping current file.'), not the rank's share.
+    # Anything else -- a failed native call (kernel fault, sticky HIP error, out of memory), a torch
+    # RuntimeError, a programming error -- is NOT a page to skip: the rank remembers it, reports its
+    # remaining pages as failed so that rank `dst` sees every page, still enters the gather, and
+    # re-raises afterwards, so the process ends non-zero instead of returning 'skipped pages'.
+    page_errors = _page_errors()
+    fatal = None
+
+    def is_page_error(exc):
+        from . import _native
+        return isinstance(exc, page_errors) and not isinstance(exc, _native.NativeArgumentError)
     for mdl, ks in by_model.values():
+        if fatal is not None:
+            recs += [page_failed(my_ids[k]) for k in ks]
+            continue
         try:
             recs += run(mdl, ks)
-        except Exception:                         # noqa: BLE001 -- see above
+        except Exception as exc:                  # noqa: BLE001 -- sorted into page / fatal just below
+            if not is_page_error(exc):
+                fatal = exc
+                recs += [page_failed(my_ids[k]) for k in ks]
+                continue
             for k in ks:
+                if fatal is not None:
+                    recs.append(page_failed(my_ids[k]))
+                    continue
                 try:
                     recs += run(mdl, [k])
-                except Exception as exc:          # noqa: BLE001
-                    warnings.warn("page %d failed on this rank and is skipped: %r" % (my_ids[k], exc))
+                except Exception as exc1:         # noqa: BLE001
+                    if is_page_error(exc1):
+                        warnings.warn("page %d failed on this rank and is skipped: %r" % (my_ids[k], exc1))
+                    else:
+                        fatal = exc1
                     recs.append(page_failed(my_ids[k]))
     local = np.concatenate(recs, axis=0) if recs else np.zeros((0, RECORD_FIELDS), np.int32)
     if device is None:
         nccl = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
         device = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
     work, out = gather_to_root(pack_records_device(local, capacity, device, strict=False), group=group, dst=dst)
-    if local.shape[0] > capacity:                 # after the collective: nobody is left waiting
+    if fatal is not None:                         # after the collective: nobody is left waiting
+        raise fatal
+    if local.shape[0] > capacity:
         raise ValueError("more records (%d) than the agreed capacity (%d)" % (local.shape[0], capacity))
     return None if out is None else unpack_gathered(out)
 

@@ -13,7 +13,7 @@ if [ "$1" = build ]; then
   for a in ${ABLS:-0 1 2 4 8 16 31}; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DTA_P1_ABLATE=${P1:-$a} -DTA_P2_ABLATE=${P2:-0} -c $CS/ta_nw2.hip -o $OUT/ta_nw2_$a.o
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $OUT/libta_abl$a.so $CS/ta_common.o $CS/ta_nw.o $OUT/ta_nw2_$a.o \
-        $CS/ta_nw_general.o $CS/ta_lstm.o $CS/ta_lineest.o $CS/ta_preproc.o
+        $CS/ta_nw_general.o $CS/ta_lstm.o $CS/ta_lstm_f64.o $CS/ta_lineest.o $CS/ta_preproc.o
     rm $OUT/ta_nw2_$a.o
   done
 else

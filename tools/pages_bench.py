@@ -120,20 +120,21 @@ def run(npages, seed0=100):
     from text_alignment_amd import alignToOCR as atocr
     rec = make_recognizer()
     pages, trs = zip(*[make_page(seed0 + k) for k in range(npages)])
-    def best_of(n, pages_, trs_):
-        """shortest of n passes (the host side of a pass -- numpy, uploads from pageable memory -- varies by
-        +-20 % from call to call on a shared box; the device work does not)"""
-        best, out = 1e30, None
+    def median_of(n, pages_, trs_):
+        """median of n passes (median of >= 10), each a whole process_batch call incl. the final
+        synchronize; the host side of a pass -- numpy, uploads from pageable memory -- varies by +-20 % from call to
+        call on a shared box, the device work does not"""
+        ts, out = [], None
         for _ in range(n):
             t0 = time.perf_counter()
             out = atocr.process_batch(pages_, trs_, rec, PARAMS)
             torch.cuda.synchronize()
-            best = min(best, time.perf_counter() - t0)
-        return best, out
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), out
     for _ in range(3):                       # warm-up at full size (staging buffers, streams, allocator)
         atocr.process_batch(list(pages), list(trs), rec, PARAMS)
     torch.cuda.synchronize()
-    dt, res = best_of(3, list(pages), list(trs))
+    dt, res = median_of(10, list(pages), list(trs))
     # BASELINE configs[2]: one page end to end (30 strips + one NW problem), latency of a lone call
     import gc
     gc.collect()                               # a generation-2 collection in mid-call costs ~20 ms
@@ -148,14 +149,14 @@ def run(npages, seed0=100):
     for _ in range(2):
         atocr.process_batch(list(rpages), list(rtrs), rec, PARAMS)
     torch.cuda.synchronize()
-    raw_dt, _ = best_of(3, list(rpages), list(rtrs))
+    raw_dt, _ = median_of(10, list(rpages), list(rtrs))
     # and from whole page images: preprocessing and line finding on the device as well
     nimg = npages
     ipages = [RawPage(make_page_image(seed0 + 9000 + k)) for k in range(nimg)]
     itrs = list(trs[:nimg])
     atocr.process_batch(ipages, itrs, rec, PARAMS)         # warm: the page planes come out of torch's caching allocator
     torch.cuda.synchronize()
-    img_dt, _ = best_of(3, ipages, itrs)
+    img_dt, _ = median_of(10, ipages, itrs)
     return {"pages": npages, "seconds": dt, "pages_per_s": npages / dt, "lines_per_s": npages * 30 / dt,
             "single_page_ms": 1e3 * sorted(lat)[2],
             "page_images": {"pages": nimg, "pages_per_s": nimg / img_dt, "seconds": img_dt,
@@ -163,7 +164,7 @@ def run(npages, seed0=100):
             "raw_strips": {"pages_per_s": npages / raw_dt, "seconds": raw_dt,
                            "note": "strips as 60-row uint8 images, normalised by csrc/ta_lineest.hip"},
             "syllable_boxes": sum(len(r[0]) for r in res),
-            "timing": "shortest of 3 passes after warm-up, each a whole process_batch call incl. the final synchronize",
+            "timing": "median of 10 passes after warm-up, each a whole process_batch call incl. the final synchronize",
             "note": "process_batch end to end: host upload + K3/K4/K5 + NW + host glue (numpy arrays, page_batch.py)"}
 
 
