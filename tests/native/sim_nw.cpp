@@ -213,7 +213,14 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
     // 64: nw_trace2_kernel's kWinLanes): a walk that needs a lane above l_lo stops, and the SAME chunk is
     // re-filled up to the group the walk stands in with the window at its lane.  Bytes outside the window
     // stay 0xEE here, so a walk that read one would fail with -7.
-    (void)GSPAN;
+    // GSPAN >= 1000: the data flow of nw_trace2w_kernel (several waves per problem, each re-filling the chunk it
+    // expects into a buffer of its own): whole chunks are kept (WL = 64; the entry lane of a chunk re-filled ahead of
+    // the walk is not known), a chunk entered through its halo is re-filled to the first group of the chunk just left
+    // with two steps of it -- what the one-wave flow does as well, so an expected chunk that turns out right IS the
+    // chunk the walk needs -- and a position in a chunk's first two steps goes to the chunk before at once (tb_job_at)
+    // instead of through a walk of zero steps.
+    const bool skip_halo = GSPAN >= 1000;
+    if (skip_halo) GSPAN -= 1000;
     const int xadj6 = xadj * 64, yadj6 = yadj * 64;
     std::vector<uint8_t> rev;
     int x = n, y = m, st = 0;
@@ -232,6 +239,7 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
         int l = ((x - 1) % L::SR) / R, r = (x - 1) % R, k = (y - 1) + l;
         int ck = (k / SPG) / KCG;
         int g_top = k / SPG;
+        if (skip_halo && ck > 0 && k < ck * KCG * SPG + 2) ck -= 1;      // tb_job_at
         bool in_strip = true;
         while (in_strip) {
             if (++guard > 8 * (n + m) + 64) return -9;
@@ -351,8 +359,10 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
             if (x <= 0 || y <= 0 || l < 0) in_strip = false;
             else if (k >= kvalid) {
                 if (steps == 0) return -12;                   // no progress: the entry lane is always in its window
+                if (skip_halo) return -13;                    // whole chunks are kept: the walk cannot run off a window
                 g_top = k / SPG;                              // ran off the window's top lane: same chunk, window at l
             } else {
+                if (skip_halo && steps == 0) return -14;     // tb_job_at never starts a walk in a chunk's halo
                 g_top = g0;
                 ck -= 1;
                 if (ck < 0) return -5;

@@ -87,13 +87,16 @@ def test_sim_matches_oracle_synth(sim, R):
         assert got.tolist() == want.tolist(), (R, n, m, seed)
 
 
-@pytest.mark.parametrize("kcg,gspan", [(1, 1), (2, 3), (4, 8), (12, 12), (16, 16), (16, 32), (32, 96)])
+@pytest.mark.parametrize("kcg,gspan", [(1, 1), (2, 3), (4, 8), (12, 12), (16, 16), (16, 32), (32, 96),
+                                       (1, 1064), (3, 1064), (16, 1064)])
 def test_two_phase_sim_matches_oracle(sim, kcg, gspan):
     """Checkpointed score-only fill + chunked tagged re-fill (the two-phase aligner's data flow): tiny
     checkpoint periods force many restarts and halo steps; `gspan` below 64 is the number of lanes of a
     chunk whose pointer bytes are kept (nw_trace2_kernel keeps 32 at a checkpoint period of 16): windows
     of 1 .. 16 lanes make the walk run off the window's top lane all the time, and the chunk is then
-    re-filled around the new position."""
+    re-filled around the new position.  gspan = 1064: the flow of the several-waves-per-problem kernel
+    (nw_trace2w_kernel): whole chunks kept, every chunk after a strip's first entered through its halo in a buffer
+    re-filled for exactly that, positions in a chunk's first two steps sent to the chunk before at once."""
     rng = np.random.default_rng(500 + kcg)
     for k in range(60):
         asz = [2, 4, 27][k % 3]

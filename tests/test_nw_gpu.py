@@ -482,6 +482,52 @@ def test_two_phase_walk_runs_off_the_lane_window(tsc):
         assert (want == 1).sum() >= len(t_list[k]) - len(o_list[k])
 
 
+@pytest.mark.parametrize("tb_waves", [1, 2, 4])
+def test_two_phase_traceback_waves_per_problem(tsc, tb_waves):
+    """Phase 2's launch shapes: one wave per problem (large batches) and two / four waves that deal the chunks of
+    the path among themselves and re-fill the chunk each EXPECTS ahead of the walk (nw_trace2w_kernel; the library
+    picks by batch size, TA_NW_TBWAVES forces).  Same alignments, bit for bit, on everything that stresses the
+    speculation: walks that start in a strip's first row (probe) and leave strips in every state (pending states),
+    long gap runs (the expected chunk is wrong many times in a row: the walk leaves the strip early, or stays in a
+    chunk's lane range for hundreds of columns), table edges, all-tie tables, ragged sizes from 0, two runs of the
+    same batch (nothing left over in the workspace or LDS)."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(4242)
+    t_list, o_list, prm = [], [], []
+    for k, (n, m) in enumerate([(257, 300), (513, 1), (257, 1), (513, 2), (769, 640), (257, 64), (512, 300), (258, 257),
+                                (513, 513), (257, 5), (1025, 70), (1281, 1300), (2049, 2049), (256, 256), (1024, 3),
+                                (0, 0), (0, 9), (9, 0), (1, 1), (63, 65), (64, 64), (300, 4500), (2100, 600)]):
+        for sc in (SYSTEMS[0], SYSTEMS[k % len(SYSTEMS)], SYSTEMS[(3 * k + 1) % len(SYSTEMS)]):
+            t, o = _random_problem(rng, n, m, [2, 3, 27][k % 3], k % 2 == 1)
+            t_list.append(t); o_list.append(o); prm.append(sc)
+    base = rng.integers(0, 27, size=1500).astype(np.int32)
+    ins = rng.integers(0, 27, size=3000).astype(np.int32)
+    for t, o in [(rng.integers(0, 10, size=2500).astype(np.int32), rng.integers(20, 30, size=2700).astype(np.int32)),
+                 (base, np.concatenate([base[:700], ins, base[700:]])), (np.concatenate([base[:700], ins, base[700:]]), base),
+                 (np.zeros(3000, np.int32), np.zeros(2600, np.int32)), (base, base[::-1].copy())]:
+        for sc in (SYSTEMS[0], SYSTEMS[6], SYSTEMS[9], [3, -2, -1, -8, 0, -3]):
+            t_list.append(t); o_list.append(o); prm.append(sc)
+    for runlen, at, system in [(130, 250, SYSTEMS[0]), (517, 700, [8, -4, -7, -7, -1, -1]), (900, 130, [8, -4, -7, -7, 0, 0]),
+                               (256, 1024, SYSTEMS[0]), (640, 896, [3, -3, 0, 0, 0, 0])]:
+        junk = (27 + rng.integers(0, 4, size=runlen)).astype(np.int32)
+        o = base.copy()
+        o[rng.random(o.size) < 0.05] = 26
+        t_list.append(np.concatenate([base[:at], junk, base[at:]])); o_list.append(o); prm.append(system)
+        t_list.append(o); o_list.append(np.concatenate([base[:at], junk, base[at:]])); prm.append(system)
+    for k in range(300):
+        n, m = int(rng.integers(0, 900)), int(rng.integers(0, 900))
+        t, o = _random_problem(rng, n, m, [2, 4, 27][k % 3], k % 2 == 0)
+        t_list.append(t); o_list.append(o); prm.append(SYSTEMS[int(rng.integers(0, len(SYSTEMS)))])
+    batch = tsc.NWBatch(t_list, o_list, prm, two_phase=True)
+    batch.tb_waves = tb_waves
+    for _ in range(2):
+        batch.ops.fill_(7)
+        batch.run()
+    bad = [k for k, got in enumerate(batch.results())
+           if got.tolist() != nw_oracle.align_ids(t_list[k], o_list[k], prm[k]).tolist()]
+    assert not bad, (tb_waves, bad[:10], [(len(t_list[k]), len(o_list[k]), prm[k]) for k in bad[:5]])
+
+
 def test_adversarial_paths(tsc, two_phase):
     """Paths that stress the windowed traceback and the tie rules: disjoint alphabets (the path
     hugs the table edges), a 3000-token insertion in the middle (one horizontal / vertical run

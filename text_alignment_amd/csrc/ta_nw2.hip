@@ -539,7 +539,7 @@ static_assert(kWinLanes >= 8 && kWinLanes <= 64, "window lanes");
 #define TA_P2_ABLATE 0      // timing experiments only: 2 re-fill one group only, 4 no walk
 #endif
 
-template <bool CARRIED, bool SAMEGO>
+template <bool CARRIED, bool SAMEGO, int WL = kWinLanes>
 __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], int (&V)[4], int (&H)[4], int& dsave,
                                              const int (&tc)[4], const int2* hvt, const uint16_t* ow,
                                              uint4* win, int2* hvb, int g0, int g_top, int m, int lane,
@@ -561,7 +561,7 @@ __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], in
         if constexpr (CARRIED) return cell_carried_tagged_hw<SAMEGO>(kr, d_ul, x_u, y_l, t, o, d, x, y);
         else return cell_hw(kr, d_ul, x_u, y_l, t, o, d, x, y);
     };
-    const bool in_win = (unsigned)(lane - l_lo) < (unsigned)kWinLanes;
+    const bool in_win = (unsigned)(lane - l_lo) < (unsigned)WL;
     load_group(g0);
     // unpredicated groups: from the one in which the last lane has started on (a lane past its last column
     // goes on over pad codes; what it computes reaches only lanes that are past theirs, pointer bytes
@@ -635,7 +635,7 @@ __device__ __forceinline__ void refill_chunk(const CellRegs& kr, int (&D)[4], in
         } else {
             edge_group(g, oc, hd, acc);
         }
-        if (kWinLanes == 64 || in_win) win[(g - g0) * kWinLanes + (lane - l_lo)] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+        if (WL == 64 || in_win) win[(g - g0) * WL + (lane - l_lo)] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
     }
 }
 
@@ -859,6 +859,265 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// phase 2 for SMALL and MEDIUM batches: NWV waves per problem, speculating along the path.
+//
+// With one wave per problem (above) a problem's traceback is a chain of ~6 chunks per strip, each
+// set-up -> re-fill (70 %) -> walk, and at a thousand problems that lone wave per SIMD IS the launch's
+// time (1024 x 2048^2: 0.70 ms, 64 problems: 0.63 ms -- latency, not throughput).  But which chunk
+// comes next is almost always known before the walk gets there: the chunk BEFORE the one it is in,
+// same strip, entered through the two halo steps.  So the chunks along the path are dealt to the
+// waves of a workgroup round-robin -- iteration i (the i-th chunk of the path) belongs to wave
+// i mod NWV.  A wave re-fills the chunk it EXPECTS its iteration to be (the newest job it knows, moved
+// back by the iterations in between) into its own LDS window while the waves before it are still
+// busy, then waits for the token of iteration i - 1 (position, state, alignment length so far and
+// the job of iteration i as the walk really left it), re-fills again only if the expectation was
+// wrong (the walk left the strip: once per strip), walks, and passes the token on.  Speculative
+// re-fills keep all 64 lanes of a chunk (the entry lane is not known yet; 17 KiB of LDS per wave --
+// what a batch this small can afford) and, of the halo group, the two steps a walk can enter at.
+// Results are the one-wave kernel's, bit for bit: same re-fill, same walk, same pending-state rules.
+struct TbJob { int s, ck, gtop, tops; };                     // strip, chunk, last group to re-fill, steps of that group (1..4); s < 0: none
+__device__ __forceinline__ TbJob tb_prev_job(const TbJob& j) {
+    // the chunk before, entered through its halo: groups up to the first group of the chunk just left, two steps of it
+    if (j.s < 0 || j.ck < 1) return TbJob{-1, 0, 0, 0};
+    return TbJob{j.s, j.ck - 1, j.ck * kChunk, 2};
+}
+__device__ __forceinline__ TbJob tb_job_at(int x, int y) {
+    constexpr int R = 4, SR = 256;
+    if (x <= 0 || y <= 0) return TbJob{-1, 0, 0, 0};
+    const int s = (x - 1) / SR, l = ((x - 1) % SR) / R, k = (y - 1) + l;
+    int ck = (k >> 2) / kChunk;
+    // the first two steps of a chunk carry no valid tags: they belong to the chunk before, whose re-fill runs
+    // one group further (the one-wave kernel finds that out by a walk of zero steps)
+    if (ck > 0 && k < ck * kChunk * 4 + 2) ck -= 1;
+    return TbJob{s, ck, k >> 2, (k & 3) + 1};
+}
+
+struct TbTok { int x, y, st, len, pend, flags; TbJob job; };  // flags: 1 first, 2 probe, 4 done
+constexpr int kTokInts = 10;
+
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void nw_trace2w_kernel(NwArgs a) {
+    constexpr int R = 4;
+    using L = PtrLayout<R>;
+    constexpr int SPG = L::SPG;
+    constexpr int WL = 64;                                      // whole chunks: the entry lane of a speculative chunk is unknown
+    __shared__ uint4 win_s[NWV][kChunkGroups * WL];
+    __shared__ int2 hvt_s[NWV][kChunkSteps + 8];
+    __shared__ int2 hvb_s[NWV][kChunkSteps];
+    __shared__ uint16_t ow_s[NWV][kChunkSteps + 64 + 8];
+    __shared__ int tok_s[NWV][kTokInts];
+    __shared__ int seq_s;                                       // iterations whose token is published
+
+    const int p = blockIdx.x, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t t0 = a.t_off[p], o0 = a.o_off[p];
+    const int n = (int)(a.t_off[p + 1] - t0);
+    const int m = (int)(a.o_off[p + 1] - o0);
+    uint8_t* ops = a.ops_out + a.ops_off[p];
+    const int cap = n + m;
+    if (threadIdx.x == 0) seq_s = 0;
+    __syncthreads();                                            // the only workgroup barrier: the waves run apart from here
+
+    uint4* const win = win_s[wave];
+    int2* const hvt = hvt_s[wave];
+    int2* const hvb = hvb_s[wave];
+    uint16_t* const ow = ow_s[wave];
+    // one wave's LDS writes followed by its own lanes' reads: the LDS executes a wave's operations in order; this
+    // only keeps the compiler from moving them across
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    const int32_t* prm = a.params + (size_t)p * a.params_stride;
+    const CellConsts c = make_consts(prm[0], prm[1], prm[2], prm[3], prm[4], prm[5]);
+    CellRegs kr;
+    kr.cmis = c.cmismatch; kr.cmat = c.cmatch; kr.gox6 = c.gox6; kr.goy6 = c.goy6;
+    kr.clean = ~kTagMask;
+    const bool carried = opens_nonpositive(c.gox, c.goy);
+    const int xadj = carried ? c.gox : 0, yadj = carried ? c.goy : 0;
+    const int xadj6 = xadj * 64, yadj6 = yadj * 64;
+    const Ws2 ws(max(n, 1), max(m, 1));
+    uint8_t* const ws_p = a.ws + a.ws_off[p];
+
+    // the token before iteration 0: the start of the walk (textSeqCompare.py:100-107), the same on every wave
+    TbTok T;
+    T.x = n; T.y = m; T.st = 0; T.len = 0; T.pend = 0; T.flags = 1;
+    if (n > 1 && (n - 1) % L::SR == 0) {                        // the start state PM(n, m) is a tag of the strip above
+        if (m == 1) T.flags = 0;                                // boundary column: M
+        else { T.x = n - 1; T.y = m - 1; T.pend = 3; T.flags = 1 | 2; }
+    }
+    T.job = tb_job_at(T.x, T.y);
+    if (T.job.s < 0) {                                          // an empty string: nothing to walk, boundary run only
+        if (wave == 0) {
+            int x = n, y = m, len = 0;
+            while (y > 0) { if (lane == 0) ops[cap - 1 - len] = 2; ++len; --y; }
+            while (x > 0) { if (lane == 0) ops[cap - 1 - len] = 1; ++len; --x; }
+            if (lane == 0) a.ops_len[p] = len;
+        }
+        return;
+    }
+    int kt = -1;                                                // index of the newest token this wave holds
+
+    // re-fill of one job into this wave's window (set-up + tagged fill), as the one-wave kernel does it
+    auto refill = [&](const TbJob& J) {
+        const int s = J.s, g0 = J.ck * kChunk, k0 = g0 * SPG, g_top = J.gtop;
+        const int nsteps_w = (g_top - g0 + 1) * SPG;
+        const int i_h = s * L::SR;
+        const int row0 = s * L::SR + lane * R;
+        const bool lane_has_rows = row0 < n;
+        int tc[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int i = row0 + rr + 1;
+            tc[rr] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
+        }
+        const int2* const hrow = reinterpret_cast<const int2*>(ws_p + ws.row(s)) + 1;
+        constexpr int kOwIt = (kChunkSteps + 64 + 63) / 64, kRowIt = (kChunkSteps + 1 + 63) / 64;
+#pragma unroll
+        for (int it = 0; it < kOwIt; ++it) {
+            const int i = it * 64 + lane, src = k0 - 63 + i;
+            if (i < nsteps_w + 64) ow[i] = (uint16_t)((src >= 0 && src < m) ? a.o_codes[o0 + src] : 0xFFFF);
+        }
+        const int jhi = min(m, k0 + nsteps_w);
+#pragma unroll
+        for (int it = 0; it < kRowIt; ++it) {
+            const int jj = k0 + it * 64 + lane;
+            if (jj <= jhi) {
+                int2 v;
+                if (s == 0) v = make_int2(bnd_V_row0(c, jj) + xadj6, bnd_D_row0(c, jj));
+                else {
+                    const int2 e = hrow[max(jj, 1)];
+                    v = (jj == 0) ? make_int2(0, bnd_D_col0(c, i_h)) : make_int2(enc_of(e.x), enc_of(e.y));
+                }
+                hvt[jj - k0] = v;
+            }
+        }
+        int D[R], V[R], H[R], dsave;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int i = row0 + rr + 1;
+            V[rr] = 0;
+            D[rr] = bnd_D_col0(c, i);
+            H[rr] = bnd_H_col0(c, i) + yadj6;
+        }
+        dsave = bnd_D_col0(c, row0);
+        if (g0 > 0 && lane < k0) {
+            const int* stp = reinterpret_cast<const int*>(ws_p + ws.state(s, g0 / kCkGroups)) + lane;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) { D[rr] = enc_of(stp[rr * 64]); H[rr] = enc_of(stp[(R + rr) * 64]); }
+            V[R - 1] = enc_of(stp[2 * R * 64]);
+            dsave = enc_of(stp[(2 * R + 1) * 64]);
+        }
+        wave_sync();
+        if (carried && c.gox == c.goy) refill_chunk<true, true, WL>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows, 0, J.tops);
+        else if (carried) refill_chunk<true, false, WL>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows, 0, J.tops);
+        else refill_chunk<false, false, WL>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lane, lane_has_rows, 0, J.tops);
+        wave_sync();
+    };
+
+    // every iteration publishes exactly one token, so no wave ever waits for one that does not come; the bound is a
+    // belt against a walk that makes no progress (none known): the wave that reaches it ends the walk for everyone
+    const int max_iter = 4 * (L::nstrips(max(n, 1)) * (ws.ngroups / kChunk + 2)) + 64;
+    for (int i = wave; ; i += NWV) {
+        // (1) speculation + (2) the token of iteration i - 1.  While that token is not there, the wave re-fills the
+        // job its iteration will most likely be: the job of the NEWEST token published (iteration j < i - 1), moved
+        // back by the i - 1 - j iterations in between.  A newer token that changes the expectation (the walk left the
+        // strip) replaces the speculation at once -- the waves behind the one that must re-fill the new strip's
+        // first chunk re-fill its second, third ... beside it instead of one after the other.
+        TbJob spec{-1, 0, 0, 0};
+        if (i > kt + 1) {
+            int spins = 0, based_on = -2;                         // token the current expectation comes from (-2: none yet)
+            while (true) {
+                const int have = __builtin_amdgcn_readfirstlane(
+                    __hip_atomic_load(&seq_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (have >= i) break;                            // token i - 1 is there
+                const int from = max(kt, have - 1);              // newest token to go by: the one held, or a fresher one
+                if (from != based_on) {
+                    based_on = from;
+                    TbJob want = T.job;                           // job of iteration from + 1
+                    bool over = T.flags & 4;
+                    if (from != kt) {                             // (its slot is not rewritten before iteration from + NWV > i)
+                        const int* tj = tok_s[from % NWV];
+                        want = TbJob{tj[6], tj[7], tj[8], tj[9]};
+                        over = tj[5] & 4;
+                    }
+                    for (int d = 0; d < i - from - 1; ++d) want = tb_prev_job(want);
+                    if (!over && want.s >= 0 &&
+                        !(spec.s >= 0 && want.s == spec.s && want.ck == spec.ck && want.gtop == spec.gtop)) {
+                        spec = want;
+                        refill(spec);
+                        continue;
+                    }
+                }
+                // (bounded: every iteration publishes a token, so the wait always ends -- the bound only makes sure a
+                // mistake here could never leave waves spinning on the chip; ~1 s)
+                if (++spins >= (1 << 24)) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (spins >= (1 << 24)) break;
+            const int* tk = tok_s[(i - 1) % NWV];
+            T.x = tk[0]; T.y = tk[1]; T.st = tk[2]; T.len = tk[3]; T.pend = tk[4]; T.flags = tk[5];
+            T.job = TbJob{tk[6], tk[7], tk[8], tk[9]};
+            kt = i - 1;
+        }
+        if (T.flags & 4) {
+            // the walk is over (another wave finished it).  Pass the word on as the token of THIS iteration: the
+            // wave of iteration i + 1 is waiting for it (every iteration publishes exactly one token)
+            if (lane == 0) {
+                tok_s[i % NWV][5] = 4;
+                __hip_atomic_store(&seq_s, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            break;
+        }
+        // (3) the chunk itself, unless the speculation was right
+        const TbJob J = T.job;
+        if (!(spec.s == J.s && spec.ck == J.ck && spec.gtop == J.gtop && spec.tops >= J.tops && spec.s >= 0)) refill(J);
+        // (4) walk (nw_trace2_kernel, step (e))
+        int x = T.x, y = T.y, st = T.st, len = T.len, pend = T.pend;
+        bool first = T.flags & 1, probe = T.flags & 2;
+        const int s = J.s, g0 = J.ck * kChunk, k0 = g0 * SPG;
+        const int kvalid = J.ck > 0 ? k0 + 2 : 0;
+        const int l = ((x - 1) % L::SR) / R, r = (x - 1) % R, k = (y - 1) + l;
+        bool walked = true;
+        if (pend) {                                              // (x, y): lane 63's last row, step k of this chunk
+            const int2 e = hvb[k - k0];
+            st = 2 - (((pend == 3) ? e.y : e.x) & 3);
+            pend = 0;
+            if (probe) { probe = false; first = false; x = n; y = m; walked = false; }    // that was the start state
+        }
+        if (walked) {
+            if (first && k >= kvalid) {                          // start state, textSeqCompare.py:102
+                st = ptr_pm(reinterpret_cast<const uint8_t*>(win)[(((k >> 2) - g0) * WL + l) * 16 + (k & 3) * R + r]);
+                first = false;
+            }
+            len += walk_window_vec<true, WL, true>(win, g0, kvalid, s * L::SR, x, y, st, ops + (cap - 1 - len),
+                                                   cap - len, lane, nullptr, 0);
+            if (st >= 3) { pend = st; st = 0; }                  // left the strip upwards: state pending
+        }
+        // (5) the token of this iteration
+        TbTok N;
+        N.x = x; N.y = y; N.st = st; N.len = len; N.pend = pend;
+        N.job = tb_job_at(x, y);
+        N.flags = (first ? 1 : 0) | (probe ? 2 : 0) | ((N.job.s < 0 || i >= max_iter) ? 4 : 0);
+        if (N.flags & 4) {                                       // the walk is over: boundary runs and the length
+            while (y > 0) { if (lane == 0) ops[cap - 1 - len] = 2; ++len; --y; }
+            while (x > 0) { if (lane == 0) ops[cap - 1 - len] = 1; ++len; --x; }
+            if (lane == 0) a.ops_len[p] = len;
+        }
+        if (lane == 0) {
+            int* tk = tok_s[i % NWV];
+            tk[0] = N.x; tk[1] = N.y; tk[2] = N.st; tk[3] = N.len; tk[4] = N.pend; tk[5] = N.flags;
+            tk[6] = N.job.s; tk[7] = N.job.ck; tk[8] = N.job.gtop; tk[9] = N.job.tops;
+            __hip_atomic_store(&seq_s, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (N.flags & 4) break;
+        T = N;
+        kt = i;
+    }
+}
+
 }  // namespace ta
 
 using namespace ta;
@@ -1007,7 +1266,16 @@ extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
     }
     if (flags & TA_NW_TRACEBACK) {
         if (!ops_out && (max_n + max_m) > 0) return ta_fail(TA_EINVAL, "null ops_out");
-        hipLaunchKernelGGL(nw_trace2_kernel, dim3(nprob), dim3(64), 0, st, a);
+        // waves per problem: one when the batch alone fills the SIMDs (sixteen problems per CU and more); below
+        // that, two or four that speculate along the path (nw_trace2w_kernel) -- as many as keep the launch within
+        // about two waves per SIMD (1024 SIMDs) and within the CUs' LDS in one round (measured, tools/tb_waves_time.py:
+        // 64 x 2048^2 0.63 / 0.41 / 0.29 ms with 1 / 2 / 4 waves, 512 x 0.66 / 0.55 / 0.39, 768 x 0.66 / 0.56 / 0.62,
+        // 1024 x 0.67 / 0.55 / 0.75, 1280 x 0.88 / 0.89 / 0.95; 256 x 4096^2 1.26 / 0.83 / 0.59)
+        int tbw = (int)((flags >> TA_NW_TBWAVES_SHIFT) & 0x7u);
+        if (tbw != 1 && tbw != 2 && tbw != 4) tbw = nprob <= 640 ? 4 : nprob <= 1152 ? 2 : 1;
+        if (tbw == 4) hipLaunchKernelGGL(nw_trace2w_kernel<4>, dim3(nprob), dim3(256), 0, st, a);
+        else if (tbw == 2) hipLaunchKernelGGL(nw_trace2w_kernel<2>, dim3(nprob), dim3(128), 0, st, a);
+        else hipLaunchKernelGGL(nw_trace2_kernel, dim3(nprob), dim3(64), 0, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return ta_fail_hip(e, "nw_trace2_kernel launch");
     }

@@ -114,6 +114,8 @@ class NWBatch(object):
         # phase 1 with exactly this many waves per workgroup (None = the library's own choice)
         self.no_profile = False
         self.waves = None
+        # phase 2 with exactly this many waves per problem (1, 2 or 4; None = the library's choice by batch size)
+        self.tb_waves = None
         # one-pass fill: rows per lane (2 or 4; None = the library's choice by batch size)
         self.rows = None
         p = np.asarray(params, dtype=np.int64)
@@ -202,6 +204,8 @@ class NWBatch(object):
             flags |= _native.TA_NW_NO_PROFILE
         if self.waves:
             flags |= (int(self.waves) & 0xF) << _native.TA_NW_WAVES_SHIFT
+        if self.tb_waves:
+            flags |= (int(self.tb_waves) & 0x7) << _native.TA_NW_TBWAVES_SHIFT
         return flags
 
     def results(self):
