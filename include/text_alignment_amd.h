@@ -59,7 +59,8 @@ extern "C" {
 #define TA_NW_ROWS(r) (((uint32_t)(r) & 0x7u) << TA_NW_ROWS_SHIFT)
 /* ta_nw2_batch, traceback launch shape (tests, timing): waves per problem of phase 2 -- 1 (one wave walks the chunks
  * one after the other), 2 or 4 (the chunks along the path dealt to the waves of a workgroup, each re-filling the
- * chunk it expects ahead of the walk); 0 = the library's choice by batch size.  Same results either way. */
+ * chunk it expects ahead of the walk), 3 (TWO problems per wave, 32 lanes each, walking back half-strips of 128 rows:
+ * large batches); 0 = the library's choice by batch size.  Same results either way. */
 #define TA_NW_TBWAVES_SHIFT 24
 #define TA_NW_TBWAVES(w) (((uint32_t)(w) & 0x7u) << TA_NW_TBWAVES_SHIFT)
 #define TA_NW_NO_PROFILE 64u

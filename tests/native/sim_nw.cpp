@@ -135,6 +135,10 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
     // bottom rows: row s is what strip s starts from (row 0 = the table's boundary row), strip s
     // leaves row s + 1; index [row][j], j = 0..m
     std::vector<int> HV((size_t)(std::max(nstrips, 1) + 1) * (m + 2)), HD(HV.size());
+    // ... and, for the half-strip flow of nw_trace2h_kernel, the bottom rows of lanes 31 and 63 of every strip
+    // (Ws2 with kSubRows = 2): sub row 0 = the table's boundary row, sub row 1 + 2 s + q = last row of lanes
+    // 32 q .. 32 q + 31 of strip s; the row above half-strip hs is sub row hs
+    std::vector<int> SV((size_t)(2 * std::max(nstrips, 1) + 1) * (m + 2)), SD(SV.size());
 
     // phase 1 keeps V~ + gox / H~ + goy (the carried cell of nw_cell.h) when no gap open is
     // positive, exactly as nw_score_kernel does; phase 2 undoes the offsets where it reads them
@@ -143,7 +147,7 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
 
     // ---------------- phase 1: raw fill ----------------
     {
-        for (int j = 0; j <= m; ++j) { HV[j] = raw_of(bnd_V_row0(c, j)) + xadj; HD[j] = raw_of(bnd_D_row0(c, j)); }
+        for (int j = 0; j <= m; ++j) { HV[j] = raw_of(bnd_V_row0(c, j)) + xadj; HD[j] = raw_of(bnd_D_row0(c, j)); SV[j] = HV[j]; SD[j] = HD[j]; }
         for (int s = 0; s < nstrips; ++s) {
             const int* hv = &HV[(size_t)s * (m + 2)];
             const int* hd = &HD[(size_t)s * (m + 2)];
@@ -198,6 +202,11 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
                             const int j = k - l + 1;
                             hv_out[j] = V[l][R - 1]; hd_out[j] = D[l][R - 1];
                         }
+                        if ((l & 31) == 31) {
+                            const int j = k - l + 1;
+                            const size_t b = (size_t)(1 + 2 * s + l / 32) * (m + 2);
+                            SV[b + j] = V[l][R - 1]; SD[b + j] = D[l][R - 1];
+                        }
                     }
                 }
             }
@@ -219,8 +228,14 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
     // with two steps of it -- what the one-wave flow does as well, so an expected chunk that turns out right IS the
     // chunk the walk needs -- and a position in a chunk's first two steps goes to the chunk before at once (tb_job_at)
     // instead of through a walk of zero steps.
+    // GSPAN >= 2000: the half-strip flow of nw_trace2h_kernel on top of that: a strip restarts in two halves of 32 lanes
+    // (from the same state checkpoints and from lane 31's bottom row), a step that leaves a HALF-strip upwards is
+    // pending, and a half-strip's whole chunk is kept.
+    const bool halves = GSPAN >= 2000;
+    if (halves) GSPAN -= 1000;
     const bool skip_halo = GSPAN >= 1000;
     if (skip_halo) GSPAN -= 1000;
+    const int LWs = halves ? 32 : kLanes;                   // lanes of the unit phase 2 restarts
     const int xadj6 = xadj * 64, yadj6 = yadj * 64;
     std::vector<uint8_t> rev;
     int x = n, y = m, st = 0;
@@ -229,13 +244,15 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
     // in state M) or of XG / V~ (4, left in state X) of the cell (x, y) the walk now stands on.
     int pend = 0;
     bool probe = false;                               // start state of a walk that begins in a strip's first row
-    if ((n - 1) % L::SR == 0 && n > 1) {              // textSeqCompare.py:102 reads PM(n, m) = tag of D(n-1, m-1)
+    if ((n - 1) % (LWs * R) == 0 && n > 1) {          // textSeqCompare.py:102 reads PM(n, m) = tag of D(n-1, m-1)
         if (m == 1) { st = 0; first = false; }        // D(n-1, 0): boundary column, M
         else { x = n - 1; y = m - 1; pend = 3; probe = true; }
     }
     int guard = 0;
     while (x > 0 && y > 0) {
         const int s = (x - 1) / L::SR;
+        const int hs = (x - 1) / (LWs * R);                  // (half-)strip index; lanes lb .. lb + LWs - 1 of strip s
+        const int lb = halves ? (hs & 1) * LWs : 0;
         int l = ((x - 1) % L::SR) / R, r = (x - 1) % R, k = (y - 1) + l;
         int ck = (k / SPG) / KCG;
         int g_top = k / SPG;
@@ -249,8 +266,14 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
             // form; tags only where they are known analytically (the table's boundary row)
             const int jhi = std::min(m, (g_top + 1) * SPG);
             std::vector<int> hvt(m + 2, 0), hdt(m + 2, 0);
-            for (int j = std::max(0, k0); j <= jhi; ++j) {
-                if (s == 0) { hvt[j] = bnd_V_row0(c, j) + xadj6; hdt[j] = bnd_D_row0(c, j); continue; }
+            for (int j = std::max(0, k0 - lb); j <= jhi; ++j) {
+                if (hs == 0) { hvt[j] = bnd_V_row0(c, j) + xadj6; hdt[j] = bnd_D_row0(c, j); continue; }
+                if (halves) {
+                    const size_t b = (size_t)hs * (m + 2);
+                    hvt[j] = enc_of(SV[b + j]); hdt[j] = enc_of(SD[b + j]);
+                    if (j == 0) { hvt[j] = 0; hdt[j] = bnd_D_col0(c, hs * LWs * R); }   // column 0 of the row above (kernel: analytic)
+                    continue;
+                }
                 const size_t b = (size_t)s * (m + 2);
                 hvt[j] = enc_of(HV[b + j]); hdt[j] = enc_of(HD[b + j]);
             }
@@ -277,8 +300,8 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
             }
             // tagged fill of groups g0..g_top into the chunk buffer; the tagged outputs of the strip's
             // bottom row are kept per step for a pending state
-            const int WL = (GSPAN > 0 && GSPAN < 64) ? GSPAN : 64;
-            const int l_lo = std::max(0, l - (WL - 1));
+            const int WL = halves ? LWs : (GSPAN > 0 && GSPAN < 64) ? GSPAN : 64;
+            const int l_lo = halves ? lb : std::max(0, l - (WL - 1));
             std::vector<uint8_t> wbuf((size_t)(g_top - g0 + 1) * 1024, 0xEE);
             std::vector<int> capV((size_t)(g_top - g0 + 1) * SPG, 0), capD(capV.size(), 0);
             std::vector<char> capOk(capV.size(), 0);
@@ -291,14 +314,14 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
                 for (int q = 0; q < nq; ++q) {
                     const int kk = g * SPG + q;
                     int vup[kLanes], dnext[kLanes];
-                    for (int ll = 0; ll < kLanes; ++ll) {
+                    for (int ll = lb; ll < lb + LWs; ++ll) {
                         const int j = kk - ll + 1;
-                        if (ll == 0) { const int jj = std::min(std::max(j, 0), m); vup[ll] = hvt[jj]; dnext[ll] = hdt[jj]; }
+                        if (ll == lb) { const int jj = std::min(std::max(j, 0), m); vup[ll] = hvt[jj]; dnext[ll] = hdt[jj]; }
                         else { vup[ll] = V[ll - 1][R - 1]; dnext[ll] = D[ll - 1][R - 1]; }
                     }
                     int nD[kLanes][R], nV[kLanes][R], nH[kLanes][R];
-                    bool act[kLanes];
-                    for (int ll = 0; ll < kLanes; ++ll) {
+                    bool act[kLanes] = {false};
+                    for (int ll = lb; ll < lb + LWs; ++ll) {
                         const int j = kk - ll + 1;
                         act[ll] = (j >= 1 && j <= m);
                         if (!act[ll]) continue;
@@ -314,13 +337,13 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
                             nD[ll][rr] = d; nV[ll][rr] = v; nH[ll][rr] = h;
                         }
                     }
-                    for (int ll = 0; ll < kLanes; ++ll) {
+                    for (int ll = lb; ll < lb + LWs; ++ll) {
                         if (!act[ll]) continue;
                         for (int rr = 0; rr < R; ++rr) { D[ll][rr] = nD[ll][rr]; V[ll][rr] = nV[ll][rr]; H[ll][rr] = nH[ll][rr]; }
                         dsave[ll] = dnext[ll];
                     }
-                    if (act[kLanes - 1]) {
-                        capV[kk - k0] = V[kLanes - 1][R - 1]; capD[kk - k0] = D[kLanes - 1][R - 1]; capOk[kk - k0] = 1;
+                    if (act[lb + LWs - 1]) {                  // the (half-)strip's bottom row, tagged
+                        capV[kk - k0] = V[lb + LWs - 1][R - 1]; capD[kk - k0] = D[lb + LWs - 1][R - 1]; capOk[kk - k0] = 1;
                     }
                 }
                 for (int ll = l_lo; ll < std::min(kLanes, l_lo + WL); ++ll) memcpy(&wbuf[((size_t)(g - g0) * 64 + ll) * 16], acc[ll], 16);
@@ -329,7 +352,7 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
                 return wbuf[((size_t)(kk / SPG - g0) * 64 + ll) * 16 + (kk % SPG) * R + rr];
             };
             if (pend) {                                   // the cell the walk stands on: bottom row of this strip
-                if (l != kLanes - 1 || r != R - 1) return -10;
+                if (l != lb + LWs - 1 || r != R - 1) return -10;
                 if (k < k0 || k / SPG > g_top || !capOk[k - k0]) return -11;
                 const int tagged = (pend == 3) ? capD[k - k0] : capV[k - k0];
                 st = 2 - (tagged & 3);
@@ -348,7 +371,7 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
                 if (b == 0xEE) return -7;
                 const int up = (st != 2), left = (st != 1);
                 rev.push_back((uint8_t)st);
-                const bool leaves_up = up && l == 0 && r == 0 && s > 0;   // PM / PX of the strip's first row
+                const bool leaves_up = up && l == lb && r == 0 && hs > 0;   // PM / PX of the (half-)strip's first row
                 if (leaves_up) pend = 3 + st;
                 else st = 2 - (int)((b >> (2 * st)) & 3u);
                 const int wrap = up & (r == 0);
@@ -356,7 +379,7 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
                 x -= up; y -= left; k -= left + wrap; l -= wrap;
                 ++steps;
             }
-            if (x <= 0 || y <= 0 || l < 0) in_strip = false;
+            if (x <= 0 || y <= 0 || l < lb) in_strip = false;
             else if (k >= kvalid) {
                 if (steps == 0) return -12;                   // no progress: the entry lane is always in its window
                 if (skip_halo) return -13;                    // whole chunks are kept: the walk cannot run off a window

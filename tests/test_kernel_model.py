@@ -88,7 +88,7 @@ def test_sim_matches_oracle_synth(sim, R):
 
 
 @pytest.mark.parametrize("kcg,gspan", [(1, 1), (2, 3), (4, 8), (12, 12), (16, 16), (16, 32), (32, 96),
-                                       (1, 1064), (3, 1064), (16, 1064)])
+                                       (1, 1064), (3, 1064), (16, 1064), (1, 2064), (4, 2064), (16, 2064)])
 def test_two_phase_sim_matches_oracle(sim, kcg, gspan):
     """Checkpointed score-only fill + chunked tagged re-fill (the two-phase aligner's data flow): tiny
     checkpoint periods force many restarts and halo steps; `gspan` below 64 is the number of lanes of a
@@ -96,7 +96,9 @@ def test_two_phase_sim_matches_oracle(sim, kcg, gspan):
     of 1 .. 16 lanes make the walk run off the window's top lane all the time, and the chunk is then
     re-filled around the new position.  gspan = 1064: the flow of the several-waves-per-problem kernel
     (nw_trace2w_kernel): whole chunks kept, every chunk after a strip's first entered through its halo in a buffer
-    re-filled for exactly that, positions in a chunk's first two steps sent to the chunk before at once."""
+    re-filled for exactly that, positions in a chunk's first two steps sent to the chunk before at once.
+    gspan = 2064: the half-strip flow of the large-batch kernel (nw_trace2h_kernel): strips restart in halves of 32
+    lanes from lane 31's bottom row, pending states at half-strip borders, the start probe at n = 128 h + 1."""
     rng = np.random.default_rng(500 + kcg)
     for k in range(60):
         asz = [2, 4, 27][k % 3]
@@ -126,7 +128,7 @@ def test_two_phase_sim_matches_oracle(sim, kcg, gspan):
     # walks that START in a strip's first row (n = 256 s + 1: the start state is a tag of the strip
     # above) and that cross strip borders in every state, under every scoring system
     for k, (n, m) in enumerate([(257, 300), (513, 1), (257, 1), (513, 2), (769, 640), (257, 64), (512, 300),
-                                (258, 257), (513, 513), (257, 5)]):
+                                (258, 257), (513, 513), (257, 5), (129, 200), (385, 1), (385, 2), (129, 64), (641, 700)]):
         for sc in SYSTEMS[k % 3::3]:
             t = rng.integers(0, 3, size=n)
             o = rng.integers(0, 3, size=m)

@@ -482,11 +482,12 @@ def test_two_phase_walk_runs_off_the_lane_window(tsc):
         assert (want == 1).sum() >= len(t_list[k]) - len(o_list[k])
 
 
-@pytest.mark.parametrize("tb_waves", [1, 2, 4])
+@pytest.mark.parametrize("tb_waves", [1, 2, 3, 4])
 def test_two_phase_traceback_waves_per_problem(tsc, tb_waves):
     """Phase 2's launch shapes: one wave per problem (large batches) and two / four waves that deal the chunks of
     the path among themselves and re-fill the chunk each EXPECTS ahead of the walk (nw_trace2w_kernel; the library
-    picks by batch size, TA_NW_TBWAVES forces).  Same alignments, bit for bit, on everything that stresses the
+    picks by batch size, TA_NW_TBWAVES forces; 3 = the large-batch shape: two problems per wave, each walking back
+    half-strips in 32 lanes, nw_trace2h_kernel).  Same alignments, bit for bit, on everything that stresses the
     speculation: walks that start in a strip's first row (probe) and leave strips in every state (pending states),
     long gap runs (the expected chunk is wrong many times in a row: the walk leaves the strip early, or stays in a
     chunk's lane range for hundreds of columns), table edges, all-tie tables, ragged sizes from 0, two runs of the
@@ -496,7 +497,8 @@ def test_two_phase_traceback_waves_per_problem(tsc, tb_waves):
     t_list, o_list, prm = [], [], []
     for k, (n, m) in enumerate([(257, 300), (513, 1), (257, 1), (513, 2), (769, 640), (257, 64), (512, 300), (258, 257),
                                 (513, 513), (257, 5), (1025, 70), (1281, 1300), (2049, 2049), (256, 256), (1024, 3),
-                                (0, 0), (0, 9), (9, 0), (1, 1), (63, 65), (64, 64), (300, 4500), (2100, 600)]):
+                                (0, 0), (0, 9), (9, 0), (1, 1), (63, 65), (64, 64), (300, 4500), (2100, 600),
+                                (129, 200), (385, 1), (385, 2), (129, 64), (641, 700), (128, 128), (1153, 90)]):
         for sc in (SYSTEMS[0], SYSTEMS[k % len(SYSTEMS)], SYSTEMS[(3 * k + 1) % len(SYSTEMS)]):
             t, o = _random_problem(rng, n, m, [2, 3, 27][k % 3], k % 2 == 1)
             t_list.append(t); o_list.append(o); prm.append(sc)

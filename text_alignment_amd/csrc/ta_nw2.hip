@@ -43,6 +43,16 @@ static_assert(kCkGroups % 4 == 0 && kCkGroups >= 4, "whole blocks of four groups
 constexpr int kStateInts = 10;                // D[4], H[4], V[3], dsave
 constexpr int kWsRange = 0x7ffff000;          // record count of a workspace buffer descriptor: every real offset is below
 
+// Bottom rows kept per strip: not only the strip's last row (lane 63's, what the next strip starts from) but also
+// lane 31's, so that phase 2 can restart HALF-strips of 128 rows (32 lanes) and carry two problems' half-strips in one
+// wave (nw_trace2h_kernel).  The same two store instructions per group write both rows (each storing lane has its
+// own offset); measured on phase 1 at 4096 x 4096^2: 11.30 ms with the strip rows only, 11.39 with lanes 31 and 63,
+// 11.70 with lanes 15 / 31 / 47 / 63 (quarter-strips would save phase 2 no more than they cost here).
+#ifndef TA_SUBROWS
+#define TA_SUBROWS 2
+#endif
+constexpr int kSubRows = TA_SUBROWS;
+constexpr int kSubLanes = 64 / kSubRows;
 // per-problem layout of the phase-1/2 workspace (all offsets in bytes, 16-byte aligned)
 struct Ws2 {
     int nstrips, ngroups, nck;
@@ -52,17 +62,19 @@ struct Ws2 {
         nstrips = L::nstrips(n);
         ngroups = L::ngroups(m);
         nck = ngroups / kCkGroups + 1;
-        // bottom rows: row s is the row above strip s -- (XG or V~, D) per column, what the strip's
-        // first lane consumes -- row 0 the table's boundary row; strip s leaves row s + 1.  Entry j
-        // sits at index j + 1, so that the four entries a group reads start on a 16-byte boundary.
-        // Phase 1 hands a strip's results to the next strip through them (they are in L2 when the
-        // next wave, ~25 groups behind, reads them) and phase 2 restarts from them.
+        // bottom rows: row 0 is the table's boundary row, row 1 + kSubRows s + q the last row of lanes 16 q .. 16 q + 15
+        // of strip s -- (XG or V~, D) per column, what the lane below consumes; top(s) = row kSubRows s is the row above
+        // strip s.  Entry j sits at index j + 1, so that the four entries a group reads start on a 16-byte boundary.
+        // Phase 1 hands a strip's results to the next strip through them (they are in L2 when the next wave, ~25
+        // groups behind, reads them) and phase 2 restarts from them.  A lane that has passed its last column goes on
+        // over pad columns (phase 1's steady loop): lane 15 writes entries up to column m + 51, hence the pitch.
         rows = 0;
-        row_pitch = ((int64_t)(m + 8) * 8 + 15) & ~(int64_t)15;
-        stck = rows + (int64_t)(nstrips + 1) * row_pitch;
+        row_pitch = ((int64_t)(m + 72) * 8 + 15) & ~(int64_t)15;
+        stck = rows + (int64_t)(nstrips * kSubRows + 1) * row_pitch;
         total = stck + (int64_t)nstrips * nck * kStateInts * 64 * 4;
     }
     __host__ __device__ int64_t row(int r) const { return rows + (int64_t)r * row_pitch; }
+    __host__ __device__ int64_t top(int s) const { return row(s * kSubRows); }          // the row above strip s
     __host__ __device__ int64_t state(int s, int ck) const {
         return stck + ((int64_t)(s * nck + ck) * kStateInts * 64) * 4;
     }
@@ -255,8 +267,11 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
         for (int r = 0; r < R; ++r) tcmp[r] = tc[r] << code_shift;           // -1 stays negative
         const bool lane_has_rows = row0 < n;
         const int prod_pass = (wave == 0) ? pass - 1 : pass;
-        const int2* const hvd = reinterpret_cast<const int2*>(ws_p + ws.row(s)) + 1;       // the row above: entry j
-        int2* const hvo = reinterpret_cast<int2*>(ws_p + ws.row(s + 1)) + 1;               // this strip's bottom row
+        const int2* const hvd = reinterpret_cast<const int2*>(ws_p + ws.top(s)) + 1;       // the row above: entry j
+        // the bottom row this lane writes if it is the last of its 16 (lanes 15, 31, 47: sub-strip rows for
+        // phase 2; lane 63: the strip's own, which the next strip starts from)
+        const bool sub_last = (lane & (kSubLanes - 1)) == kSubLanes - 1;
+        int2* const hvo = reinterpret_cast<int2*>(ws_p + ws.row(s * kSubRows + (lane / kSubLanes) + 1)) + 1;
 
         auto wait_span = [&](int g_first) {
             if (W == 1 || s == 0) return;
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
                         v_u = V[r];
                     }
                     dsave = d_next;
-                    if (lane == 63) hvo[j] = make_int2(V[R - 1], D[R - 1]);
+                    if (sub_last) hvo[j] = make_int2(V[R - 1], D[R - 1]);
                 }
             }
             publish(g);
@@ -373,8 +388,9 @@ __global__ __launch_bounds__(W * 64, MODE == 1 ? 5 : 2) void nw_score_kernel(NwA
             // >= kWsRange, i.e. out of the descriptor's range, for every lane but 63; g_hi != 0 only when
             // ws.total < kWsRange, so lane 63's own offsets are all in range)
             static_assert((uint64_t)kWsRange * 2 < (1ull << 32), "only63 + offset stays below 2^32");
-            const uint32_t only63 = (lane == 63) ? 0u : (uint32_t)kWsRange;       // in range for lane 63 only
-            uint32_t vo_w = only63 + (uint32_t)(ws.row(s + 1) + 8 + (int64_t)(g * SPG - 62) * 8);
+            const uint32_t only63 = sub_last ? 0u : (uint32_t)kWsRange;           // in range for lanes 15, 31, 47, 63 only
+            // entry j = k - lane + 1 of the lane's own bottom row (index j + 1)
+            uint32_t vo_w = only63 + (uint32_t)(ws.row(s * kSubRows + (lane / kSubLanes) + 1) + 8 + (int64_t)(g * SPG - lane + 1) * 8);
             int crd = (kOPad + g * SPG - lane) * (int)sizeof(LC); // byte offset of the next group's codes (per lane)
             asm volatile("" : "+v"(crd));                         // a running VGPR pointer, immediate offsets below
             const unsigned char* const oc_b = reinterpret_cast<const unsigned char*>(ocode);
@@ -704,7 +720,7 @@ __global__ __launch_bounds__(64) void nw_trace2_kernel(NwArgs a) {
             const int i = row0 + rr + 1;
             tc[rr] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
         }
-        const int2* const hrow = reinterpret_cast<const int2*>(ws_p + ws.row(s)) + 1;     // the row above: entry j
+        const int2* const hrow = reinterpret_cast<const int2*>(ws_p + ws.top(s)) + 1;     // the row above: entry j
 
         int ck = (k >> 2) / kChunk;                             // chunk the walk is in
         int g_top = k >> 2;                                     // last group to re-fill
@@ -973,7 +989,7 @@ __global__ __launch_bounds__(64 * NWV) void nw_trace2w_kernel(NwArgs a) {
             const int i = row0 + rr + 1;
             tc[rr] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
         }
-        const int2* const hrow = reinterpret_cast<const int2*>(ws_p + ws.row(s)) + 1;
+        const int2* const hrow = reinterpret_cast<const int2*>(ws_p + ws.top(s)) + 1;
         constexpr int kOwIt = (kChunkSteps + 64 + 63) / 64, kRowIt = (kChunkSteps + 1 + 63) / 64;
 #pragma unroll
         for (int it = 0; it < kOwIt; ++it) {
@@ -1116,6 +1132,342 @@ __global__ __launch_bounds__(64 * NWV) void nw_trace2w_kernel(NwArgs a) {
         T = N;
         kt = i;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// phase 2 for LARGE batches: TWO problems per wave, each in 32 lanes, walking back HALF-strips.
+//
+// The one-wave kernel re-fills whole 64-lane chunks although a walk enters a chunk at some lane l and only lanes
+// <= l matter: every strip costs 256 + 63 skewed steps of a full wave.  With lane 31's bottom row kept by phase 1
+// (Ws2, kSubRows = 2) a strip falls into two half-strips of 128 rows that restart independently -- from the same
+// state checkpoints (lanes 0 .. 31 or 32 .. 63 of them) and from the row above the half -- and a half-strip costs
+// 128 + 31 steps of HALF a wave.  So a wave carries two problems, one per 32 lanes, each running the one-wave
+// kernel's loop (set-up, tagged re-fill of a chunk, walk, next chunk) on its own half-strips; the two halves share
+// the instruction stream and diverge only in trip counts (the compiler's EXEC masking: the half with the shorter
+// re-fill or walk waits for the other).  Per problem ~0.58 of the re-filled wave-groups of the one-wave kernel.
+// Everything that was wave-uniform there (position, state, chunk, pointers) is per lane here, equal within a half;
+// ballots are split per half; a half's LDS arrays are its own.  Results are the one-wave kernel's, bit for bit.
+constexpr int kHalfLanes = 32;
+static_assert(kSubRows == 2 && kSubLanes == kHalfLanes, "nw_trace2h_kernel restarts half-strips: phase 1 must keep lane 31's rows");
+
+template <bool CARRIED, bool SAMEGO>
+__device__ __forceinline__ void refill_half(const CellRegs& kr, int (&D)[4], int (&V)[4], int (&H)[4], int& dsave,
+                                            const int (&tc)[4], const int2* hvt, const uint16_t* ow, uint4* win,
+                                            int2* hvb, int g0, int g_top, int m, int lam, int lb, bool lane_has_rows,
+                                            int top_steps) {
+    constexpr int R = 4, SPG = 4, LW = kHalfLanes;
+    const int k0 = g0 * SPG;
+    const bool first_lane = lam == 0;
+    int oc_next[SPG];
+    int2 hd_next[SPG];
+    auto load_group = [&](int g) {
+#pragma unroll
+        for (int q = 0; q < SPG; ++q) {
+            const int kk = g * SPG + q;
+            oc_next[q] = ow[kk - k0 + (LW - 1) - lam];
+            hd_next[q] = hvt[min(kk + 1, m + lb) - k0];          // column j = kk + 1 - lb of the row above, clamped to m
+        }
+    };
+    auto cell = [&](int d_ul, int x_u, int y_l, int t, int o, int& d, int& x, int& y) -> unsigned {
+        if constexpr (CARRIED) return cell_carried_tagged_hw<SAMEGO>(kr, d_ul, x_u, y_l, t, o, d, x, y);
+        else return cell_hw(kr, d_ul, x_u, y_l, t, o, d, x, y);
+    };
+    // values from the lane above; the first lane of a half takes the row above the half-strip (lane 32 must not see lane 31)
+    auto shift_in = [&](int& v_up, int v_src, int& d_next, int d_src) {
+        const int hv = v_up, hd = d_next;
+        wave_shr1_pair_sched(v_up, v_src, d_next, d_src);
+        v_up = first_lane ? hv : v_up;
+        d_next = first_lane ? hd : d_next;
+    };
+    load_group(g0);
+    const int gs_lo = (63 + SPG - 1) / SPG;                   // from here on every lane of the strip has started
+    auto steady_group = [&](int g, const int (&oc)[SPG], const int2 (&hd)[SPG], unsigned (&acc)[4], auto nq_c) {
+        constexpr int NQ = decltype(nq_c)::value;
+        int2 cap[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            int v_up = hd[q].x, d_next = hd[q].y;
+            shift_in(v_up, V[R - 1], d_next, D[R - 1]);
+            int d_ul = dsave, v_u = v_up;
+            unsigned b[R];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int d_old = D[rr];
+                b[rr] = cell(d_ul, v_u, H[rr], tc[rr], oc[q], D[rr], V[rr], H[rr]);
+                d_ul = d_old;
+                v_u = V[rr];
+            }
+            acc[q] = pack4(b[0], b[1], b[2], b[3]);
+            dsave = d_next;
+            cap[q] = make_int2(V[R - 1], D[R - 1]);
+        }
+        if (lam == LW - 1) {                                  // the half-strip's bottom row, tagged: for pending states
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) hvb[g * SPG - k0 + q] = cap[q];
+        }
+    };
+    auto edge_group = [&](int g, const int (&oc)[SPG], const int2 (&hd)[SPG], unsigned (&acc)[4]) {
+#pragma unroll
+        for (int q = 0; q < SPG; ++q) {
+            const int kk = g * SPG + q;
+            const int j = kk - (lb + lam) + 1;
+            const bool active = (j >= 1) && (j <= m) && lane_has_rows;
+            int v_up = hd[q].x, d_next = hd[q].y;
+            shift_in(v_up, V[R - 1], d_next, D[R - 1]);
+            if (active) {
+                int d_ul = dsave, v_u = v_up;
+                unsigned b[R];
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) {
+                    const int d_old = D[rr];
+                    b[rr] = cell(d_ul, v_u, H[rr], tc[rr], oc[q], D[rr], V[rr], H[rr]);
+                    d_ul = d_old;
+                    v_u = V[rr];
+                }
+                acc[q] = pack4(b[0], b[1], b[2], b[3]);
+                dsave = d_next;
+                if (lam == LW - 1) hvb[kk - k0] = make_int2(V[R - 1], D[R - 1]);
+            }
+        }
+    };
+    for (int g = g0; g <= g_top; ++g) {
+        int oc[SPG];
+        int2 hd[SPG];
+#pragma unroll
+        for (int q = 0; q < SPG; ++q) { oc[q] = oc_next[q]; hd[q] = hd_next[q]; }
+        unsigned acc[4] = {0u, 0u, 0u, 0u};
+        if (g < g_top) {
+            load_group(g + 1);
+            if (g >= gs_lo) steady_group(g, oc, hd, acc, std::integral_constant<int, SPG>{});
+            else edge_group(g, oc, hd, acc);
+        } else if (g >= gs_lo) {
+            if (top_steps <= 2) steady_group(g, oc, hd, acc, std::integral_constant<int, 2>{});
+            else steady_group(g, oc, hd, acc, std::integral_constant<int, SPG>{});
+        } else {
+            edge_group(g, oc, hd, acc);
+        }
+        win[(g - g0) * LW + lam] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+// walk_window_vec (nw_hw.h) for one half of a wave: 32 lanes look ahead along the run, the ballots are split per half,
+// position and state are per-lane copies.  win: [(group - gw_lo) * 32 + (strip lane - lb)]; x_lo: the row above the
+// half-strip.  A step that leaves a half-strip below the table's first upwards ends the walk with st = 3 + state.
+__device__ __forceinline__ int walk_half(const uint4* win, int gw_lo, int klow, int x_lo, int lb, int& x, int& y, int& st,
+                                         uint8_t* opsbuf, int max_ops, int lam, int half) {
+    constexpr int R = 4, LW = kHalfLanes;
+    const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
+    int cnt = 0;
+    while (true) {
+        const int up = (st != 2), left = (st != 1);
+        const int xi = x - lam * up, yi = y - lam * left;
+        const int li = ((xi - 1 - x_lo) >> 2) + lb;                       // strip lane of the cell this lane looks at
+        const int ki = (yi - 1) + li;
+        const bool valid = (xi > x_lo) & (yi > 0) & (ki >= klow);
+        unsigned b = 0;
+        if (valid) b = wb[((ki >> 2) - gw_lo) * (LW * 16) + (li - lb) * 16 + (ki & 3) * R + ((xi - 1) & (R - 1))];
+        int nxt = 2 - (int)((b >> (2 * st)) & 3u);
+        if (up && x_lo > 0 && xi == x_lo + 1) nxt = 3 + st;
+        const unsigned long long vm64 = __ballot(valid);
+        const unsigned long long cm64 = __ballot(valid && nxt == st);
+        const unsigned vmask = half ? (unsigned)(vm64 >> 32) : (unsigned)vm64;
+        const unsigned cmask = half ? (unsigned)(cm64 >> 32) : (unsigned)cm64;
+        if ((vmask & 1u) == 0u) break;                                     // the current cell is out
+        const int run = (~cmask == 0u) ? LW : (int)__builtin_ctz(~cmask);  // lanes 0 .. run - 1 stay in st
+        int steps = run, st_new = st;
+        const int nxt_at = __shfl(nxt, half * LW + min(run, LW - 1), 64);  // (every lane of the half asks the same lane)
+        if (run < LW && ((vmask >> run) & 1u)) {                           // the step that leaves state st
+            steps = run + 1;
+            st_new = nxt_at;
+        }
+        steps = min(steps, max_ops - cnt);
+        if (steps < run + 1) st_new = st;                                  // truncated inside the run
+        if (lam < steps) opsbuf[-(cnt + lam)] = (uint8_t)st;
+        cnt += steps;
+        x -= steps * up;
+        y -= steps * left;
+        st = st_new;
+        if (cnt >= max_ops) break;
+    }
+    return cnt;
+}
+
+__global__ __launch_bounds__(64) void nw_trace2h_kernel(NwArgs a) {
+    constexpr int R = 4, LW = kHalfLanes, SRH = LW * R;        // 128 rows per half-strip
+    using L = PtrLayout<R>;
+    constexpr int SPG = L::SPG;
+    __shared__ uint4 win_s[2][kChunkGroups * LW];
+    __shared__ int2 hvt_s[2][kChunkSteps + 8];
+    __shared__ int2 hvb_s[2][kChunkSteps];
+    __shared__ uint16_t ow_s[2][kChunkSteps + LW + 8];
+
+    const int lane = threadIdx.x, half = lane >> 5, lam = lane & (LW - 1);
+    const int pr = blockIdx.x * 2 + half;
+    const bool alive = pr < a.nprob;
+    const int p = alive ? pr : a.nprob - 1;                     // (an odd batch: the last wave's second half idles)
+    const int64_t t0 = a.t_off[p], o0 = a.o_off[p];
+    const int n = alive ? (int)(a.t_off[p + 1] - t0) : 0;
+    const int m = alive ? (int)(a.o_off[p + 1] - o0) : 0;
+    uint8_t* const ops = a.ops_out + a.ops_off[p];
+    const int cap = n + m;
+    uint4* const win = win_s[half];
+    int2* const hvt = hvt_s[half];
+    int2* const hvb = hvb_s[half];
+    uint16_t* const ow = ow_s[half];
+    // a half's LDS writes followed by its own lanes' reads: the LDS executes a wave's operations in order; this only
+    // keeps the compiler from moving them across
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    int x = n, y = m, len = 0, st = 0, pend = 0;
+    bool first = true, probe = false;
+    if (n > 1 && (n - 1) % SRH == 0) {                          // the start state PM(n, m) is a tag of the half-strip above
+        if (m == 1) { st = 0; first = false; }
+        else { x = n - 1; y = m - 1; pend = 3; probe = true; }
+    }
+    const int32_t* prm = a.params + (size_t)p * a.params_stride;
+    const CellConsts c = make_consts(prm[0], prm[1], prm[2], prm[3], prm[4], prm[5]);
+    CellRegs kr;
+    kr.cmis = c.cmismatch; kr.cmat = c.cmatch; kr.gox6 = c.gox6; kr.goy6 = c.goy6;
+    kr.clean = ~kTagMask;
+    const bool carried = opens_nonpositive(c.gox, c.goy);
+    const int xadj = carried ? c.gox : 0, yadj = carried ? c.goy : 0;
+    const int xadj6 = xadj * 64, yadj6 = yadj * 64;
+    const Ws2 ws(max(n, 1), max(m, 1));
+    uint8_t* const ws_p = a.ws + a.ws_off[p];
+
+    while (x > 0 && y > 0) {
+        const int hs = (x - 1) / SRH;                           // half-strip the walk is in: strip hs / 2, lanes lb ..
+        const int s = hs >> 1, lb = (hs & 1) * LW;
+        int l = ((x - 1) % L::SR) / R;                          // strip lane
+        int r = (x - 1) % R;
+        int k = (y - 1) + l;
+        const int i_h = hs * SRH;                               // 1-based index of the row above the half-strip
+        const int row0 = s * L::SR + (lb + lam) * R;
+        const bool lane_has_rows = row0 < n;
+        int tc[R];
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {
+            const int i = row0 + rr + 1;
+            tc[rr] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
+        }
+        const int2* const hrow = reinterpret_cast<const int2*>(ws_p + ws.row(hs)) + 1;    // the row above: entry j
+
+        int ck = (k >> 2) / kChunk;
+        int g_top = k >> 2;
+        if (ck > 0 && k < ck * kChunk * SPG + 2) ck -= 1;       // a chunk's first two steps belong to the chunk before
+        bool in_strip = true;
+        constexpr int kOwIt = (kChunkSteps + LW + LW - 1) / LW, kRowIt = (kChunkSteps + 1 + LW - 1) / LW;
+        int in_ow[kOwIt], in_st[kStateInts];
+        int2 in_row[kRowIt];
+        int in_ck = -1, in_gtop = -1;                           // what the registers hold (this half-strip)
+        auto fetch_inputs = [&](int ck_, int gtop_) {
+            const int g0_ = ck_ * kChunk, k0_ = g0_ * SPG;
+            const int nsteps_ = (gtop_ - g0_ + 1) * SPG;
+#pragma unroll
+            for (int it = 0; it < kOwIt; ++it) {
+                const int src = k0_ - lb - (LW - 1) + it * LW + lam;
+                in_ow[it] = (src >= 0 && src < m) ? a.o_codes[o0 + src] : 0xFFFF;
+            }
+            const int jlo_ = k0_ - lb, jhi_ = min(m, jlo_ + nsteps_);
+#pragma unroll
+            for (int it = 0; it < kRowIt; ++it) {
+                const int jj = min(jlo_ + it * LW + lam, jhi_);
+                if (hs == 0) in_row[it] = make_int2(bnd_V_row0(c, max(jj, 0)) + xadj6, bnd_D_row0(c, max(jj, 0)));
+                else {
+                    const int2 e = hrow[max(jj, 1)];
+                    in_row[it] = (jj <= 0) ? make_int2(0, bnd_D_col0(c, i_h)) : make_int2(enc_of(e.x), enc_of(e.y));
+                }
+            }
+            if (g0_ > 0) {
+                const int* stp = reinterpret_cast<const int*>(ws_p + ws.state(s, g0_ / kCkGroups)) + lb + lam;
+#pragma unroll
+                for (int q = 0; q < kStateInts; ++q) in_st[q] = stp[q * 64];
+            }
+            in_ck = ck_; in_gtop = gtop_;
+        };
+        while (in_strip) {
+            const int g0 = ck * kChunk;
+            const int k0 = g0 * SPG;
+            const int kvalid = ck > 0 ? k0 + 2 : 0;
+            const int nsteps_w = (g_top - g0 + 1) * SPG;
+            // Inputs of the re-fill, fetched into registers (fetch_inputs): (a) OCR codes ow[i] = o[(k0 - lb - 31) + i],
+            // (b) the row above, hvt[jj - (k0 - lb)] for columns jj, (c) the lane state at group g0.  The chunk after
+            // this one is nearly always the one before it in the same half-strip, whole: its inputs are requested as
+            // soon as this chunk's are in LDS and arrive under this chunk's re-fill and walk.
+            if (in_ck != ck || in_gtop != g_top) fetch_inputs(ck, g_top);
+#pragma unroll
+            for (int it = 0; it < kOwIt; ++it) {
+                const int i = it * LW + lam;
+                if (i < nsteps_w + LW) ow[i] = (uint16_t)in_ow[it];
+            }
+            const int jlo = k0 - lb, jhi = min(m, jlo + nsteps_w);
+#pragma unroll
+            for (int it = 0; it < kRowIt; ++it) {
+                const int jj = jlo + it * LW + lam;
+                if (jj <= jhi) hvt[jj - jlo] = in_row[it];
+            }
+            int D[R], V[R], H[R], dsave;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int i = row0 + rr + 1;
+                V[rr] = 0;
+                D[rr] = bnd_D_col0(c, i);
+                H[rr] = bnd_H_col0(c, i) + yadj6;
+            }
+            dsave = bnd_D_col0(c, row0);
+            if (g0 > 0 && lb + lam < k0) {
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) { D[rr] = enc_of(in_st[rr]); H[rr] = enc_of(in_st[R + rr]); }
+                V[R - 1] = enc_of(in_st[2 * R]);
+                dsave = enc_of(in_st[2 * R + 1]);
+            }
+            if (ck > 0) fetch_inputs(ck - 1, g0);              // the likely next chunk (the registers are free again)
+            wave_sync();
+            // (d) tagged re-fill of groups g0 .. g_top
+            {
+                const int top_steps = ((k >> 2) == g_top) ? (k & 3) + 1 : SPG;
+                if (carried && c.gox == c.goy) refill_half<true, true>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lam, lb, lane_has_rows, top_steps);
+                else if (carried) refill_half<true, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lam, lb, lane_has_rows, top_steps);
+                else refill_half<false, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lam, lb, lane_has_rows, top_steps);
+            }
+            wave_sync();
+            // (e) walk the chunk
+            const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
+            if (pend) {                                        // (x, y): last row of this half-strip, step k of this chunk
+                const int2 e = hvb[k - k0];
+                st = 2 - (((pend == 3) ? e.y : e.x) & 3);
+                pend = 0;
+                if (probe) {                                   // that was the start state: back to (n, m)
+                    probe = false; first = false;
+                    x = n; y = m;
+                    break;
+                }
+            }
+            if (first && k >= kvalid) {                        // start state, textSeqCompare.py:102
+                st = ptr_pm(wb[(((k >> 2) - g0) * LW + (l - lb)) * 16 + (k & 3) * R + r]);
+                first = false;
+            }
+            len += walk_half(win, g0, kvalid, i_h, lb, x, y, st, ops + (cap - 1 - len), cap - len, lam, half);
+            if (st >= 3) { pend = st; st = 0; }                // left the half-strip upwards: state pending
+            l = (x > i_h) ? ((x - 1) % L::SR) / R : -1;
+            r = (x - 1) & (R - 1);
+            k = (y - 1) + l;
+            if ((x <= 0) | (y <= 0) | (l < lb)) {
+                in_strip = false;                              // the walk left the half-strip or finished
+            } else if (k >= kvalid) {
+                g_top = k >> 2;                                // (not reached: whole half-strip chunks are kept)
+            } else {
+                g_top = g0;                                    // the chunk before, through its halo
+                ck -= 1;
+            }
+        }
+    }
+    while (y > 0) { if (lam == 0) ops[cap - 1 - len] = 2; ++len; --y; }
+    while (x > 0) { if (lam == 0) ops[cap - 1 - len] = 1; ++len; --x; }
+    if (alive && lam == 0) a.ops_len[p] = len;
 }
 
 }  // namespace ta
@@ -1272,8 +1624,10 @@ extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
         // 64 x 2048^2 0.63 / 0.41 / 0.29 ms with 1 / 2 / 4 waves, 512 x 0.66 / 0.55 / 0.39, 768 x 0.66 / 0.56 / 0.62,
         // 1024 x 0.67 / 0.55 / 0.75, 1280 x 0.88 / 0.89 / 0.95; 256 x 4096^2 1.26 / 0.83 / 0.59)
         int tbw = (int)((flags >> TA_NW_TBWAVES_SHIFT) & 0x7u);
-        if (tbw != 1 && tbw != 2 && tbw != 4) tbw = nprob <= 640 ? 4 : nprob <= 1152 ? 2 : 1;
-        if (tbw == 4) hipLaunchKernelGGL(nw_trace2w_kernel<4>, dim3(nprob), dim3(256), 0, st, a);
+        // beyond that: two problems per wave on half-strips (nw_trace2h_kernel; TA_NW_TBWAVES(3))
+        if (tbw != 1 && tbw != 2 && tbw != 3 && tbw != 4) tbw = nprob <= 640 ? 4 : nprob <= 1152 ? 2 : 3;
+        if (tbw == 3) hipLaunchKernelGGL(nw_trace2h_kernel, dim3((nprob + 1) / 2), dim3(64), 0, st, a);
+        else if (tbw == 4) hipLaunchKernelGGL(nw_trace2w_kernel<4>, dim3(nprob), dim3(256), 0, st, a);
         else if (tbw == 2) hipLaunchKernelGGL(nw_trace2w_kernel<2>, dim3(nprob), dim3(128), 0, st, a);
         else hipLaunchKernelGGL(nw_trace2_kernel, dim3(nprob), dim3(64), 0, st, a);
         hipError_t e = hipGetLastError();
