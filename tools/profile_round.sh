@@ -12,13 +12,15 @@
 # 4. matrix-pipe counters of the recogniser kernels (1920 lines, both modes) -> <round>_ocr_pmc_mfma.json
 # then (where gpurun_out/ was merged back): python3 tools/profile_summarise.py <round> gpurun_out/prof_<round>
 set -eo pipefail
-ROUND=${1:-r03}
+ROUND=${1:-r04}
+PART=${2:-all}           # traces | pmc | all (a gpurun call is limited to 20 minutes: run the two parts in two calls)
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$ROUND
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-NW="--steps 5 --warmup 2 --no-cpu-baseline --no-pipelined --no-configs --no-ocr --pages 0"
+if [ "$PART" = all ] || [ "$PART" = traces ]; then
+NW="--steps 5 --warmup 2 --no-cpu-baseline --no-configs --no-ocr --pages 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_nw" -o nw -- python3 "$REPO/bench.py" $NW > "$OUT/kt_nw.log" 2>&1
 echo "nw kernel trace done"
 for w in "1 4096 4096" "64 4096 4096" "1 8192 8192"; do
@@ -30,7 +32,7 @@ done
 # streams, ocr.LineRecognizer.run; its own trace follows)
 export TA_OCR_CLASS_SPLIT=0
 export TA_OCR_GROUP=16            # the 16-line recurrence kernel (the product's choice above 2 048 lines)
-for w in "1920 f32" "1920 split" "5760 f32"; do
+for w in "1920 f32" "1920 split" "5760 f32" "1920 f64"; do
   set -- $w
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_$1_$2" -o ocr -- python3 "$REPO/tools/ocr_only.py" $1 $2 > "$OUT/kt_ocr_$1_$2.log" 2>&1
   echo "ocr $1 $2 kernel trace done"
@@ -46,13 +48,23 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 echo "ocr 1920 split (length classes) kernel trace done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_pages_images" -o pg -- python3 "$REPO/tools/pages_img_time.py" 32 8 1 > "$OUT/kt_pages_images.log" 2>&1
 echo "page images kernel trace done"
+# BASELINE configs[1] (1024 x 2048^2) and the grid search (2187 x 800 x 900, per-problem systems): kernel traces
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_nw_c2" -o nw -- python3 "$REPO/tools/p1_time.py" profile auto 1024 2048 2048 > "$OUT/kt_nw_c2.log" 2>&1
+echo "C2 kernel trace done"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_nw_grid_search" -o nw -- python3 "$REPO/tools/grid_search_time.py" > "$OUT/kt_nw_grid_search.log" 2>&1
+echo "grid search kernel trace done"
+fi
+if [ "$PART" = all ] || [ "$PART" = pmc ]; then
 for mode in two one; do
   flag=""; [ $mode = one ] && flag="--one-pass"
   for ctr in WRITE_SIZE FETCH_SIZE; do
-    timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/${mode}_$ctr" -o nw -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-pipelined --no-configs --no-ocr --pages 0 $flag > "$OUT/${mode}_$ctr.log" 2>&1
+    timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/${mode}_$ctr" -o nw -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-configs --no-ocr --pages 0 $flag > "$OUT/${mode}_$ctr.log" 2>&1
     echo "$mode $ctr done"
   done
 done
+# SQ counters of the NW kernels (headline batch): VALU instructions, VALU-active and wave cycles, issue stalls
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/nw_pmc_sq" -o nw -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-configs --no-ocr --pages 0 > "$OUT/nw_pmc_sq.log" 2>&1
+echo "nw sq counters done"
 export TA_OCR_CLASS_SPLIT=0
 export TA_OCR_GROUP=16
 for prec in split f32; do
@@ -62,5 +74,11 @@ done
 export TA_OCR_GROUP=4
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_f32g4" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f32 > "$OUT/ocr_pmc_f32g4.log" 2>&1
 echo "ocr pmc f32 groups of 4 done"
+# where the non-MFMA third of a step of the four-line kernel goes: LDS waits / instruction counts, parked cycles
+timeout -k 10 300 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d "$OUT/ocr_pmc_f32g4_waits" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f32 > "$OUT/ocr_pmc_f32g4_waits.log" 2>&1
+echo "ocr wait counters (groups of 4) done"
 unset TA_OCR_GROUP
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_f64" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f64 > "$OUT/ocr_pmc_f64.log" 2>&1
+echo "ocr pmc f64 done"
+fi
 echo "now run: python3 tools/profile_summarise.py $ROUND gpurun_out/prof_$ROUND"

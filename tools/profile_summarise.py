@@ -57,7 +57,7 @@ def main():
             json.dump(doc, fh, indent=1)
     # matrix-pipe counters of the recogniser kernels
     kernels = {}
-    for prec in ("split", "f32", "f32g4"):
+    for prec in ("split", "f32", "f32g4", "f64"):
         path = os.path.join(out, "ocr_pmc_" + prec)
         if not os.path.isdir(path):
             continue
@@ -81,6 +81,34 @@ def main():
                        "reading": "GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES"
                                   " / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)",
                        "kernels": kernels}, fh, indent=1)
+    # SQ counters of the NW kernels (headline batch) and the wait counters of the four-line recurrence kernel
+    for sub, fname, only, note in (
+            ("nw_pmc_sq", "%s_nw_pmc_sq.json", "nw_",
+             "SQ_* counters count quad-cycles (MI355X_MICROARCH.md); VALU issue share = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES; "
+             "instructions per wave-cycle etc. follow from the raw means"),
+            ("ocr_pmc_f32g4_waits", "%s_ocr_pmc_waits_f32g4.json", "lstm_",
+             "SQ_WAIT_ANY = wave parked (s_waitcnt / barrier), SQ_WAIT_INST_ANY = issue stall, SQ_WAIT_INST_LDS = LDS issue stall; "
+             "WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES")):
+        path = os.path.join(out, sub)
+        if not os.path.isdir(path):
+            continue
+        per = {}
+        for f in glob.glob(os.path.join(path, "**", "*counter_collection.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if only not in row["Kernel_Name"]:
+                        continue
+                    d = per.setdefault(row["Kernel_Name"], {}).setdefault(row["Counter_Name"], [0.0, 0])
+                    d[0] += float(row["Counter_Value"]); d[1] += 1
+        kernels = {k: {c: v[0] / v[1] for c, v in d.items()} for k, d in per.items()}
+        for k, d in kernels.items():
+            if d.get("SQ_WAVE_CYCLES"):
+                for c in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_LDS"):
+                    if c in d:
+                        d[c + "_share_of_wave_cycles"] = d[c] / d["SQ_WAVE_CYCLES"]
+        with open(os.path.join(prof, fname % rnd), "w") as fh:
+            json.dump({"command": "rocprofv3 --pmc <counters below> --output-format csv -- see tools/profile_round.sh (" + sub + ")",
+                       "reading": note, "kernels": kernels}, fh, indent=1)
     print("profiles updated")
 
 
