@@ -179,40 +179,41 @@ def _cpu_model():
     return "unknown"
 
 
-def ocr_cpu_baseline(model_seed, no, seconds=8.0):
-    """oracle/ocr_ref_f64.py on one host core, and on TWO processes -- the reference runs `ocropus-rpred -Q 2`
-    (alignToOCR.py:24, :142-143): two worker processes, one line each at a time."""
-    from oracle import ocr_ref_f64 as R
-    om = R.synthetic_model(model_seed, no=no)
-    done, steps, t0 = 0, 0, time.perf_counter()
-    while True:
-        xs = R.synthetic_line(8000 + done, width=1000)
-        R.recognise(om, xs)
-        done += 1
-        steps += xs.shape[0]
-        dt = time.perf_counter() - t0
-        if dt > seconds:
-            break
-    out = {"value": done / dt, "unit": "lines/s", "cores": 1, "kind": "port",
-           "sample": "%d lines of width 1000 (T = 1032) through oracle/ocr_ref_f64.py, %.1f s" % (done, dt)}
+def ocr_cpu_baseline(model_seed, no, nlines=60):
+    """oracle/ocr_ref_f64.py on ONE host core, and on TWO processes -- the reference runs `ocropus-rpred -Q 2`
+    (alignToOCR.py:24, :142-143): two worker processes, one line each at a time.  Both as child interpreters with one
+    BLAS thread each (the 100 x 149 products of the loop are far too small for a threaded BLAS, which only slows them
+    down); each child times its own loop, interpreter start excluded."""
     import subprocess
-    per = max(2, done // 2)
-    code = ("import sys, os; sys.path.insert(0, %r); os.environ.setdefault('OMP_NUM_THREADS', '1'); "
-            "from oracle import ocr_ref_f64 as R; om = R.synthetic_model(%d, no=%d); s0 = int(sys.argv[1]); "
-            "[R.recognise(om, R.synthetic_line(s0 + k, width=1000)) for k in range(%d)]" % (REPO, model_seed, no, per))
-    t0 = time.perf_counter()
-    procs = [subprocess.Popen([sys.executable, "-c", code, str(8100 + per * k)]) for k in range(2)]
-    ok = True
-    for pr in procs:
-        try:
-            ok = (pr.wait(timeout=max(1.0, 90.0 - (time.perf_counter() - t0))) == 0) and ok
-        except subprocess.TimeoutExpired:
-            pr.kill()
-            ok = False
-    dt2 = time.perf_counter() - t0
-    out["two_processes"] = ({"value": 2 * per / dt2, "unit": "lines/s", "cores": 2,
-                             "sample": "2 processes x %d lines of width 1000 (the reference's -Q 2), %.1f s incl. "
-                                       "interpreter start" % (per, dt2)} if ok else {"error": "a worker failed or timed out"})
+    code = ("import sys, os, time; sys.path.insert(0, %r); os.environ['OMP_NUM_THREADS'] = '1'; "
+            "os.environ['OPENBLAS_NUM_THREADS'] = '1'; os.environ['MKL_NUM_THREADS'] = '1'; "
+            "from oracle import ocr_ref_f64 as R; om = R.synthetic_model(%d, no=%d); s0, k = int(sys.argv[1]), int(sys.argv[2]); "
+            "lines = [R.synthetic_line(s0 + i, width=1000) for i in range(k)]; t0 = time.perf_counter(); "
+            "[R.recognise(om, xs) for xs in lines]; print(time.perf_counter() - t0)" % (REPO, model_seed, no))
+
+    def run(nproc, per):
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, "-c", code, str(8000 + per * k), str(per)], stdout=subprocess.PIPE, text=True)
+                 for k in range(nproc)]
+        secs = []
+        for pr in procs:
+            try:
+                out, _ = pr.communicate(timeout=max(1.0, 120.0 - (time.perf_counter() - t0)))
+                secs.append(float(out.strip().splitlines()[-1]))
+            except (subprocess.TimeoutExpired, ValueError, IndexError):
+                pr.kill()
+                return None
+        return max(secs)
+    one = run(1, nlines)
+    if one is None:
+        return {"error": "the baseline child failed or timed out"}
+    out = {"value": nlines / one, "unit": "lines/s", "cores": 1, "kind": "port",
+           "sample": "%d lines of width 1000 (T = 1032) through oracle/ocr_ref_f64.py in one process, one BLAS thread, %.1f s"
+                     % (nlines, one)}
+    two = run(2, nlines // 2)
+    out["two_processes"] = ({"value": 2 * (nlines // 2) / two, "unit": "lines/s", "cores": 2,
+                             "sample": "2 processes x %d lines of width 1000 (the reference's -Q 2), %.1f s" % (nlines // 2, two)}
+                            if two is not None else {"error": "a worker failed or timed out"})
     return out
 
 
@@ -322,7 +323,7 @@ def nw_roofline(batch, kname, fill_ms, tb_ms, traffic, traffic_src):
             "frac": fill_rate / 1e9 / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_src,
             "kernel": kname, "kernel_ms": fill_ms, "traceback_ms": tb_ms,
-            "traceback_kernel": "nw_trace2_kernel" if batch.two_phase else "nw_traceback_kernel",
+            "traceback_kernel": batch.traceback_kernel(),
             "algorithmic_bytes_per_cell": 1,
             "step_ms": step_ms, "step_frac": cells / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "step_is": "fill + traceback device time, the metric as SURVEY.md 8(d) defines it; frac is the "
@@ -372,7 +373,7 @@ def nw_configs(tsc, torch):
         want = [nw_oracle.align_ids(t, o, DEFAULT_SYS).tolist() for t, o in uniq]
         ok = all(res[k].tolist() == want[k % distinct] for k in range(nprob))
         rows.append({"config": name, "problems": nprob, "n": n, "m": m,
-                     "mode": "two-phase" if batch.two_phase else "one-pass",
+                     "mode": "two-phase" if batch.two_phase else "one-pass", "traceback_kernel": batch.traceback_kernel(),
                      "ms": total, "fill_ms": fill, "traceback_ms": tb,
                      "cells_per_s": batch.cells / (total * 1e-3),
                      "frac": batch.cells / (total * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -405,7 +406,8 @@ def nw_grid_search(tsc, torch):
     ok = all(res[k].tolist() == nw_oracle.align_ids(pages[k // len(grid)][0], pages[k // len(grid)][1],
                                                      [int(v) for v in params[k]]).tolist() for k in sample)
     out = {"problems": nprob, "n": n, "m": m, "scoring_systems": len(grid), "pages": 3,
-           "mode": "two-phase" if batch.two_phase else "one-pass", "launches": 1,
+           "mode": "two-phase" if batch.two_phase else "one-pass", "traceback_kernel": batch.traceback_kernel(),
+           "launches": 1,
            "ms": total, "fill_ms": fill, "traceback_ms": tb, "cells_per_s": batch.cells / (total * 1e-3),
            "frac": batch.cells / (total * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "bit_exact": bool(ok), "problems_checked": len(sample),

@@ -136,6 +136,10 @@ int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
                  int32_t max_n, int32_t max_m, int64_t score_bound,
                  uint32_t flags, void* stream);
 
+/* What phase 2 (the traceback) of ta_nw2_batch launches for a batch of nprob problems: 1, 2 or 4 = waves per problem
+ * (nw_trace2_kernel / nw_trace2w_kernel), 3 = two problems per wave on half-strips (nw_trace2h_kernel: batches that
+ * fill the chip and share one scoring system).  Pure host function. */
+int32_t ta_nw2_traceback_plan(int32_t nprob, int32_t params_stride, uint32_t flags);
 /* What phase 1 of ta_nw2_batch would launch for a batch whose tallest / widest problem is
  * max_n x max_m under `flags` (the hints above): out[0] = 1 compare-select cell, 2 score profile
  * in LDS; out[1] = waves per workgroup; out[2] = dynamic LDS bytes per workgroup; out[3] = 1 if the

@@ -53,6 +53,8 @@ def _load():
     lib.ta_nw2_workspace_bytes.argtypes = [i32, i32]
     lib.ta_nw2_batch.restype = ctypes.c_int
     lib.ta_nw2_batch.argtypes = lib.ta_nw_batch.argtypes
+    lib.ta_nw2_traceback_plan.restype = i32
+    lib.ta_nw2_traceback_plan.argtypes = [i32, i32, ctypes.c_uint32]
     lib.ta_nw2_phase1_plan.restype = ctypes.c_int
     lib.ta_nw2_phase1_plan.argtypes = [i32, i32, ctypes.c_uint32, ctypes.c_void_p]
     lib.ta_nw2_phase1_plan_batch.restype = ctypes.c_int
@@ -111,7 +113,7 @@ def _load():
 
 lib = _load()
 
-EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_max_m", "ta_nw2_batch", "ta_nw2_phase1_plan", "ta_nw2_phase1_plan_batch",
+EXPORTS = ["ta_version", "ta_last_error", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_max_m", "ta_nw2_batch", "ta_nw2_phase1_plan", "ta_nw2_phase1_plan_batch", "ta_nw2_traceback_plan",
            "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general", "ta_nw_general_batch",
            "ta_lstm_packed_weight_floats", "ta_lstm_forward", "ta_lstm_f64_weight_doubles", "ta_lstm_f64_gx_bytes", "ta_lstm_xproj_f64", "ta_lstm_forward_f64", "ta_lstm_output", "ta_lstm_output_split_weight_bytes", "ta_lstm_output_split", "ta_decode",
            "ta_decode_summary", "ta_linenorm_measure", "ta_linenorm_resample",

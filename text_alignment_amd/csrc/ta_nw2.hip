@@ -1593,6 +1593,13 @@ static hipError_t launch_score(NwArgs a, int max_n, int max_m, uint32_t flags, h
     }
 }
 
+// Phase-2 launch shape: waves per problem 1, 2 or 4, or 3 = two problems per wave on half-strips.
+extern "C" int32_t ta_nw2_traceback_plan(int32_t nprob, int32_t params_stride, uint32_t flags) {
+    const int tbw = (int)((flags >> TA_NW_TBWAVES_SHIFT) & 0x7u);
+    if (tbw == 1 || tbw == 2 || tbw == 3 || tbw == 4) return tbw;
+    return nprob <= 640 ? 4 : nprob <= 1152 ? 2 : params_stride == 0 ? 3 : 1;
+}
+
 extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
                             const int32_t* o_codes, const int64_t* o_off, int32_t nprob,
                             const int32_t* params, int32_t params_stride,
@@ -1624,8 +1631,12 @@ extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
         // 64 x 2048^2 0.63 / 0.41 / 0.29 ms with 1 / 2 / 4 waves, 512 x 0.66 / 0.55 / 0.39, 768 x 0.66 / 0.56 / 0.62,
         // 1024 x 0.67 / 0.55 / 0.75, 1280 x 0.88 / 0.89 / 0.95; 256 x 4096^2 1.26 / 0.83 / 0.59)
         int tbw = (int)((flags >> TA_NW_TBWAVES_SHIFT) & 0x7u);
-        // beyond that: two problems per wave on half-strips (nw_trace2h_kernel; TA_NW_TBWAVES(3))
-        if (tbw != 1 && tbw != 2 && tbw != 3 && tbw != 4) tbw = nprob <= 640 ? 4 : nprob <= 1152 ? 2 : 3;
+        // beyond that: two problems per wave on half-strips (nw_trace2h_kernel; TA_NW_TBWAVES(3)) -- when the batch
+        // shares one scoring system: the two halves of a wave run in lockstep, and problems scored differently
+        // have paths of very different length (the grid search, 2187 x 800 x 900 with a system per problem: 0.76 ms
+        // against 0.59 with one wave per problem; the same shape under one system 0.52 against 0.53)
+        if (tbw != 1 && tbw != 2 && tbw != 3 && tbw != 4)
+            tbw = nprob <= 640 ? 4 : nprob <= 1152 ? 2 : params_stride == 0 ? 3 : 1;
         if (tbw == 3) hipLaunchKernelGGL(nw_trace2h_kernel, dim3((nprob + 1) / 2), dim3(64), 0, st, a);
         else if (tbw == 4) hipLaunchKernelGGL(nw_trace2w_kernel<4>, dim3(nprob), dim3(256), 0, st, a);
         else if (tbw == 2) hipLaunchKernelGGL(nw_trace2w_kernel<2>, dim3(nprob), dim3(128), 0, st, a);

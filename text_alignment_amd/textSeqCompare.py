@@ -208,6 +208,13 @@ class NWBatch(object):
             flags |= (int(self.tb_waves) & 0x7) << _native.TA_NW_TBWAVES_SHIFT
         return flags
 
+    def traceback_kernel(self):
+        """name of the traceback kernel run() launches for this batch (bench / profile labels)"""
+        if not self.two_phase:
+            return "nw_traceback_kernel"
+        w = _native.lib.ta_nw2_traceback_plan(self.nprob, self.params_stride, self.phase1_flags())
+        return {1: "nw_trace2_kernel", 2: "nw_trace2w_kernel<2>", 4: "nw_trace2w_kernel<4>", 3: "nw_trace2h_kernel"}[w]
+
     def results(self):
         """Host copies of the alignment columns, one uint8 array per problem."""
         if self.nprob == 0:

@@ -20,7 +20,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 if [ "$PART" = all ] || [ "$PART" = traces ]; then
-NW="--steps 5 --warmup 2 --no-cpu-baseline --no-configs --no-ocr --pages 0"
+NW="--steps 20 --warmup 3 --no-cpu-baseline --no-configs --no-ocr --pages 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_nw" -o nw -- python3 "$REPO/bench.py" $NW > "$OUT/kt_nw.log" 2>&1
 echo "nw kernel trace done"
 for w in "1 4096 4096" "64 4096 4096" "1 8192 8192"; do
