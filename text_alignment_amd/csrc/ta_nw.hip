@@ -211,6 +211,15 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
                     // operation each -- have been issued since its stores, so once all but the XCHK / 2
                     // youngest operations are done, they are.  The last export of a strip drains.
                     int* const word = &gprog[s / W];
+                    // The invariant this rests on, spelled out so that a change trips over it: between two exports
+                    // this wave issues AT LEAST kVmemPerGroup vector-memory operations per group (today exactly one:
+                    // the group's 16-byte pointer store; more per group only makes the wait stricter), vmcnt retires
+                    // them in issue order, so "all but the XCHK / 2 youngest are done" implies the previous export's
+                    // stores -- XCHK * kVmemPerGroup >= XCHK / 2 operations older -- are done.  Batching the pointer
+                    // stores of several groups into one instruction would break it: lower XCHK / 2 with it.
+                    constexpr int kVmemPerGroup = 1;
+                    static_assert(XCHK % 2 == 0 && XCHK * kVmemPerGroup >= XCHK / 2 && XCHK / 2 >= 1 && XCHK / 2 <= 63,
+                                  "the progress word of an export follows its stores by a counted vmcnt wait");
                     if (exp_pending > 0 && g != ngroups - 1) {    // (the last export may follow the one before closely: it drains)
                         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(XCHK / 2) : "memory");
                         if (lane == 0) __hip_atomic_store(word, exp_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
