@@ -1340,6 +1340,13 @@ __global__ __launch_bounds__(64) void nw_trace2h_kernel(NwArgs a) {
     const int xadj6 = xadj * 64, yadj6 = yadj * 64;
     const Ws2 ws(max(n, 1), max(m, 1));
     uint8_t* const ws_p = a.ws + a.ws_off[p];
+#if TA_P2_PROFILE
+    // (wave-level clocks: the halves move in lockstep, so a phase's time is the slower half's; pc_groups / pc_iters
+    // count THIS half's own re-filled groups and walk iterations)
+    long long pc_setup = 0, pc_fill = 0, pc_walk = 0, pc_chunks = 0, pc_t = __builtin_readcyclecounter(), pc_groups = 0;
+    const long long pc_start = pc_t;
+    long long pc_iters = 0;
+#endif
 
     while (x > 0 && y > 0) {
         const int hs = (x - 1) / SRH;                           // half-strip the walk is in: strip hs / 2, lanes lb ..
@@ -1429,6 +1436,7 @@ __global__ __launch_bounds__(64) void nw_trace2h_kernel(NwArgs a) {
             }
             if (ck > 0) fetch_inputs(ck - 1, g0);              // the likely next chunk (the registers are free again)
             wave_sync();
+            PC_LAP(pc_setup)
             // (d) tagged re-fill of groups g0 .. g_top
             {
                 const int top_steps = ((k >> 2) == g_top) ? (k & 3) + 1 : SPG;
@@ -1437,6 +1445,10 @@ __global__ __launch_bounds__(64) void nw_trace2h_kernel(NwArgs a) {
                 else refill_half<false, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lam, lb, lane_has_rows, top_steps);
             }
             wave_sync();
+            PC_LAP(pc_fill)
+#if TA_P2_PROFILE
+            pc_chunks += 1; pc_groups += g_top - g0 + 1;
+#endif
             // (e) walk the chunk
             const uint8_t* wb = reinterpret_cast<const uint8_t*>(win);
             if (pend) {                                        // (x, y): last row of this half-strip, step k of this chunk
@@ -1455,6 +1467,7 @@ __global__ __launch_bounds__(64) void nw_trace2h_kernel(NwArgs a) {
             }
             len += walk_half(win, g0, kvalid, i_h, lb, x, y, st, ops + (cap - 1 - len), cap - len, lam, half);
             if (st >= 3) { pend = st; st = 0; }                // left the half-strip upwards: state pending
+            PC_LAP(pc_walk)
             l = (x > i_h) ? ((x - 1) % L::SR) / R : -1;
             r = (x - 1) & (R - 1);
             k = (y - 1) + l;
@@ -1471,6 +1484,13 @@ __global__ __launch_bounds__(64) void nw_trace2h_kernel(NwArgs a) {
     while (y > 0) { if (lam == 0) ops[cap - 1 - len] = 2; ++len; --y; }
     while (x > 0) { if (lam == 0) ops[cap - 1 - len] = 1; ++len; --x; }
     if (alive && lam == 0) a.ops_len[p] = len;
+#if TA_P2_PROFILE
+    if (alive && lam == 0) {                           // row 0 of the workspace is phase 1's: free by now
+        long long* out = reinterpret_cast<long long*>(ws_p + ws.row(0));
+        out[0] = pc_setup; out[1] = pc_fill; out[2] = pc_walk; out[3] = pc_chunks; out[4] = pc_groups; out[5] = len;
+        out[6] = pc_iters; out[7] = __builtin_readcyclecounter() - pc_start;
+    }
+#endif
 }
 
 }  // namespace ta
