@@ -909,6 +909,32 @@ __device__ __forceinline__ TbJob tb_job_at(int x, int y) {
     return TbJob{s, ck, k >> 2, (k & 3) + 1};
 }
 
+// The job d iterations after the one that starts at (x, y) as job j, if the path keeps to the diagonal: chunk after
+// chunk through the halo while the strip lasts (k falls by 5/4 per diagonal step: a column and a quarter lane), then
+// the chunk of the strip above that the diagonal enters -- with two groups of margin on its entry group, whole groups:
+// a re-fill that went further than the walk's entry point serves it as well (tb_serves).
+__device__ __forceinline__ TbJob tb_predict(int x, int y, TbJob j, int d) {
+    for (; d > 0 && j.s >= 0; --d) {
+        const int l = ((x - 1) % 256) / 4, k = (y - 1) + l;
+        const int to_top = x - j.s * 256;                        // diagonal steps until the walk leaves the strip
+        const int to_halo = j.ck > 0 ? ((k - (j.ck * kChunk * 4 + 1)) * 4 + 4) / 5 : (1 << 28);
+        if (to_halo < to_top) {
+            x -= to_halo; y -= to_halo;
+            j = (y > 0) ? tb_prev_job(j) : TbJob{-1, 0, 0, 0};
+        } else {
+            x -= to_top; y -= to_top;
+            j = tb_job_at(x, y);
+            if (j.s >= 0) { j.gtop = min(j.gtop + 2, j.ck * kChunk + kChunk); j.tops = 4; }
+        }
+    }
+    return j;
+}
+// a window re-filled for `spec` holds everything the walk of job `j` reads: same chunk, re-filled at least as far
+__device__ __forceinline__ bool tb_serves(const TbJob& spec, const TbJob& j) {
+    return spec.s >= 0 && spec.s == j.s && spec.ck == j.ck &&
+           (spec.gtop > j.gtop || (spec.gtop == j.gtop && spec.tops >= j.tops));
+}
+
 struct TbTok { int x, y, st, len, pend, flags; TbJob job; };  // flags: 1 first, 2 probe, 4 done
 constexpr int kTokInts = 10;
 
@@ -1039,7 +1065,8 @@ __global__ __launch_bounds__(64 * NWV) void nw_trace2w_kernel(NwArgs a) {
     for (int i = wave; ; i += NWV) {
         // (1) speculation + (2) the token of iteration i - 1.  While that token is not there, the wave re-fills the
         // job its iteration will most likely be: the job of the NEWEST token published (iteration j < i - 1), moved
-        // back by the i - 1 - j iterations in between.  A newer token that changes the expectation (the walk left the
+        // on by the i - 1 - j iterations in between along the diagonal (tb_predict: the chunk before while the strip
+        // lasts, then the chunk of the strip above the diagonal enters).  A newer token that changes the expectation (the walk left the
         // strip) replaces the speculation at once -- the waves behind the one that must re-fill the new strip's
         // first chunk re-fill its second, third ... beside it instead of one after the other.
         TbJob spec{-1, 0, 0, 0};
@@ -1052,14 +1079,16 @@ __global__ __launch_bounds__(64 * NWV) void nw_trace2w_kernel(NwArgs a) {
                 const int from = max(kt, have - 1);              // newest token to go by: the one held, or a fresher one
                 if (from != based_on) {
                     based_on = from;
-                    TbJob want = T.job;                           // job of iteration from + 1
+                    TbJob want = T.job;                           // job of iteration from + 1, starting at (px, py)
+                    int px = T.x, py = T.y;
                     bool over = T.flags & 4;
                     if (from != kt) {                             // (its slot is not rewritten before iteration from + NWV > i)
                         const int* tj = tok_s[from % NWV];
                         want = TbJob{tj[6], tj[7], tj[8], tj[9]};
+                        px = tj[0]; py = tj[1];
                         over = tj[5] & 4;
                     }
-                    for (int d = 0; d < i - from - 1; ++d) want = tb_prev_job(want);
+                    want = tb_predict(px, py, want, i - from - 1);
                     if (!over && want.s >= 0 &&
                         !(spec.s >= 0 && want.s == spec.s && want.ck == spec.ck && want.gtop == spec.gtop)) {
                         spec = want;
@@ -1089,7 +1118,7 @@ __global__ __launch_bounds__(64 * NWV) void nw_trace2w_kernel(NwArgs a) {
         }
         // (3) the chunk itself, unless the speculation was right
         const TbJob J = T.job;
-        if (!(spec.s == J.s && spec.ck == J.ck && spec.gtop == J.gtop && spec.tops >= J.tops && spec.s >= 0)) refill(J);
+        if (!tb_serves(spec, J)) refill(J);
         // (4) walk (nw_trace2_kernel, step (e))
         int x = T.x, y = T.y, st = T.st, len = T.len, pend = T.pend;
         bool first = T.flags & 1, probe = T.flags & 2;
