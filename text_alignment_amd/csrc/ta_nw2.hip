@@ -1645,11 +1645,19 @@ static hipError_t launch_score(NwArgs a, int max_n, int max_m, uint32_t flags, h
     }
 }
 
-// Phase-2 launch shape: waves per problem 1, 2 or 4, or 3 = two problems per wave on half-strips.
+// Phase-2 launch shape: waves per problem 1, 2 or 4, or 3 = two problems per wave on half-strips.  By batch size,
+// from measurements at 2048^2 / 4096^2 (tools/tb_waves_time.py, profiles/r04_traceback_waves_per_problem.txt; ms
+// with 1 / 2 / 4 waves / half-strip pairs): 64 x 2048^2 0.63 / 0.36 / 0.22 / 0.86, 768 x 0.66 / 0.49 / 0.47 / 0.86,
+// 1024 x 0.67 / 0.51 / 0.57 / 0.87 (four-wave workgroups hold 75 KB of LDS: two per CU, 512 at a time, so 1024 problems
+// are two rounds of them but one of two-wave workgroups), 1280 x 0.89 / 0.78 / 0.72 / 0.88, 1536 x 0.90 / 0.97 / 0.84 / 0.89, 2048 x 0.93 / 1.17 / 1.11 /
+// 0.90, 4096 x 4096^2 2.89 / 3.94 / 4.31 / 2.44.  Half-strip pairs only when the batch shares one scoring system.
 extern "C" int32_t ta_nw2_traceback_plan(int32_t nprob, int32_t params_stride, uint32_t flags) {
     const int tbw = (int)((flags >> TA_NW_TBWAVES_SHIFT) & 0x7u);
     if (tbw == 1 || tbw == 2 || tbw == 3 || tbw == 4) return tbw;
-    return nprob <= 640 ? 4 : nprob <= 1152 ? 2 : params_stride == 0 ? 3 : 1;
+    if (nprob <= 832) return 4;
+    if (nprob <= 1088) return 2;
+    if (nprob <= 1600) return 4;
+    return params_stride == 0 ? 3 : 1;
 }
 
 extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
@@ -1677,18 +1685,12 @@ extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
     }
     if (flags & TA_NW_TRACEBACK) {
         if (!ops_out && (max_n + max_m) > 0) return ta_fail(TA_EINVAL, "null ops_out");
-        // waves per problem: one when the batch alone fills the SIMDs (sixteen problems per CU and more); below
-        // that, two or four that speculate along the path (nw_trace2w_kernel) -- as many as keep the launch within
-        // about two waves per SIMD (1024 SIMDs) and within the CUs' LDS in one round (measured, tools/tb_waves_time.py:
-        // 64 x 2048^2 0.63 / 0.41 / 0.29 ms with 1 / 2 / 4 waves, 512 x 0.66 / 0.55 / 0.39, 768 x 0.66 / 0.56 / 0.62,
-        // 1024 x 0.67 / 0.55 / 0.75, 1280 x 0.88 / 0.89 / 0.95; 256 x 4096^2 1.26 / 0.83 / 0.59)
-        int tbw = (int)((flags >> TA_NW_TBWAVES_SHIFT) & 0x7u);
-        // beyond that: two problems per wave on half-strips (nw_trace2h_kernel; TA_NW_TBWAVES(3)) -- when the batch
-        // shares one scoring system: the two halves of a wave run in lockstep, and problems scored differently
-        // have paths of very different length (the grid search, 2187 x 800 x 900 with a system per problem: 0.76 ms
-        // against 0.59 with one wave per problem; the same shape under one system 0.52 against 0.53)
-        if (tbw != 1 && tbw != 2 && tbw != 3 && tbw != 4)
-            tbw = nprob <= 640 ? 4 : nprob <= 1152 ? 2 : params_stride == 0 ? 3 : 1;
+        // launch shape by batch size (ta_nw2_traceback_plan above): several waves per problem that speculate along the
+        // path for small and medium batches, two problems per wave on half-strips for batches that fill the chip and
+        // share one scoring system -- the two halves of a wave run in lockstep, and problems scored differently have
+        // paths of very different length (the grid search, 2187 x 800 x 900 with a system per problem: 0.76 ms against
+        // 0.59 with one wave per problem; the same shape under one system 0.52 against 0.53)
+        const int tbw = ta_nw2_traceback_plan(nprob, params_stride, flags);
         if (tbw == 3) hipLaunchKernelGGL(nw_trace2h_kernel, dim3((nprob + 1) / 2), dim3(64), 0, st, a);
         else if (tbw == 4) hipLaunchKernelGGL(nw_trace2w_kernel<4>, dim3(nprob), dim3(256), 0, st, a);
         else if (tbw == 2) hipLaunchKernelGGL(nw_trace2w_kernel<2>, dim3(nprob), dim3(128), 0, st, a);
