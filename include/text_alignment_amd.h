@@ -60,7 +60,8 @@ extern "C" {
 /* ta_nw2_batch, traceback launch shape (tests, timing): waves per problem of phase 2 -- 1 (one wave walks the chunks
  * one after the other), 2 or 4 (the chunks along the path dealt to the waves of a workgroup, each re-filling the
  * chunk it expects ahead of the walk), 3 (TWO problems per wave, 32 lanes each, walking back half-strips of 128 rows:
- * large batches); 0 = the library's choice by batch size.  Same results either way. */
+ * large batches), 5 / 6 (both: two / four waves per pair of problems on half-strips: medium batches); 0 = the library's
+ * choice by batch size.  Same results either way. */
 #define TA_NW_TBWAVES_SHIFT 24
 #define TA_NW_TBWAVES(w) (((uint32_t)(w) & 0x7u) << TA_NW_TBWAVES_SHIFT)
 #define TA_NW_NO_PROFILE 64u
@@ -138,7 +139,8 @@ int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
 
 /* What phase 2 (the traceback) of ta_nw2_batch launches for a batch of nprob problems: 1, 2 or 4 = waves per problem
  * (nw_trace2_kernel / nw_trace2w_kernel), 3 = two problems per wave on half-strips (nw_trace2h_kernel: batches that
- * fill the chip and share one scoring system).  Pure host function. */
+ * fill the chip and share one scoring system), 5 / 6 = two / four waves per pair of problems on half-strips
+ * (nw_trace2hw_kernel: medium batches under one scoring system).  Pure host function. */
 int32_t ta_nw2_traceback_plan(int32_t nprob, int32_t params_stride, uint32_t flags);
 /* What phase 1 of ta_nw2_batch would launch for a batch whose tallest / widest problem is
  * max_n x max_m under `flags` (the hints above): out[0] = 1 compare-select cell, 2 score profile

@@ -482,12 +482,13 @@ def test_two_phase_walk_runs_off_the_lane_window(tsc):
         assert (want == 1).sum() >= len(t_list[k]) - len(o_list[k])
 
 
-@pytest.mark.parametrize("tb_waves", [1, 2, 3, 4])
+@pytest.mark.parametrize("tb_waves", [1, 2, 3, 4, 5, 6])
 def test_two_phase_traceback_waves_per_problem(tsc, tb_waves):
     """Phase 2's launch shapes: one wave per problem (large batches) and two / four waves that deal the chunks of
     the path among themselves and re-fill the chunk each EXPECTS ahead of the walk (nw_trace2w_kernel; the library
     picks by batch size, TA_NW_TBWAVES forces; 3 = the large-batch shape: two problems per wave, each walking back
-    half-strips in 32 lanes, nw_trace2h_kernel).  Same alignments, bit for bit, on everything that stresses the
+    half-strips in 32 lanes, nw_trace2h_kernel; 5 / 6 = both at once: two / four waves per PAIR of problems on
+    half-strips, nw_trace2hw_kernel).  Same alignments, bit for bit, on everything that stresses the
     speculation: walks that start in a strip's first row (probe) and leave strips in every state (pending states),
     long gap runs (the expected chunk is wrong many times in a row: the walk leaves the strip early, or stays in a
     chunk's lane range for hundreds of columns), table edges, all-tie tables, ragged sizes from 0, two runs of the

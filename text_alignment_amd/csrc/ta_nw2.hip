@@ -1522,6 +1522,267 @@ __global__ __launch_bounds__(64) void nw_trace2h_kernel(NwArgs a) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// phase 2 for MEDIUM batches: both of the above at once -- two problems per wave on half-strips (nw_trace2h_kernel:
+// ~0.58 of the re-filled cells) AND several waves per pair of problems that re-fill the chunks they expect ahead of
+// the walk (nw_trace2w_kernel: the chain of set-up -> re-fill -> walk off the critical path).  A workgroup of NWV
+// waves owns two problems, one per 32 lanes of every wave; iteration i -- one chunk job of each problem -- belongs to
+// wave i mod NWV, which re-fills the jobs it expects for BOTH halves into its own LDS windows, waits for the tokens of
+// iteration i - 1 (one per half), re-fills again the halves whose expectation was wrong, walks both and passes the
+// tokens on.  A half whose problem is finished idles (its token says so); the workgroup leaves when both are.
+struct HJob { int hs, ck, gtop, tops; };                       // half-strip, chunk, last group, steps of it; hs < 0: none
+__device__ __forceinline__ HJob hjob_at(int x, int y) {
+    if (x <= 0 || y <= 0) return HJob{-1, 0, 0, 0};
+    const int l = ((x - 1) % 256) / 4, k = (y - 1) + l;
+    int ck = (k >> 2) / kChunk;
+    if (ck > 0 && k < ck * kChunk * 4 + 2) ck -= 1;              // a chunk's first two steps belong to the chunk before
+    return HJob{(x - 1) / (kHalfLanes * 4), ck, k >> 2, (k & 3) + 1};
+}
+__device__ __forceinline__ HJob hjob_prev(const HJob& j) {
+    if (j.hs < 0 || j.ck < 1) return HJob{-1, 0, 0, 0};
+    return HJob{j.hs, j.ck - 1, j.ck * kChunk, 2};
+}
+__device__ __forceinline__ HJob hjob_predict(int x, int y, HJob j, int d) {        // tb_predict on half-strips
+    for (; d > 0; --d) {
+        if (j.hs < 0) break;
+        const int l = ((x - 1) % 256) / 4, k = (y - 1) + l;
+        const int to_top = x - j.hs * (kHalfLanes * 4);
+        const int to_halo = j.ck > 0 ? ((k - (j.ck * kChunk * 4 + 1)) * 4 + 4) / 5 : (1 << 28);
+        if (to_halo < to_top) {
+            x -= to_halo; y -= to_halo;
+            j = (y > 0) ? hjob_prev(j) : HJob{-1, 0, 0, 0};
+        } else {
+            x -= to_top; y -= to_top;
+            j = hjob_at(x, y);
+            if (j.hs >= 0) { j.gtop = min(j.gtop + 2, j.ck * kChunk + kChunk); j.tops = 4; }
+        }
+    }
+    return j;
+}
+__device__ __forceinline__ bool hjob_serves(const HJob& spec, const HJob& j) {
+    return spec.hs >= 0 && spec.hs == j.hs && spec.ck == j.ck &&
+           (spec.gtop > j.gtop || (spec.gtop == j.gtop && spec.tops >= j.tops));
+}
+
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV) void nw_trace2hw_kernel(NwArgs a) {
+    constexpr int R = 4, LW = kHalfLanes, SRH = LW * R;
+    using L = PtrLayout<R>;
+    constexpr int SPG = L::SPG;
+    constexpr int kTok = 10;
+    __shared__ uint4 win_s[NWV][2][kChunkGroups * LW];
+    __shared__ int2 hvt_s[NWV][2][kChunkSteps + 8];
+    __shared__ int2 hvb_s[NWV][2][kChunkSteps];
+    __shared__ uint16_t ow_s[NWV][2][kChunkSteps + LW + 8];
+    __shared__ int tok_s[NWV][2][kTok];
+    __shared__ int seq_s;
+
+    const int lane = threadIdx.x & 63, half = lane >> 5, lam = lane & (LW - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pr = blockIdx.x * 2 + half;
+    const bool alive = pr < a.nprob;
+    const int p = alive ? pr : a.nprob - 1;
+    const int64_t t0 = a.t_off[p], o0 = a.o_off[p];
+    const int n = alive ? (int)(a.t_off[p + 1] - t0) : 0;
+    const int m = alive ? (int)(a.o_off[p + 1] - o0) : 0;
+    uint8_t* const ops = a.ops_out + a.ops_off[p];
+    const int cap = n + m;
+    uint4* const win = win_s[wave][half];
+    int2* const hvt = hvt_s[wave][half];
+    int2* const hvb = hvb_s[wave][half];
+    uint16_t* const ow = ow_s[wave][half];
+    if (threadIdx.x == 0) seq_s = 0;
+    __syncthreads();                                            // the only workgroup barrier
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int32_t* prm = a.params + (size_t)p * a.params_stride;
+    const CellConsts c = make_consts(prm[0], prm[1], prm[2], prm[3], prm[4], prm[5]);
+    CellRegs kr;
+    kr.cmis = c.cmismatch; kr.cmat = c.cmatch; kr.gox6 = c.gox6; kr.goy6 = c.goy6;
+    kr.clean = ~kTagMask;
+    const bool carried = opens_nonpositive(c.gox, c.goy);
+    const int xadj = carried ? c.gox : 0, yadj = carried ? c.goy : 0;
+    const int xadj6 = xadj * 64, yadj6 = yadj * 64;
+    const Ws2 ws(max(n, 1), max(m, 1));
+    uint8_t* const ws_p = a.ws + a.ws_off[p];
+
+    // this half's token before iteration 0 (the same on every wave): flags 1 first, 2 probe, 4 done
+    int tx = n, ty = m, tst = 0, tlen = 0, tpend = 0, tflags = 1;
+    if (n > 1 && (n - 1) % SRH == 0) {
+        if (m == 1) tflags = 0;
+        else { tx = n - 1; ty = m - 1; tpend = 3; tflags = 1 | 2; }
+    }
+    HJob tj = hjob_at(tx, ty);
+    if (tj.hs < 0) {                                            // an empty string (or no problem in this half): boundary run only
+        tflags = 4;
+        if (wave == 0) {
+            int x = n, y = m, len = 0;
+            while (y > 0) { if (lam == 0) ops[cap - 1 - len] = 2; ++len; --y; }
+            while (x > 0) { if (lam == 0) ops[cap - 1 - len] = 1; ++len; --x; }
+            if (alive && lam == 0) a.ops_len[p] = len;
+        }
+    }
+    if (__all((tflags & 4) != 0)) return;
+    int kt = -1;
+
+    // tagged re-fill of this half's job J (set-up + refill_half) where `on`; the other half waits
+    auto refill = [&](const HJob& J, bool on) {
+        if (on) {
+            const int hs = J.hs, s = hs >> 1, lb = (hs & 1) * LW;
+            const int g0 = J.ck * kChunk, k0 = g0 * SPG, g_top = J.gtop;
+            const int nsteps_w = (g_top - g0 + 1) * SPG;
+            const int i_h = hs * SRH;
+            const int row0 = s * L::SR + (lb + lam) * R;
+            const bool lane_has_rows = row0 < n;
+            int tc[R];
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int i = row0 + rr + 1;
+                tc[rr] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
+            }
+            const int2* const hrow = reinterpret_cast<const int2*>(ws_p + ws.row(hs)) + 1;
+            constexpr int kOwIt = (kChunkSteps + LW + LW - 1) / LW, kRowIt = (kChunkSteps + 1 + LW - 1) / LW;
+#pragma unroll
+            for (int it = 0; it < kOwIt; ++it) {
+                const int i = it * LW + lam, src = k0 - lb - (LW - 1) + i;
+                if (i < nsteps_w + LW) ow[i] = (uint16_t)((src >= 0 && src < m) ? a.o_codes[o0 + src] : 0xFFFF);
+            }
+            const int jlo = k0 - lb, jhi = min(m, jlo + nsteps_w);
+#pragma unroll
+            for (int it = 0; it < kRowIt; ++it) {
+                const int jj = jlo + it * LW + lam;
+                if (jj <= jhi) {
+                    int2 v;
+                    if (hs == 0) v = make_int2(bnd_V_row0(c, max(jj, 0)) + xadj6, bnd_D_row0(c, max(jj, 0)));
+                    else {
+                        const int2 e = hrow[max(jj, 1)];
+                        v = (jj <= 0) ? make_int2(0, bnd_D_col0(c, i_h)) : make_int2(enc_of(e.x), enc_of(e.y));
+                    }
+                    hvt[jj - jlo] = v;
+                }
+            }
+            int D[R], V[R], H[R], dsave;
+#pragma unroll
+            for (int rr = 0; rr < R; ++rr) {
+                const int i = row0 + rr + 1;
+                V[rr] = 0;
+                D[rr] = bnd_D_col0(c, i);
+                H[rr] = bnd_H_col0(c, i) + yadj6;
+            }
+            dsave = bnd_D_col0(c, row0);
+            if (g0 > 0 && lb + lam < k0) {
+                const int* stp = reinterpret_cast<const int*>(ws_p + ws.state(s, g0 / kCkGroups)) + lb + lam;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) { D[rr] = enc_of(stp[rr * 64]); H[rr] = enc_of(stp[(R + rr) * 64]); }
+                V[R - 1] = enc_of(stp[2 * R * 64]);
+                dsave = enc_of(stp[(2 * R + 1) * 64]);
+            }
+            wave_sync();
+            if (carried && c.gox == c.goy) refill_half<true, true>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lam, lb, lane_has_rows, J.tops);
+            else if (carried) refill_half<true, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lam, lb, lane_has_rows, J.tops);
+            else refill_half<false, false>(kr, D, V, H, dsave, tc, hvt, ow, win, hvb, g0, g_top, m, lam, lb, lane_has_rows, J.tops);
+            wave_sync();
+        }
+    };
+
+    const int max_iter = 8 * (2 * L::nstrips(max(n, 1)) * (ws.ngroups / kChunk + 2)) + 64;
+    const int max_iter_w = __builtin_amdgcn_readfirstlane(max(__shfl(max_iter, 0, 64), __shfl(max_iter, LW, 64)));
+    for (int i = wave; ; i += NWV) {
+        // (1) speculation + (2) the tokens of iteration i - 1
+        HJob spec{-1, 0, 0, 0};
+        if (i > kt + 1) {
+            int spins = 0, based_on = -2;
+            while (true) {
+                const int have = __builtin_amdgcn_readfirstlane(
+                    __hip_atomic_load(&seq_s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (have >= i) break;
+                const int from = max(kt, have - 1);
+                if (from != based_on) {
+                    based_on = from;
+                    HJob want = tj;
+                    int px = tx, py = ty;
+                    bool over = tflags & 4;
+                    if (from != kt) {
+                        const int* tq = tok_s[from % NWV][half];
+                        want = HJob{tq[6], tq[7], tq[8], tq[9]};
+                        px = tq[0]; py = tq[1];
+                        over = tq[5] & 4;
+                    }
+                    if (over) want = HJob{-1, 0, 0, 0};
+                    else want = hjob_predict(px, py, want, i - from - 1);
+                    const bool change = want.hs >= 0 &&
+                        !(spec.hs >= 0 && want.hs == spec.hs && want.ck == spec.ck && want.gtop == spec.gtop);
+                    if (__any(change)) {
+                        if (change) spec = want;
+                        refill(spec, change);
+                        continue;
+                    }
+                }
+                if (++spins >= (1 << 24)) break;                 // (bounded: a mistake could never leave waves spinning)
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (spins >= (1 << 24)) break;
+            const int* tk = tok_s[(i - 1) % NWV][half];
+            tx = tk[0]; ty = tk[1]; tst = tk[2]; tlen = tk[3]; tpend = tk[4]; tflags = tk[5];
+            tj = HJob{tk[6], tk[7], tk[8], tk[9]};
+            kt = i - 1;
+        }
+        if (__all((tflags & 4) != 0)) {                          // both walks are over: pass the word on and leave
+            if (lam == 0) tok_s[i % NWV][half][5] = 4;
+            if (lane == 0) __hip_atomic_store(&seq_s, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
+        const bool live = (tflags & 4) == 0;                     // this half still walks
+        // (3) the chunk itself where the speculation was wrong
+        const HJob J = tj;
+        const bool need = live && !hjob_serves(spec, J);
+        if (__any(need)) refill(J, need);
+        // (4) walk (nw_trace2h_kernel, step (e))
+        int x = tx, y = ty, st = tst, len = tlen, pend = tpend;
+        bool first = tflags & 1, probe = tflags & 2;
+        if (live) {
+            const int hs = J.hs, lb = (hs & 1) * LW, i_h = hs * SRH;
+            const int g0 = J.ck * kChunk, k0 = g0 * SPG;
+            const int kvalid = J.ck > 0 ? k0 + 2 : 0;
+            const int l = ((x - 1) % L::SR) / R, r = (x - 1) % R, k = (y - 1) + l;
+            bool walked = true;
+            if (pend) {
+                const int2 e = hvb[k - k0];
+                st = 2 - (((pend == 3) ? e.y : e.x) & 3);
+                pend = 0;
+                if (probe) { probe = false; first = false; x = n; y = m; walked = false; }
+            }
+            if (walked) {
+                if (first && k >= kvalid) {
+                    st = ptr_pm(reinterpret_cast<const uint8_t*>(win)[(((k >> 2) - g0) * LW + (l - lb)) * 16 + (k & 3) * R + r]);
+                    first = false;
+                }
+                len += walk_half(win, g0, kvalid, i_h, lb, x, y, st, ops + (cap - 1 - len), cap - len, lam, half);
+                if (st >= 3) { pend = st; st = 0; }
+            }
+        }
+        // (5) the tokens of this iteration
+        HJob nj = live ? hjob_at(x, y) : HJob{-1, 0, 0, 0};
+        int nflags = (first ? 1 : 0) | (probe ? 2 : 0) | ((!live || nj.hs < 0 || i >= max_iter_w) ? 4 : 0);
+        if (live && (nflags & 4)) {                              // this half's walk ends here: boundary runs and the length
+            while (y > 0) { if (lam == 0) ops[cap - 1 - len] = 2; ++len; --y; }
+            while (x > 0) { if (lam == 0) ops[cap - 1 - len] = 1; ++len; --x; }
+            if (alive && lam == 0) a.ops_len[p] = len;
+        }
+        if (lam == 0) {
+            int* tk = tok_s[i % NWV][half];
+            tk[0] = x; tk[1] = y; tk[2] = st; tk[3] = len; tk[4] = pend; tk[5] = nflags;
+            tk[6] = nj.hs; tk[7] = nj.ck; tk[8] = nj.gtop; tk[9] = nj.tops;
+        }
+        if (lane == 0) __hip_atomic_store(&seq_s, i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__all((nflags & 4) != 0)) break;
+        tx = x; ty = y; tst = st; tlen = len; tpend = pend; tflags = nflags; tj = nj;
+        kt = i;
+    }
+}
+
 }  // namespace ta
 
 using namespace ta;
@@ -1645,19 +1906,25 @@ static hipError_t launch_score(NwArgs a, int max_n, int max_m, uint32_t flags, h
     }
 }
 
-// Phase-2 launch shape: waves per problem 1, 2 or 4, or 3 = two problems per wave on half-strips.  By batch size,
-// from measurements at 2048^2 / 4096^2 (tools/tb_waves_time.py, profiles/r04_traceback_waves_per_problem.txt; ms
-// with 1 / 2 / 4 waves / half-strip pairs): 64 x 2048^2 0.63 / 0.36 / 0.22 / 0.86, 768 x 0.66 / 0.49 / 0.47 / 0.86,
-// 1024 x 0.67 / 0.51 / 0.57 / 0.87 (four-wave workgroups hold 75 KB of LDS: two per CU, 512 at a time, so 1024 problems
-// are two rounds of them but one of two-wave workgroups), 1280 x 0.89 / 0.78 / 0.72 / 0.88, 1536 x 0.90 / 0.97 / 0.84 / 0.89, 2048 x 0.93 / 1.17 / 1.11 /
-// 0.90, 4096 x 4096^2 2.89 / 3.94 / 4.31 / 2.44.  Half-strip pairs only when the batch shares one scoring system.
+// Phase-2 launch shape: 1, 2 or 4 = waves per problem (nw_trace2_kernel / nw_trace2w_kernel), 3 = two problems per wave
+// on half-strips (nw_trace2h_kernel), 5 / 6 = two / four waves per PAIR of problems on half-strips
+// (nw_trace2hw_kernel).  By batch size, from measurements at 2048^2 (tools/tb_waves_time.py,
+// profiles/r04_traceback_waves_per_problem.txt; ms with 1 / 2 / 4 waves / pairs / pairs x 2 / pairs x 4):
+//    64 x 0.63 / 0.36 / 0.22 / 0.86 /  --  /  --        768 x 0.66 / 0.50 / 0.48 / 0.87 / 0.66 / 0.46
+//  1024 x 0.67 / 0.52 / 0.56 / 0.87 / 0.67 / 0.48      1280 x 0.91 / 0.78 / 0.72 / 0.88 / 0.68 / 0.73
+//  1536 x 0.91 / 0.97 / 0.84 / 0.89 / 0.68 / 0.73      2048 x 0.93 / 1.02 / 1.11 / 0.91 / 0.72 / 0.90
+//  3072 x 1.21 / 1.51 / 1.65 / 1.23 / 1.34 / 1.34      4096 x 1.49 / 2.06 / 2.16 / 1.24 / 1.41 / 1.75
+// and 4096 x 4096^2 2.88 / 3.93 / 4.31 / 2.45 / 2.86 / 3.55 (four-wave workgroups hold 75 - 81 KB of LDS: two per CU).
+// The pair kernels only when the batch shares one scoring system (their halves run in lockstep, and problems scored
+// differently have paths of very different length).
 extern "C" int32_t ta_nw2_traceback_plan(int32_t nprob, int32_t params_stride, uint32_t flags) {
     const int tbw = (int)((flags >> TA_NW_TBWAVES_SHIFT) & 0x7u);
-    if (tbw == 1 || tbw == 2 || tbw == 3 || tbw == 4) return tbw;
+    if (tbw >= 1 && tbw <= 6) return tbw;
     if (nprob <= 832) return 4;
-    if (nprob <= 1088) return 2;
-    if (nprob <= 1600) return 4;
-    return params_stride == 0 ? 3 : 1;
+    if (params_stride != 0) return nprob <= 1088 ? 2 : nprob <= 1600 ? 4 : 1;
+    if (nprob <= 1088) return 6;
+    if (nprob <= 2560) return 5;
+    return 3;
 }
 
 extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
@@ -1692,6 +1959,8 @@ extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
         // 0.59 with one wave per problem; the same shape under one system 0.52 against 0.53)
         const int tbw = ta_nw2_traceback_plan(nprob, params_stride, flags);
         if (tbw == 3) hipLaunchKernelGGL(nw_trace2h_kernel, dim3((nprob + 1) / 2), dim3(64), 0, st, a);
+        else if (tbw == 5) hipLaunchKernelGGL(nw_trace2hw_kernel<2>, dim3((nprob + 1) / 2), dim3(128), 0, st, a);
+        else if (tbw == 6) hipLaunchKernelGGL(nw_trace2hw_kernel<4>, dim3((nprob + 1) / 2), dim3(256), 0, st, a);
         else if (tbw == 4) hipLaunchKernelGGL(nw_trace2w_kernel<4>, dim3(nprob), dim3(256), 0, st, a);
         else if (tbw == 2) hipLaunchKernelGGL(nw_trace2w_kernel<2>, dim3(nprob), dim3(128), 0, st, a);
         else hipLaunchKernelGGL(nw_trace2_kernel, dim3(nprob), dim3(64), 0, st, a);

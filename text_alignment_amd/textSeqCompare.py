@@ -114,7 +114,8 @@ class NWBatch(object):
         # phase 1 with exactly this many waves per workgroup (None = the library's own choice)
         self.no_profile = False
         self.waves = None
-        # phase 2 with exactly this many waves per problem (1, 2 or 4; None = the library's choice by batch size)
+        # phase 2 launch shape (TA_NW_TBWAVES: 1, 2, 4 waves per problem; 3 half-strip pairs; 5, 6 pairs with 2, 4 waves;
+        # None = the library's choice by batch size)
         self.tb_waves = None
         # one-pass fill: rows per lane (2 or 4; None = the library's choice by batch size)
         self.rows = None
@@ -213,7 +214,8 @@ class NWBatch(object):
         if not self.two_phase:
             return "nw_traceback_kernel"
         w = _native.lib.ta_nw2_traceback_plan(self.nprob, self.params_stride, self.phase1_flags())
-        return {1: "nw_trace2_kernel", 2: "nw_trace2w_kernel<2>", 4: "nw_trace2w_kernel<4>", 3: "nw_trace2h_kernel"}[w]
+        return {1: "nw_trace2_kernel", 2: "nw_trace2w_kernel<2>", 4: "nw_trace2w_kernel<4>", 3: "nw_trace2h_kernel",
+                5: "nw_trace2hw_kernel<2>", 6: "nw_trace2hw_kernel<4>"}[w]
 
     def results(self):
         """Host copies of the alignment columns, one uint8 array per problem."""

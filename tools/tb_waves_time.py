@@ -22,7 +22,7 @@ for nprob, n, m in shapes:
     torch.cuda.synchronize()
     ref = None
     out = []
-    for w in (1, 2, 4, 3):
+    for w in (1, 2, 4, 3, 5, 6):
         batch.tb_waves = w
         ts = []
         for _ in range(9):
@@ -32,7 +32,7 @@ for nprob, n, m in shapes:
             ts.append(e0.elapsed_time(e1))
         res = [r.tolist() for r in batch.results()[:16]]
         ref = res if ref is None else ref
-        out.append("%s %.3f ms%s" % ("%d waves" % w if w != 3 else "half-strip pairs", sorted(ts)[len(ts) // 2],
+        out.append("%s %.3f ms%s" % ({3: "half-strip pairs", 5: "pairs x 2 waves", 6: "pairs x 4 waves"}.get(w, "%d waves" % w), sorted(ts)[len(ts) // 2],
                                      "" if res == ref else " (DIFFERENT RESULT)"))
     print("%5d x %d x %d: %s" % (nprob, n, m, ";  ".join(out)), flush=True)
     del batch
