@@ -259,7 +259,7 @@ static int run2(const int32_t* t, int n, const int32_t* o, int m, const int* p, 
         if (skip_halo && ck > 0 && k < ck * KCG * SPG + 2) ck -= 1;      // tb_job_at
         // a chunk re-filled AHEAD of the walk for a strip entry (tb_predict) goes two groups further than the diagonal's
         // entry group, whole groups: a window re-filled further than the walk's entry point serves it as well
-        if (skip_halo && !halves) g_top = std::min(g_top + 2, ck * KCG + KCG);
+        if (skip_halo) g_top = std::min(g_top + 2, ck * KCG + KCG);     // (nw_trace2w_kernel and, on half-strips, nw_trace2hw_kernel)
         bool in_strip = true;
         while (in_strip) {
             if (++guard > 8 * (n + m) + 64) return -9;
