@@ -195,3 +195,17 @@ def test_no_buffer_store_data_hazard_in_the_built_library():
 """
     got = chk.findings(bad)
     assert len(got) == 2 and "soffset" in got[0] and "v_max_i32_e32 v10" in got[1], got
+
+
+def test_traceback_plan_is_a_pure_function_of_batch_shape(native):
+    """ta_nw2_traceback_plan (host only): the phase-2 launch shape ta_nw2_batch picks -- several waves per problem for
+    small batches, half-strip pairs (alone or with speculating waves) for larger ones under ONE scoring system, never
+    a pair kernel with a scoring system per problem (their halves run in lockstep); TA_NW_TBWAVES forces a shape."""
+    plan = native.lib.ta_nw2_traceback_plan
+    assert [plan(n, 0, 0) for n in (1, 64, 832)] == [4, 4, 4]
+    assert [plan(n, 0, 0) for n in (833, 1024, 1088)] == [6, 6, 6]
+    assert [plan(n, 0, 0) for n in (1089, 2048, 2560)] == [5, 5, 5]
+    assert [plan(n, 0, 0) for n in (2561, 4096, 100000)] == [3, 3, 3]
+    assert all(plan(n, 6, 0) in (1, 2, 4) for n in (1, 500, 1000, 1500, 2187, 4096))
+    for w in (1, 2, 3, 4, 5, 6):
+        assert plan(4096, 0, w << native.TA_NW_TBWAVES_SHIFT) == w and plan(7, 6, w << native.TA_NW_TBWAVES_SHIFT) == w
