@@ -85,12 +85,14 @@ constexpr int kOPad = 64;     // o-code padding in front (lanes that have not st
 constexpr int kOTail = 80;    // steps run to m + 62 (+ group round-up) past the last code
 constexpr int kCheck = 16;    // hand-off progress is checked / published every kCheck groups
 
-// LDS carve (dynamic): int2 hvd[m+2] | int2 dummy[64*4] | code ocode[kOPad+m+kOTail] | int prog[16]
+// LDS carve (dynamic): int2 pad[kHvdPad] hvd[m+2] | int2 dummy[64*4] | code ocode[kOPad+m+kOTail] | int prog[16]
 //                      | uint32 profile[waves][apad][64]   (phase 1 with a score profile only)
+constexpr int kHvdPad = 64;   // entries in front of the hand-off row: lane 63's bottom-row writes for the virtual columns
+                              // j <= 0 of a strip's start-up groups land here (ta_nw.hip, from_zero)
 struct NwLds {
     size_t hvd_bytes, dummy_bytes, oc_bytes, tbl_off, total;
     __host__ __device__ explicit NwLds(int m, int code_bytes = 2, int tbl_bytes = 0) {
-        hvd_bytes = ((size_t)(m + 2) * 8 + 15) & ~(size_t)15;
+        hvd_bytes = ((size_t)(kHvdPad + m + 2) * 8 + 15) & ~(size_t)15;
         dummy_bytes = 64 * 4 * 8;
         oc_bytes = ((size_t)(kOPad + m + kOTail) * code_bytes + 15) & ~(size_t)15;
         tbl_off = hvd_bytes + dummy_bytes + oc_bytes + 64;
@@ -151,6 +153,22 @@ __device__ __forceinline__ unsigned cell_carried_tagged_c(const CellRegs& k, int
     yg = max(dgy, yr);
     // (the pointer byte through the asm v_bfi_b32 helpers: hipcc would split each into two v_and + an or;
     // their results are not needed before the group's bytes are packed, so no pad lands behind them)
+    return v_bfi3((unsigned)d_ul, v_bfi12((unsigned)xg_u, (unsigned)yg_l));
+}
+// the same with the mismatch score given per call: the virtual columns j <= 0 of a strip's start-up groups score
+// -(1 + gex) (encoded, tag M), which keeps a lane's column-0 boundary state in place (ta_nw.hip, from_zero)
+template <bool SAMEGO = false>
+__device__ __forceinline__ unsigned cell_carried_tagged_miss(const CellRegs& k, int miss, int d_ul, int xg_u, int yg_l,
+                                                             int t, int o, int& d, int& xg, int& yg) {
+    const int cs = (t == o) ? k.cmat : miss;
+    const int mr = (d_ul & k.clean) + cs;
+    const int xr = (xg_u & k.clean) | kTagX;
+    const int yr = yg_l & k.clean;
+    d = max(max(mr, xr), yr);
+    const int dgx = d + k.gox6;
+    const int dgy = SAMEGO ? dgx : d + k.goy6;
+    xg = max(dgx, xr);
+    yg = max(dgy, yr);
     return v_bfi3((unsigned)d_ul, v_bfi12((unsigned)xg_u, (unsigned)yg_l));
 }
 __device__ __forceinline__ unsigned cell_c(const CellRegs& k, int d_ul, int v_u, int h_l, int t, int o,

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
     const int xadj6 = carried ? c.gox6 : 0, yadj6 = carried ? c.goy6 : 0;
 
     const NwLds lds(m);
-    int2* hvd = reinterpret_cast<int2*>(smem);
+    int2* hvd = reinterpret_cast<int2*>(smem) + kHvdPad;
     int2* dummy = reinterpret_cast<int2*>(smem + lds.hvd_bytes);
     uint16_t* ocode = reinterpret_cast<uint16_t*>(smem + lds.hvd_bytes + lds.dummy_bytes);
     int* prog = reinterpret_cast<int*>(smem + lds.hvd_bytes + lds.dummy_bytes + lds.oc_bytes);
@@ -131,6 +131,18 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
     // groups [g_lo, g_hi) are "steady": every lane is inside 1 <= j <= m on every step
     const int g_lo = (63 + SPG - 1) / SPG;
     const int g_hi = m / SPG;
+    // The start-up groups of a strip (lanes start one step apart) through the steady body instead of the EXEC-predicated
+    // one: a lone problem's strips are a CHAIN -- a strip can start only when the one above is 62 steps + a block ahead,
+    // so the 64 start-up steps of every strip are on the critical path, and the predicated body takes ~2.5 x a steady
+    // step.  A lane that has not reached column 1 runs over VIRTUAL columns j <= 0 whose "mismatch" score is
+    // -(1 + gex) (tag M): with the carried cell that leaves its column-0 boundary state exactly in place -- D = b_i | M
+    // (M^ = b_(i-1) - (1 + gex) = b_i ties with YG = b_i and the M tag wins, as at the boundary), YG' = max(b_i + goy, b_i)
+    // with the boundary's own tag, the XG chain of a virtual column (from -2^24 at the strip's edge) stays <= b_i + gox
+    // because b falls with i iff gex <= -1 (the condition) -- and the D the DPP shift hands down is the b of the lane
+    // above.  Pointer bytes of virtual cells are garbage nobody reads; lane 63's bottom-row writes for j <= 0 land in
+    // the pad in front of the hand-off row.
+    const bool from_zero = carried && c.gex <= -1 && g_lo + 2 < g_hi;
+    const int cpad = ((-(1 + c.gex)) * 64) | kTagM;
     int pass = 0;
 
     for (int s = chunk * W + wave; s < nstrips; s += (WIDE ? nstrips : W), ++pass) {
@@ -142,7 +154,7 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
             const int i = row0 + r + 1;
             D[r] = bnd_D_col0(c, i);
             H[r] = bnd_H_col0(c, i) + yadj6;
-            V[r] = 0;
+            V[r] = from_zero ? -(1 << 30) : 0;
             tc[r] = (i <= n) ? a.t_codes[t0 + i - 1] : -1;
         }
         int dsave = bnd_D_col0(c, row0);
@@ -279,6 +291,11 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
             if constexpr (FORM == 0) return cell_c(kr, d_ul, x_u, y_l, t, o, d, x, y);
             else return cell_carried_tagged_c<FORM == 2>(kr, d_ul, x_u, y_l, t, o, d, x, y);
         };
+        // (start-up groups under from_zero: the mismatch score of a step is the virtual columns' while k < lane)
+        auto cell_su = [&](int miss, int d_ul, int x_u, int y_l, int t, int o, int& d, int& x, int& y) -> unsigned {
+            if constexpr (FORM == 0) return cell_c(kr, d_ul, x_u, y_l, t, o, d, x, y);
+            else return cell_carried_tagged_miss<FORM == 2>(kr, miss, d_ul, x_u, y_l, t, o, d, x, y);
+        };
         // 16 pointer bytes of a group (byte q * R + r: step q, row r) -> one 16-byte piece
         auto store_piece = [&](int gg, const unsigned (&bb)[16]) {
             *reinterpret_cast<uint4*>(out + (int64_t)gg * 1024) =
@@ -323,7 +340,7 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
         wait_span(0);
         load_group(0);
         int g = 0;
-        const int e1 = min(g_lo, ngroups);
+        const int e1 = from_zero ? 0 : min(g_lo, ngroups);
         for (; g < e1; ++g) group_edge(g);
 
         if (g < g_hi) {
@@ -352,15 +369,17 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
             };
             auto steady = [&](int gg, const int (&oc)[SPG], const int2 (&hd)[SPG]) {
                 unsigned bb[16];
+                const bool su = from_zero && gg < g_lo;               // a start-up group: some lanes are in virtual columns
 #pragma unroll
                 for (int q = 0; q < SPG; ++q) {
                     int v_up = hd[q].x, d_next = hd[q].y;
                     wave_shr1_pair<1>(v_up, V[R - 1], d_next, D[R - 1]);
                     int d_ul = dsave, v_u = v_up;
+                    const int miss = (su && gg * SPG + q < lane) ? cpad : kr.cmis;
 #pragma unroll
                     for (int r = 0; r < R; ++r) {
                         const int d_old = D[r];
-                        bb[q * R + r] = cell(d_ul, v_u, H[r], tc[r], oc[q], D[r], V[r], H[r]);
+                        bb[q * R + r] = cell_su(miss, d_ul, v_u, H[r], tc[r], oc[q], D[r], V[r], H[r]);
                         d_ul = d_old;
                         v_u = V[r];
                     }
@@ -377,6 +396,16 @@ __global__ __launch_bounds__(W * 64) void nw_fill_kernel(NwArgs a) {
             // issues one instruction of ANY kind per ~5.5 cycles (tools/ubench/lone_wave.hip), so the ~25
             // scalar instructions per step that the per-group form spent on control were a quarter of
             // such a launch's critical path.
+            if (from_zero) {                                        // the start-up groups, two at a time (g_lo is even)
+                static_assert(((63 + SPG - 1) / SPG) % 2 == 0, "start-up groups in pairs");
+                while (g < g_lo) {
+                    fetch(g + 1, ocB, hdB);
+                    steady(g, ocA, hdA);
+                    fetch(g + 2, ocA, hdA);
+                    steady(g + 1, ocB, hdB);
+                    g += 2;
+                }
+            }
             if constexpr (CHK % 2 == 0) {
                 if ((g % CHK) == 0 && g + CHK < g_hi) {
                     const uint16_t* ocp = ocode + (kOPad + (g + 1) * SPG - lane);   // codes of the next group to fetch
