@@ -122,8 +122,9 @@ int ta_nw_batch(const int32_t* t_codes, const int64_t* t_off,
  * ta_nw2_batch: the same aligner in two phases -- a score-only wavefront fill that leaves
  * checkpoints, then a traceback that re-derives pointers only in windows around the path
  * (csrc/ta_nw2.hip).  Arguments and results exactly as ta_nw_batch, except that `ws` regions are
- * ta_nw2_workspace_bytes(n, m) long (checkpoints + a 128 KiB window scratch instead of the
- * 1 B/cell pointer matrix).  TA_NW_FILL = phase 1, TA_NW_TRACEBACK = phase 2.
+ * ta_nw2_workspace_bytes(n, m) long (lane-state checkpoints every 16 groups + the bottom rows of every
+ * half-strip of 128 rows: ~0.3 B per cell instead of the 1 B/cell pointer matrix).  TA_NW_FILL = phase 1,
+ * TA_NW_TRACEBACK = phase 2.
  */
 int64_t ta_nw2_workspace_bytes(int32_t n, int32_t m);
 /* widest OCR string ta_nw2_batch takes (its LDS holds the OCR codes only; the hand-off rows between
