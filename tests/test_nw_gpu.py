@@ -531,6 +531,33 @@ def test_two_phase_traceback_waves_per_problem(tsc, tb_waves):
     assert not bad, (tb_waves, bad[:10], [(len(t_list[k]), len(o_list[k]), prm[k]) for k in bad[:5]])
 
 
+@pytest.mark.parametrize("tb_waves", [3, 5, 6])
+def test_fuzz_pair_kernels_ragged_sizes(tsc, tb_waves):
+    """The traceback kernels that carry TWO problems per wave (half-strips of 128 rows; with and without speculating
+    waves) on 1 200 random problems of very different sizes -- the two halves of a wave finish their problems rounds
+    apart, cross half-strip and strip borders at different times, and one of them is often idle -- first under one
+    scoring system (what the library pairs up by itself), then under a system per problem; odd batch size."""
+    from oracle import nw_oracle
+    rng = np.random.default_rng(777 + tb_waves)
+    t_list, o_list = [], []
+    for k in range(1201):
+        n = int(rng.integers(0, 1400)) if k % 7 else int(rng.integers(0, 40))
+        m = int(rng.integers(0, 1400)) if k % 5 else int(rng.integers(0, 40))
+        t, o = _random_problem(rng, n, m, [2, 4, 27][k % 3], k % 2 == 0)
+        t_list.append(t); o_list.append(o)
+    for prm in (SYSTEMS[0], [SYSTEMS[int(v)] for v in rng.integers(0, len(SYSTEMS), size=len(t_list))]):
+        batch = tsc.NWBatch(t_list, o_list, prm, two_phase=True)
+        batch.tb_waves = tb_waves
+        batch.run()
+        res = batch.results()
+        bad = []
+        for k in range(len(t_list)):
+            sysk = prm if isinstance(prm[0], int) else prm[k]
+            if res[k].tolist() != nw_oracle.align_ids(t_list[k], o_list[k], sysk).tolist():
+                bad.append(k)
+        assert not bad, (tb_waves, bad[:10], [(len(t_list[k]), len(o_list[k])) for k in bad[:5]])
+
+
 def test_adversarial_paths(tsc, two_phase):
     """Paths that stress the windowed traceback and the tie rules: disjoint alphabets (the path
     hugs the table edges), a 3000-token insertion in the middle (one horizontal / vertical run
