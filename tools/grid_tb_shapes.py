@@ -1,3 +1,5 @@
+"""Traceback launch shapes on the grid search's batch (2 187 problems of 800 x 900, a scoring system per problem):
+fill / traceback time with the library's choice and with TA_NW_TBWAVES forced to 1, 3 (half-strip pairs), 2."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
