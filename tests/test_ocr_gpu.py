@@ -321,6 +321,36 @@ def test_f64_mode_group_edges_continuation_and_chunks(monkeypatch):
             assert float(np.abs(g[dname, :, :, gi] - want).max()) < 1e-12, (dname, name)
 
 
+def test_f64_mode_class_pipeline_is_bit_identical(monkeypatch):
+    """float64 mode on a batch large enough for the per-class pipeline (projection class by class, the recurrence of
+    each class on a side stream as soon as its projection is done, own pieces of the Gx buffer): LSTM outputs bit for bit
+    those of the one-after-the-other order, also when the buffer bound cuts the batch into several runs; and a
+    few lines against the oracle, so that a wrong piece of the buffer cannot pass as 'equal to itself'."""
+    from oracle import ocr_ref_f64 as R
+    from text_alignment_amd import ocr
+    om = R.synthetic_model(7001, no=96)
+    rec = ocr.LineRecognizer(ocr.LineModel(om.fwd, om.rev, om.W2, om.codec), precision="f64")
+    lines = [R.synthetic_line(9300 + k, width=40 + (37 * k) % 160) for k in range(20 * 16 + 5)]
+    st = rec.prepare(lines)
+    assert st["ngroups"] >= ocr.F64_CLASS_MIN_GROUPS
+    monkeypatch.setattr(ocr, "F64_CLASS_PIPELINE", False)
+    rec.run(st, output=False, decode=False)
+    torch.cuda.synchronize()
+    serial = st["hout"].clone()
+    monkeypatch.setattr(ocr, "F64_CLASS_PIPELINE", True)
+    for max_rows in (ocr.F64_GX_MAX_ROWS, int(st["rows"]) // 3):
+        monkeypatch.setattr(ocr, "F64_GX_MAX_ROWS", max_rows)
+        st["hout"].zero_()
+        rec.run(st, output=False, decode=False)
+        torch.cuda.synchronize()
+        assert torch.equal(st["hout"], serial), max_rows
+    hout = serial.cpu().numpy()
+    for b in (0, 7, 160, len(lines) - 1):
+        s0 = int(st["row_start_host"][b])
+        want = R.bilstm_states(om, lines[b])
+        assert float(np.abs(hout[s0:s0 + lines[b].shape[0]] - want).max()) < 1e-6, b
+
+
 def test_group_boundaries_and_order():
     """15, 16, 17 and 33 lines (group edges), results independent of batch composition."""
     R, ocr, om, pm = _models(7001, 96)

@@ -46,9 +46,22 @@ constexpr int kKH = kNs / 4;        // 25 k-steps over h
 constexpr int kXK = 52;             // [1, x(48), 3 zeros]
 constexpr int kKX = kXK / 4;        // 13 k-steps over [1, x]
 constexpr int kW = 4;               // waves per workgroup
-constexpr int kMaxNT = 7;           // tiles of wave 0; waves 1..3 take 6
+constexpr int kMaxNT = 7;           // tile slots per wave in the packed weights (xproj: tiles of wave 0, waves 1..3 take 6;
+                                    // recurrence: six own tiles + the split one)
+constexpr int kOwnTiles = 6;        // recurrence: tiles a wave owns; the 25th is split along k
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+#ifdef TA_F64_PROFILE
+// -DTA_F64_PROFILE: cycle counters of wave 0 of every workgroup (tools/f64_time.py): [0] tiles' MFMAs + cell update,
+// [1] h to LDS / output store / next accumulator loads, [2] the step's barrier, [3] steps
+__device__ unsigned long long g_prof[4];
+__device__ __forceinline__ unsigned long long prof_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+#endif
 
 // Gx layout inside a row (400 doubles): per tile of 4 units 16 doubles = [gate pair 2][unit-in-tile 4][2]: a lane owns
 // the four gates of one (row, unit) and moves them with two 16-byte accesses; the four lanes of a row's tile make each
@@ -203,34 +216,68 @@ struct Seq64Args {
     const int32_t* tstart;     // optional [lines][2]: steps of the sequence already done
 };
 
-template <int NT>
+// The f64 MFMA holds the SIMD's vector issue for its 64 cycles: any VALU instruction between two MFMAs of a chain
+// is paid in full (tools/ubench/mfma_f64_ops.hip: 64 cycles per MFMA back to back, 93 with the two v_accvgpr_read_b32
+// the compiler uses to feed an operand it keeps in AGPRs; an LDS read between them is free, and so is an A operand the
+// MFMA reads from AGPRs itself).  A wave's weights (300 .. 318 registers) do not fit the 256 architectural VGPRs next
+// to everything else, so the first kAgprDoubles of them are PINNED in AGPRs and named as such in the instruction; the
+// accumulators stay in VGPRs (Gx arrives there, the cell update reads them there).  Written as inline assembly, so the
+// wait states the compiler would insert after a matrix instruction are ours to provide (mfma_settle).
+constexpr int kAgprDoubles = 120;
+template <bool IN_AGPR>
+__device__ __forceinline__ void mfma_f64(f64x4& acc, double aw, double b) {
+    if (IN_AGPR) asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "a"(aw), "v"(b));
+    else asm("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(aw), "v"(b));
+}
+// before the first MFMA of a chain: a VALU instruction may just have written one of its operands (the compiler
+// leaves two wait states between such a write and the builtin)
+__device__ __forceinline__ void mfma_begin(f64x4& acc) { asm volatile("s_nop 3" : "+v"(acc)); }
+// after the last MFMA of a chain, before anything else reads its result: 16 passes = 18 wait states (what the
+// compiler puts after the builtin: s_nop 15, s_nop 2)
+__device__ __forceinline__ void mfma_settle(f64x4& acc) { asm volatile("s_nop 15\n s_nop 2" : "+v"(acc)); }
+
+// Tiles of a step: every wave owns six (tiles 6 wave .. 6 wave + 5); the 25th (units 96 .. 99) is split along k --
+// waves 1, 2, 3 take k-steps 0..8, 9..16, 17..24 of it at the start of their step and leave the partial sums in LDS,
+// wave 0 (which takes none) adds them to Gx in that fixed order when its own six tiles are done and updates those
+// four units' cells.  A step therefore costs a SIMD six tiles + ~0.35 of one instead of seven (25 tiles on four SIMDs).
+// K0, NK: this wave's k-steps of the split tile (NK = 0: the wave that sums the parts).
+template <int K0, int NK>
 __device__ __forceinline__ void seq_f64_body(const Seq64Args& a, double (&hs)[2][kNs][kLines], const double (&peep_s)[3][kNs],
+                                             double (&part)[kW - 1][4][64], unsigned& part_flag,
                                              const int (&s_line)[kLines], const int (&s_T)[kLines],
                                              const long long (&s_row)[kLines], int dir, int wave, int lane, int Tmax) {
-    const int tile0 = tile0_of(wave);
-    // recurrent weights of this wave's tiles: A fragments, constant over time (NT * 25 * 2 registers)
+    constexpr int NT = kOwnTiles;
+    constexpr bool kSums = NK == 0;
+    const int tile0 = NT * wave;
+    // recurrent weights of this wave's tiles: A fragments, constant over time
     double Aw[NT][kKH];
+    double Ap[NK > 0 ? NK : 1];
     {
         const double* wp = a.wh + ((size_t)(dir * kW + wave) * kMaxNT * kKH) * 64 + lane;
 #pragma unroll
         for (int s = 0; s < NT; ++s)
 #pragma unroll
             for (int kk = 0; kk < kKH; ++kk) Aw[s][kk] = wp[((size_t)s * kKH + kk) * 64];
+#pragma unroll
+        for (int i = 0; i < NK; ++i) Ap[i] = wp[((size_t)NT * kKH + K0 + i) * 64];
     }
-    // this lane's accumulators: the four gates of (line slot li, unit 4 (tile0 + s) + kq), s < NT
+    // this lane's accumulators: the four gates of (line slot li, unit 4 (tile0 + s) + kq), s < NT; wave 0 also those
+    // of unit 96 + kq
     const int li = lane & 15, kq = lane >> 4;
     const int myT = s_T[li];
     const long long myrow = s_row[li];
     const int myid = s_line[li];
     const int ubase = 4 * tile0 + kq;
-    const double* gxd = a.gx + (size_t)dir * a.gx_rows * kCols + 16 * tile0 + 2 * kq;
+    constexpr int kSplitTile = kTiles - 1;
+    const int usplit = 4 * kSplitTile + kq;
+    const double* gxd = a.gx + (size_t)dir * a.gx_rows * kCols + 2 * kq;
     auto gx_row = [&](int t) -> const double* {
         int tt = t < myT ? t : myT - 1;
         if (dir) tt = myT - 1 - tt;                            // Reversed(LSTM): run on xs[::-1]
         const long long row = myT > 0 ? myrow - a.gx_row0 + tt : 0;     // an empty slot reads row 0 of the buffer (never used)
         return gxd + row * kCols;
     };
-    double c[NT];
+    double c[NT], csplit = 0.0;
     int ts = 0;
 #pragma unroll
     for (int s = 0; s < NT; ++s) c[s] = 0.0;
@@ -238,55 +285,128 @@ __device__ __forceinline__ void seq_f64_body(const Seq64Args& a, double (&hs)[2]
         if (a.c0) {
 #pragma unroll
             for (int s = 0; s < NT; ++s) c[s] = a.c0[((size_t)myid * 2 + dir) * kNs + ubase + 4 * s];
+            if (kSums) csplit = a.c0[((size_t)myid * 2 + dir) * kNs + usplit];
         }
         if (a.tstart) ts = a.tstart[(size_t)myid * 2 + dir];
     }
-    float* houtp = a.hout + dir * kNs + ubase;
+    float* houtp = a.hout + dir * kNs;
 
-    auto load_acc = [&](f64x4 (&acc)[NT], int s, const double* g) {
-        const f64x2 lo = *reinterpret_cast<const f64x2*>(g + 16 * s);
-        const f64x2 hi = *reinterpret_cast<const f64x2*>(g + 16 * s + 8);
-        acc[s] = (f64x4){lo[0], lo[1], hi[0], hi[1]};
+    auto load_gx = [&](const double* g, int tile) -> f64x4 {
+        const f64x2 lo = *reinterpret_cast<const f64x2*>(g + 16 * tile);
+        const f64x2 hi = *reinterpret_cast<const f64x2*>(g + 16 * tile + 8);
+        return (f64x4){lo[0], lo[1], hi[0], hi[1]};
     };
-    f64x4 acc[NT];
+    f64x4 acc[NT], accs = {0.0, 0.0, 0.0, 0.0};
     {
         const double* g = gx_row(0);
 #pragma unroll
-        for (int s = 0; s < NT; ++s) load_acc(acc, s, g);
+        for (int s = 0; s < NT; ++s) acc[s] = load_gx(g, tile0 + s);
     }
-
+#ifdef TA_F64_PROFILE
+    unsigned long long p_comp = 0, p_move = 0, p_bar = 0;
+#endif
     for (int t = 0; t < Tmax; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
         const bool past0 = (t > 0) | (ts > 0);
-        const bool more = t + 1 < Tmax;
         const double* gnext = gx_row(t + 1);
+        const int tt = dir ? myT - 1 - t : t;
+        float* hrow = houtp + (myrow + tt) * (2 * kNs);       // (dereferenced only while t < myT)
+        // the split tile's Gx of THIS step: asked for first, so that when it is needed (after the six tiles) the
+        // wait counts only loads issued after it -- a load carried across the loop edge is waited for with
+        // vmcnt(0), which here would also wait for the tile loads issued moments before
+        if (kSums) accs = load_gx(gx_row(t), kSplitTile);
+        // The B operand of the step (h_{t-1}: B[k][j] = unit k of line j, lane j + 16 (k % 4)): once from LDS into
+        // registers, for all tiles.
+        double B[kKH];
+#pragma unroll
+        for (int kk = 0; kk < kKH; ++kk) B[kk] = hs[cur][4 * kk + kq][li];
+        if (NK > 0) {
+            f64x4 pacc = {0.0, 0.0, 0.0, 0.0};
+            mfma_begin(pacc);
+#pragma unroll
+            for (int i = 0; i < NK; ++i) mfma_f64<false>(pacc, Ap[i], B[K0 + i]);
+            mfma_settle(pacc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[wave - 1][r][lane] = pacc[r];
+            // a wave's LDS instructions execute in order: the count follows the four stores of all its lanes.  The fences
+            // name the LDS only -- a plain workgroup release / acquire also drains the Gx loads in flight (vmcnt(0))
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            if (lane == 0) __hip_atomic_fetch_add(&part_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         // Tile by tile: the 25 k-steps of a tile (one dependent accumulator chain: 64 cycles per MFMA either way),
-        // its cell update, then the loads of ITS accumulators for the next step.  With the k-steps outermost the
-        // first MFMA of a step needs every tile's x part at once, the last of which was requested moments before
-        // (a memory latency exposed per step); in this order a tile's loads have most of a step to arrive.  The B
-        // operand (h_{t-1}: B[k][j] = unit k of line j, lane j + 16 (k % 4)) is re-read from LDS per tile.
+        // its cell update, then the loads of ITS accumulators for the next step (they have a whole step to arrive).
 #pragma unroll
         for (int s = 0; s < NT; ++s) {
+#ifdef TA_F64_PROFILE
+            const unsigned long long p0 = prof_now();
+#endif
+            mfma_begin(acc[s]);
 #pragma unroll
-            for (int kk = 0; kk < kKH; ++kk)
-                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aw[s][kk], hs[cur][4 * kk + kq][li], acc[s], 0, 0, 0);
+            for (int kk = 0; kk < kKH; ++kk) {
+                if (s * kKH + kk < kAgprDoubles) mfma_f64<true>(acc[s], Aw[s][kk], B[kk]);
+                else mfma_f64<false>(acc[s], Aw[s][kk], B[kk]);
+            }
+            mfma_settle(acc[s]);
             const int unit = ubase + 4 * s;
             const double h = lstm_cell_f64(acc[s][0], acc[s][1], acc[s][2], acc[s][3], c[s], past0,
                                            peep_s[0][unit], peep_s[1][unit], peep_s[2][unit]);
+#ifdef TA_F64_PROFILE
+            unsigned long long p1;                                 // (h as an input: the stamp follows the cell update)
+            asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(p1) : "v"(h) : "memory");
+#endif
             hs[nxt][unit][li] = h;
-            if (t < myT) {
-                const int tt = dir ? myT - 1 - t : t;
-                houtp[(myrow + tt) * (2 * kNs) + 4 * s] = (float)h;
-            }
-            if (more) load_acc(acc, s, gnext);
+            if (t < myT) hrow[unit] = (float)h;
+            acc[s] = load_gx(gnext, tile0 + s);            // (unconditional: gx_row clamps past the end; a conditional load would
+                                                           // make every later wait count it as possibly absent)
+#ifdef TA_F64_PROFILE
+            p_comp += p1 - p0;
+            p_move += prof_now() - p1;
+#endif
         }
+        if (kSums) {
+#ifdef TA_F64_PROFILE
+            const unsigned long long p0 = prof_now();
+#endif
+            // the parts were posted at the start of the other waves' step; the wait is bounded all the same
+            const unsigned want = (unsigned)(kW - 1) * (unsigned)(t + 1);
+            for (int spin = 0; spin < (1 << 22); ++spin)
+                if (__hip_atomic_load(&part_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#pragma unroll
+            for (int w = 0; w < kW - 1; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) accs[r] += part[w][r][lane];
+            const double h = lstm_cell_f64(accs[0], accs[1], accs[2], accs[3], csplit, past0,
+                                           peep_s[0][usplit], peep_s[1][usplit], peep_s[2][usplit]);
+            hs[nxt][usplit][li] = h;
+            if (t < myT) hrow[usplit] = (float)h;
+#ifdef TA_F64_PROFILE
+            p_move += prof_now() - p0;
+#endif
+        }
+#ifdef TA_F64_PROFILE
+        const unsigned long long pb = prof_now();
+#endif
         __syncthreads();
+#ifdef TA_F64_PROFILE
+        p_bar += prof_now() - pb;
+#endif
     }
+#ifdef TA_F64_PROFILE
+    if (wave == 0 && lane == 0) {
+        atomicAdd(&g_prof[0], p_comp);
+        atomicAdd(&g_prof[1], p_move);
+        atomicAdd(&g_prof[2], p_bar);
+        atomicAdd(&g_prof[3], (unsigned long long)Tmax);
+    }
+#endif
 }
 
 __global__ __launch_bounds__(kW * 64) void lstm_seq_f64_kernel(Seq64Args a) {
     __shared__ __attribute__((aligned(16))) double hs[2][kNs][kLines];       // h of the 16 lines, [unit][line]
     __shared__ double peep_s[3][kNs];
+    __shared__ double part[kW - 1][4][64];                                   // the split tile's partial sums
+    __shared__ unsigned part_flag;                                           // parts posted so far (3 per step)
     __shared__ int s_line[kLines];
     __shared__ int s_T[kLines];
     __shared__ long long s_row[kLines];
@@ -294,6 +414,7 @@ __global__ __launch_bounds__(kW * 64) void lstm_seq_f64_kernel(Seq64Args a) {
     const int grp = blockIdx.x >> 1, dir = blockIdx.x & 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) part_flag = 0;
     if (tid < kLines) {
         const int id = a.group_lines[grp * kLines + tid];
         s_line[tid] = id;
@@ -314,8 +435,10 @@ __global__ __launch_bounds__(kW * 64) void lstm_seq_f64_kernel(Seq64Args a) {
         }
     }
     __syncthreads();
-    if (wave == 0) seq_f64_body<7>(a, hs, peep_s, s_line, s_T, s_row, dir, wave, lane, Tmax);
-    else seq_f64_body<6>(a, hs, peep_s, s_line, s_T, s_row, dir, wave, lane, Tmax);
+    if (wave == 0) seq_f64_body<0, 0>(a, hs, peep_s, part, part_flag, s_line, s_T, s_row, dir, wave, lane, Tmax);
+    else if (wave == 1) seq_f64_body<0, 9>(a, hs, peep_s, part, part_flag, s_line, s_T, s_row, dir, wave, lane, Tmax);
+    else if (wave == 2) seq_f64_body<9, 8>(a, hs, peep_s, part, part_flag, s_line, s_T, s_row, dir, wave, lane, Tmax);
+    else seq_f64_body<17, 8>(a, hs, peep_s, part, part_flag, s_line, s_T, s_row, dir, wave, lane, Tmax);
 }
 
 }  // namespace ta64
@@ -329,6 +452,17 @@ extern "C" int64_t ta_lstm_f64_weight_doubles(int32_t which) {
     if (which == 2) return (int64_t)2 * 3 * kNs;
     return 0;
 }
+
+#ifdef TA_F64_PROFILE
+extern "C" int ta_lstm_f64_profile(unsigned long long* out4, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_prof), sizeof(g_prof));
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : ta_fail_hip(e, "ta_lstm_f64_profile");
+}
+#endif
 
 extern "C" int64_t ta_lstm_f64_gx_bytes(int64_t rows) { return rows < 0 ? 0 : (int64_t)2 * rows * kCols * 8; }
 

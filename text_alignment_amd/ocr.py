@@ -180,8 +180,8 @@ def _pack_lstm4(model):
 def _pack_lstm_f64(model):
     """weights of the float64 recurrence (csrc/ta_lstm_f64.hip): A fragments of v_mfma_f64_16x16x4_f64.  The 400
     pre-activations of a step are tiled as 25 tiles of 16 rows = (4 gates) x (4 units), row i = 4 gate + unit-in-tile;
-    waves take tiles 0..6, 7..12, 13..18, 19..24.
-    wh [dir 2][wave 4][slot 7][k-step 25][lane 64] = W_gate(i // 4)[unit 4 (tile0(wave) + slot) + i % 4][49 + 4 kstep + lane // 16]
+    a wave owns tiles 6 wave .. 6 wave + 5 (slots 0..5); slot 6 is tile 24, which the waves split along k.
+    wh [dir 2][wave 4][slot 7][k-step 25][lane 64] = W_gate(i // 4)[unit 4 tile(wave, slot) + i % 4][49 + 4 kstep + lane // 16]
     wx [dir 2][tile 25][k-step 13][lane 64]        = W_gate(2 (i // 8) + i % 2)[unit 4 tile + (i % 8) // 2][kp = 4 kstep + lane // 16]
                                                      (kp <= 48; B fragments, column i of a tile = position i of the tile in a row of Gx)
     with i = lane % 16; peep [dir 2][WIP, WFP, WOP][100]."""
@@ -200,9 +200,8 @@ def _pack_lstm_f64(model):
             for kk in range(13):
                 wx[d, tile, kk] = Wx[gates, units, 4 * kk + kq]
         for wv in range(4):
-            tile0 = 0 if wv == 0 else 1 + 6 * wv
-            for s in range(7 if wv == 0 else 6):
-                units = 4 * (tile0 + s) + i % 4
+            for s in range(7):
+                units = 4 * (6 * wv + s if s < 6 else 24) + i % 4
                 for kk in range(25):
                     wh[d, wv, s, kk] = Wh[i // 4, units, 4 * kk + kq]
         for q, name in enumerate(("WIP", "WFP", "WOP")):
@@ -230,6 +229,14 @@ FORCE_CLASS_SPLIT = (os.environ["TA_OCR_CLASS_SPLIT"] == "1") if os.environ.get(
 CLASS_SPLIT_MIN_LINES = 384     # below this (a few pages) the recurrence's tail has nothing worth hiding
 GROUP4_MAX_LINES = 2048         # exact-f32 mode: batches up to this size run in groups of 4 lines (see prepare)
 F64_GX_MAX_ROWS = 3200000       # float64 mode: rows whose hoisted input projection (6 400 B per row) is held at once: 20 GB
+# float64 mode: runs of this many groups (16 lines each) or more are pipelined per length class (forward_f64); cuts as
+# shares of the run's groups.  Measured (tools/f64_time.py, lines of 800 .. 2000 columns): two halves 17.3 ms per 1 920
+# lines against 19.0 one after the other (384 / 960 / 3 840 / 5 760 lines: 14.1 / 15.6 / 33.3 / 54.3 against 14.4 / 16.2 /
+# 34.4 / 55.7); three or four classes are SLOWER (20 .. 21 ms: the projection of the last class is left a third of the
+# CUs), and so are unequal halves (0.45 or 0.55: 19.3).  TA_OCR_F64_PIPE=0 switches it off, TA_OCR_F64_CUTS=a,b sets the cuts (timing).
+F64_CLASS_PIPELINE = os.environ.get("TA_OCR_F64_PIPE", "1") != "0"
+F64_CLASS_MIN_GROUPS = 16
+F64_CLASS_CUTS = tuple(float(v) for v in os.environ.get("TA_OCR_F64_CUTS", "0.5").split(",") if v)[:3]
 # class-split state: the side streams per device, and the verdict of the one-off timing check per (device, mode)
 # (a recogniser on another GPU or in another mode is timed for itself); guarded by a lock -- page threads share it
 _split_state = {"streams": {}, "ok": {}, "times_ms": {}}
@@ -477,8 +484,17 @@ class LineRecognizer(object):
         def forward_f64(g0, g1, stream_):
             """float64 mode: the input projection of every row of a run of groups in one GEMM (Gx, 6 400 bytes per row,
             held for at most F64_GX_MAX_ROWS rows at a time -- runs of groups are contiguous row ranges), then the
-            recurrence over those groups; both on stream_, which also orders the reuse of the buffer."""
+            recurrence over those groups.
+
+            A run of F64_CLASS_MIN_GROUPS groups or more is cut into length classes (groups are in order of falling length;
+            F64_CLASS_CUTS: the longer half and the shorter half), each with its own piece of the Gx buffer: the
+            projections are enqueued on stream_ class by class, and the recurrence of every class but the last goes
+            to a side stream as soon as ITS projection is done.  The longest lines set the recurrence's time (a chain
+            of T dependent steps), so they start after half of the projection instead of all of it, and the
+            projection of the shorter class runs on the CUs that recurrence has not claimed.  Same kernels on the
+            same rows: results are bit for bit those of the one-after-the-other order."""
             grow = st["group_row_host"]
+            piped = F64_CLASS_PIPELINE and stream_ == stream
             a = g0
             while a < g1:
                 b = a + 1
@@ -489,13 +505,32 @@ class LineRecognizer(object):
                 if self._gx is None or self._gx.numel() * 8 < need:
                     self._gx = None                                  # (free the old one first)
                     self._gx = torch.empty(max(need // 8, 1), dtype=torch.float64, device=self.device)
-                _native.check(lib.ta_lstm_xproj_f64(st["x"].data_ptr() + 4 * NI * r0, r1 - r0, self.wx64.data_ptr(),
-                                                    self._gx.data_ptr(), stream_), "ta_lstm_xproj_f64")
-                _native.check(lib.ta_lstm_forward_f64(
-                    self._gx.data_ptr(), r0, r1 - r0, st["row_off"].data_ptr(), st["T"].data_ptr(),
-                    st["group_lines"].data_ptr() + 4 * G * a, b - a, self.wh64.data_ptr(), self.peep64.data_ptr(),
-                    st["hout"].data_ptr(), cont[0].data_ptr() if cont else None, cont[1].data_ptr() if cont else None,
-                    cont[2].data_ptr() if cont else None, stream_), "ta_lstm_forward_f64")
+                cuts = [a, b]
+                if piped and b - a >= F64_CLASS_MIN_GROUPS:
+                    cuts = sorted(set([a, b] + [a + int(round(f * (b - a))) for f in F64_CLASS_CUTS]))
+                side = _class_streams(self.device) if len(cuts) > 2 else []
+                used, off = [], 0
+                for k in range(len(cuts) - 1):
+                    ca, cb = cuts[k], cuts[k + 1]
+                    c0, c1 = int(grow[ca]), int(grow[cb])
+                    gx = self._gx.data_ptr() + off
+                    off += lib.ta_lstm_f64_gx_bytes(c1 - c0)
+                    _native.check(lib.ta_lstm_xproj_f64(st["x"].data_ptr() + 4 * NI * c0, c1 - c0, self.wx64.data_ptr(),
+                                                        gx, stream_), "ta_lstm_xproj_f64")
+                    seq_stream = stream_
+                    if k < len(cuts) - 2:                            # every class but the last: its own stream
+                        done = torch.cuda.Event()
+                        done.record(cs)
+                        side[k].wait_event(done)
+                        seq_stream = side[k].cuda_stream
+                        used.append(side[k])
+                    _native.check(lib.ta_lstm_forward_f64(
+                        gx, c0, c1 - c0, st["row_off"].data_ptr(), st["T"].data_ptr(),
+                        st["group_lines"].data_ptr() + 4 * G * ca, cb - ca, self.wh64.data_ptr(), self.peep64.data_ptr(),
+                        st["hout"].data_ptr(), cont[0].data_ptr() if cont else None, cont[1].data_ptr() if cont else None,
+                        cont[2].data_ptr() if cont else None, seq_stream), "ta_lstm_forward_f64")
+                for sd in used:                                      # (also orders the reuse of the buffer)
+                    cs.wait_stream(sd)
                 a = b
 
         # (h0 / c0 / tstart of a continuation are indexed by LINE id, not by position in the launch: a launch over
