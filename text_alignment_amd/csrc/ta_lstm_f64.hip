@@ -14,22 +14,27 @@
 //                             v_mfma_f64_16x16x4_f64, rows x 52 x 400 per direction.
 //  Kr lstm_seq_f64_kernel     one workgroup of FOUR waves (one per SIMD, 512 registers each) per (16 lines,
 //                             direction).  The recurrent weights W[:, 49:] (4 x 100 x 100 float64 = 320 KB) live in
-//                             the CU's registers as B fragments for the whole kernel; h_{t-1} of the 16 lines is the A
-//                             operand in LDS (float64); per step the accumulators start from Gx (the loads are issued
-//                             a step ahead) and take 25 k-steps of v_mfma_f64_16x16x4_f64; cell state and gate
-//                             functions in float64 (own exp: range reduction + degree-11 polynomial, 1e-15).
+//                             the CU's registers as A fragments for the whole kernel (the first 120 doubles of a wave
+//                             pinned in AGPRs, which the MFMA reads itself); h_{t-1} of the 16 lines is the B operand,
+//                             kept in LDS (float64) and read into registers once per step; per step the accumulators
+//                             start from Gx (the loads are issued a step ahead) and take 25 k-steps of
+//                             v_mfma_f64_16x16x4_f64; cell state and gate functions in float64 (own exp: range
+//                             reduction + degree-10 polynomial, 3e-13).
 //
 // Tiling of the 400 pre-activations of a step: 25 tiles of 16 = (4 units) x (4 gates).  The WEIGHTS are the A operand
 // (M = 16 tile rows, row i = 4 * gate + unit-in-tile), the 16 lines the B operand's columns.  The f64 MFMA returns
 // D[i][j] in lane j + 16 (i mod 4), register i / 4 (tools/ubench/mfma_f64.hip): lane (j, q) therefore holds, in its
 // four accumulator registers, the four GATES of (line j, unit 4 tile + q) -- the cell update needs no exchange between
 // lanes, and the four values are 32 contiguous bytes of Gx (two 16-byte loads / stores).  No padding: 25 tiles x 25
-// k-steps are exactly 400 x 100.  Waves take 7, 6, 6, 6 tiles.
+// k-steps are exactly 400 x 100.  Every wave owns six tiles; the 25th is split along k between waves 1..3 and summed by
+// wave 0 (seq_f64_body).  In the projection kernel waves take 7, 6, 6, 6 column tiles.
 //
-// Measured (tools/ubench/mfma_f64.hip, profiles/r04_mfma_f64.txt): 64 cycles per MFMA per SIMD (= the 78.6 TF
-// float64 peak), the same for one dependent accumulator chain; a wave's v_fma_f64 beside another wave's f64 MFMAs
-// on the same SIMD gets one issue per 69 cycles -- the matrix instruction runs on the vector f64 units, so the gate
-// math cannot hide under it and a step costs MFMA time + gate time.
+// Measured (tools/ubench/mfma_f64.hip, mfma_f64_ops.hip, cell_f64.hip; profiles/r04_mfma_f64.txt, r04_mfma_f64_ops.txt,
+// r04_cell_f64.txt): 64 cycles per MFMA per SIMD (= the 78.6 TF float64 peak), the same for one dependent accumulator
+// chain; the matrix instruction holds the SIMD's vector issue while it runs -- a wave's v_fma_f64 beside another
+// wave's f64 MFMAs gets one issue per 69 cycles, and any VALU instruction between two MFMAs of a chain costs its full
+// ~6 .. 11 cycles (LDS reads do not) -- so the gate math cannot hide under the MFMAs and a step costs MFMA time + gate
+// time: (25 x 1623 + 25 x ~700) / 4 SIMDs = 14 500 cycles; the kernel takes 15 600.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -46,9 +51,8 @@ constexpr int kKH = kNs / 4;        // 25 k-steps over h
 constexpr int kXK = 52;             // [1, x(48), 3 zeros]
 constexpr int kKX = kXK / 4;        // 13 k-steps over [1, x]
 constexpr int kW = 4;               // waves per workgroup
-constexpr int kMaxNT = 7;           // tile slots per wave in the packed weights (xproj: tiles of wave 0, waves 1..3 take 6;
-                                    // recurrence: six own tiles + the split one)
-constexpr int kOwnTiles = 6;        // recurrence: tiles a wave owns; the 25th is split along k
+constexpr int kMaxNT = 7;           // tile slots per wave in the packed recurrent weights: six own tiles + the 25th
+constexpr int kOwnTiles = 6;        // recurrence: tiles a wave owns (6 wave .. 6 wave + 5); the 25th is split along k
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -67,7 +71,9 @@ __device__ __forceinline__ unsigned long long prof_now() {
 // the four gates of one (row, unit) and moves them with two 16-byte accesses; the four lanes of a row's tile make each
 // access a contiguous 64-byte piece.
 __host__ __device__ constexpr int gx_index(int unit, int gate) { return 16 * (unit / 4) + 8 * (gate / 2) + 2 * (unit % 4) + (gate % 2); }
-__host__ __device__ constexpr int tile0_of(int wave) { return wave == 0 ? 0 : 1 + 6 * wave; }   // 0, 7, 13, 19
+// the projection's column tiles per wave: 0..6, 7..12, 13..18, 19..24 (giving the waves the 25th in turn, row tile by
+// row tile, measured SLOWER: 6.1 against 5.4 ms per 2.76 M rows -- the kernel waits on its stores, not on the MFMAs)
+__host__ __device__ constexpr int tile0_of(int wave) { return wave == 0 ? 0 : 1 + 6 * wave; }
 __host__ __device__ constexpr int ntiles_of(int wave) { return wave == 0 ? 7 : 6; }
 
 // ---------------------------------------------------------------------------------------------
