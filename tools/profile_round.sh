@@ -31,6 +31,7 @@ done
 # per-kernel traces: one launch per kernel (the product splits large batches into length classes on side
 # streams, ocr.LineRecognizer.run; its own trace follows)
 export TA_OCR_CLASS_SPLIT=0
+export TA_OCR_F64_PIPE=0          # float64 mode: one projection and one recurrence launch per pass
 export TA_OCR_GROUP=16            # the 16-line recurrence kernel (the product's choice above 2 048 lines)
 for w in "1920 f32" "1920 split" "5760 f32" "1920 f64"; do
   set -- $w
@@ -44,6 +45,11 @@ for n in 30 1920; do
 done
 unset TA_OCR_CLASS_SPLIT
 unset TA_OCR_GROUP
+unset TA_OCR_F64_PIPE
+# float64 mode as the product runs it: projection and recurrence per length class (two halves), the recurrence of the
+# longer half on a side stream
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_1920_f64_classes" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f64 > "$OUT/kt_ocr_1920_f64_classes.log" 2>&1
+echo "ocr 1920 f64 (length classes) kernel trace done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_1920_split_classes" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 split > "$OUT/kt_ocr_1920_split_classes.log" 2>&1
 echo "ocr 1920 split (length classes) kernel trace done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_pages_images" -o pg -- python3 "$REPO/tools/pages_img_time.py" 32 8 1 > "$OUT/kt_pages_images.log" 2>&1
@@ -78,6 +84,7 @@ echo "ocr pmc f32 groups of 4 done"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --output-format csv -d "$OUT/ocr_pmc_f32g4_waits" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f32 > "$OUT/ocr_pmc_f32g4_waits.log" 2>&1
 echo "ocr wait counters (groups of 4) done"
 unset TA_OCR_GROUP
+export TA_OCR_F64_PIPE=0
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_f64" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f64 > "$OUT/ocr_pmc_f64.log" 2>&1
 echo "ocr pmc f64 done"
 fi
