@@ -246,8 +246,8 @@ int ta_lstm_forward(const float* x, const int64_t* row_off, const int32_t* T,
  * ta_lstm_forward_f64: the recurrence over `ngroups` groups of 16 lines (group_lines = int32[ngroups][16], -1 =
  *   empty slot) whose rows lie in [gx_row0, gx_row0 + gx_rows) -- row_off / hout use ABSOLUTE rows, gx holds the
  *   projection of rows gx_row0 .. only.  wh = ta_lstm_f64_weight_doubles(0) doubles
- *   [dir 2][wave 4][slot 7][k-step 25][lane 64] = W_gate(i / 4)[unit 4 (tile0(wave) + slot) + i % 4][49 + 4 kstep + lane / 16],
- *   tile0 = 0, 7, 13, 19 (slot 6 of waves 1..3 unused); peep = double[2][3][100]: WIP, WFP, WOP per direction.
+ *   [dir 2][wave 4][slot 7][k-step 25][lane 64] = W_gate(i / 4)[unit 4 tile + i % 4][49 + 4 kstep + lane / 16],
+ *   tile = 6 wave + slot for slots 0..5 and 24 for slot 6 (the tile the waves split along k); peep = double[2][3][100]: WIP, WFP, WOP per direction.
  *   hout [rows][200] float (the float64 outputs rounded once).  h0 / c0 (double[lines][2][100]) / tstart as in
  *   ta_lstm_forward.
  */

@@ -214,7 +214,8 @@ struct Seq64Args {
     const int64_t* row_off;    // per line: first (absolute) row
     const int32_t* T;          // per line: timesteps
     const int32_t* group_lines;// [ngroups][16] line ids, -1 = empty slot
-    const double* wh;          // [dir 2][wave 4][slot 7][k-step 25][lane 64]: A fragments, W_gate(i / 4)[unit 4 (tile0(wave) + slot) + i % 4][49 + 4 kstep + lane / 16], i = lane % 16
+    const double* wh;          // [dir 2][wave 4][slot 7][k-step 25][lane 64]: A fragments, W_gate(i / 4)[unit 4 tile + i % 4][49 + 4 kstep + lane / 16],
+                               // i = lane % 16, tile = 6 wave + slot (slots 0..5) or 24 (slot 6: the tile split along k)
     const double* peep;        // [dir 2][3: WIP, WFP, WOP][100]
     float* hout;               // [rows][200] (absolute rows)
     const double* h0;          // optional [lines][2][100]: outputs before the first step
