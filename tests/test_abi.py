@@ -171,6 +171,36 @@ def test_c_example_runs_and_matches_oracle(native):
         assert out[0] == "".join(tra) and out[1] == "".join(ocr), (t, o, out)
 
 
+def test_inline_asm_f64_mfmas_keep_their_wait_states():
+    """csrc/ta_lstm_f64.hip issues v_mfma_f64_16x16x4_f64 as inline assembly (AGPR-resident weights named in the
+    instruction), which the compiler's hazard recogniser does not see: the wait states around a chain are the kernel's
+    own (mfma_begin / mfma_settle).  Checked on the disassembly of the built library (tools/check_mfma_hazard.py): no
+    instruction but the next MFMA of the chain touches a result within 18 wait states, no VALU write of a source
+    within 2 before."""
+    from tools import check_mfma_hazard as chk
+    from text_alignment_amd import _native
+    found, nmfma, nco = chk.check(_native.LIB_PATH)
+    assert nco >= 1 and nmfma >= 625             # the recurrence's 25 x 25 tiles are there
+    assert found == []
+    # the checker itself
+    bad = """
+0000000000001000 <kern>:
+	v_mfma_f64_16x16x4_f64 v[42:49], a[0:1], v[102:103], v[42:49]  // 000000001000: D3EE002A 04AACD00
+	v_mfma_f64_16x16x4_f64 v[42:49], a[2:3], v[104:105], v[42:49]  // 000000001008: D3EE002A 04AAD102
+	s_nop 15                                                   // 000000001010: BF80000F
+	v_max_f64 v[52:53], v[48:49], v[48:49]                     // 000000001014: D2680034 00026130
+	v_mov_b32_e32 v60, v1                                      // 00000000101C: 7E780301
+	v_mfma_f64_16x16x4_f64 v[70:77], v[60:61], v[104:105], v[70:77]  // 000000001020: D3EE0046 051AD13C
+	s_nop 15                                                   // 000000001028: BF80000F
+	s_nop 2                                                    // 00000000102C: BF800002
+	v_max_f64 v[52:53], v[76:77], v[76:77]                     // 000000001030: D2680034 0002994C
+"""
+    got, n = chk.findings(bad)
+    assert n == 3 and len(got) == 2, got
+    assert "after 16 wait state(s)" in got[0] and "v_max_f64" in got[0]
+    assert "v_mov_b32_e32" in got[1] and "0 wait state(s) before" in got[1]
+
+
 def test_no_buffer_store_data_hazard_in_the_built_library():
     """16-byte buffer stores must not carry an SGPR soffset, and no VALU
     instruction may write a store's data VGPRs within two issue slots behind it.  Checked on the
