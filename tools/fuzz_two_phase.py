@@ -1,6 +1,7 @@
 """Ad-hoc fuzz of the aligner against the C oracle: random sizes around strip / block / checkpoint
 borders, every scoring system of the test suite, similar and unrelated sequences.
-    python tools/fuzz_two_phase.py [rounds] [seed] [two-phase | rows2 | rows4 | rows2-wide | rows4-wide]"""
+    python tools/fuzz_two_phase.py [rounds] [seed] [two-phase | rows2 | rows4 | rows2-wide | rows4-wide] [tb_waves 1..6]
+(tb_waves: the two-phase traceback's launch shape, NWBatch.tb_waves; default: the library's choice)"""
 import os
 import sys
 
@@ -17,6 +18,7 @@ SYSTEMS = [[8, -4, -7, -7, -3, 0], [10, -5, -7, -7, -7, -7], [5, -10, -2, -7, 0,
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 shape = sys.argv[3] if len(sys.argv) > 3 else "two-phase"
+tb_waves = int(sys.argv[4]) if len(sys.argv) > 4 else None
 special = [1, 2, 3, 4, 63, 64, 65, 255, 256, 257, 258, 511, 512, 513, 768, 769, 1023, 1024, 1025, 2047, 2048, 2049]
 bad = 0
 for rnd in range(rounds):
@@ -44,6 +46,7 @@ for rnd in range(rounds):
         prm = SYSTEMS[rnd % len(SYSTEMS)]
     if shape == "two-phase":
         batch = tsc.NWBatch(t_list, o_list, prm, two_phase=True)
+        batch.tb_waves = tb_waves
     else:
         batch = tsc.NWBatch(t_list, o_list, prm, two_phase=False, wide=True if shape.endswith("wide") else None)
         batch.rows = 2 if shape.startswith("rows2") else 4
