@@ -250,6 +250,11 @@ int ta_lstm_forward(const float* x, const int64_t* row_off, const int32_t* T,
  *   tile = 6 wave + slot for slots 0..5 and 24 for slot 6 (the tile the waves split along k); peep = double[2][3][100]: WIP, WFP, WOP per direction.
  *   hout [rows][200] float (the float64 outputs rounded once).  h0 / c0 (double[lines][2][100]) / tstart as in
  *   ta_lstm_forward.
+ * ta_lstm_forward_f64_g4: the same recurrence, bit for bit the same outputs, over groups of FOUR lines (group_lines =
+ *   int32[ngroups][4]) on v_mfma_f64_4x4x4_4b_f64: a quarter of the cost per step, for batches whose 16-line groups
+ *   would not fill the GPU or would wait for their longest line.  wh4 = ta_lstm_f64_weight_doubles(3) doubles
+ *   [dir 2][tile 25][k-step 25][lane 64] = W_gate(lane % 4)[unit 4 tile + (lane / 4) % 4][49 + 4 kstep + lane / 16];
+ *   every other argument as in ta_lstm_forward_f64.
  */
 int64_t ta_lstm_f64_weight_doubles(int32_t which);
 int64_t ta_lstm_f64_gx_bytes(int64_t rows);
@@ -258,6 +263,10 @@ int ta_lstm_forward_f64(const double* gx, int64_t gx_row0, int64_t gx_rows, cons
                         const int32_t* T, const int32_t* group_lines, int32_t ngroups, const double* wh,
                         const double* peep, float* hout, const double* h0, const double* c0,
                         const int32_t* tstart, void* stream);
+int ta_lstm_forward_f64_g4(const double* gx, int64_t gx_row0, int64_t gx_rows, const int64_t* row_off,
+                           const int32_t* T, const int32_t* group_lines, int32_t ngroups, const double* wh4,
+                           const double* peep, float* hout, const double* h0, const double* c0,
+                           const int32_t* tstart, void* stream);
 int ta_lstm_output(const float* y, int64_t rows, const float* w2p, int32_t no,
                    float* probs, float* logits, float* summary, void* stream);
 int64_t ta_lstm_output_split_weight_bytes(int32_t no);

@@ -363,7 +363,7 @@ def test_group_boundaries_and_order():
     assert rec.recognise([]) == []
 
 
-@pytest.mark.parametrize("precision,group", [("f32", None), ("f32", "16"), ("split", None)])
+@pytest.mark.parametrize("precision,group", [("f32", None), ("f32", "16"), ("split", None), ("f64", None), ("f64", "16")])
 def test_class_split_launches_equal_single_launches(precision, group, monkeypatch):
     """run(): the recurrence and the output layer per length class on side streams (large batches) against
     one launch each -- same kernels on the same rows, so states, summaries, probabilities and decode are
@@ -377,7 +377,7 @@ def test_class_split_launches_equal_single_launches(precision, group, monkeypatc
         monkeypatch.setattr(ocr, "FORCE_GROUP", int(group))   # the kernel large batches take, on a batch a test can afford
     st = rec.prepare(lines)
     G = st["group_size"]
-    assert G == (4 if precision == "f32" and not group else 16) and st["ngroups"] == (len(lines) + G - 1) // G
+    assert G == (4 if precision in ("f32", "f64") and not group else 16) and st["ngroups"] == (len(lines) + G - 1) // G
     T, start = st["T_host"], st["row_start_host"]
     order = np.argsort(-T, kind="stable")
     assert np.array_equal(start[order], np.cumsum(T[order]) - T[order])           # sorted layout, no holes
@@ -436,6 +436,83 @@ def test_four_line_groups_equal_sixteen_line_groups(monkeypatch):
         _segmented_states(rec, st, om, lines, 37, group=G)
         seg[G] = st["hout"].clone()
     assert torch.equal(seg[4], seg[16])
+
+
+def test_f64_four_line_groups_equal_sixteen_line_groups(monkeypatch):
+    """Float64 mode has two recurrence kernels as well: groups of 16 lines on v_mfma_f64_16x16x4_f64 and groups of 4 on
+    v_mfma_f64_4x4x4_4b_f64 (csrc/ta_lstm_f64.hip: lstm_seq_f64_kernel / lstm_seq4_f64_kernel).  A block's 4-term product is
+    the fma chain k = 0..3 of the 16 x 16 x 4 form, the accumulators start from the same Gx, the 25th tile is summed
+    from the same three partial chains and the cell update is the same function: LSTM outputs equal to the BIT.  Ragged
+    lengths, 1 .. 21 lines (every fill of the last group), both directions, a continued sequence (double h0 / c0 /
+    tstart) through both entry points, and a few lines against the float64 oracle so that 'equal' is not 'equally wrong'."""
+    from oracle import ocr_ref_f64 as R
+    from text_alignment_amd import _native, ocr
+    om = R.synthetic_model(7002, no=64)
+    rec = ocr.LineRecognizer(ocr.LineModel(om.fwd, om.rev, om.W2, om.codec), precision="f64")
+    rng = np.random.default_rng(23)
+    pool = [R.synthetic_line(9700 + k, width=int(w)) for k, w in enumerate(rng.integers(1, 260, size=21))]
+    for cnt in (1, 2, 3, 4, 5, 7, 8, 16, 17, 21):
+        got = {}
+        for G in (4, 16):
+            monkeypatch.setattr(ocr, "FORCE_GROUP", G)
+            st = rec.prepare(pool[:cnt])
+            assert st["group_size"] == G
+            rec.run(st, want_logits=True)
+            torch.cuda.synchronize()
+            got[G] = [(st["hout"][int(s):int(s + t)].clone(), st["logits"][int(s):int(s + t)].clone())
+                      for s, t in zip(st["row_start_host"], st["T_host"])] + [rec.decoded(st)]
+        for a, b in zip(got[4][:-1], got[16][:-1]):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), cnt
+        assert got[4][-1] == got[16][-1]
+        if cnt in (5, 21):
+            for k in (0, cnt - 1):
+                want = R.bilstm_states(om, pool[k])
+                assert float(np.abs(got[4][k][0].cpu().numpy() - want).max()) < 1e-6, (cnt, k)
+    monkeypatch.setattr(ocr, "FORCE_GROUP", None)
+    assert rec.prepare(pool[:5])["group_size"] == 4           # the product's own choice for a small batch
+    # continued sequences: segments of 37 steps from the oracle's float64 states, through both entry points
+    lines = [ln for ln in pool if ln.shape[0] >= 60][:7]
+    st = rec.prepare(lines)
+    dev = rec.device
+    row_off, T, h0, c0, ts = [], [], [], [], []
+    for b, xs in enumerate(lines):
+        Tl = xs.shape[0]
+        f_h, f_c = R.lstm_forward(om.fwd, xs, return_cell=True)
+        r_h, r_c = R.lstm_forward(om.rev, xs[::-1], return_cell=True)
+        for a in range(0, Tl, 37):
+            e = min(a + 37, Tl)
+            row_off.append(int(st["row_start_host"][b]) + a); T.append(e - a)
+            zero, done_rev = np.zeros(100), Tl - e
+            h0.append([f_h[a - 1] if a > 0 else zero, r_h[done_rev - 1] if done_rev > 0 else zero])
+            c0.append([f_c[a - 1] if a > 0 else zero, r_c[done_rev - 1] if done_rev > 0 else zero])
+            ts.append([a, done_rev])
+    nseg = len(T)
+    order = np.argsort(-np.asarray(T), kind="stable")
+
+    def d(a, dt):
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(a), dtype=dt)).to(dev)
+    common = (d(row_off, np.int64), d(T, np.int32), d(h0, np.float64), d(c0, np.float64), d(ts, np.int32))
+    rows = st["rows"]
+    gx = torch.empty(_native.lib.ta_lstm_f64_gx_bytes(rows) // 8, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _native.check(_native.lib.ta_lstm_xproj_f64(st["x"].data_ptr(), rows, rec.wx64.data_ptr(), gx.data_ptr(), stream), "xproj")
+    seg = {}
+    for G, fn, wh in ((4, _native.lib.ta_lstm_forward_f64_g4, rec.wh64g4), (16, _native.lib.ta_lstm_forward_f64, rec.wh64)):
+        ngroups = (nseg + G - 1) // G
+        gl = np.full((ngroups, G), -1, dtype=np.int32)
+        gl.reshape(-1)[:nseg] = order
+        gld = d(gl, np.int32)
+        st["hout"].zero_()
+        _native.check(fn(gx.data_ptr(), 0, rows, common[0].data_ptr(), common[1].data_ptr(), gld.data_ptr(), ngroups,
+                         wh.data_ptr(), rec.peep64.data_ptr(), st["hout"].data_ptr(), common[2].data_ptr(),
+                         common[3].data_ptr(), common[4].data_ptr(), stream), "forward_f64 G=%d" % G)
+        torch.cuda.synchronize()
+        seg[G] = st["hout"].clone()
+    assert torch.equal(seg[4], seg[16])
+    hout = seg[4].cpu().numpy()
+    for b, xs in enumerate(lines):
+        s0 = int(st["row_start_host"][b])
+        assert float(np.abs(hout[s0:s0 + xs.shape[0]] - R.bilstm_states(om, xs)).max()) < 1e-6, b
 
 
 def test_input_too_large():

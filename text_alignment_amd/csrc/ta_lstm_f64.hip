@@ -57,6 +57,9 @@ constexpr int kOwnTiles = 6;        // recurrence: tiles a wave owns (6 wave .. 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 #ifdef TA_F64_PROFILE
+#ifndef TA_F64_PROF_WAVE
+#define TA_F64_PROF_WAVE 0          // the four-line kernel: the wave that reports ([0] MFMA phase, [1] transpose + cell update + stores, [2] barrier)
+#endif
 // -DTA_F64_PROFILE: cycle counters of wave 0 of every workgroup (tools/f64_time.py): [0] tiles' MFMAs + cell update,
 // [1] h to LDS / output store / next accumulator loads, [2] the step's barrier, [3] steps
 __device__ unsigned long long g_prof[4];
@@ -77,60 +80,77 @@ __host__ __device__ constexpr int tile0_of(int wave) { return wave == 0 ? 0 : 1 
 __host__ __device__ constexpr int ntiles_of(int wave) { return wave == 0 ? 7 : 6; }
 
 // ---------------------------------------------------------------------------------------------
-// float64 gate functions.  exp: x = n ln2 + r, |r| <= ln2 / 2; e^r by its Taylor polynomial of degree 10
-// (remainder < 3e-13 relative: four orders below what the chaotic spec model needs), scaled by 2^n with
-// v_ldexp_f64.  Valid for |x| < 700.
-__device__ __forceinline__ double exp_f64(double x) {
-    // n = rint(x log2 e) by the magic-number add: the integer lands in the low mantissa bits of t (|n| < 2^31 here)
+// float64 gate functions.  exp: x = n ln2 + r, |r| <= ln2 / 2; e^r by a degree-9 polynomial (the interpolant at the
+// Chebyshev nodes of the interval: 1.9e-14 relative, round 5 -- the degree-10 Taylor polynomial it replaces had 3e-13),
+// scaled by 2^n with v_ldexp_f64.  |x| <= 40 here (the callers clamp), so n ln2 is exact enough with ln2 as ONE double
+// (|n| <= 58: 1.3e-15).  SCALE = 2 evaluates e^(2 x') from x' = x / 2 (the tanh's e^(-2 c)): the same reduction on
+// r / 2 with the coefficients scaled by powers of two, which is exact -- no instruction for the doubling.
+#ifndef TA_F64_RCP_NEWTON
+#define TA_F64_RCP_NEWTON 1
+#endif
+template <int SCALE>
+__device__ __forceinline__ double exp_scaled_f64(double xs) {                // e^(SCALE xs), |SCALE xs| <= 40
+#pragma clang fp contract(off)
+    // n = rint(SCALE xs log2 e) by the magic-number add: the integer lands in the low mantissa bits of t
     const double kMagic = 6755399441055744.0;                             // 1.5 * 2^52
-    const double t = __builtin_fma(x, 1.4426950408889634074, kMagic);
+    const double t = __builtin_fma(xs, SCALE * 1.4426950408889634074, kMagic);
     const double n = t - kMagic;
-    double r = __builtin_fma(-n, 6.93147180369123816490e-01, x);          // ln2 split as in fdlibm: hi has 32 bits
-    r = __builtin_fma(-n, 1.90821492927058770002e-10, r);
-    double p = 1.0 / 3628800.0;                                           // degree 10: remainder r^11 / 11! < 3e-13 relative
-    p = __builtin_fma(p, r, 1.0 / 362880.0);
-    p = __builtin_fma(p, r, 1.0 / 40320.0);
-    p = __builtin_fma(p, r, 1.0 / 5040.0);
-    p = __builtin_fma(p, r, 1.0 / 720.0);
-    p = __builtin_fma(p, r, 1.0 / 120.0);
-    p = __builtin_fma(p, r, 1.0 / 24.0);
-    p = __builtin_fma(p, r, 1.0 / 6.0);
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
+    const double r = __builtin_fma(n, -0.69314718055994530942 / SCALE, xs); // = (SCALE xs - n ln2) / SCALE
+    constexpr double s1 = SCALE, s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1, s6 = s4 * s2, s7 = s4 * s3,
+                     s8 = s4 * s4, s9 = s8 * s1;
+    double p = 2.763264057801236e-06 * s9;
+    p = __builtin_fma(p, r, 2.488445976576625e-05 * s8);
+    p = __builtin_fma(p, r, 0.00019841190647903092 * s7);
+    p = __builtin_fma(p, r, 0.0013888801749630082 * s6);
+    p = __builtin_fma(p, r, 0.008333333367311192 * s5);
+    p = __builtin_fma(p, r, 0.041666667040552045 * s4);
+    p = __builtin_fma(p, r, 0.16666666666615648 * s3);
+    p = __builtin_fma(p, r, 0.4999999999943859 * s2);
+    p = __builtin_fma(p, r, 1.0000000000000013 * s1);
+    p = __builtin_fma(p, r, 1.0000000000000135);
     return __builtin_ldexp(p, (int)__builtin_bit_cast(long long, t));     // low dword of t = n (two's complement)
 }
-// 1 / d for d in [1, 1 + e^20]: the hardware reciprocal refined by two Newton steps (quadratic: whatever the
-// seed's accuracy above 2^-14, the result is within an ulp or two)
+__device__ __forceinline__ double exp_f64(double x) { return exp_scaled_f64<1>(x); }
+// 1 / d for d in [1, 1e40]: the hardware reciprocal (measured 4.5e-8 relative: tools/ubench/cell_f64.hip,
+// profiles/r05_cell_f64.txt) refined by ONE Newton step (quadratic: 2e-15; the cell update's error against long double
+// arithmetic is 2.1e-14 with one step or two -- the exponentials' polynomial)
 __device__ __forceinline__ double rcp_f64(double d) {
+#pragma clang fp contract(off)
     double y = __builtin_amdgcn_rcp(d);
-    double e = __builtin_fma(-d, y, 1.0);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-d, y, 1.0);
-    return __builtin_fma(y, e, y);
+#pragma unroll
+    for (int i = 0; i < TA_F64_RCP_NEWTON; ++i) {
+        const double e = __builtin_fma(-d, y, 1.0);
+        y = __builtin_fma(y, e, y);
+    }
+    return y;
 }
+__device__ __forceinline__ double clamp20(double v) { return __builtin_fmin(__builtin_fmax(v, -20.0), 20.0); }
 // ocropy's sigmoid is 1 / (1 + exp(clip(-x, -20, 20)))   -- in float64 the clip is visible
 // (sigma(-25) = 2.06e-9 with it, 1.4e-11 without), so it is kept; tanh(x) = (1 - e) / (1 + e) with e = exp(-2x), |x|
 // clamped to 20 (tanh(20) = 1 - 8e-18 rounds to 1).
 
 // One LSTM cell update (`forward_py`) from the four pre-activations of a (line, unit) pair.
-// past0: not the first step of the whole sequence (the peepholes on the old cell state and the output peephole are
-// skipped at t = 0).
-__device__ __forceinline__ double lstm_cell_f64(double gi, double gf, double go, double ci_pre, double& c, bool past0,
-                                                double wip, double wfp, double wop) {
+// c: the cell state, ZERO before the first step of a sequence (the input / forget peepholes and the old state's share then
+// vanish by themselves); wop_t: the output peephole, zero at the first step of the whole sequence (skipped at t = 0).
+// Every operation is spelled out (no contraction left to the compiler): the 16-line and the 4-line kernel round alike.
+__device__ __forceinline__ double lstm_cell_f64(double gi, double gf, double go, double ci_pre, double& c,
+                                                double wip, double wfp, double wop_t) {
+#pragma clang fp contract(off)
     // every gate is a ratio with denominator 1 + e^z; the three of the cell-state update share ONE reciprocal
-    // (of the product of their denominators, at most (1 + e^20)^3 ~ 1e26), the two of the output another
-    const double cp = past0 ? c : 0.0;
-    const double ea = exp_f64(-2.0 * __builtin_fmin(__builtin_fmax(ci_pre, -20.0), 20.0));               // tanh(ci_pre) = (1 - ea) / (1 + ea)
-    const double eb = exp_f64(__builtin_fmin(__builtin_fmax(-__builtin_fma(wip, cp, gi), -20.0), 20.0)); // sigma = 1 / (1 + eb), ocropy's clip
-    const double ef = exp_f64(__builtin_fmin(__builtin_fmax(-__builtin_fma(wfp, cp, gf), -20.0), 20.0));
-    const double pa = (1.0 + ea) * (1.0 + eb), pf = 1.0 + ef;
+    // (of the product of their denominators, at most (1 + e^40) (1 + e^20)^2 ~ 1e35), the two of the output another
+    const double cp = c;
+    const double ea = exp_scaled_f64<2>(-clamp20(ci_pre));                       // tanh(ci_pre) = (1 - ea) / (1 + ea)
+    const double eb = exp_f64(clamp20(-__builtin_fma(wip, cp, gi)));             // sigma = 1 / (1 + eb), ocropy's clip
+    const double ef = exp_f64(clamp20(-__builtin_fma(wfp, cp, gf)));
+    const double da = 1.0 + ea;
+    const double pa = __builtin_fma(da, eb, da), pf = 1.0 + ef;                  // (1 + ea) (1 + eb)
     const double r3 = rcp_f64(pa * pf);
-    const double cn = __builtin_fma((1.0 - ea) * pf, r3, (pa * r3) * cp);      // ci * gi + gf * c
-    const double ec = exp_f64(-2.0 * __builtin_fmin(__builtin_fmax(cn, -20.0), 20.0));
-    const double eo = exp_f64(__builtin_fmin(__builtin_fmax(-__builtin_fma(past0 ? wop : 0.0, cn, go), -20.0), 20.0));
+    const double cn = __builtin_fma((1.0 - ea) * pf, r3, (pa * r3) * cp);        // ci * gi + gf * c
+    const double ec = exp_scaled_f64<2>(-clamp20(cn));
+    const double eo = exp_f64(clamp20(-__builtin_fma(wop_t, cn, go)));
+    const double dc = 1.0 + ec;
     c = cn;
-    return (1.0 - ec) * rcp_f64((1.0 + ec) * (1.0 + eo));                       // tanh(c) * go
+    return (1.0 - ec) * rcp_f64(__builtin_fma(dc, eo, dc));                      // tanh(c) * go
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -289,13 +309,15 @@ __device__ __forceinline__ void seq_f64_body(const Seq64Args& a, double (&hs)[2]
 #pragma unroll
     for (int s = 0; s < NT; ++s) c[s] = 0.0;
     if (myid >= 0) {
-        if (a.c0) {
+        if (a.tstart) ts = a.tstart[(size_t)myid * 2 + dir];
+        if (a.c0 && ts > 0) {                                  // (a sequence that starts here starts from c = 0)
 #pragma unroll
             for (int s = 0; s < NT; ++s) c[s] = a.c0[((size_t)myid * 2 + dir) * kNs + ubase + 4 * s];
             if (kSums) csplit = a.c0[((size_t)myid * 2 + dir) * kNs + usplit];
         }
-        if (a.tstart) ts = a.tstart[(size_t)myid * 2 + dir];
     }
+    // the output peephole is skipped at the first step of the whole sequence: 0 / 1 factor, 1 from the second step on
+    double wop_on = ts > 0 ? 1.0 : 0.0;
     float* houtp = a.hout + dir * kNs;
 
     auto load_gx = [&](const double* g, int tile) -> f64x4 {
@@ -314,7 +336,6 @@ __device__ __forceinline__ void seq_f64_body(const Seq64Args& a, double (&hs)[2]
 #endif
     for (int t = 0; t < Tmax; ++t) {
         const int cur = t & 1, nxt = cur ^ 1;
-        const bool past0 = (t > 0) | (ts > 0);
         const double* gnext = gx_row(t + 1);
         const int tt = dir ? myT - 1 - t : t;
         float* hrow = houtp + (myrow + tt) * (2 * kNs);       // (dereferenced only while t < myT)
@@ -355,8 +376,8 @@ __device__ __forceinline__ void seq_f64_body(const Seq64Args& a, double (&hs)[2]
             }
             mfma_settle(acc[s]);
             const int unit = ubase + 4 * s;
-            const double h = lstm_cell_f64(acc[s][0], acc[s][1], acc[s][2], acc[s][3], c[s], past0,
-                                           peep_s[0][unit], peep_s[1][unit], peep_s[2][unit]);
+            const double h = lstm_cell_f64(acc[s][0], acc[s][1], acc[s][2], acc[s][3], c[s],
+                                           peep_s[0][unit], peep_s[1][unit], wop_on * peep_s[2][unit]);
 #ifdef TA_F64_PROFILE
             unsigned long long p1;                                 // (h as an input: the stamp follows the cell update)
             asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(p1) : "v"(h) : "memory");
@@ -383,14 +404,15 @@ __device__ __forceinline__ void seq_f64_body(const Seq64Args& a, double (&hs)[2]
             for (int w = 0; w < kW - 1; ++w)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) accs[r] += part[w][r][lane];
-            const double h = lstm_cell_f64(accs[0], accs[1], accs[2], accs[3], csplit, past0,
-                                           peep_s[0][usplit], peep_s[1][usplit], peep_s[2][usplit]);
+            const double h = lstm_cell_f64(accs[0], accs[1], accs[2], accs[3], csplit,
+                                           peep_s[0][usplit], peep_s[1][usplit], wop_on * peep_s[2][usplit]);
             hs[nxt][usplit][li] = h;
             if (t < myT) hrow[usplit] = (float)h;
 #ifdef TA_F64_PROFILE
             p_move += prof_now() - p0;
 #endif
         }
+        wop_on = 1.0;
 #ifdef TA_F64_PROFILE
         const unsigned long long pb = prof_now();
 #endif
@@ -448,15 +470,293 @@ __global__ __launch_bounds__(kW * 64) void lstm_seq_f64_kernel(Seq64Args a) {
     else seq_f64_body<17, 8>(a, hs, peep_s, part, part_flag, s_line, s_T, s_row, dir, wave, lane, Tmax);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Kr4: the recurrence on groups of FOUR lines (round 5) -- the same arithmetic, bit for bit, on v_mfma_f64_4x4x4_4b_f64.
+//
+// The recurrence is a chain of T dependent steps per workgroup and a step of Kr costs what its 16 x 16 x 4 tiles cost
+// however few of the 16 columns are lines: a page of 30 lines is two groups per direction (four workgroups, 14 ms), and
+// even 1 920 lines are ONE round of 240 workgroups on 256 CUs whose time is the longest line's chain.  The 4 x 4 x 4 form
+// computes four independent 4 x 4 x 4 blocks per instruction in 16 cycles (tools/ubench/mfma_f64_4x4.hip,
+// profiles/r05_mfma_f64_4x4.txt: the same 16 multiply-adds per cycle and SIMD as the 16 x 16 x 4 form; a dependent chain
+// needs four wait states, hidden by three chains per wave and two waves per SIMD).  Operand layout (measured there):
+//     A[i][k] of block b in lane i + 4 b + 16 k,   B[k][j] of block b in lane j + 4 b + 16 k,   D[i][j] of block b in lane j + 4 b + 16 i.
+// A tile is the same 16 weight rows as in Kr -- (4 gates) x (4 units) -- laid out as block b = unit-in-tile, row i = gate;
+// B is h_{t-1} of the four lines, the same for all four blocks (an LDS broadcast read); D puts gate i of (unit b, line j)
+// into lane j + 4 b + 16 i: the four gates of a cell sit in the four 16-lane ROWS of the wave, at the same place in each.
+// A wave owns three tiles (three accumulator chains); a 4 x 4 transpose of (accumulator, row) by the gfx950 row swaps
+// (v_permlane16_swap, v_permlane32_swap: 8 instructions for doubles) gives the lanes of row r the four gates of tile r,
+// whose cell they update -- the function Kr calls, from accumulators that took the same fma chain (Gx, then k ascending:
+// one block's 4-term product is the fma chain k = 0..3 of the 16 x 16 x 4 form, checked in the microbenchmark), so the two
+// kernels' outputs are equal to the bit.  Eight waves (two per SIMD, 256 registers each: 150 hold the wave's weights) cover
+// 24 tiles; the 25th is wave 7's fourth, computed as the three partial chains Kr splits it into (k-steps 0..8, 9..16,
+// 17..24 from zero, added to Gx in that order) and updated by the 16 lanes of its fourth row.
+constexpr int kG4 = 4;              // lines per workgroup
+constexpr int kW4 = 8;              // waves per workgroup
+
+struct Seq64G4Args {
+    const double* gx;          // as Seq64Args
+    int64_t gx_row0, gx_rows;
+    const int64_t* row_off;
+    const int32_t* T;
+    const int32_t* group_lines;// [ngroups][4] line ids, -1 = empty slot
+    const double* wh4;         // [dir 2][tile 25][k-step 25][lane 64]: A fragments of the 4 x 4 x 4 form,
+                               // W_gate(lane % 4)[unit 4 tile + (lane / 4) % 4][49 + 4 kstep + lane / 16]
+    const double* peep;
+    float* hout;
+    const double* h0;
+    const double* c0;
+    const int32_t* tstart;
+};
+
+__device__ __forceinline__ void swap_rows16(double& a, double& b) {       // a.row1 <-> b.row0, a.row3 <-> b.row2
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    const u32x2 lo = __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+    const u32x2 hi = __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    a = __builtin_bit_cast(double, (unsigned long long)lo[0] | ((unsigned long long)hi[0] << 32));
+    b = __builtin_bit_cast(double, (unsigned long long)lo[1] | ((unsigned long long)hi[1] << 32));
+}
+__device__ __forceinline__ void swap_rows32(double& a, double& b) {       // a.rows 2, 3 <-> b.rows 0, 1
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    const u32x2 lo = __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false);
+    const u32x2 hi = __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+    a = __builtin_bit_cast(double, (unsigned long long)lo[0] | ((unsigned long long)hi[0] << 32));
+    b = __builtin_bit_cast(double, (unsigned long long)lo[1] | ((unsigned long long)hi[1] << 32));
+}
+
+// Every wave owns tiles 3 wave .. 3 wave + 2.  The 25th tile (units 96..99) is computed as the three partial chains Kr splits
+// it into -- k-steps 0..8, 9..16, 17..24 from zero -- by waves 4, 5, 6 (one per SIMD 0, 1, 2; K0, NK: this wave's k-steps),
+// at the START of their step; the parts go through LDS to wave 3 (SUMS; it shares SIMD 3 with wave 7 and has no part of its
+// own), whose fourth row of lanes adds them to Gx in Kr's order and updates those four units' cells.  A SIMD's step is
+// then 150 + 9 / 8 / 8 / 0 MFMAs (the first form gave wave 7 all 25: 175 on SIMD 3 and a step 10 % longer).
+template <int K0, int NK, bool SUMS>
+__device__ __forceinline__ void seq4_f64_body(const Seq64G4Args& a, double (&hs)[2][kNs][kG4], double (&part)[3][64],
+                                              const double (&ap_s)[kKH][64], unsigned& part_flag, const int (&s_line)[kG4], const int (&s_T)[kG4],
+                                              const long long (&s_row)[kG4], int dir, int wave, int lane, int Tmax) {
+    constexpr int kSplitTile = kTiles - 1;
+    const int tile0 = 3 * wave;
+    double Aw[3][kKH];
+    {
+        const double* wp = a.wh4 + ((size_t)(dir * kTiles + tile0) * kKH) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int kk = 0; kk < kKH; ++kk) Aw[s][kk] = wp[((size_t)s * kKH + kk) * 64];
+    }
+    // roles of this lane.  Before the transpose (accumulators, Gx): gate `row`, unit-in-tile ub, line j of each of the wave's
+    // tiles; as B operand: k = row, line j; after the transpose: the cell (tile slot `row`, unit ub, line j).
+    const int j = lane & 3, ub = (lane >> 2) & 3, row = lane >> 4;
+    const int myT = s_T[j];
+    const long long myrow = s_row[j];
+    const int myid = s_line[j];
+    const bool has_cell = SUMS || row < 3;
+    const int mytile = row < 3 ? tile0 + row : kSplitTile;
+    const int unit = 4 * mytile + ub;
+    const double* pp = a.peep + (size_t)dir * 3 * kNs;
+    const double wip = pp[unit], wfp = pp[kNs + unit], wop = pp[2 * kNs + unit];
+    // Gx of (gate `row`, unit ub of a tile): position 16 tile + 8 (gate / 2) + 2 ub + gate % 2 of the row (gx_index);
+    // the summing lanes take all four gates of (unit ub of tile 24): two 16-byte pieces at 16 * 24 + 2 ub (+ 8)
+    const double* gxrow0 = a.gx + (size_t)dir * a.gx_rows * kCols;
+    const int gx_own = 8 * (row >> 1) + 2 * ub + (row & 1);
+    // running pointers: the Gx row of the current step (stepping +-400 doubles while the line lasts, then staying on its
+    // last row -- what it computes past its end is never stored) and the hout element of this lane's cell (+-200 floats)
+    const long long gstep = dir ? -(long long)kCols : (long long)kCols;
+    const double* gcur = gxrow0 + (myT > 0 ? myrow - a.gx_row0 + (dir ? myT - 1 : 0) : 0) * kCols;
+    double c = 0.0;
+    int ts = 0;
+    if (myid >= 0) {
+        if (a.tstart) ts = a.tstart[(size_t)myid * 2 + dir];
+        if (a.c0 && has_cell && ts > 0) c = a.c0[((size_t)myid * 2 + dir) * kNs + unit];
+    }
+    double wop_t = ts > 0 ? wop : 0.0;                       // the output peephole is skipped at the sequence's first step
+    float* hptr = a.hout + dir * kNs + unit + (myrow + (dir ? myT - 1 : 0)) * (2 * kNs);
+    const long long hstep = dir ? -2 * kNs : 2 * kNs;
+    double acc[3];
+    f64x2 gs01 = {0.0, 0.0}, gs23 = {0.0, 0.0};
+    {
+        const double* g = gcur;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) acc[s] = g[16 * (tile0 + s) + gx_own];
+        if (SUMS) {
+            gs01 = *reinterpret_cast<const f64x2*>(g + 16 * kSplitTile + 2 * ub);
+            gs23 = *reinterpret_cast<const f64x2*>(g + 16 * kSplitTile + 2 * ub + 8);
+        }
+    }
+#ifdef TA_F64_PROFILE
+    unsigned long long q_mfma = 0, q_cell = 0, q_bar = 0;
+#endif
+    for (int t = 0; t < Tmax; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        const double* gnext = t + 1 < myT ? gcur + gstep : gcur;
+        gcur = gnext;
+        const double* hb = &hs[cur][row][j];
+#ifdef TA_F64_PROFILE
+        const unsigned long long q0 = prof_now();
+#endif
+        // The B operand of the step (h_{t-1}[unit 4 kk + row][line j]) comes from LDS in chunks of five k-steps, two chunks
+        // ahead of the MFMAs that use them (15 MFMAs = 244 cycles cover an LDS read): with the reads between the MFMAs, one
+        // group of three ahead, a SIMD's 159 MFMAs took 3 170 cycles instead of 2 590 -- the younger wave of a SIMD runs the
+        // second half of its chains alone, every wait exposed; all 25 values at once do not fit beside the 150 weight registers
+        // The next step's accumulators (Gx) are asked for HERE, a whole step ahead: Gx streams from HBM (6 400 bytes per
+        // timestep, no reuse) and a miss takes longer than the cell update that used to cover it -- the younger wave of a
+        // SIMD, whose cell update is the last thing in a step, then waited ~600 cycles at the start of the next
+        double gn[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) gn[s] = gnext[16 * (tile0 + s) + gx_own];
+        constexpr int CH = 5, NCH = kKH / CH;
+        double B[2][CH];
+#ifdef TA_F64_SETPRIO                            // measured: no gain (4 395 against 4 265 cycles per step) -- timing builds only
+        __builtin_amdgcn_s_setprio(3);
+#endif
+#pragma unroll
+        for (int q = 0; q < 2 * CH; ++q) B[q / CH][q % CH] = hb[4 * q * kG4];
+        if (NK > 0) {
+            // this wave's part of the split tile first (its B values straight from LDS: nine or eight reads, once)
+            double pacc = 0.0;
+#pragma unroll
+            for (int i = 0; i < NK; ++i)                             // (the split tile's weights come from LDS too: 150 registers hold the wave's own)
+                pacc = __builtin_amdgcn_mfma_f64_4x4x4f64(ap_s[K0 + i][lane], hb[4 * (K0 + i) * kG4], pacc, 0, 0, 0);
+            part[wave - 4][lane] = pacc;
+            // a wave's LDS instructions execute in order: the count follows the store of all its lanes.  LDS-only fences --
+            // a plain workgroup release / acquire would also drain the Gx loads in flight
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            if (lane == 0) __hip_atomic_fetch_add(&part_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+            for (int q = 0; q < CH; ++q)
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+#if defined(TA_F64_ABL) && (TA_F64_ABL & 2)       // timing ablation: one MFMA per chunk and chain instead of five
+                    if (q == 0)
+#endif
+                    acc[s] = __builtin_amdgcn_mfma_f64_4x4x4f64(Aw[s][ch * CH + q], B[ch & 1][q], acc[s], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ch + 2 < NCH) {
+#pragma unroll
+                for (int q = 0; q < CH; ++q) B[ch & 1][q] = hb[4 * ((ch + 2) * CH + q) * kG4];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#ifdef TA_F64_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        double g0 = acc[0], g1 = acc[1], g2 = acc[2], g3 = 0.0;
+#ifdef TA_F64_PROFILE
+        unsigned long long q1;                                       // (g0 as an input: the stamp follows the MFMAs)
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(q1) : "v"(g0), "v"(g2) : "memory");
+#endif
+#pragma unroll
+        for (int s = 0; s < 3; ++s) acc[s] = gn[s];
+        // (accumulator a, row b) -> (accumulator b, row a): row r then holds gates 0..3 of tile slot r in g0..g3
+        swap_rows16(g0, g1);
+        swap_rows16(g2, g3);
+        swap_rows32(g0, g2);
+        swap_rows32(g1, g3);
+        if (SUMS) {
+            // the parts were posted at the start of the other waves' step; the wait is bounded all the same
+            const unsigned want = 3u * (unsigned)(t + 1);
+            for (int spin = 0; spin < (1 << 22); ++spin)
+                if (__hip_atomic_load(&part_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            const double* pl = &part[0][lane & 15];
+            double v[4] = {gs01[0], gs01[1], gs23[0], gs23[1]};
+#pragma unroll
+            for (int w = 0; w < 3; ++w)                              // Kr's order: Gx, then the parts of k-steps 0..8, 9..16, 17..24
+#pragma unroll
+                for (int g = 0; g < 4; ++g) v[g] += pl[w * 64 + 16 * g];
+            if (row == 3) { g0 = v[0]; g1 = v[1]; g2 = v[2]; g3 = v[3]; }
+            gs01 = *reinterpret_cast<const f64x2*>(gnext + 16 * kSplitTile + 2 * ub);
+            gs23 = *reinterpret_cast<const f64x2*>(gnext + 16 * kSplitTile + 2 * ub + 8);
+        }
+#if defined(TA_F64_ABL) && (TA_F64_ABL & 1)       // timing ablation: no cell update
+        const double h = ((g0 + g1) + (g2 + g3)) * 1e-3 + c * wip;
+#else
+        const double h = lstm_cell_f64(g0, g1, g2, g3, c, wip, wfp, wop_t);
+#endif
+        wop_t = wop;
+        if (has_cell) {
+            hs[nxt][unit][j] = h;
+            if (t < myT) *hptr = (float)h;
+        }
+        hptr += hstep;
+#ifdef TA_F64_PROFILE
+        unsigned long long q2;
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(q2) : "v"(h) : "memory");
+#endif
+        // The step's barrier orders the LDS only (h of this step for every wave's next B operand).  __syncthreads() is a
+        // workgroup fence over ALL memory: it made every wave wait for its hout store to be acknowledged by the L2 -- a
+        // write latency on the critical path of every step (the last wave's cell update, its store, the wait, the barrier).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+#ifdef TA_F64_PROFILE
+        q_mfma += q1 - q0; q_cell += q2 - q1; q_bar += prof_now() - q2;
+#endif
+    }
+#ifdef TA_F64_PROFILE
+    if (wave == TA_F64_PROF_WAVE && lane == 0) {
+        atomicAdd(&g_prof[0], q_mfma);
+        atomicAdd(&g_prof[1], q_cell);
+        atomicAdd(&g_prof[2], q_bar);
+        atomicAdd(&g_prof[3], (unsigned long long)Tmax);
+    }
+#endif
+}
+
+__global__ __launch_bounds__(kW4 * 64) void lstm_seq4_f64_kernel(Seq64G4Args a) {
+    __shared__ __attribute__((aligned(16))) double hs[2][kNs][kG4];          // h of the four lines, [unit][line]
+    __shared__ double part[3][64];                                           // the 25th tile's partial sums
+    __shared__ double ap_s[kKH][64];                                         // the 25th tile's A fragments (12.8 KB)
+    __shared__ unsigned part_flag;                                           // parts posted so far (3 per step)
+    __shared__ int s_line[kG4];
+    __shared__ int s_T[kG4];
+    __shared__ long long s_row[kG4];
+
+    const int grp = blockIdx.x >> 1, dir = blockIdx.x & 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) part_flag = 0;
+    if (tid < kG4) {
+        const int id = a.group_lines[grp * kG4 + tid];
+        s_line[tid] = id;
+        s_T[tid] = id >= 0 ? a.T[id] : 0;
+        s_row[tid] = id >= 0 ? a.row_off[id] : 0;
+    }
+    for (int e = tid; e < 2 * kNs * kG4; e += kW4 * 64) (&hs[0][0][0])[e] = 0.0;
+    for (int e = tid; e < kKH * 64; e += kW4 * 64) (&ap_s[0][0])[e] = a.wh4[((size_t)(dir * kTiles + kTiles - 1) * kKH) * 64 + e];
+    __syncthreads();
+    int Tmax = 0;
+#pragma unroll
+    for (int s = 0; s < kG4; ++s) Tmax = max(Tmax, s_T[s]);
+    if (a.h0) {
+        for (int e = tid; e < kG4 * kNs; e += kW4 * 64) {
+            const int slot = e / kNs, u = e % kNs;
+            const int id = s_line[slot];
+            if (id >= 0) hs[0][u][slot] = a.h0[((size_t)id * 2 + dir) * kNs + u];
+        }
+    }
+    __syncthreads();
+    if (wave == 3) seq4_f64_body<0, 0, true>(a, hs, part, ap_s, part_flag, s_line, s_T, s_row, dir, wave, lane, Tmax);
+    else if (wave == 4) seq4_f64_body<0, 9, false>(a, hs, part, ap_s, part_flag, s_line, s_T, s_row, dir, wave, lane, Tmax);
+    else if (wave == 5) seq4_f64_body<9, 8, false>(a, hs, part, ap_s, part_flag, s_line, s_T, s_row, dir, wave, lane, Tmax);
+    else if (wave == 6) seq4_f64_body<17, 8, false>(a, hs, part, ap_s, part_flag, s_line, s_T, s_row, dir, wave, lane, Tmax);
+    else seq4_f64_body<0, 0, false>(a, hs, part, ap_s, part_flag, s_line, s_T, s_row, dir, wave, lane, Tmax);
+}
+
 }  // namespace ta64
 
 using namespace ta64;
 
 extern "C" int64_t ta_lstm_f64_weight_doubles(int32_t which) {
-    // 0: wh [2][4][7][25][64]; 1: wx [2][25][13][64]; 2: peep [2][3][100]
+    // 0: wh [2][4][7][25][64]; 1: wx [2][25][13][64]; 2: peep [2][3][100]; 3: wh4 [2][25][25][64]
     if (which == 0) return (int64_t)2 * kW * kMaxNT * kKH * 64;
     if (which == 1) return (int64_t)2 * kTiles * kKX * 64;
     if (which == 2) return (int64_t)2 * 3 * kNs;
+    if (which == 3) return (int64_t)2 * kTiles * kKH * 64;          // wh4 [2][25][25][64]: the four-line kernel's
     return 0;
 }
 
@@ -501,5 +801,23 @@ extern "C" int ta_lstm_forward_f64(const double* gx, int64_t gx_row0, int64_t gx
                        reinterpret_cast<hipStream_t>(stream), a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ta_fail_hip(e, "lstm_seq_f64_kernel launch");
+    return TA_OK;
+}
+
+extern "C" int ta_lstm_forward_f64_g4(const double* gx, int64_t gx_row0, int64_t gx_rows, const int64_t* row_off,
+                                      const int32_t* T, const int32_t* group_lines, int32_t ngroups, const double* wh4,
+                                      const double* peep, float* hout, const double* h0, const double* c0,
+                                      const int32_t* tstart, void* stream) {
+    if (ngroups < 0 || gx_rows < 0 || gx_row0 < 0) return ta_fail(TA_EINVAL, "negative count");
+    if (ngroups == 0) return TA_OK;
+    if (!gx || !row_off || !T || !group_lines || !wh4 || !peep || !hout)
+        return ta_fail(TA_EINVAL, "null pointer argument");
+    if ((h0 != nullptr) != (c0 != nullptr) || (h0 != nullptr) != (tstart != nullptr))
+        return ta_fail(TA_EINVAL, "h0, c0 and tstart go together (all null, or all given)");
+    Seq64G4Args a{gx, gx_row0, gx_rows, row_off, T, group_lines, wh4, peep, hout, h0, c0, tstart};
+    hipLaunchKernelGGL(lstm_seq4_f64_kernel, dim3(2 * ngroups), dim3(kW4 * 64), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ta_fail_hip(e, "lstm_seq4_f64_kernel launch");
     return TA_OK;
 }

@@ -206,9 +206,17 @@ def _pack_lstm_f64(model):
                     wh[d, wv, s, kk] = Wh[i // 4, units, 4 * kk + kq]
         for q, name in enumerate(("WIP", "WFP", "WOP")):
             peep[d, q] = np.asarray(w[name], dtype=np.float64)
+    # the four-line kernel's A fragments (v_mfma_f64_4x4x4_4b_f64: A[i][k] of block b in lane i + 4 b + 16 k; block =
+    # unit-in-tile, row = gate): wh4 [dir 2][tile 25][k-step 25][lane 64] = W_gate(lane % 4)[unit 4 tile + (lane // 4) % 4][49 + 4 kstep + lane // 16]
+    wh4 = np.zeros((2, 25, 25, 64), dtype=np.float64)
+    for d, w in enumerate((model.fwd, model.rev)):
+        Wh = np.stack([np.asarray(w[name], dtype=np.float64) for name in ("WGI", "WGF", "WGO", "WCI")])[:, :, 1 + NI:]
+        for tile in range(25):
+            for kk in range(25):
+                wh4[d, tile, kk] = Wh[lane % 4, 4 * tile + (lane // 4) % 4, 4 * kk + lane // 16]
     lib = _native.lib
-    assert (wh.size, wx.size, peep.size) == tuple(lib.ta_lstm_f64_weight_doubles(k) for k in range(3))
-    return wh, wx, peep
+    assert (wh.size, wx.size, peep.size, wh4.size) == tuple(lib.ta_lstm_f64_weight_doubles(k) for k in range(4))
+    return wh, wx, peep, wh4
 
 
 _pool = None
@@ -228,6 +236,7 @@ FORCE_GROUP = int(os.environ["TA_OCR_GROUP"]) if os.environ.get("TA_OCR_GROUP") 
 FORCE_CLASS_SPLIT = (os.environ["TA_OCR_CLASS_SPLIT"] == "1") if os.environ.get("TA_OCR_CLASS_SPLIT") in ("0", "1") else None
 CLASS_SPLIT_MIN_LINES = 384     # below this (a few pages) the recurrence's tail has nothing worth hiding
 GROUP4_MAX_LINES = 2048         # exact-f32 mode: batches up to this size run in groups of 4 lines (see prepare)
+F64_GROUP4_MAX_LINES = 1 << 30  # float64 mode: groups of 4 lines (lstm_seq4_f64_kernel) up to this batch size
 F64_GX_MAX_ROWS = 3200000       # float64 mode: rows whose hoisted input projection (6 400 B per row) is held at once: 20 GB
 # float64 mode: runs of this many groups (16 lines each) or more are pipelined per length class (forward_f64); cuts as
 # shares of the run's groups.  Measured (tools/f64_time.py, lines of 800 .. 2000 columns): two halves 17.3 ms per 1 920
@@ -332,7 +341,7 @@ class LineRecognizer(object):
             self.w2s = torch.from_numpy(w2s).to(self.device)
             self.w2bias = torch.from_numpy(bias).to(self.device)
         if self.mode == 3:
-            self.wh64, self.wx64, self.peep64 = (torch.from_numpy(w).to(self.device) for w in _pack_lstm_f64(model))
+            self.wh64, self.wx64, self.peep64, self.wh64g4 = (torch.from_numpy(w).to(self.device) for w in _pack_lstm_f64(model))
             self._gx = None
 
     # ---- host -> device ------------------------------------------------------------------
@@ -408,8 +417,10 @@ class LineRecognizer(object):
         # 1 920 lines: 960 short workgroups pack onto the CUs instead of 240 long ones idling for the
         # longest, 8.7 instead of 10.0 ms); large batches keep the 16-line kernel, whose step has less
         # overhead per line (2 560 lines: 12.7 against 13.5 ms for the whole pass).
-        G = 4 if (self.mode == 0 and n <= GROUP4_MAX_LINES) else 16
-        if FORCE_GROUP is not None and self.mode == 0:
+        # Float64 mode has the same pair (v_mfma_f64_16x16x4 / v_mfma_f64_4x4x4_4b, equal to the bit as well); there
+        # the small groups win at every batch size measured (F64_GROUP4_MAX_LINES).
+        G = 4 if ((self.mode == 0 and n <= GROUP4_MAX_LINES) or (self.mode == 3 and n <= F64_GROUP4_MAX_LINES)) else 16
+        if FORCE_GROUP is not None and self.mode in (0, 3):
             G = FORCE_GROUP
         ngroups = (n + G - 1) // G
         group_lines = np.full((max(ngroups, 1), G), -1, dtype=np.int32)
@@ -506,7 +517,7 @@ class LineRecognizer(object):
                     self._gx = None                                  # (free the old one first)
                     self._gx = torch.empty(max(need // 8, 1), dtype=torch.float64, device=self.device)
                 cuts = [a, b]
-                if piped and b - a >= F64_CLASS_MIN_GROUPS:
+                if piped and (b - a) * G >= 16 * F64_CLASS_MIN_GROUPS:
                     cuts = sorted(set([a, b] + [a + int(round(f * (b - a))) for f in F64_CLASS_CUTS]))
                 side = _class_streams(self.device) if len(cuts) > 2 else []
                 used, off = [], 0
@@ -524,9 +535,10 @@ class LineRecognizer(object):
                         side[k].wait_event(done)
                         seq_stream = side[k].cuda_stream
                         used.append(side[k])
-                    _native.check(lib.ta_lstm_forward_f64(
+                    seq = lib.ta_lstm_forward_f64_g4 if G == 4 else lib.ta_lstm_forward_f64
+                    _native.check(seq(
                         gx, c0, c1 - c0, st["row_off"].data_ptr(), st["T"].data_ptr(),
-                        st["group_lines"].data_ptr() + 4 * G * ca, cb - ca, self.wh64.data_ptr(), self.peep64.data_ptr(),
+                        st["group_lines"].data_ptr() + 4 * G * ca, cb - ca, (self.wh64g4 if G == 4 else self.wh64).data_ptr(), self.peep64.data_ptr(),
                         st["hout"].data_ptr(), cont[0].data_ptr() if cont else None, cont[1].data_ptr() if cont else None,
                         cont[2].data_ptr() if cont else None, seq_stream), "ta_lstm_forward_f64")
                 for sd in used:                                      # (also orders the reuse of the buffer)
@@ -558,6 +570,10 @@ class LineRecognizer(object):
                                                  stream_), "ta_lstm_output")
         if class_split is None:
             class_split = lstm and output and _class_split_wanted(self, st)
+        if self.mode == 3:
+            # float64 mode pipelines its own two kernels over length classes (forward_f64) with pieces of ONE Gx buffer;
+            # three concurrent per-class launches of it would share that buffer -- the class split is not for this mode
+            class_split = False
         if class_split and lstm and output and ng >= 3:
             cuts = [0, max(1, int(round(0.1 * ng))), max(2, int(round(0.3 * ng))), ng]
             side = _class_streams(self.device)
