@@ -256,11 +256,13 @@ def bench_ocr(args, rank, precision=None, nlines=None):
         # float64 mode: hoisted input projection (a f64 GEMM) + the recurrence on v_mfma_f64_16x16x4_f64 (timed
         # together as "lstm": one run() issues both per run of groups); algorithmic flops per timestep as in f32 mode
         tf = tsteps * 238400.0 / (lstm_ms * 1e-3) / 1e12
+        traffic, traffic_src = measured_f64_traffic(nlines)
         roof = {"bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": tf / F64_MFMA_PEAK_TF, "traffic": None,
-                "kernel": "lstm_seq_f64_kernel (+ lstm_xproj_f64_kernel)",
+                "frac": tf / F64_MFMA_PEAK_TF, "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": "%s (+ lstm_xproj_f64_kernel)" % ("lstm_seq4_f64_kernel" if st["group_size"] == 4 else "lstm_seq_f64_kernel"),
                 "flops": "algorithmic: 238400 per timestep, all of them float64 (no padding: 25 x 25 tiles are exactly 400 x 100; the x part pads 49 -> 52)",
-                "peak_is": "f64 matrix peak: v_mfma_f64_16x16x4_f64 at 64 cycles per SIMD (measured, profiles/r04_mfma_f64.txt)"}
+                "peak_is": "f64 matrix peak: v_mfma_f64_16x16x4_f64 at 64 cycles per SIMD, v_mfma_f64_4x4x4_4b_f64 at 16 -- the same 16 "
+                           "multiply-adds per cycle and SIMD (measured, profiles/r04_mfma_f64.txt, r05_mfma_f64_4x4.txt)"}
     elif f32:
         # exact f32 arithmetic of this recurrence is bounded by the f32-input MFMA rate; algorithmic
         # flops per timestep: 2 dirs x 4 gates x 100 units x 149 inputs x 2
@@ -293,6 +295,21 @@ def bench_ocr(args, rank, precision=None, nlines=None):
                            st["n"] >= ocr.CLASS_SPLIT_MIN_LINES and rec.mode == 1,
             "lines_per_workgroup": st["group_size"],
             "roofline": roof}
+
+
+def measured_f64_traffic(nlines):
+    """HBM bytes of one float64 pass (projection + recurrence kernels) from the separate --pmc WRITE_SIZE / FETCH_SIZE
+    passes kept under profiles/ (tools/profile_round.sh); read, not measured in this run."""
+    name, path = _profile_file("r05_ocr_f64_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        e = d.get(str(nlines))
+        if e:
+            return float(e["hbm_bytes_per_pass"]), "profiles/" + name
+    except (OSError, KeyError, ValueError, TypeError):
+        pass
+    return None, None
 
 
 def ocr_mode_agreement():
@@ -560,25 +577,33 @@ def main():
 
     ocr_res = None
     if not args.no_ocr:
-        ocr_res = bench_ocr(args, rank)                      # the default mode: what pages run and tests compare
-        other = "split" if ocr_res["precision"] == "f32" else "f32"
-        alt = bench_ocr(args, rank, precision=other)
-        ocr_res["%s_mode" % other] = {
-            "lines_per_s": alt["lines_per_s"], "ms": alt["ms"], "roofline": alt["roofline"], "dtype": alt["dtype"],
-            "note": "opt-in: LineRecognizer(model, precision=%r); agreement of both modes with the float64 "
-                    "restatement under `agreement`" % other}
-        f64 = bench_ocr(args, rank, precision="f64")
-        ocr_res["f64_mode"] = {
-            "lines_per_s": f64["lines_per_s"], "ms": f64["ms"], "roofline": f64["roofline"], "dtype": f64["dtype"],
-            "note": "opt-in: LineRecognizer(model, precision='f64') -- the mode in which the north_star's 1e-3 logit "
-                    "tolerance holds FREE-RUNNING on every line of this (chaotic, random-weight) model: "
-                    "tests/test_ocr_gpu.py::test_spec_model_benchmark_widths_free_running_f64, and `agreement` below"}
+        ocr_res = bench_ocr(args, rank)                      # the default mode (float64): what pages run and tests compare
+        notes = {"f32": "opt-in fast mode: LineRecognizer(model, precision='f32') -- exact float32 arithmetic (a k-ordered "
+                        "fmaf chain); narrower than the reference's float64, agreement under `agreement`",
+                 "split": "opt-in fastest mode: LineRecognizer(model, precision='split') -- 16-bit matrix cores, split "
+                          "operands; agreement under `agreement`",
+                 "f64": "LineRecognizer(model, precision='f64') -- the reference's arithmetic type; the mode in which the "
+                        "north_star's 1e-3 logit tolerance holds FREE-RUNNING on every line of this (chaotic, "
+                        "random-weight) model: tests/test_ocr_gpu.py::test_spec_model_benchmark_widths_free_running_f64"}
+        ocr_res["note"] = "default mode (ocr.DEFAULT_PRECISION = %r): %s" % (ocr_res["precision"], notes[ocr_res["precision"]])
+        for other in ("f64", "f32", "split"):
+            if other == ocr_res["precision"]:
+                continue
+            alt = bench_ocr(args, rank, precision=other)
+            ocr_res["%s_mode" % other] = {
+                "lines_per_s": alt["lines_per_s"], "ms": alt["ms"], "roofline": alt["roofline"], "dtype": alt["dtype"],
+                "lines_per_workgroup": alt["lines_per_workgroup"], "note": notes[other]}
         if args.ocr_lines_large > args.ocr_lines:
-            # 240 workgroups on 256 CUs leave the longest line group in charge of the time; with
-            # several workgroups per CU (longest first) the same kernels fill the chip
+            # three times the lines: several rounds of workgroups per CU (longest first)
             big = bench_ocr(args, rank, nlines=args.ocr_lines_large)
-            ocr_res["large_batch"] = {"lines": big["lines"], "lines_per_s": big["lines_per_s"], "ms": big["ms"],
-                                      "roofline_frac": big["roofline"]["frac"]}
+            ocr_res["large_batch"] = {"lines": big["lines"], "precision": big["precision"], "lines_per_s": big["lines_per_s"],
+                                      "ms": big["ms"], "roofline_frac": big["roofline"]["frac"],
+                                      "lines_per_workgroup": big["lines_per_workgroup"]}
+            if big["precision"] != "f32":
+                big32 = bench_ocr(args, rank, nlines=args.ocr_lines_large, precision="f32")
+                ocr_res["large_batch"]["f32_mode"] = {"lines_per_s": big32["lines_per_s"], "ms": big32["ms"],
+                                                      "roofline_frac": big32["roofline"]["frac"],
+                                                      "lines_per_workgroup": big32["lines_per_workgroup"]}
         agree = ocr_mode_agreement()
         if agree is not None:
             ocr_res["agreement"] = agree

@@ -65,11 +65,11 @@ def _expected(page, transcript, om, R, nw_oracle, params=None, rec=None, report=
     return js, ocr
 
 
-@pytest.mark.parametrize("precision", [None, "split", "f64"])
+@pytest.mark.parametrize("precision", [None, "f32", "split"])
 def test_single_page_process_matches_oracle_pipeline(precision):
     """BASELINE configs[2]: one page of 30 strips through process() with both kernels live, in the
-    recogniser's DEFAULT mode (precision=None: whatever ocr.DEFAULT_PRECISION is -- the mode bench.py
-    times), in the opt-in split mode and in float64 mode, free-running on a random-weight model, against the
+    recogniser's DEFAULT mode (precision=None: whatever ocr.DEFAULT_PRECISION is -- float64 since round 5, the mode
+    bench.py times first) and in the opt-in exact-f32 and split modes, free-running on a random-weight model, against the
     checker pipeline.  Measured agreement with the float64 restatement is printed."""
     from oracle import nw_oracle, ocr_ref_f64 as R
     from text_alignment_amd import alignToOCR as atocr, ocr, page as page_mod
@@ -93,7 +93,7 @@ def test_single_page_process_matches_oracle_pipeline(precision):
         # enters the expected pipeline with the product's characters) is not taken in the default mode nor in
         # float64 mode: every line's decode IS the float64 restatement's
         assert report["lines_with_explained_differences"] == 0 and report["chars_agree"] == report["chars"]
-    if precision == "f64":
+    if (precision or ocr.DEFAULT_PRECISION) == "f64":
         assert report["logit_err_max"] < 1e-4
     assert "".join(c.char for c in all_chars) == want_ocr
     assert got == want

@@ -138,3 +138,27 @@ def check(rc, what):
         if rc == TA_ERANGE:
             raise OverflowError("%s: %s" % (what, msg))
         raise RuntimeError("%s failed (%d): %s" % (what, rc, msg))
+
+
+def upload_packed(arrays, device):
+    """Several small host arrays to the device in ONE asynchronous transfer: packed (16-byte aligned) into a pinned
+    buffer, copied non_blocking on torch's current stream, returned as typed views of one device buffer.  A
+    `tensor.to(device)` from pageable memory costs ~0.25 ms of host time each; a batch's metadata was ten of them."""
+    import numpy as np
+    import torch
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    offs, total = [], 0
+    for a in arrays:
+        offs.append(total)
+        total += (a.nbytes + 15) // 16 * 16
+    host = torch.empty(max(total, 16), dtype=torch.uint8, pin_memory=True)
+    hv = host.numpy()
+    for a, off in zip(arrays, offs):
+        if a.nbytes:
+            hv[off:off + a.nbytes] = a.reshape(-1).view(np.uint8)
+    dev = host.to(device, non_blocking=True)
+    out = []
+    for a, off in zip(arrays, offs):
+        t = dev[off:off + a.nbytes].view(getattr(torch, a.dtype.name))
+        out.append(t.reshape(a.shape))
+    return out

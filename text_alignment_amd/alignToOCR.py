@@ -376,45 +376,117 @@ def _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, 
     return results
 
 
+# process_batch runs batches larger than this as a two-stage pipeline over chunks of PIPELINE_CHUNK_PAGES pages: while
+# the recogniser kernels of chunk k run, the host copies the strips of chunk k + 1 into its staging buffer and finishes
+# chunk k - 1 (characters, alignment, syllable boxes).  One host thread; results are those of the unchunked call.
+PIPELINE_CHUNK_PAGES = 16
+_side_streams = {}
+
+
+def _nw_stream(device):
+    """the aligner's launches of a chunk go to a side stream: on the recogniser's stream they would queue behind the
+    next chunk's recurrence and the host would wait for it"""
+    import torch
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indices_out=None,
                   parallel=parallel, arrays_out=None):
     """`process` for many pages at once: the strips of ALL pages go through the line recogniser
-    in one batch, the transcript/OCR alignments of all pages run in one NW launch, and the glue in
+    in one batch (large batches: in chunks of PIPELINE_CHUNK_PAGES pages, host and device overlapped), the
+    transcript/OCR alignments of a chunk's pages run in one NW launch, and the glue in
     between runs on arrays (text_alignment_amd.page_batch) -- the shape in which a GPU is worth
     using.  Per page the result equals process(page, transcript, model, seq_align_params).
     Returns a list of (syl_boxes, image, lines_peak_locs, all_chars); the two box lists are
     sequences that build their CharBox objects on access.  indices_out, if given, receives per page
     the index of each box's syllable among the transcript's non-empty syllables; arrays_out the
     boxes themselves as an int array [k, 4] (ulx, uly, lrx, lry)."""
-    from . import page_batch as pb
     rec = _recognizer_for(ocropus_model)
+    pages, transcripts = list(pages), list(transcripts)
+    n, C = len(pages), PIPELINE_CHUNK_PAGES
+    if n <= C + C // 2:
+        ctx = _pb_begin(rec, pages, transcripts, seq_align_params, parallel)
+        _pb_launch(ctx)
+        return _pb_finish(ctx, indices_out, arrays_out)
+    # chunk k + 1's strips are copied to the staging buffer by the pool while this thread finishes chunk k - 1 and the
+    # device runs chunk k; at most two chunks are in flight
+    results, flight = [], []
+    for a in range(0, n, C):
+        b = n if n - (a + C) < C // 2 else min(a + C, n)        # (no sliver of a last chunk)
+        ctx = _pb_begin(rec, pages[a:b], transcripts[a:b], seq_align_params, parallel)
+        if len(flight) == 2:
+            results.extend(_pb_finish(flight.pop(0), indices_out, arrays_out))
+        _pb_launch(ctx)
+        flight.append(ctx)
+        if b == n:
+            break
+    for ctx in flight:
+        results.extend(_pb_finish(ctx, indices_out, arrays_out))
+    return results
+
+
+def _pb_begin(rec, pages, transcripts, seq_align_params, workers):
+    """first stage of process_batch for one chunk, host part: line finding, the layout of the chunk's rows, the staging
+    copies STARTED (pool threads), and the host work that needs no OCR result"""
+    from . import page_batch as pb
     raw_dims = [_raw_dim(pg) for pg in pages]            # bad page types fail before any GPU work
-    found = find_lines_all(list(pages), workers=parallel)
+    found = find_lines_all(list(pages), workers=workers)
     strips_per_page = [f[3] for f in found]
     all_strips = [st for strips in strips_per_page for st in strips]
-    prepared = page_mod.prepared_lines(all_strips, workers=parallel)
+    prepared = page_mod.prepared_lines(all_strips, workers=workers)
     lines = [xs for xs, _ in prepared]
     widths = [w for _, w in prepared]
-    st = rec.prepare(lines)
+    st = rec.prepare(lines, defer=True)
+    syls_all = [latsyl.syllabify_text(tr) for tr in transcripts]
+    t_cp = [np.frombuffer(tr.encode('utf-32-le'), dtype='<u4').astype(np.int64) for tr in transcripts]
+    return {"rec": rec, "pages": pages, "transcripts": transcripts, "params": seq_align_params, "raw_dims": raw_dims,
+            "found": found, "strips_per_page": strips_per_page, "all_strips": all_strips, "lines": lines,
+            "widths": widths, "st": st, "syls_all": syls_all, "t_cp": t_cp,
+            "cps": pb.codec_code_points(rec.model.codec)}
+
+
+def _pb_launch(ctx):
+    """first stage, device part: the rows' transfer, the recogniser kernels and the download of the decoded characters
+    -- everything enqueued, nothing waited for but the staging copies"""
+    import torch
+    rec, st = ctx["rec"], ctx["st"]
+    rec.complete(st)
     rec.last_T = st["T_host"]
     rec._last_state = st
     rec.run(st)
+    # the decoder's outputs come back through pinned buffers behind an event of their own: a plain .cpu() issued later
+    # would queue behind whatever the stream has been given since (the next chunk's kernels)
+    host = {}
+    for key in ("dec_t", "dec_c", "dec_n"):
+        host[key] = torch.empty(st[key].shape, dtype=st[key].dtype, pin_memory=True)
+        host[key].copy_(st[key], non_blocking=True)
+    ctx["host"] = host
+    ctx["done"] = torch.cuda.Event()
+    ctx["done"].record()
 
+
+def _pb_finish(ctx, indices_out, arrays_out):
+    """second stage: characters and boxes of every line, abbreviations, ONE NW launch for the chunk's pages, syllable boxes"""
+    import torch
+    from . import page_batch as pb
+    rec, pages, transcripts, seq_align_params = ctx["rec"], ctx["pages"], ctx["transcripts"], ctx["params"]
+    raw_dims, found, strips_per_page, all_strips = ctx["raw_dims"], ctx["found"], ctx["strips_per_page"], ctx["all_strips"]
+    lines, widths, st, syls_all, t_cp, cps = ctx["lines"], ctx["widths"], ctx["st"], ctx["syls_all"], ctx["t_cp"], ctx["cps"]
     params, fn = tsc.parse_scoring_system(seq_align_params)
-    cps = pb.codec_code_points(rec.model.codec)
     if fn is not None or cps is None or not tsc._is_integral(params):
+        rec._last_state, rec.last_T = st, st["T_host"]
         return _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, widths,
                                       transcripts, seq_align_params, indices_out)
 
-    # host work that needs no OCR result runs while the recogniser kernels do
-    syls_all = [latsyl.syllabify_text(tr) for tr in transcripts]
-    t_cp = [np.frombuffer(tr.encode('utf-32-le'), dtype='<u4').astype(np.int64) for tr in transcripts]
-
     # ---- every character of every line: code points + boxes (alignToOCR.py:160-182) ----
     nlines = len(all_strips)
-    dec_t = st["dec_t"].cpu().numpy()
-    dec_c = st["dec_c"].cpu().numpy()
-    dec_n = st["dec_n"].cpu().numpy()[:nlines].astype(np.int64) if nlines else np.zeros(0, np.int64)
+    ctx["done"].synchronize()
+    dec_t = ctx["host"]["dec_t"].numpy()
+    dec_c = ctx["host"]["dec_c"].numpy()
+    dec_n = ctx["host"]["dec_n"].numpy()[:nlines].astype(np.int64) if nlines else np.zeros(0, np.int64)
     x_min = np.array([s.offset_x for s in all_strips], dtype=np.int64)
     y_min = np.array([s.offset_y for s in all_strips], dtype=np.int64)
     y_max = y_min + np.array([s.height for s in all_strips], dtype=np.int64)
@@ -434,15 +506,22 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
         idxs.append(idx)
     o_cp = [np.frombuffer(tx.encode('utf-32-le'), dtype='<u4').astype(np.int64) for tx in texts]
     alphabet = np.unique(np.concatenate(t_cp + o_cp)) if (t_cp or o_cp) else np.zeros(0, np.int64)
-    try:
-        batch = tsc.NWBatch([np.searchsorted(alphabet, a).astype(np.int32) for a in t_cp],
-                            [np.searchsorted(alphabet, a).astype(np.int32) for a in o_cp],
-                            [int(v) for v in params])
-    except OverflowError:
+    # (the aligner's inputs come from the host and its buffers are the side stream's own: nothing to wait for)
+    all_ops = None
+    with torch.cuda.stream(_nw_stream(rec.device)):
+        try:
+            batch = tsc.NWBatch([np.searchsorted(alphabet, a).astype(np.int32) for a in t_cp],
+                                [np.searchsorted(alphabet, a).astype(np.int32) for a in o_cp],
+                                [int(v) for v in params])
+            batch.run()
+            all_ops = batch.results()
+            del batch
+        except OverflowError:
+            pass
+    if all_ops is None:
+        rec._last_state, rec.last_T = st, st["T_host"]
         return _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, widths,
                                       transcripts, seq_align_params, indices_out)
-    batch.run()
-    all_ops = batch.results()
 
     # ---- syllable boxes (alignToOCR.py:277-328): all plain pages in one set of array operations ----
     plain = [k for k in range(len(pages)) if pb.plain_page(transcripts[k], syls_all[k])]

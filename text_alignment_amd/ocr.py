@@ -29,7 +29,10 @@ class RecognitionError(Exception):
 
 MAX_CLASSES = 128        # csrc/ta_lstm.hip: kMaxCT = 8 class tiles of 16
 PRECISIONS = ("f32", "split", "f64")
-DEFAULT_PRECISION = "f32"
+# The default is the reference's arithmetic type: ocropy computes in float64 numpy, and "f64" is
+# the mode in which the 1e-3 logit tolerance holds free-running on every line.  "f32" (1.7x faster on the recogniser
+# alone, ~1.1x on whole pages) and "split" are opt-in fast modes with a measured agreement (bench.py: ocr.agreement).
+DEFAULT_PRECISION = "f64"
 
 
 class LineModel(object):
@@ -220,13 +223,15 @@ def _pack_lstm_f64(model):
 
 
 _pool = None
+COPY_THREADS = 4        # pool threads that copy prepared lines into the pinned staging buffer (8 until round 5: with the
+                        # copies of a chunk running under the previous chunk's host stage, four keep up)
 
 
 def _copy_pool():
     global _pool
     if _pool is None:
         from concurrent.futures import ThreadPoolExecutor
-        _pool = ThreadPoolExecutor(8)
+        _pool = ThreadPoolExecutor(COPY_THREADS)
     return _pool
 
 
@@ -309,14 +314,17 @@ def _is_raw_strip(ln):
 
 class LineRecognizer(object):
     """precision:
-    "f32" (the default) runs the recurrence as an exact f32-input MFMA chain -- bit for bit a k-ordered
-    float32 fmaf chain, i.e. what any float32 implementation of ocropy's loop computes.
-    "split" (opt-in, 2.1x faster) runs it on the 16-bit matrix cores with split operands (weights
+    "f64" (the default since round 5) accumulates, carries state and evaluates the gate functions in float64 on the
+    f64 matrix cores (csrc/ta_lstm_f64.hip) -- the arithmetic type of the reference's recogniser; the 1e-3 logit
+    tolerance holds FREE-RUNNING on every line of the (chaotic) spec model (worst 1.5e-5 over 384 lines).
+    "f32" (opt-in) runs the recurrence as an exact f32-input MFMA chain -- bit for bit a k-ordered float32 fmaf
+    chain, i.e. what any float32 implementation of ocropy's loop computes.
+    "split" (opt-in, fastest) runs it on the 16-bit matrix cores with split operands (weights
     bf16 + fp16 = 19 significant bits, activations three bf16 terms + one fp16, f32 accumulation,
     four products per k-step); its pre-activation error is about three times the f32 mode's.
-    Both hold the 1e-3 logit parity of the spec model per 128-step segment; FREE-RUNNING on that
-    (chaotic) model at 800 .. 2000 columns, against the float64 restatement (96 lines per model,
-    tools/ocr_mode_agreement.py, profiles/r03_ocr_mode_agreement.json): f32 median logit error
+    The two float32 modes hold the 1e-3 logit parity of the spec model per 128-step segment; FREE-RUNNING on that
+    model at 800 .. 2000 columns, against the float64 restatement (96 lines per model,
+    tools/ocr_mode_agreement.py, profiles/r04_ocr_mode_agreement.json): f32 median logit error
     9.1e-5 / 2.7e-5 (models 7001 / 7002), 88 / 94 of 96 lines within 1e-3; split 3.3e-4 / 3.5e-5,
     78 / 91 of 96; decoded characters: f32 identical on all 19 614 of the sample, split one different.
     ("bf16x3", the name of the split mode's first form, is accepted.)"""
@@ -345,45 +353,75 @@ class LineRecognizer(object):
             self._gx = None
 
     # ---- host -> device ------------------------------------------------------------------
-    def _upload_rows(self, lines, row_start, rows):
-        """All prepared lines as one [rows, 48] float32 device tensor (line k at rows row_start[k] ...).  The lines are copied (and, if
-        need be, converted) straight into a pinned staging buffer by a few threads -- numpy releases
-        the GIL for these copies, and at ~275 KB per line a page is 8 MB, so one thread's memcpy
-        rate would bound the whole pipeline -- and go over PCIe in one asynchronous transfer."""
+    def _stage_rows_begin(self, lines, row_start, rows):
+        """Start copying all prepared lines into the pinned staging buffer (line k at rows row_start[k] ...).  The lines
+        are copied (and, if need be, converted) by a few pool threads -- numpy releases the GIL for these copies, and at
+        ~275 KB per line a page is 8 MB, so one thread's memcpy rate would bound the whole pipeline.  Returns what
+        _stage_rows_end needs; the caller may do other host work in between (alignToOCR.process_batch finishes the
+        previous chunk of pages there)."""
         if rows == 0:
-            return torch.zeros((1, NI), dtype=torch.float32, device=self.device)
-        stage = getattr(self, "_stage", None)
-        if stage is None or stage.shape[0] < rows:
-            stage = self._stage = torch.empty((int(rows * 1.25) + 1024, NI), dtype=torch.float32, pin_memory=True)
-        view = stage.numpy()
+            return None
+        # two staging buffers in turn: the copies of a batch may start while the previous batch's transfer is in flight
+        slots = getattr(self, "_stage_slots", None)
+        if slots is None:
+            slots = self._stage_slots = [{"buf": None, "done": None}, {"buf": None, "done": None}]
+            self._stage_next = 0
+        slot = slots[self._stage_next]
+        self._stage_next ^= 1
+        if slot["done"] is not None:
+            slot["done"].synchronize()              # the transfer before last still reads this buffer
+        if slot["buf"] is None or slot["buf"].shape[0] < rows:
+            slot["buf"] = None
+            slot["buf"] = torch.empty((int(rows * 1.25) + 1024, NI), dtype=torch.float32, pin_memory=True)
+        view = slot["buf"].numpy()
 
         def copy(span):
             for k in range(*span):
                 view[row_start[k]:row_start[k] + lines[k].shape[0]] = lines[k]
-        nthreads = min(8, max(1, len(lines) // 64))
+        nthreads = min(COPY_THREADS, max(1, len(lines) // 64))
         if nthreads == 1:
             copy((0, len(lines)))
-        else:
-            done_rows = np.cumsum([ln.shape[0] for ln in lines])
-            cuts = np.searchsorted(done_rows, np.linspace(0, rows, nthreads + 1)).tolist()
-            cuts[0], cuts[-1] = 0, len(lines)
-            list(_copy_pool().map(copy, [(cuts[i], cuts[i + 1]) for i in range(nthreads)]))
-        x_dev = torch.empty((rows, NI), dtype=torch.float32, device=self.device)
-        x_dev.copy_(stage[:rows], non_blocking=True)
-        # the staging buffer is reused by the next batch: the transfer has to be over before then
-        self._stage_done = torch.cuda.Event()
-        self._stage_done.record()
+            return (rows, [], slot)
+        done_rows = np.cumsum([ln.shape[0] for ln in lines])
+        cuts = np.searchsorted(done_rows, np.linspace(0, rows, nthreads + 1)).tolist()
+        cuts[0], cuts[-1] = 0, len(lines)
+        return (rows, [_copy_pool().submit(copy, (cuts[i], cuts[i + 1])) for i in range(nthreads)], slot)
+
+    def _stage_rows_end(self, pending):
+        """Wait for the staging copies and send the rows over PCIe in one asynchronous transfer ON THE UPLOAD STREAM: the
+        copy engine then works beside the kernels of whatever batch the compute stream is busy with, and the compute
+        stream only waits for the event.  The device tensor comes from the upload stream's pool and is recorded as
+        used by the compute stream (the allocator must not hand it out again before that stream is done with it)."""
+        if pending is None:
+            return torch.zeros((1, NI), dtype=torch.float32, device=self.device)
+        rows, futures, slot = pending
+        for f in futures:
+            f.result()
+        up = getattr(self, "_up_stream", None)
+        if up is None:
+            up = self._up_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(up):
+            x_dev = torch.empty((rows, NI), dtype=torch.float32, device=self.device)
+            x_dev.copy_(slot["buf"][:rows], non_blocking=True)
+            # the staging buffer is reused by the batch after next: the transfer has to be over before then
+            slot["done"] = torch.cuda.Event()
+            slot["done"].record(up)
+        main.wait_event(slot["done"])
+        x_dev.record_stream(main)
         return x_dev
 
+    def _upload_rows(self, lines, row_start, rows):
+        """All prepared lines as one [rows, 48] float32 device tensor (line k at rows row_start[k] ...)."""
+        return self._stage_rows_end(self._stage_rows_begin(lines, row_start, rows))
+
     # ---- batched device pass -------------------------------------------------------------
-    def prepare(self, lines):
+    def prepare(self, lines, defer=False):
         """Upload lines and allocate outputs.  A line is either a prepared (T, 48) float array
         (ink = 1, padded) or a raw 2-D uint8 strip (white background; a host array or a tensor already
         on the device), which is normalised on the device (lineest_gpu, csrc/ta_lineest.hip) without a
-        host round trip."""
-        done = getattr(self, "_stage_done", None)
-        if done is not None:
-            done.synchronize()
+        host round trip.  defer = True (host lines only): the staging copies are started and the call returns;
+        `complete(st)` -- or `run(st)` -- waits for them and does the device part."""
         raw = [k for k, ln in enumerate(lines) if _is_raw_strip(ln)]
         n = len(lines)
         T = np.zeros(n, dtype=np.int64)
@@ -429,8 +467,10 @@ class LineRecognizer(object):
         rows = int(T.sum())
         raw_set = set(raw)
         host = [k for k in range(n) if k not in raw_set]
+        pending = None
         if not raw:
-            x_dev = self._upload_rows(lines, row_start, rows)
+            pending = self._stage_rows_begin(lines, row_start, rows)
+            x_dev = None
         elif not host:
             x_dev = x_raw                           # the normaliser wrote its rows in this layout
         else:                                   # mixed batch: stitch the two sources together
@@ -450,12 +490,26 @@ class LineRecognizer(object):
             group_row[:ngroups] = row_start[order[::G]]
         group_row[ngroups:] = rows
         st = {"n": n, "rows": rows, "T_host": T, "row_start_host": row_start, "ngroups": ngroups,
-              "group_row_host": group_row, "group_size": G}
+              "group_row_host": group_row, "group_size": G,
+              "_pending": (pending, x_dev, group_lines, len(lines))}
+        if not (defer and not raw):
+            self.complete(st)
+        return st
+
+    def complete(self, st):
+        """the device part of prepare(): the rows' transfer, the batch's metadata, the output buffers"""
+        if "_pending" not in st:
+            return st
+        pending, x_dev, group_lines, nlines = st.pop("_pending")
+        n, rows, T, row_start = st["n"], st["rows"], st["T_host"], st["row_start_host"]
+        lines = [None] * nlines
+        if x_dev is None:
+            x_dev = self._stage_rows_end(pending)
         dev = self.device
         st["x"] = x_dev
-        st["row_off"] = torch.from_numpy(row_start if n else np.zeros(1, np.int64)).to(dev)
-        st["T"] = torch.from_numpy(T.astype(np.int32) if len(lines) else np.zeros(1, np.int32)).to(dev)
-        st["group_lines"] = torch.from_numpy(group_lines).to(dev)
+        st["row_off"], st["T"], st["group_lines"] = _native.upload_packed(
+            [row_start if n else np.zeros(1, np.int64), T.astype(np.int32) if len(lines) else np.zeros(1, np.int32),
+             group_lines], dev)
         st["hout"] = torch.empty((max(rows, 1), 2 * NS), dtype=torch.float32, device=dev)
         st["probs"] = None            # full probabilities only on request (tests, inspection)
         st["logits"] = None
@@ -478,6 +532,7 @@ class LineRecognizer(object):
         5.85 -> 5.2 ms per 1 920 lines, against 4.7 for the recurrence alone).  Same kernels on the same rows:
         results are bit for bit those of the single launches.  class_split = True / False forces the choice
         (tests, timing); None leaves it to _class_split_wanted."""
+        self.complete(st)
         if st["n"] == 0:
             return
         lib = _native.lib

@@ -146,8 +146,6 @@ class NWBatch(object):
         self.ops_off_host = ops_off
         self.cap_host = cap
 
-        def dev(a):
-            return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
         cat_t = np.concatenate(t_list) if self.nprob and t_off[-1] else np.zeros(1, np.int32)
         cat_o = np.concatenate(o_list) if self.nprob and o_off[-1] else np.zeros(1, np.int32)
         if (cat_t.max(initial=0) >= 65535) or (cat_o.max(initial=0) >= 65535):
@@ -164,13 +162,9 @@ class NWBatch(object):
                 self.hints |= (max_code + 1) << _native.TA_NW_ALPHABET_SHIFT
             if (p[:, 2] == p[:, 3]).all():
                 self.hints |= _native.TA_NW_OPENS_SAME
-        self.t_codes = dev(cat_t.astype(np.int32))
-        self.o_codes = dev(cat_o.astype(np.int32))
-        self.t_off = dev(t_off)
-        self.o_off = dev(o_off)
-        self.params = dev(p.astype(np.int32))
-        self.ws_off = dev(ws_off[:-1].copy() if self.nprob else ws_off)
-        self.ops_off = dev(ops_off[:-1].copy() if self.nprob else ops_off)
+        (self.t_codes, self.o_codes, self.t_off, self.o_off, self.params, self.ws_off, self.ops_off) = _native.upload_packed(
+            [cat_t.astype(np.int32), cat_o.astype(np.int32), t_off, o_off, p.astype(np.int32),
+             ws_off[:-1].copy() if self.nprob else ws_off, ops_off[:-1].copy() if self.nprob else ops_off], self.device)
         self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=self.device)
         self.ops = torch.empty(max(int(ops_off[-1]), 16), dtype=torch.uint8, device=self.device)
         self.ops_len = torch.zeros(max(self.nprob, 1), dtype=torch.int32, device=self.device)

@@ -76,11 +76,11 @@ class RawPage(object):
         self.dim = Image(px.shape[1], px.shape[0]).dim
 
 
-def make_recognizer(seed=7001, no=40):
+def make_recognizer(seed=7001, no=40, precision=None):
     from text_alignment_amd import ocr
     model = ocr.LineModel.random(seed, no=no)
     model.W2[0, 0] += 4.0            # favour blanks: many short runs -> many characters
-    return ocr.LineRecognizer(model)
+    return ocr.LineRecognizer(model, precision=precision or ocr.DEFAULT_PRECISION)
 
 
 def setup_sharded(pages_per_rank, rank, world, seed0=100):
@@ -115,57 +115,117 @@ def run_sharded(job):
                                   job["capacity"], PARAMS)
 
 
-def run(npages, seed0=100):
+def _device_busy_ms(fn):
+    """device time of one call of fn (kernels + copies of every stream it uses) from a torch profiler trace:
+    the union of the device intervals -- the GPU-busy time of a pass"""
     import torch
-    from text_alignment_amd import alignToOCR as atocr
+    from torch.profiler import profile, ProfilerActivity
+    try:
+        with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+            fn()
+            torch.cuda.synchronize()
+        iv = sorted((e.time_range.start, e.time_range.end) for e in prof.events()
+                    if getattr(e, "device_type", None) is not None and "CUDA" in str(e.device_type))
+        busy, cur_a, cur_b = 0.0, None, None
+        for a, b in iv:
+            if cur_b is None or a > cur_b:
+                if cur_b is not None:
+                    busy += cur_b - cur_a
+                cur_a, cur_b = a, b
+            else:
+                cur_b = max(cur_b, b)
+        if cur_b is not None:
+            busy += cur_b - cur_a
+        return busy / 1e3 if busy > 0 else None
+    except Exception:                                   # (no profiler support: the figure is simply absent)
+        return None
+
+
+def run(npages, seed0=100):
+    import threading
+    import torch
+    from text_alignment_amd import alignToOCR as atocr, ocr
     rec = make_recognizer()
     pages, trs = zip(*[make_page(seed0 + k) for k in range(npages)])
-    def median_of(n, pages_, trs_):
+
+    def median_of(n, pages_, trs_, rec_=None):
         """median of n passes (median of >= 10), each a whole process_batch call incl. the final
         synchronize; the host side of a pass -- numpy, uploads from pageable memory -- varies by +-20 % from call to
-        call on a shared box, the device work does not"""
-        ts, out = [], None
+        call on a shared box, the device work does not.  Also the host CPU seconds of the median pass's neighbours
+        (time.process_time: all threads of this process)."""
+        ts, cpu, out = [], [], None
         for _ in range(n):
-            t0 = time.perf_counter()
-            out = atocr.process_batch(pages_, trs_, rec, PARAMS)
+            c0, t0 = time.process_time(), time.perf_counter()
+            out = atocr.process_batch(pages_, trs_, rec_ or rec, PARAMS)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
-        return float(np.median(ts)), out
+            cpu.append(time.process_time() - c0)
+        return float(np.median(ts)), out, float(np.median(cpu))
     for _ in range(3):                       # warm-up at full size (staging buffers, streams, allocator)
         atocr.process_batch(list(pages), list(trs), rec, PARAMS)
     torch.cuda.synchronize()
-    dt, res = median_of(10, list(pages), list(trs))
+    dt, res, cpu_s = median_of(10, list(pages), list(trs))
+    busy_ms = _device_busy_ms(lambda: atocr.process_batch(list(pages), list(trs), rec, PARAMS))
     # BASELINE configs[2]: one page end to end (30 strips + one NW problem), latency of a lone call
     import gc
     gc.collect()                               # a generation-2 collection in mid-call costs ~20 ms
-    lat = []
-    for k in range(5):
-        t1 = time.perf_counter()
-        atocr.process_batch([pages[k]], [trs[k]], rec, PARAMS)
+
+    def single_page(rec_):
+        lat = []
+        for k in range(5):
+            t1 = time.perf_counter()
+            atocr.process_batch([pages[k]], [trs[k]], rec_, PARAMS)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        return 1e3 * sorted(lat)[2]
+    lat_ms = single_page(rec)
+    # the opt-in exact-f32 mode on the same pages (the default is float64 since round 5)
+    other = None
+    if rec.mode != 0:
+        rec32 = make_recognizer(precision="f32")
+        for _ in range(2):
+            atocr.process_batch(list(pages), list(trs), rec32, PARAMS)
         torch.cuda.synchronize()
-        lat.append(time.perf_counter() - t1)
+        dt32, _, cpu32 = median_of(10, list(pages), list(trs), rec32)
+        other = {"pages_per_s": npages / dt32, "seconds": dt32, "single_page_ms": single_page(rec32),
+                 "host_cpu_ms_per_page": 1e3 * cpu32 / npages,
+                 "note": "LineRecognizer(model, precision='f32'): opt-in fast mode, same pages"}
+        del rec32
     # the same from raw strips: line normaliser on the device in front of the recogniser
     rpages, rtrs = zip(*[make_page(seed0 + 5000 + k, raw=True) for k in range(npages)])
     for _ in range(2):
         atocr.process_batch(list(rpages), list(rtrs), rec, PARAMS)
     torch.cuda.synchronize()
-    raw_dt, _ = median_of(10, list(rpages), list(rtrs))
+    raw_dt, _, raw_cpu = median_of(10, list(rpages), list(rtrs))
     # and from whole page images: preprocessing and line finding on the device as well
     nimg = npages
     ipages = [RawPage(make_page_image(seed0 + 9000 + k)) for k in range(nimg)]
     itrs = list(trs[:nimg])
     atocr.process_batch(ipages, itrs, rec, PARAMS)         # warm: the page planes come out of torch's caching allocator
     torch.cuda.synchronize()
-    img_dt, _ = median_of(10, ipages, itrs)
-    return {"pages": npages, "seconds": dt, "pages_per_s": npages / dt, "lines_per_s": npages * 30 / dt,
-            "single_page_ms": 1e3 * sorted(lat)[2],
-            "page_images": {"pages": nimg, "pages_per_s": nimg / img_dt, "seconds": img_dt,
-                            "note": "4400 x 1400 uint8 page images: csrc/ta_preproc.hip + ta_lineest.hip in front"},
-            "raw_strips": {"pages_per_s": npages / raw_dt, "seconds": raw_dt,
-                           "note": "strips as 60-row uint8 images, normalised by csrc/ta_lineest.hip"},
-            "syllable_boxes": sum(len(r[0]) for r in res),
-            "timing": "median of 10 passes after warm-up, each a whole process_batch call incl. the final synchronize",
-            "note": "process_batch end to end: host upload + K3/K4/K5 + NW + host glue (numpy arrays, page_batch.py)"}
+    img_dt, _, img_cpu = median_of(10, ipages, itrs)
+    out = {"pages": npages, "precision": {0: "f32", 1: "split", 3: "f64"}[rec.mode], "seconds": dt,
+           "pages_per_s": npages / dt, "lines_per_s": npages * 30 / dt,
+           "single_page_ms": lat_ms,
+           "host": {"cpu_ms_per_page": 1e3 * cpu_s / npages, "cpu_s_per_pass": cpu_s,
+                    "cpu_over_wall": cpu_s / dt, "threads_alive": threading.active_count(),
+                    "copy_pool_threads": ocr.COPY_THREADS if ocr._pool is not None else 0,
+                    "gpu_busy_ms_per_pass": busy_ms, "gpu_busy_frac": (busy_ms * 1e-3 / dt) if busy_ms else None,
+                    "pipeline_chunk_pages": atocr.PIPELINE_CHUNK_PAGES,
+                    "note": "cpu: time.process_time over the pass (all threads of the process: the interpreter's one "
+                            "thread + the strip-copy pool); gpu_busy: union of device intervals of one pass (torch profiler)"},
+           "page_images": {"pages": nimg, "pages_per_s": nimg / img_dt, "seconds": img_dt,
+                           "host_cpu_ms_per_page": 1e3 * img_cpu / nimg,
+                           "note": "4400 x 1400 uint8 page images: csrc/ta_preproc.hip + ta_lineest.hip in front"},
+           "raw_strips": {"pages_per_s": npages / raw_dt, "seconds": raw_dt, "host_cpu_ms_per_page": 1e3 * raw_cpu / npages,
+                          "note": "strips as 60-row uint8 images, normalised by csrc/ta_lineest.hip"},
+           "syllable_boxes": sum(len(r[0]) for r in res),
+           "timing": "median of 10 passes after warm-up, each a whole process_batch call incl. the final synchronize",
+           "note": "process_batch end to end: host upload + K3/K4/K5 + NW + host glue (numpy arrays, page_batch.py), "
+                   "chunks of pages pipelined (host stage of one chunk under the device stage of the next)"}
+    if other is not None:
+        out["f32_mode"] = other
+    return out
 
 
 if __name__ == "__main__":
@@ -177,8 +237,9 @@ if __name__ == "__main__":
         from text_alignment_amd import alignToOCR as atocr
         rec = make_recognizer()
         pages, trs = zip(*[make_page(100 + k) for k in range(n)])
+        atocr.process_batch(list(pages), list(trs), rec, PARAMS)
         pr = cProfile.Profile()
         pr.enable()
         atocr.process_batch(list(pages), list(trs), rec, PARAMS)
         pr.disable()
-        pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+        pstats.Stats(pr).sort_stats("tottime").print_stats(30)
