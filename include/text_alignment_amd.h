@@ -41,7 +41,8 @@ extern "C" {
  *   - a caller ASSERTION, like TA_NW_CODES8: every token id of every problem is < a.  It is not checked.  The
  *     OCR ids index the per-wave profile directly (row pitch 256 B, a + 1 rows), so an id >= a reads another
  *     wave's table or LDS beyond the profile and ids >= 256 wrap: the alignment comes out silently WRONG,
- *     not slower.  Derive `a` from the data (max id + 1), as text_alignment_amd.textSeqCompare.NWBatch does.
+ *     not slower.  Derive `a` from the data (max id + 1), as text_alignment_amd.textSeqCompare.NWBatch does,
+ *     or add TA_NW_CHECK_IDS while bringing a caller up.
  *   - HINTS that change speed only: every gap open is <= 0 and match/mismatch minus both gap extends fit a
  *     signed byte.  A problem that does not meet them (and, under TA_NW_OPENS_SAME, one whose two gap opens
  *     differ) is still aligned correctly, through the kernel's general cell.
@@ -65,6 +66,11 @@ extern "C" {
 #define TA_NW_TBWAVES_SHIFT 24
 #define TA_NW_TBWAVES(w) (((uint32_t)(w) & 0x7u) << TA_NW_TBWAVES_SHIFT)
 #define TA_NW_NO_PROFILE 64u
+/* ta_nw2_batch, debug guard for the two caller assertions above (TA_NW_CODES8: ids < 255; TA_NW_ALPHABET(a): ids < a):
+ * with this bit the call first checks every token id of the batch on the device, WAITS for the result (one stream
+ * synchronisation: not for timed code) and returns TA_EINVAL -- nothing else launched -- if an id breaks an assertion
+ * the flags make.  Without it a violated assertion gives silently wrong alignments. */
+#define TA_NW_CHECK_IDS 128u
 #define TA_NW_WAVES_SHIFT 16
 #define TA_NW_WAVES(w) (((uint32_t)(w) & 0xFu) << TA_NW_WAVES_SHIFT)
 

@@ -66,5 +66,27 @@ int main(int argc, char** argv) {
     }
     ta[len] = oa[len] = 0;
     printf("%s\n%s\n", ta, oa);
-    return (i == n && j == m) ? 0 : 3;
+    if (!(i == n && j == m)) return 3;
+
+    /* The two-phase aligner and its debug guard (TA_NW_CHECK_IDS).  The ids here are character codes (< 128):
+     * asserting an alphabet of 27 is a caller bug that would silently give wrong alignments -- with the guard the
+     * call is refused (TA_EINVAL) before anything is launched; asserting 128 is true, and the call gives the
+     * alignment of the one-pass kernel above. */
+    const int64_t ws2_bytes = ta_nw2_workspace_bytes(n, m);
+    void* d_ws2 = NULL;
+    CHECK_HIP(hipMalloc(&d_ws2, (size_t)(ws2_bytes > 16 ? ws2_bytes : 16)));
+    CHECK_HIP(hipMemset(d_len, 0, sizeof(int32_t)));
+    const uint32_t base = TA_NW_FILL | TA_NW_TRACEBACK | TA_NW_CHECK_IDS;
+    const int rc_bad = ta_nw2_batch(d_t, d_toff, d_o, d_ooff, 1, d_prm, 0, d_ws2, d_zero, d_ops, d_zero, d_len,
+                                    n, m, bound, base | TA_NW_CODES8 | TA_NW_ALPHABET(27), NULL);
+    const int rc_ok = ta_nw2_batch(d_t, d_toff, d_o, d_ooff, 1, d_prm, 0, d_ws2, d_zero, d_ops, d_zero, d_len,
+                                   n, m, bound, base | TA_NW_CODES8 | TA_NW_ALPHABET(128), NULL);
+    CHECK_HIP(hipDeviceSynchronize());
+    int32_t len2 = 0;
+    unsigned char* ops2 = malloc((size_t)(n + m + 16));
+    CHECK_HIP(hipMemcpy(&len2, d_len, sizeof len2, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(ops2, d_ops, (size_t)(n + m), hipMemcpyDeviceToHost));
+    const int same = len2 == len && memcmp(ops2 + n + m - len2, ops + n + m - len, (size_t)len) == 0;
+    printf("check_ids: wrong alphabet rc=%d, true alphabet rc=%d, two-phase equals one-pass=%d\n", rc_bad, rc_ok, same);
+    return (rc_bad == TA_EINVAL && rc_ok == TA_OK && same) ? 0 : 4;
 }

@@ -169,6 +169,8 @@ def test_c_example_runs_and_matches_oracle(native):
         out = subprocess.run([exe, t, o], check=True, capture_output=True, text=True, timeout=120).stdout.split("\n")
         tra, ocr = nw_oracle.perform_alignment(list(t), list(o))
         assert out[0] == "".join(tra) and out[1] == "".join(ocr), (t, o, out)
+        # TA_NW_CHECK_IDS: an alphabet the ids do not fit is refused, a true one gives the same alignment
+        assert out[2] == "check_ids: wrong alphabet rc=-1, true alphabet rc=0, two-phase equals one-pass=1", out[2]
 
 
 def test_inline_asm_f64_mfmas_keep_their_wait_states():

@@ -641,3 +641,30 @@ def test_phase1_variants_and_forced_hints(tsc, variant, waves):
         for k, got in enumerate(same.results()):
             want = nw_oracle.align_ids(t_list[k], o_list[k], system)
             assert got.tolist() == want.tolist(), (k, sizes[k], system)
+
+
+@pytest.mark.gpu
+def test_check_ids_flag_refuses_a_false_alphabet_assertion(tsc):
+    """TA_NW_ALPHABET(a) / TA_NW_CODES8 are caller assertions the kernel does not check: an id >= a indexes LDS beyond
+    the score profile and the alignment is silently wrong.  TA_NW_CHECK_IDS (debug guard, one stream synchronisation)
+    verifies them on the device first: a false assertion fails the call with TA_EINVAL (NativeArgumentError here) and
+    launches nothing; a true one changes nothing."""
+    from oracle import nw_oracle
+    from text_alignment_amd import _native
+    rng = np.random.default_rng(5)
+    probs = [_random_problem(rng, n, m, 27, True) for n, m in [(300, 280), (700, 64), (65, 513)]]
+    t_list, o_list = [p[0] for p in probs], [p[1] for p in probs]
+    batch = tsc.NWBatch(t_list, o_list, [8, -4, -7, -7, -3, 0], two_phase=True)
+    amax = int(max(max(t.max(), o.max()) for t, o in probs)) + 1
+    assert batch.hints >> _native.TA_NW_ALPHABET_SHIFT & 0xFF == amax
+    batch.check_ids = True
+    batch.run()                                               # the wrapper's own hints are true
+    for (t, o), got in zip(probs, batch.results()):
+        assert got.tolist() == nw_oracle.align_ids(t, o, [8, -4, -7, -7, -3, 0]).tolist()
+    batch.ops_len.zero_()
+    batch.hints = (batch.hints & ~(0xFF << _native.TA_NW_ALPHABET_SHIFT)) | ((amax - 3) << _native.TA_NW_ALPHABET_SHIFT)
+    with pytest.raises(_native.NativeArgumentError, match="token id is outside"):
+        batch.run()
+    import torch
+    torch.cuda.synchronize()
+    assert int(batch.ops_len.abs().sum()) == 0                # refused before anything was launched

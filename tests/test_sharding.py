@@ -280,3 +280,34 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert ps2["gather_ok"] and ps1["gather_ok"]
     assert ps2["syllable_boxes"] == ps1["syllable_boxes"] > 0
     assert ps2["records_sha16"] == ps1["records_sha16"]
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_at_world_size_one():
+    """The path `bench.py --gpus 8` takes -- `torch.distributed.run`, backend "nccl" (= RCCL), device tensors through
+    `dist.gather` in sharding.gather_to_root, the all_reduce's of the timing on a device tensor -- executed once on the
+    one GPU there is: world size 1, launched exactly as the driver launches ranks.  Until round 5 every rehearsal of the
+    gather ran on gloo with host tensors; the first RCCL execution must not be the driver's 8-GPU run.  Asserted: the
+    backend really is nccl, the gather is complete, and the records equal a plain single process's over the same pages
+    (the loop being sharded: alignToOCR.py:407-438)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--batch", "8", "--steps", "1", "--warmup", "0", "--pages", "4", "--no-cpu-baseline", "--no-configs", "--no-ocr"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    lines = {}
+    for name, cmd in (("rccl", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                                "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(repo, "bench.py"),
+                                "--force-dist", "--backend", "nccl"]),
+                      ("plain", [sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1"])):
+        r = subprocess.run(cmd + common, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines[name] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    rccl, plain = lines["rccl"], lines["plain"]
+    assert rccl["n_gpus"] == 1 and rccl["config"]["bit_exact_vs_oracle"]
+    ps, pp = rccl["pages_sharded"], plain["pages_sharded"]
+    assert ps["backend"] == "nccl" and ps["ranks"] == 1 and ps["pages"] == 4
+    assert ps["gather_ok"] and pp["gather_ok"]
+    assert ps["syllable_boxes"] == pp["syllable_boxes"] > 0
+    assert ps["records_sha16"] == pp["records_sha16"]

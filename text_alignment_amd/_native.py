@@ -20,6 +20,7 @@ TA_EINVAL, TA_ERANGE, TA_EHIP, TA_ELIMIT = -1, -2, -3, -4
 TA_NW_FILL, TA_NW_TRACEBACK, TA_NW_CODES8, TA_NW_WIDE, TA_NW_NARROW = 1, 2, 4, 8, 16
 TA_NW_OPENS_SAME, TA_NW_ALPHABET_SHIFT = 32, 8
 TA_NW_NO_PROFILE, TA_NW_WAVES_SHIFT, TA_NW_ROWS_SHIFT, TA_NW_TBWAVES_SHIFT = 64, 16, 20, 24
+TA_NW_CHECK_IDS = 128
 
 
 class NativeLibraryError(RuntimeError):

@@ -379,7 +379,9 @@ def _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, 
 # process_batch runs batches larger than this as a two-stage pipeline over chunks of PIPELINE_CHUNK_PAGES pages: while
 # the recogniser kernels of chunk k run, the host copies the strips of chunk k + 1 into its staging buffer and finishes
 # chunk k - 1 (characters, alignment, syllable boxes).  One host thread; results are those of the unchunked call.
-PIPELINE_CHUNK_PAGES = 16
+PIPELINE_CHUNK_PAGES = int(os.environ.get("TA_PAGE_CHUNK", "16"))          # (the variable: timing experiments)
+PIPELINE_CHUNK_PAGES_RAW = int(os.environ.get("TA_PAGE_CHUNK_RAW", "32"))    # raw strips: the device normaliser in front
+PIPELINE_CHUNK_PAGES_IMAGES = int(os.environ.get("TA_PAGE_CHUNK_IMAGES", "64"))
 _side_streams = {}
 
 
@@ -406,7 +408,15 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     boxes themselves as an int array [k, 4] (ulx, uly, lrx, lry)."""
     rec = _recognizer_for(ocropus_model)
     pages, transcripts = list(pages), list(transcripts)
-    n, C = len(pages), PIPELINE_CHUNK_PAGES
+    # pages that still need the preprocessing kernels (page images) take larger chunks: their line finding waits for the
+    # device several times per batch of pages, and those waits queue behind a previous chunk's recogniser
+    # (measured at 64 pages, chunks of 8 / 16 / 32: normalised strips 1 410 / 1 515 / 1 515 pages/s, raw strips -- whose
+    # normaliser returns its data-dependent widths with a device wait per chunk -- 670 / 866 / 1 005; page images ~450-500
+    # whatever the chunk)
+    images = any(not isinstance(pg, page_mod.PreparedPage) for pg in pages)
+    raw = not images and any(st.prepared is None for pg in pages for st in getattr(pg, "strips", ()))
+    n = len(pages)
+    C = PIPELINE_CHUNK_PAGES_IMAGES if images else (PIPELINE_CHUNK_PAGES_RAW if raw else PIPELINE_CHUNK_PAGES)
     if n <= C + C // 2:
         ctx = _pb_begin(rec, pages, transcripts, seq_align_params, parallel)
         _pb_launch(ctx)

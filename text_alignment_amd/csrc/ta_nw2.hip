@@ -1941,6 +1941,37 @@ extern "C" int32_t ta_nw2_traceback_plan(int32_t nprob, int32_t params_stride, u
     return 3;
 }
 
+// TA_NW_CHECK_IDS: every token id of the batch against the bound the caller's flags assert (one workgroup per problem)
+__global__ __launch_bounds__(256) void nw_check_ids_kernel(NwArgs a, int bound, int* bad) {
+    const int p = blockIdx.x;
+    int mine = 0;
+    for (int64_t i = a.t_off[p] + threadIdx.x; i < a.t_off[p + 1]; i += 256) mine |= (unsigned)a.t_codes[i] >= (unsigned)bound;
+    for (int64_t i = a.o_off[p] + threadIdx.x; i < a.o_off[p + 1]; i += 256) mine |= (unsigned)a.o_codes[i] >= (unsigned)bound;
+    if (__ballot(mine) != 0 && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
+
+static int check_ids(const NwArgs& a, uint32_t flags, hipStream_t st) {
+    int bound = 65535;                                        // the ABI's own limit (ids < 65536; 65535 is the pad code)
+    if (flags & TA_NW_CODES8) bound = 255;
+    const int alpha = (int)((flags >> TA_NW_ALPHABET_SHIFT) & 0xFFu);
+    if (alpha > 0 && !(flags & TA_NW_NO_PROFILE)) bound = alpha < bound ? alpha : bound;
+    int* bad = nullptr;
+    hipError_t e = hipMalloc(&bad, sizeof(int));
+    if (e != hipSuccess) return ta_fail_hip(e, "TA_NW_CHECK_IDS: hipMalloc");
+    int host_bad = 0;
+    e = hipMemsetAsync(bad, 0, sizeof(int), st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(nw_check_ids_kernel, dim3(a.nprob), dim3(256), 0, st, a, bound, bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&host_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(bad);
+    if (e != hipSuccess) return ta_fail_hip(e, "TA_NW_CHECK_IDS");
+    if (host_bad) return ta_fail(TA_EINVAL, "a token id is outside the range the flags assert (TA_NW_CODES8 / TA_NW_ALPHABET)");
+    return TA_OK;
+}
+
 extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
                             const int32_t* o_codes, const int64_t* o_off, int32_t nprob,
                             const int32_t* params, int32_t params_stride,
@@ -1961,6 +1992,10 @@ extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
              ops_out, ops_off, ops_len, nprob};
     if ((flags & TA_NW_FILL) && max_n > 0 && max_m > 0) {
         if (!t_codes || !o_codes || !ws) return ta_fail(TA_EINVAL, "null code/workspace pointer");
+        if (flags & TA_NW_CHECK_IDS) {
+            const int rc = check_ids(a, flags, st);
+            if (rc != TA_OK) return rc;
+        }
         const hipError_t e = launch_score(a, max_n, max_m, flags, st);
         if (e != hipSuccess) return ta_fail_hip(e, "nw_score_kernel launch");
     }

@@ -249,8 +249,11 @@ def process_shard(my_pages, my_transcripts, my_ids, my_models, capacity, seq_ali
     # (alignToOCR.py:240-243: 'OCRopus failed! Skipping current file.'), not the rank's share.
     # Anything else -- a failed native call (kernel fault, sticky HIP error, out of memory), a torch
     # RuntimeError, a programming error -- is NOT a page to skip: the rank remembers it, reports its
-    # remaining pages as failed so that rank `dst` sees every page, still enters the gather, and
-    # re-raises afterwards, so the process ends non-zero instead of returning 'skipped pages'.
+    # remaining pages as failed so that rank `dst` sees every page, still enters the gather IF IT CAN, and
+    # re-raises afterwards, so the process ends non-zero instead of returning 'skipped pages'.  "If it can":
+    # after a HOST-side failure (a bad argument, an exception in the glue) the gather works and nobody waits; after a
+    # DEVICE fault under nccl the packing or the collective itself raises on the poisoned context -- the first
+    # error is then raised at once, the process exits non-zero and the launcher (torchrun) tears the group down.
     page_errors = _page_errors()
     fatal = None
 
@@ -284,7 +287,12 @@ def process_shard(my_pages, my_transcripts, my_ids, my_models, capacity, seq_ali
     if device is None:
         nccl = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
         device = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
-    work, out = gather_to_root(pack_records_device(local, capacity, device, strict=False), group=group, dst=dst)
+    try:
+        work, out = gather_to_root(pack_records_device(local, capacity, device, strict=False), group=group, dst=dst)
+    except Exception:                             # noqa: BLE001
+        if fatal is not None:                     # the device is gone: report the FIRST failure, promptly
+            raise fatal
+        raise
     if fatal is not None:                         # after the collective: nobody is left waiting
         raise fatal
     if local.shape[0] > capacity:

@@ -195,6 +195,8 @@ class NWBatch(object):
     def phase1_flags(self):
         """Hint and override bits of a ta_nw2_batch / ta_nw2_phase1_plan_batch call for this batch."""
         flags = self.hints
+        if getattr(self, "check_ids", False):        # debug guard: the library verifies the id bounds the hints assert
+            flags |= _native.TA_NW_CHECK_IDS
         if self.no_profile:
             flags |= _native.TA_NW_NO_PROFILE
         if self.waves:
