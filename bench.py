@@ -401,6 +401,58 @@ def nw_configs(tsc, torch):
     return rows
 
 
+def nw_end_to_end(tsc, torch, batch_n):
+    """"also report ... end-to-end incl. H2D/D2H and Python wrapper".  The call being replaced is
+    `perform_alignment(list(transcript), list(ocr), params)` (alignToOCR.py:273), one pair per call, Python lists of
+    single characters in and out.  Two figures per batch shape (the headline batch and BASELINE configs[1]):
+      lists:  ONE perform_alignment_batch call on host lists -- token encoding, H2D of the codes, both kernels, D2H of
+              the alignment columns, the two '_'-marked token lists per pair rebuilt (what a caller of the reference's
+              surface gets); the Python objects in and out are the cost here, not the GPU;
+      arrays: NWBatch on host id arrays -> host column arrays (H2D + kernels + D2H, no per-token Python objects).
+    Median of 3 calls after one warm-up; two pairs of each run compared with the oracle's lists."""
+    from oracle import nw_oracle
+    from tools.synth import synth_pair_ids
+    alphabet = "abcdefghijklmnopqrstuvwxyz "
+    rows = []
+    for name, nprob, n, m, distinct in [("headline %dx4096^2" % batch_n, batch_n, 4096, 4096, 16),
+                                        ("C2 1024x2048^2", 1024, 2048, 2048, 8)]:
+        uniq = [synth_pair_ids(n, m, 7321 + k) for k in range(distinct)]
+        as_list = [([alphabet[c] for c in t], [alphabet[c] for c in o]) for t, o in uniq]
+        pairs = [as_list[k % distinct] for k in range(nprob)]
+        cells = float(nprob) * n * m
+
+        def lists():
+            return tsc.perform_alignment_batch(pairs, DEFAULT_SYS)
+
+        def arrays():
+            b = tsc.NWBatch([uniq[k % distinct][0] for k in range(nprob)], [uniq[k % distinct][1] for k in range(nprob)],
+                            DEFAULT_SYS)
+            b.run()
+            return b.results()
+        out = {"config": name, "problems": nprob, "n": n, "m": m}
+        for key, fn in (("lists", lists), ("arrays", arrays)):
+            fn()
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = fn()
+                ts.append(time.perf_counter() - t0)
+            dt = sorted(ts)[1]
+            out[key] = {"seconds": dt, "cells_per_s": cells / dt}
+            if key == "lists":
+                ok = all(res[k] == nw_oracle.perform_alignment(*as_list[k % distinct]) for k in (0, nprob - 1))
+                out["lists"]["equal_to_oracle_lists"] = bool(ok)
+            del res
+        rows.append(out)
+        torch.cuda.empty_cache()
+    return {"shapes": rows,
+            "note": "host lists / host arrays in and out of ONE call; the resident rate is `value` (headline) and "
+                    "`configs` (C2).  lists: Python token lists as the reference's surface takes and returns them "
+                    "(alignToOCR.py:273) -- 8 192 + ~8 800 Python objects per 4096^2 pair; arrays: int32 ids in, uint8 "
+                    "alignment columns out"}
+
+
 def nw_grid_search(tsc, torch):
     """SURVEY.md 8(d)'s secondary run / row N2: the reference's grid search (evaluate_text_alignment.py:134-198) is
     2 187 page-sized alignments -- 3 pages x the 729 scoring systems of :181-188 -- one `perform_alignment` call each
@@ -615,10 +667,11 @@ def main():
         from tools import pages_bench
         pages_res = pages_bench.run(args.pages, seed0=100)
 
-    configs = grid = None
+    configs = grid = e2e = None
     if world == 1 and not args.no_configs and not args.one_pass:
         configs = nw_configs(tsc, torch)
         grid = nw_grid_search(tsc, torch)
+        e2e = nw_end_to_end(tsc, torch, args.batch)
 
     if rank == 0:
         # bit-exact check of the timed output against the oracle (checker only): every distinct
@@ -652,6 +705,8 @@ def main():
             out["configs"] = configs
         if grid is not None:
             out["grid_search"] = grid
+        if e2e is not None:
+            out["nw_end_to_end"] = e2e
         if ocr_res is not None:
             out["ocr"] = ocr_res
         if pages_res is not None:

@@ -53,7 +53,22 @@ def _is_integral(params):
 
 def encode_tokens(*seqs):
     """Dense int32 ids for arbitrary hashable tokens; equal tokens <=> equal ids
-    (the aligner only ever compares tokens with ==, textSeqCompare.py:32)."""
+    (the aligner only ever compares tokens with ==, textSeqCompare.py:32).  Sequences of single characters -- what
+    alignToOCR.py:273 passes, `list(transcript)` -- are encoded by their code points in one numpy pass; anything else
+    (the bigrams of textSeqCompare.py:185-186, numbers, tuples) token by token through a dict."""
+    try:
+        if all(type(tok) is str for seq in seqs for tok in seq) and \
+                all(len(seq) == 0 or max(map(len, seq)) == 1 == min(map(len, seq)) for seq in seqs):
+            cps = [np.frombuffer("".join(seq).encode("utf-32-le"), dtype="<u4") for seq in seqs]
+            alphabet, first = np.unique(np.concatenate(cps) if cps else np.zeros(0, "<u4"), return_index=True)
+            # ids in order of first appearance, as the dict path numbers them
+            rank = np.empty(len(alphabet), dtype=np.int32)
+            rank[np.argsort(first, kind="stable")] = np.arange(len(alphabet), dtype=np.int32)
+            out = [rank[np.searchsorted(alphabet, c)] if len(c) else np.zeros(0, np.int32) for c in cps]
+            ids = {chr(int(c)): int(r) for c, r in zip(alphabet, rank)}
+            return out, ids
+    except TypeError:
+        pass
     ids = {}
     out = []
     for seq in seqs:
@@ -66,17 +81,19 @@ def encode_tokens(*seqs):
 
 def ops_to_alignment(ops, transcript, ocr):
     """Alignment columns (0 pair, 1 transcript token over a gap, 2 gap over an OCR token) ->
-    the reference's two token lists with '_' gap markers (textSeqCompare.py:116-162)."""
-    tra, oc = [], []
-    i = j = 0
-    for op in ops:
-        if op == 0:
-            tra.append(transcript[i]); oc.append(ocr[j]); i += 1; j += 1
-        elif op == 1:
-            tra.append(transcript[i]); oc.append(GAP); i += 1
-        else:
-            tra.append(GAP); oc.append(ocr[j]); j += 1
-    return tra, oc
+    the reference's two token lists with '_' gap markers (textSeqCompare.py:116-162).  On arrays: the token a column
+    shows is the running count of the columns that consumed one."""
+    ops = np.asarray(ops)
+    if ops.size == 0:
+        return [], []
+    has_t, has_o = ops != 2, ops != 1
+    t_obj = np.fromiter(transcript, dtype=object, count=len(transcript))
+    o_obj = np.fromiter(ocr, dtype=object, count=len(ocr))
+    tra = np.full(ops.size, GAP, dtype=object)
+    oc = np.full(ops.size, GAP, dtype=object)
+    tra[has_t] = t_obj[:int(has_t.sum())]
+    oc[has_o] = o_obj[:int(has_o.sum())]
+    return tra.tolist(), oc.tolist()
 
 
 class NWBatch(object):

@@ -12,7 +12,7 @@
 # 4. matrix-pipe counters of the recogniser kernels (1920 lines, both modes) -> <round>_ocr_pmc_mfma.json
 # then (where gpurun_out/ was merged back): python3 tools/profile_summarise.py <round> gpurun_out/prof_<round>
 set -eo pipefail
-ROUND=${1:-r04}
+ROUND=${1:-r05}
 PART=${2:-all}           # traces | pmc | all (a gpurun call is limited to 20 minutes: run the two parts in two calls)
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$ROUND
@@ -42,6 +42,11 @@ export TA_OCR_GROUP=4             # the 4-line kernel (the product's choice up t
 for n in 30 1920; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_${n}_f32_g4" -o ocr -- python3 "$REPO/tools/ocr_only.py" $n f32 > "$OUT/kt_ocr_${n}_f32_g4.log" 2>&1
   echo "ocr $n f32 (groups of 4) kernel trace done"
+done
+# float64 mode on groups of four lines (the product's choice since round 5), one projection and one recurrence launch
+for n in 30 1920 5760; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_${n}_f64_g4" -o ocr -- python3 "$REPO/tools/ocr_only.py" $n f64 > "$OUT/kt_ocr_${n}_f64_g4.log" 2>&1
+  echo "ocr $n f64 (groups of 4) kernel trace done"
 done
 unset TA_OCR_CLASS_SPLIT
 unset TA_OCR_GROUP
@@ -85,7 +90,18 @@ timeout -k 10 300 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES S
 echo "ocr wait counters (groups of 4) done"
 unset TA_OCR_GROUP
 export TA_OCR_F64_PIPE=0
+# float64 mode: HBM traffic of the projection and the recurrence (separate counter passes), both group sizes
+for g in 4 16; do
+  for ctr in WRITE_SIZE FETCH_SIZE; do
+    TA_OCR_GROUP=$g timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/ocr_f64g${g}_$ctr" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f64 > "$OUT/ocr_f64g${g}_$ctr.log" 2>&1
+    echo "ocr f64 groups of $g $ctr done"
+  done
+done
+TA_OCR_GROUP=4 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_f64g4" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f64 > "$OUT/ocr_pmc_f64g4.log" 2>&1
+echo "ocr pmc f64 groups of 4 done"
+export TA_OCR_GROUP=16
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_f64" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f64 > "$OUT/ocr_pmc_f64.log" 2>&1
 echo "ocr pmc f64 done"
+unset TA_OCR_GROUP
 fi
 echo "now run: python3 tools/profile_summarise.py $ROUND gpurun_out/prof_$ROUND"

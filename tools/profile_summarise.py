@@ -55,9 +55,34 @@ def main():
                "config": {"batch": 4096, "n": 4096, "m": 4096}, "kernels": kernels}
         with open(os.path.join(prof, fname % rnd), "w") as fh:
             json.dump(doc, fh, indent=1)
+    # float64 recogniser: HBM bytes per launch of the projection and the recurrence kernels (1 920 lines), both group sizes
+    f64 = {}
+    for g in (4, 16):
+        wr = counter_means(os.path.join(out, "ocr_f64g%d_WRITE_SIZE" % g), "WRITE_SIZE", only="lstm_")
+        rd = counter_means(os.path.join(out, "ocr_f64g%d_FETCH_SIZE" % g), "FETCH_SIZE", only="lstm_")
+        if not wr and not rd:
+            continue
+        kernels = {}
+        for k in sorted(set(wr) | set(rd)):
+            w, r = wr.get(k, 0.0), rd.get(k, 0.0)
+            kernels[k] = {"WRITE_SIZE_KiB_mean": w, "FETCH_SIZE_KiB_mean": r, "hbm_bytes_per_launch": w * 1024 + 2 * r * 1024}
+        f64["groups_of_%d" % g] = {"kernels": kernels,
+                                  "hbm_bytes_per_pass": sum(v["hbm_bytes_per_launch"] for k, v in kernels.items()
+                                                            if "xproj_f64" in k or "seq_f64" in k or "seq4_f64" in k)}
+    if f64:
+        doc = {"command": "TA_OCR_F64_PIPE=0 TA_OCR_GROUP=<4|16> rocprofv3 --pmc WRITE_SIZE (and, separately, FETCH_SIZE) "
+                          "--output-format csv -- python3 tools/ocr_only.py 1920 f64",
+               "units": "counter values are KiB (x1024 -> bytes); FETCH_SIZE doubled per MI355X_MICROARCH.md (HBM section)",
+               "algorithmic": "Gx: 2 directions x 2 763 143 rows x 400 doubles = 17.7 GB written by the projection and read "
+                              "once by the recurrence; x: 0.53 GB read; hout: 2.2 GB written",
+               "1920": {"hbm_bytes_per_pass": f64.get("groups_of_4", f64.get("groups_of_16"))["hbm_bytes_per_pass"],
+                        "is": "projection + recurrence kernels of the product's choice (groups of four lines)"}}
+        doc.update(f64)
+        with open(os.path.join(prof, "%s_ocr_f64_hbm_traffic.json" % rnd), "w") as fh:
+            json.dump(doc, fh, indent=1)
     # matrix-pipe counters of the recogniser kernels
     kernels = {}
-    for prec in ("split", "f32", "f32g4", "f64"):
+    for prec in ("split", "f32", "f32g4", "f64", "f64g4"):
         path = os.path.join(out, "ocr_pmc_" + prec)
         if not os.path.isdir(path):
             continue
