@@ -110,7 +110,8 @@ int32_t ta_nw_max_m(void);
  *                           ops_len[p] bytes, forward order, 0 = (t,o) pair, 1 = (t,'_'),
  *                           2 = ('_',o)  (textSeqCompare.py:115-164 after the reversal at :167)
  *   ops_off          [dev]  int64[nprob]
- *   ops_len          [dev]  int32[nprob] alignment lengths (written by the traceback)
+ *   ops_len          [dev]  int32[nprob] alignment lengths (written by the traceback; ta_nw2_batch sets them to -1
+ *                           first, and a problem whose length is still negative afterwards was not walked)
  *   max_n, max_m            host-side maxima of the problem sizes (sizes LDS and the grid)
  *   score_bound             host-side bound on (max_n + max_m + 2) * max|param| used for the
  *                           overflow check (TA_ERANGE if it does not fit 2^23)

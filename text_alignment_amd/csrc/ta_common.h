@@ -10,19 +10,25 @@
 int ta_fail(int code, const char* what);
 int ta_fail_hip(hipError_t e, const char* where);
 
-// Raise of a kernel's dynamic-LDS limit above the default 64 KiB, once per kernel instantiation AND device (the
-// attribute belongs to the device's copy of the code object; a process that drives several GPUs needs it on each).
+// Raise of a kernel's dynamic-LDS limit above the default 64 KiB, once per KERNEL and device (the attribute belongs to the
+// device's copy of the code object; a process that drives several GPUs needs it on each).  The guard is keyed on the
+// kernel's ADDRESS: instantiations of one template share a function-pointer TYPE (all lstm_output_kernel<NCT> are
+// void (*)(OutArgs)), so a guard per type would skip the attribute for every instantiation after the first.
 // Thread-safe; the only mutable state the library keeps besides the lazily loaded code object.
+#include <mutex>
+#include <set>
+#include <utility>
 template <typename K>
 static inline hipError_t allow_full_lds(K kernel) {
-    constexpr int kMaxDev = 64;
-    static std::atomic<int> done[kMaxDev];
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < kMaxDev && done[dev].load(std::memory_order_acquire)) return hipSuccess;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess && dev >= 0 && dev < kMaxDev) done[dev].store(1, std::memory_order_release);
+    const std::pair<int, const void*> key(dev, reinterpret_cast<const void*>(kernel));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(key)) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.insert(key);
     return e;
 }

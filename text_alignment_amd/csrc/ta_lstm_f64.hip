@@ -397,9 +397,11 @@ __device__ __forceinline__ void seq_f64_body(const Seq64Args& a, double (&hs)[2]
 #endif
             // the parts were posted at the start of the other waves' step; the wait is bounded all the same
             const unsigned want = (unsigned)(kW - 1) * (unsigned)(t + 1);
-            for (int spin = 0; spin < (1 << 22); ++spin)
-                if (__hip_atomic_load(&part_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) break;
+            bool arrived = false;
+            for (int spin = 0; spin < (1 << 22) && !arrived; ++spin)
+                arrived = __hip_atomic_load(&part_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            if (!arrived) accs[0] = __builtin_nan("");         // a wait that ran out must show: NaN outputs, not plausible ones
 #pragma unroll
             for (int w = 0; w < kW - 1; ++w)
 #pragma unroll
@@ -659,11 +661,13 @@ __device__ __forceinline__ void seq4_f64_body(const Seq64G4Args& a, double (&hs)
         if (SUMS) {
             // the parts were posted at the start of the other waves' step; the wait is bounded all the same
             const unsigned want = 3u * (unsigned)(t + 1);
-            for (int spin = 0; spin < (1 << 22); ++spin)
-                if (__hip_atomic_load(&part_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) break;
+            bool arrived = false;
+            for (int spin = 0; spin < (1 << 22) && !arrived; ++spin)
+                arrived = __hip_atomic_load(&part_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             const double* pl = &part[0][lane & 15];
             double v[4] = {gs01[0], gs01[1], gs23[0], gs23[1]};
+            if (!arrived) v[0] = __builtin_nan("");            // a wait that ran out must show: NaN outputs, not plausible ones
 #pragma unroll
             for (int w = 0; w < 3; ++w)                              // Kr's order: Gx, then the parts of k-steps 0..8, 9..16, 17..24
 #pragma unroll

@@ -2006,6 +2006,12 @@ extern "C" int ta_nw2_batch(const int32_t* t_codes, const int64_t* t_off,
         // share one scoring system -- the two halves of a wave run in lockstep, and problems scored differently have
         // paths of very different length (the grid search, 2187 x 800 x 900 with a system per problem: 0.76 ms against
         // 0.59 with one wave per problem; the same shape under one system 0.52 against 0.53)
+        // every length starts as -1: the multi-wave tracebacks wait for each other's tokens with BOUNDED spins, and a walk
+        // that gave up must not leave the length of an earlier run (or of nothing) behind -- the host refuses a negative one
+        {
+            const hipError_t em = hipMemsetAsync(ops_len, 0xFF, sizeof(int32_t) * (size_t)nprob, st);
+            if (em != hipSuccess) return ta_fail_hip(em, "ops_len reset");
+        }
         const int tbw = ta_nw2_traceback_plan(nprob, params_stride, flags);
         if (tbw == 3) hipLaunchKernelGGL(nw_trace2h_kernel, dim3((nprob + 1) / 2), dim3(64), 0, st, a);
         else if (tbw == 5) hipLaunchKernelGGL(nw_trace2hw_kernel<2>, dim3((nprob + 1) / 2), dim3(128), 0, st, a);

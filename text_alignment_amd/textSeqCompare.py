@@ -236,6 +236,9 @@ class NWBatch(object):
             return []
         ops = self.ops.cpu().numpy()
         lens = self.ops_len.cpu().numpy()
+        if (lens[:self.nprob] < 0).any():         # ta_nw2_batch resets the lengths to -1 before its traceback launch
+            raise RuntimeError("traceback of problem %d did not finish (a bounded wait between its waves ran out)"
+                               % int(np.nonzero(lens[:self.nprob] < 0)[0][0]))
         out = []
         for k in range(self.nprob):
             end = int(self.ops_off_host[k] + self.cap_host[k])

@@ -61,8 +61,24 @@ def main():
             call(b, h, nprob, True, True, s2)
             main_s.wait_stream(s1); main_s.wait_stream(s2)
 
+        def round_shaped(cut):
+            # the fill exactly as one launch would dispatch it (part A, then part B right behind on the same stream); the
+            # traceback of part A on a second stream as soon as A's fill is done -- beside B's fill, which leaves most of the
+            # chip idle when A was a whole round of resident workgroups -- and the traceback of part B behind its fill
+            def fn():
+                s1.wait_stream(main_s); s2.wait_stream(main_s)
+                call(b, 0, cut, True, False, s1)
+                ev = torch.cuda.Event(); ev.record(s1)
+                call(b, cut, nprob, True, True, s1)
+                s2.wait_event(ev)
+                call(b, 0, cut, False, True, s2)
+                main_s.wait_stream(s1); main_s.wait_stream(s2)
+            return fn
+
         out = []
-        for name, fn in (("one launch pair", one), ("halves staggered", staggered), ("halves side by side", side_by_side)):
+        cuts = [c for c in (512, 640, 768, 896) if c < nprob] if nprob <= 2048 else []
+        for name, fn in [("one launch pair", one), ("halves staggered", staggered), ("halves side by side", side_by_side)] + \
+                [("first %d then the rest, tracebacks overlapped" % c, round_shaped(c)) for c in cuts]:
             for _ in range(3):
                 fn()
             torch.cuda.synchronize()
