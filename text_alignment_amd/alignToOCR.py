@@ -383,6 +383,19 @@ PIPELINE_CHUNK_PAGES = int(os.environ.get("TA_PAGE_CHUNK", "16"))          # (th
 PIPELINE_CHUNK_PAGES_RAW = int(os.environ.get("TA_PAGE_CHUNK_RAW", "32"))    # raw strips: the device normaliser in front
 PIPELINE_CHUNK_PAGES_IMAGES = int(os.environ.get("TA_PAGE_CHUNK_IMAGES", "64"))
 _side_streams = {}
+_SPLIT_FINISH = os.environ.get("TA_PB_SPLIT_FINISH", "1") != "0"      # (timing experiments)
+_TWO_STREAMS = os.environ.get("TA_PB_TWO_STREAMS", "1") != "0"
+
+
+def _ocr_streams(device):
+    """two compute streams for the recogniser kernels of consecutive chunks: on ONE stream the projection of chunk k + 1
+    cannot start before the last workgroup of chunk k's recurrence has finished, and a chunk's recurrence is one round of
+    workgroups whose CUs free up one by one as the shorter lines end (mean / longest line = 0.71)"""
+    import torch
+    key = ("ocr", device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _side_streams:
+        _side_streams[key] = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+    return _side_streams[key]
 
 
 def _nw_stream(device):
@@ -423,16 +436,29 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
         return _pb_finish(ctx, indices_out, arrays_out)
     # chunk k + 1's strips are copied to the staging buffer by the pool while this thread finishes chunk k - 1 and the
     # device runs chunk k; at most two chunks are in flight
+    import torch
     results, flight = [], []
+    streams = _ocr_streams(rec.device)
+    caller = torch.cuda.current_stream(rec.device)
+    for st_ in streams:
+        st_.wait_stream(caller)                                  # whatever the caller enqueued before this call
     for a in range(0, n, C):
         b = n if n - (a + C) < C // 2 else min(a + C, n)        # (no sliver of a last chunk)
         ctx = _pb_begin(rec, pages[a:b], transcripts[a:b], seq_align_params, parallel)
-        if len(flight) == 2:
-            results.extend(_pb_finish(flight.pop(0), indices_out, arrays_out))
-        _pb_launch(ctx)
+        oldest = flight.pop(0) if len(flight) == 2 else None
+        if oldest is not None:
+            _pb_finish_a(oldest)                                 # ... its NW launch runs under the next chunk's launch
+            if not _SPLIT_FINISH:
+                results.extend(_pb_finish_b(oldest, indices_out, arrays_out))
+        with torch.cuda.stream(streams[(a // C) % 2] if _TWO_STREAMS else caller):
+            _pb_launch(ctx)
         flight.append(ctx)
+        if oldest is not None and _SPLIT_FINISH:
+            results.extend(_pb_finish_b(oldest, indices_out, arrays_out))
         if b == n:
             break
+    for st_ in streams:
+        caller.wait_stream(st_)
     for ctx in flight:
         results.extend(_pb_finish(ctx, indices_out, arrays_out))
     return results
@@ -479,17 +505,22 @@ def _pb_launch(ctx):
 
 
 def _pb_finish(ctx, indices_out, arrays_out):
-    """second stage: characters and boxes of every line, abbreviations, ONE NW launch for the chunk's pages, syllable boxes"""
+    _pb_finish_a(ctx)
+    return _pb_finish_b(ctx, indices_out, arrays_out)
+
+
+def _pb_finish_a(ctx):
+    """second stage, first half: characters and boxes of every line, abbreviations, ONE NW launch for the chunk's pages
+    and the download of its alignment columns STARTED"""
     import torch
     from . import page_batch as pb
     rec, pages, transcripts, seq_align_params = ctx["rec"], ctx["pages"], ctx["transcripts"], ctx["params"]
     raw_dims, found, strips_per_page, all_strips = ctx["raw_dims"], ctx["found"], ctx["strips_per_page"], ctx["all_strips"]
     lines, widths, st, syls_all, t_cp, cps = ctx["lines"], ctx["widths"], ctx["st"], ctx["syls_all"], ctx["t_cp"], ctx["cps"]
     params, fn = tsc.parse_scoring_system(seq_align_params)
+    ctx["nw"] = None
     if fn is not None or cps is None or not tsc._is_integral(params):
-        rec._last_state, rec.last_T = st, st["T_host"]
-        return _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, widths,
-                                      transcripts, seq_align_params, indices_out)
+        return
 
     # ---- every character of every line: code points + boxes (alignToOCR.py:160-182) ----
     nlines = len(all_strips)
@@ -517,21 +548,32 @@ def _pb_finish(ctx, indices_out, arrays_out):
     o_cp = [np.frombuffer(tx.encode('utf-32-le'), dtype='<u4').astype(np.int64) for tx in texts]
     alphabet = np.unique(np.concatenate(t_cp + o_cp)) if (t_cp or o_cp) else np.zeros(0, np.int64)
     # (the aligner's inputs come from the host and its buffers are the side stream's own: nothing to wait for)
-    all_ops = None
     with torch.cuda.stream(_nw_stream(rec.device)):
         try:
             batch = tsc.NWBatch([np.searchsorted(alphabet, a).astype(np.int32) for a in t_cp],
                                 [np.searchsorted(alphabet, a).astype(np.int32) for a in o_cp],
                                 [int(v) for v in params])
             batch.run()
-            all_ops = batch.results()
-            del batch
+            batch.fetch_begin()
+            ctx["nw"] = batch
         except OverflowError:
             pass
-    if all_ops is None:
+    ctx["texts"], ctx["idxs"], ctx["boxes"] = texts, idxs, boxes
+
+
+def _pb_finish_b(ctx, indices_out, arrays_out):
+    """second stage, second half: the alignment columns (waited for here), syllable boxes (alignToOCR.py:277-328)"""
+    from . import page_batch as pb
+    rec, pages, transcripts, seq_align_params = ctx["rec"], ctx["pages"], ctx["transcripts"], ctx["params"]
+    raw_dims, found, strips_per_page = ctx["raw_dims"], ctx["found"], ctx["strips_per_page"]
+    lines, widths, st, syls_all = ctx["lines"], ctx["widths"], ctx["st"], ctx["syls_all"]
+    if ctx["nw"] is None:                 # a scoring callable / non-integral numbers / a multi-character codec / too large
         rec._last_state, rec.last_T = st, st["T_host"]
         return _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, widths,
                                       transcripts, seq_align_params, indices_out)
+    all_ops = ctx["nw"].results()
+    ctx["nw"] = None
+    texts, idxs, boxes = ctx["texts"], ctx["idxs"], ctx["boxes"]
 
     # ---- syllable boxes (alignToOCR.py:277-328): all plain pages in one set of array operations ----
     plain = [k for k in range(len(pages)) if pb.plain_page(transcripts[k], syls_all[k])]

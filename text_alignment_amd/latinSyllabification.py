@@ -98,6 +98,8 @@ def syllabify_word(inp):
 
 def syllabify_text(input):
     syls = []
+    memo = _memo
     for word in input.split(' '):
-        syls.extend(syllabify_word(word))
+        hit = memo.get(word)                  # (chant texts repeat their words: most of them are here already)
+        syls.extend(hit if hit is not None else syllabify_word(word))
     return syls

@@ -350,7 +350,7 @@ class LineRecognizer(object):
             self.w2bias = torch.from_numpy(bias).to(self.device)
         if self.mode == 3:
             self.wh64, self.wx64, self.peep64, self.wh64g4 = (torch.from_numpy(w).to(self.device) for w in _pack_lstm_f64(model))
-            self._gx = None
+            self._gx = {}           # Gx scratch per compute stream (process_batch runs consecutive chunks on two streams)
 
     # ---- host -> device ------------------------------------------------------------------
     def _stage_rows_begin(self, lines, row_start, rows):
@@ -385,7 +385,29 @@ class LineRecognizer(object):
         done_rows = np.cumsum([ln.shape[0] for ln in lines])
         cuts = np.searchsorted(done_rows, np.linspace(0, rows, nthreads + 1)).tolist()
         cuts[0], cuts[-1] = 0, len(lines)
-        return (rows, [_copy_pool().submit(copy, (cuts[i], cuts[i + 1])) for i in range(nthreads)], slot)
+        copies = [_copy_pool().submit(copy, (cuts[i], cuts[i + 1])) for i in range(nthreads)]
+        # the transfer itself is issued by the pool as soon as the last copy is done (queued behind the copies: it cannot
+        # starve them), not by the caller when it next looks -- in the page pipeline that was 2.4 ms of PCIe time per
+        # chunk on the critical path between two chunks' kernels
+        return (rows, [_copy_pool().submit(self._issue_upload, copies, rows, slot)], slot)
+
+    def _issue_upload(self, copies, rows, slot):
+        for f in copies:
+            f.result()
+        up = self._upload_stream()
+        with torch.cuda.stream(up):
+            x_dev = torch.empty((rows, NI), dtype=torch.float32, device=self.device)
+            x_dev.copy_(slot["buf"][:rows], non_blocking=True)
+            # the staging buffer is reused by the batch after next: the transfer has to be over before then
+            slot["done"] = torch.cuda.Event()
+            slot["done"].record(up)
+        return x_dev
+
+    def _upload_stream(self):
+        up = getattr(self, "_up_stream", None)
+        if up is None:
+            up = self._up_stream = torch.cuda.Stream(device=self.device)
+        return up
 
     def _stage_rows_end(self, pending):
         """Wait for the staging copies and send the rows over PCIe in one asynchronous transfer ON THE UPLOAD STREAM: the
@@ -395,18 +417,8 @@ class LineRecognizer(object):
         if pending is None:
             return torch.zeros((1, NI), dtype=torch.float32, device=self.device)
         rows, futures, slot = pending
-        for f in futures:
-            f.result()
-        up = getattr(self, "_up_stream", None)
-        if up is None:
-            up = self._up_stream = torch.cuda.Stream(device=self.device)
         main = torch.cuda.current_stream(self.device)
-        with torch.cuda.stream(up):
-            x_dev = torch.empty((rows, NI), dtype=torch.float32, device=self.device)
-            x_dev.copy_(slot["buf"][:rows], non_blocking=True)
-            # the staging buffer is reused by the batch after next: the transfer has to be over before then
-            slot["done"] = torch.cuda.Event()
-            slot["done"].record(up)
+        x_dev = futures[0].result() if futures else self._issue_upload([], rows, slot)
         main.wait_event(slot["done"])
         x_dev.record_stream(main)
         return x_dev
@@ -560,7 +572,8 @@ class LineRecognizer(object):
             projection of the shorter class runs on the CUs that recurrence has not claimed.  Same kernels on the
             same rows: results are bit for bit those of the one-after-the-other order."""
             grow = st["group_row_host"]
-            piped = F64_CLASS_PIPELINE and stream_ == stream
+            # (groups of four lines leave the projection no idle CUs to hide under: measured no gain, so no side streams)
+            piped = F64_CLASS_PIPELINE and stream_ == stream and G != 4
             a = g0
             while a < g1:
                 b = a + 1
@@ -568,9 +581,11 @@ class LineRecognizer(object):
                     b += 1
                 r0, r1 = int(grow[a]), int(grow[b])
                 need = lib.ta_lstm_f64_gx_bytes(r1 - r0)
-                if self._gx is None or self._gx.numel() * 8 < need:
-                    self._gx = None                                  # (free the old one first)
-                    self._gx = torch.empty(max(need // 8, 1), dtype=torch.float64, device=self.device)
+                gx_buf = self._gx.get(stream)
+                if gx_buf is None or gx_buf.numel() * 8 < need:
+                    gx_buf = None
+                    self._gx.pop(stream, None)                       # (free the old one first)
+                    gx_buf = self._gx[stream] = torch.empty(max(need // 8, 1), dtype=torch.float64, device=self.device)
                 cuts = [a, b]
                 if piped and (b - a) * G >= 16 * F64_CLASS_MIN_GROUPS:
                     cuts = sorted(set([a, b] + [a + int(round(f * (b - a))) for f in F64_CLASS_CUTS]))
@@ -579,7 +594,7 @@ class LineRecognizer(object):
                 for k in range(len(cuts) - 1):
                     ca, cb = cuts[k], cuts[k + 1]
                     c0, c1 = int(grow[ca]), int(grow[cb])
-                    gx = self._gx.data_ptr() + off
+                    gx = gx_buf.data_ptr() + off
                     off += lib.ta_lstm_f64_gx_bytes(c1 - c0)
                     _native.check(lib.ta_lstm_xproj_f64(st["x"].data_ptr() + 4 * NI * c0, c1 - c0, self.wx64.data_ptr(),
                                                         gx, stream_), "ta_lstm_xproj_f64")

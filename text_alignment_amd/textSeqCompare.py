@@ -230,12 +230,29 @@ class NWBatch(object):
         return {1: "nw_trace2_kernel", 2: "nw_trace2w_kernel<2>", 4: "nw_trace2w_kernel<4>", 3: "nw_trace2h_kernel",
                 5: "nw_trace2hw_kernel<2>", 6: "nw_trace2hw_kernel<4>"}[w]
 
+    def fetch_begin(self):
+        """start the download of the alignment columns (pinned buffers, an event on the current stream); `results()` then
+        only waits for that event -- a caller with other host work puts it in between"""
+        if self.nprob == 0:
+            return
+        self._host_ops = torch.empty(self.ops.shape, dtype=self.ops.dtype, pin_memory=True)
+        self._host_len = torch.empty(self.ops_len.shape, dtype=self.ops_len.dtype, pin_memory=True)
+        self._host_ops.copy_(self.ops, non_blocking=True)
+        self._host_len.copy_(self.ops_len, non_blocking=True)
+        self._fetched = torch.cuda.Event()
+        self._fetched.record()
+
     def results(self):
         """Host copies of the alignment columns, one uint8 array per problem."""
         if self.nprob == 0:
             return []
-        ops = self.ops.cpu().numpy()
-        lens = self.ops_len.cpu().numpy()
+        if getattr(self, "_fetched", None) is not None:
+            self._fetched.synchronize()
+            ops, lens = self._host_ops.numpy(), self._host_len.numpy()
+            self._fetched = None
+        else:
+            ops = self.ops.cpu().numpy()
+            lens = self.ops_len.cpu().numpy()
         if (lens[:self.nprob] < 0).any():         # ta_nw2_batch resets the lengths to -1 before its traceback launch
             raise RuntimeError("traceback of problem %d did not finish (a bounded wait between its waves ran out)"
                                % int(np.nonzero(lens[:self.nprob] < 0)[0][0]))

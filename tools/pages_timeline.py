@@ -1,0 +1,29 @@
+"""Device timeline of ONE process_batch pass on synthetic pages (torch profiler): every device interval with its
+stream, start and duration -- what overlaps what in the chunk pipeline.   python tools/pages_timeline.py [npages]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+
+from tools import pages_bench as pb
+from text_alignment_amd import alignToOCR as atocr
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+rec = pb.make_recognizer()
+pages, trs = zip(*[pb.make_page(100 + k) for k in range(n)])
+for _ in range(3):
+    atocr.process_batch(list(pages), list(trs), rec, pb.PARAMS)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+    atocr.process_batch(list(pages), list(trs), rec, pb.PARAMS)
+    torch.cuda.synchronize()
+ev = [e for e in prof.events() if getattr(e, "device_type", None) is not None and "CUDA" in str(e.device_type)]
+ev.sort(key=lambda e: e.time_range.start)
+t0 = ev[0].time_range.start
+for e in ev:
+    d = e.time_range.end - e.time_range.start
+    if d >= 50:
+        print("%9.3f ms  +%8.3f ms  %s" % ((e.time_range.start - t0) / 1e3, d / 1e3, e.name[:70]))
+print("span %.3f ms" % ((max(e.time_range.end for e in ev) - t0) / 1e3))
