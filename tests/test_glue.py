@@ -226,3 +226,47 @@ def test_llocs_parser_matches_reference():
             atocr.chars_from_llocs(llocs, s["offset_x"], s["offset_y"], s["offset_y"] + s["height"], got)
         assert [[b.char, [int(b.ul[0]), int(b.ul[1])], [int(b.lr[0]), int(b.lr[1])]] for b in got] == c["chars"]
     assert ties >= 20            # the fixture does exercise the half-to-even cases
+
+
+def test_token_encoding_and_list_rebuild_fast_paths_equal_the_token_by_token_forms():
+    """textSeqCompare.encode_tokens / ops_to_alignment (host side of perform_alignment, no GPU): single-character strings
+    take numpy passes, anything else -- bigrams (textSeqCompare.py:185-186), numbers, mixed -- the token-by-token dict;
+    both number tokens by first appearance, so ids (and with them alignments) never depend on the path.  The rebuilt
+    lists are the reference's: a column shows the next unconsumed token or '_' (textSeqCompare.py:116-162)."""
+    from text_alignment_amd import textSeqCompare as tsc
+
+    def by_token(*seqs):
+        ids, out = {}, []
+        for seq in seqs:
+            out.append([ids.setdefault(tok, len(ids)) for tok in seq])
+        return out, ids
+
+    def rebuild(ops, t, o):
+        tra, oc, i, j = [], [], 0, 0
+        for op in ops:
+            tra.append(t[i] if op != 2 else '_'); oc.append(o[j] if op != 1 else '_')
+            i += op != 2; j += op != 1
+        return tra, oc
+    rng = np.random.default_rng(9)
+    for trial in range(120):
+        n, m = (int(v) for v in rng.integers(0, 30, 2))
+        t = [chr(int(c)) for c in rng.integers(97, 104, n)]
+        o = [chr(int(c)) for c in rng.integers(97, 106, m)]
+        if trial % 4 == 1:
+            t = list(zip(t, t[1:]))                                  # bigram tuples
+        if trial % 4 == 2:
+            o = [ord(c) for c in o]                                  # numbers
+        if trial % 4 == 3 and t:
+            t = list(u"dūß€\U0001F600 _~"[:len(t)])       # beyond Latin-1, beyond the BMP, the gap marker itself
+        (a, b), ids = tsc.encode_tokens(t, o)
+        (a2, b2), ids2 = by_token(t, o)
+        assert a.tolist() == a2 and b.tolist() == b2 and ids == ids2, (t, o)
+        assert a.dtype == np.int32 and b.dtype == np.int32
+        i = j = 0
+        ops = []
+        while i < len(t) or j < len(o):
+            op = int(rng.choice([k for k, ok in ((0, i < len(t) and j < len(o)), (1, i < len(t)), (2, j < len(o))) if ok]))
+            ops.append(op); i += op != 2; j += op != 1
+        assert tsc.ops_to_alignment(np.array(ops, dtype=np.uint8), t, o) == rebuild(ops, t, o)
+    assert tsc.ops_to_alignment(np.zeros(0, np.uint8), [], []) == ([], [])
+    assert tsc.encode_tokens([], [])[0][0].tolist() == []
