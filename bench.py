@@ -315,7 +315,7 @@ def measured_f64_traffic(nlines):
 def ocr_mode_agreement():
     """Free-running agreement of the recogniser's modes (f32, split, f64) with oracle/ocr_ref_f64.py, as measured by
     tools/ocr_mode_agreement.py on the GPU box and kept under profiles/ (read, not measured here)."""
-    name, path = _profile_file("r04_ocr_mode_agreement.json", "r03_ocr_mode_agreement.json")
+    name, path = _profile_file("r05_ocr_mode_agreement.json", "r04_ocr_mode_agreement.json")
     try:
         with open(path) as f:
             d = json.load(f)

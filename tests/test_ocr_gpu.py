@@ -186,7 +186,7 @@ def test_spec_model_benchmark_widths_free_running(seed, no, precision):
     FREE-RUNNING (the kernels' own state all the way), the two opt-in float32 modes (the default, float64, has the
     strict test below):
     what the north_star's "logits within 1e-3" looks like on a chaotic random-weight model.  Measured
-    on 96 lines per model (tools/ocr_mode_agreement.py, profiles/r03_ocr_mode_agreement.json): f32 median
+    on 96 lines per model (tools/ocr_mode_agreement.py, profiles/r05_ocr_mode_agreement.json): f32 median
     1.3e-4 / 2.4e-5, 89 / 94 lines within 1e-3, worst line 1.5e-2; split median 3.5e-4 / 3.4e-5, 72 / 92
     lines, worst 6.6e-2; decode identical on every line in both modes.  Asserted here on 16 lines:
     the median and the share of lines within 1e-3 (per mode), a loose bound on the worst line, and that

@@ -324,7 +324,7 @@ class LineRecognizer(object):
     four products per k-step); its pre-activation error is about three times the f32 mode's.
     The two float32 modes hold the 1e-3 logit parity of the spec model per 128-step segment; FREE-RUNNING on that
     model at 800 .. 2000 columns, against the float64 restatement (96 lines per model,
-    tools/ocr_mode_agreement.py, profiles/r04_ocr_mode_agreement.json): f32 median logit error
+    tools/ocr_mode_agreement.py, profiles/r05_ocr_mode_agreement.json): f32 median logit error
     9.1e-5 / 2.7e-5 (models 7001 / 7002), 88 / 94 of 96 lines within 1e-3; split 3.3e-4 / 3.5e-5,
     78 / 91 of 96; decoded characters: f32 identical on all 19 614 of the sample, split one different.
     ("bf16x3", the name of the split mode's first form, is accepted.)"""
