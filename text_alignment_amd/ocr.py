@@ -336,6 +336,10 @@ class LineRecognizer(object):
             raise ValueError("precision must be 'f32', 'split' or 'f64'")
         self.model = model
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            # pin the index: "cuda" alone means the CALLING THREAD's current device, and the pool threads that issue the
+            # rows' transfer start on device 0 whatever device this rank's main thread has selected
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.mode = {"f32": 0, "f64": 3}.get(precision, 1)
         wp, peep, w2p = _pack_lstm(model)
         if self.mode == 1:
@@ -385,6 +389,7 @@ class LineRecognizer(object):
         done_rows = np.cumsum([ln.shape[0] for ln in lines])
         cuts = np.searchsorted(done_rows, np.linspace(0, rows, nthreads + 1)).tolist()
         cuts[0], cuts[-1] = 0, len(lines)
+        self._upload_stream()                       # (created here, on the caller's thread and device)
         copies = [_copy_pool().submit(copy, (cuts[i], cuts[i + 1])) for i in range(nthreads)]
         # the transfer itself is issued by the pool as soon as the last copy is done (queued behind the copies: it cannot
         # starve them), not by the caller when it next looks -- in the page pipeline that was 2.4 ms of PCIe time per

@@ -107,6 +107,8 @@ class NWBatch(object):
     def __init__(self, t_list, o_list, params, device="cuda", two_phase=None, wide=None):
         assert len(t_list) == len(o_list)
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.nprob = len(t_list)
         self.n = np.array([len(t) for t in t_list], dtype=np.int64)
         self.m = np.array([len(o) for o in o_list], dtype=np.int64)
