@@ -39,7 +39,7 @@ F64_MFMA_PEAK_TF = 78.6        # f64 matrix peak (spec); measured: v_mfma_f64_16
                                # at 2.4 GHz (tools/ubench/mfma_f64.hip, profiles/r04_mfma_f64.txt)
 DEFAULT_SYS = [8, -4, -7, -7, -3, 0]
 P1_VALU_PER_BLOCK = 382        # nw_score_kernel, score profile + one gap open: VALU instructions per 64 cells of a lane
-P1_NS_PER_VALU = 1.72          # measured issue interval of that instruction mix (profiles/r02_valu_issue_rates.txt)
+P1_NS_PER_VALU = 1.72          # measured issue interval of that instruction mix (profiles/r05_valu_issue_rates.txt: 1.722 at 8 waves per SIMD; round 2: 1.72)
 
 
 def _profile_file(*names):
@@ -256,7 +256,7 @@ def bench_ocr(args, rank, precision=None, nlines=None):
         # float64 mode: hoisted input projection (a f64 GEMM) + the recurrence on v_mfma_f64_16x16x4_f64 (timed
         # together as "lstm": one run() issues both per run of groups); algorithmic flops per timestep as in f32 mode
         tf = tsteps * 238400.0 / (lstm_ms * 1e-3) / 1e12
-        traffic, traffic_src = measured_f64_traffic(nlines)
+        traffic, traffic_src = measured_ocr_traffic(nlines, "f64", st["group_size"])
         roof = {"bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tf / F64_MFMA_PEAK_TF, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "%s (+ lstm_xproj_f64_kernel)" % ("lstm_seq4_f64_kernel" if st["group_size"] == 4 else "lstm_seq_f64_kernel"),
@@ -269,8 +269,9 @@ def bench_ocr(args, rank, precision=None, nlines=None):
         tf = tsteps * 238400.0 / (lstm_ms * 1e-3) / 1e12
         kern = "lstm_seq4_kernel" if st["group_size"] == 4 else "lstm_seq_kernel"
         busy, busy_src = measured_mfma_busy(kern) if nlines == 1920 else (None, None)
+        traffic, traffic_src = measured_ocr_traffic(nlines, "f32", st["group_size"])
         roof = {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": tf / F32_MFMA_PEAK_TF, "traffic": None,
+                "frac": tf / F32_MFMA_PEAK_TF, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "lstm_seq4_kernel" if st["group_size"] == 4 else "lstm_seq_kernel",
                 "flops": "algorithmic: 238400 per timestep (the kernel executes 14 % more on padded tiles)",
                 "peak_is": "f32-input MFMA (v_mfma_f32_4x4x1_16B_f32 for groups of 4 lines, v_mfma_f32_16x16x4_f32 for "
@@ -281,8 +282,9 @@ def bench_ocr(args, rank, precision=None, nlines=None):
         # 160 padded inputs and 112 padded units, both directions: 2 x 7 x 80 MFMAs of 16384 flop per 16
         # lines and timestep -- priced against the pipe it runs on
         tf = tsteps / 16.0 * 2 * 7 * 80 * 16384.0 / (lstm_ms * 1e-3) / 1e12
+        traffic, traffic_src = measured_ocr_traffic(nlines, "split", st["group_size"])
         roof = {"bound": "mfma", "achieved": tf, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": tf / BF16_MFMA_PEAK_TF, "traffic": None, "kernel": "lstm_seq_split_kernel",
+                "frac": tf / BF16_MFMA_PEAK_TF, "traffic": traffic, "traffic_source": traffic_src, "kernel": "lstm_seq_split_kernel",
                 "flops": "executed: 4 split products per k-step, 16-bit operands, padded tiles",
                 "peak_is": "dense bf16 / fp16 MFMA (v_mfma_f32_16x16x32_bf16 / _f16), the instructions the kernel issues"}
     return {"lines_per_s": nlines / dt, "timesteps_per_s": tsteps / dt, "lines": nlines,
@@ -297,16 +299,21 @@ def bench_ocr(args, rank, precision=None, nlines=None):
             "roofline": roof}
 
 
-def measured_f64_traffic(nlines):
-    """HBM bytes of one float64 pass (projection + recurrence kernels) from the separate --pmc WRITE_SIZE / FETCH_SIZE
-    passes kept under profiles/ (tools/profile_round.sh); read, not measured in this run."""
-    name, path = _profile_file("r05_ocr_f64_hbm_traffic.json")
+def measured_ocr_traffic(nlines, precision, group):
+    """HBM bytes of one pass of the recurrence kernels of a mode (float64: projection + recurrence) from the separate
+    --pmc WRITE_SIZE / FETCH_SIZE passes kept under profiles/ (tools/profile_round.sh); read, not measured in this run."""
+    name, path = _profile_file("r05_ocr_hbm_traffic.json", "r05_ocr_f64_hbm_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        e = d.get(str(nlines))
-        if e:
-            return float(e["hbm_bytes_per_pass"]), "profiles/" + name
+        if "modes" in d:
+            e = d["modes"].get("%s_g%d_%d" % (precision, group, nlines))
+            if e:
+                return float(e["hbm_bytes_per_pass"]), "profiles/" + name
+        elif precision == "f64":
+            e = d.get(str(nlines))
+            if e:
+                return float(e["hbm_bytes_per_pass"]), "profiles/" + name
     except (OSError, KeyError, ValueError, TypeError):
         pass
     return None, None
@@ -351,11 +358,11 @@ def nw_roofline(batch, kname, fill_ms, tb_ms, traffic, traffic_src):
     if batch.two_phase:
         # the score kernel never writes the algorithmic byte (0.22 B/cell of checkpoints instead): HBM is a
         # yardstick for it, VALU issue is what binds it.  Floor of its instruction mix: 382 VALU instructions
-        # per 64 cells of a lane at 1.72 ns per wave-instruction and SIMD (profiles/r02_valu_issue_rates.txt)
+        # per 64 cells of a lane at 1.72 ns per wave-instruction and SIMD (profiles/r05_valu_issue_rates.txt)
         floor_ms = cells / 4096.0 * P1_VALU_PER_BLOCK * P1_NS_PER_VALU * 1e-6 / 1024.0
         roof.update({"binding_unit": "valu-issue", "valu_issue_floor_ms": floor_ms,
                      "valu_issue_frac": floor_ms / fill_ms,
-                     "valu_issue_source": "profiles/r02_valu_issue_rates.txt; %d VALU per 64 cells x 64 lanes at "
+                     "valu_issue_source": "profiles/r05_valu_issue_rates.txt; %d VALU per 64 cells x 64 lanes at "
                                           "%.2f ns per wave-instruction per SIMD" % (P1_VALU_PER_BLOCK, P1_NS_PER_VALU)})
     return roof
 

@@ -97,6 +97,15 @@ for g in 4 16; do
     echo "ocr f64 groups of $g $ctr done"
   done
 done
+# the opt-in modes' recurrence kernels: the same two counter passes (f32 on groups of four lines, split operands)
+export TA_OCR_CLASS_SPLIT=0
+for w in "f32 4" "split 16"; do
+  set -- $w
+  for ctr in WRITE_SIZE FETCH_SIZE; do
+    TA_OCR_GROUP=$2 timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/ocr_$1g$2_$ctr" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 $1 > "$OUT/ocr_$1g$2_$ctr.log" 2>&1
+    echo "ocr $1 groups of $2 $ctr done"
+  done
+done
 TA_OCR_GROUP=4 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_f64g4" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f64 > "$OUT/ocr_pmc_f64g4.log" 2>&1
 echo "ocr pmc f64 groups of 4 done"
 export TA_OCR_GROUP=16

@@ -69,6 +69,22 @@ def main():
         f64["groups_of_%d" % g] = {"kernels": kernels,
                                   "hbm_bytes_per_pass": sum(v["hbm_bytes_per_launch"] for k, v in kernels.items()
                                                             if "xproj_f64" in k or "seq_f64" in k or "seq4_f64" in k)}
+    # every mode's recurrence kernels in one file (bench.py: ocr.*.roofline.traffic)
+    modes = {}
+    for prec, g, pick in (("f64", 4, ("xproj_f64", "seq4_f64")), ("f64", 16, ("xproj_f64", "seq_f64_kernel")),
+                          ("f32", 4, ("lstm_seq4_kernel",)), ("split", 16, ("lstm_seq_split_kernel",))):
+        wr = counter_means(os.path.join(out, "ocr_%sg%d_WRITE_SIZE" % (prec, g)), "WRITE_SIZE", only="lstm_")
+        rd = counter_means(os.path.join(out, "ocr_%sg%d_FETCH_SIZE" % (prec, g)), "FETCH_SIZE", only="lstm_")
+        ks = {k: wr.get(k, 0.0) * 1024 + 2 * rd.get(k, 0.0) * 1024 for k in set(wr) | set(rd) if any(p in k for p in pick)}
+        if ks:
+            modes["%s_g%d_1920" % (prec, g)] = {"kernels": ks, "hbm_bytes_per_pass": sum(ks.values())}
+    if modes:
+        with open(os.path.join(prof, "%s_ocr_hbm_traffic.json" % rnd), "w") as fh:
+            json.dump({"command": "TA_OCR_CLASS_SPLIT=0 TA_OCR_F64_PIPE=0 TA_OCR_GROUP=<g> rocprofv3 --pmc WRITE_SIZE (and, separately, "
+                                  "FETCH_SIZE) --output-format csv -- python3 tools/ocr_only.py 1920 <mode>",
+                       "units": "bytes per launch = WRITE_SIZE*1024 + 2*FETCH_SIZE*1024 (counter unit KiB; FETCH_SIZE doubled per "
+                                "MI355X_MICROARCH.md, HBM section); summed over the mode's recurrence kernels (float64: projection + recurrence)",
+                       "modes": modes}, fh, indent=1)
     if f64:
         doc = {"command": "TA_OCR_F64_PIPE=0 TA_OCR_GROUP=<4|16> rocprofv3 --pmc WRITE_SIZE (and, separately, FETCH_SIZE) "
                           "--output-format csv -- python3 tools/ocr_only.py 1920 f64",
