@@ -88,7 +88,8 @@ def _fake_process_batch(pages, transcripts, model, seq_align_params=None, indice
     same boxes for the same page"""
     from text_alignment_amd import alignToOCR as atocr, latinSyllabification as latsyl
     out = []
-    for pg, tr in zip(pages, transcripts):
+    models = model if isinstance(model, (list, tuple)) else [model] * len(pages)
+    for pg, tr, model in zip(pages, transcripts, models):
         if pg.get("bad"):                      # e.g. page.prepared_lines' 'empty or constant text-line image'
             raise ValueError("empty or constant text-line image")
         if pg.get("fatal"):                    # e.g. _native.check after a kernel fault

@@ -414,13 +414,27 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     in one batch (large batches: in chunks of PIPELINE_CHUNK_PAGES pages, host and device overlapped), the
     transcript/OCR alignments of a chunk's pages run in one NW launch, and the glue in
     between runs on arrays (text_alignment_amd.page_batch) -- the shape in which a GPU is worth
-    using.  Per page the result equals process(page, transcript, model, seq_align_params).
+    using.  Per page the result equals process(page, transcript, model, seq_align_params).  `ocropus_model` is one model
+    for all pages or a list with one per page.
     Returns a list of (syl_boxes, image, lines_peak_locs, all_chars); the two box lists are
     sequences that build their CharBox objects on access.  indices_out, if given, receives per page
     the index of each box's syllable among the transcript's non-empty syllables; arrays_out the
     boxes themselves as an int array [k, 4] (ulx, uly, lrx, lry)."""
-    rec = _recognizer_for(ocropus_model)
     pages, transcripts = list(pages), list(transcripts)
+    n = len(pages)
+    # one model for all pages, or one per page (the reference's two manuscripts have a model each, alignToOCR.py:390-405):
+    # pages are grouped by recogniser, every chunk has one, and the pipeline runs on across the groups
+    if isinstance(ocropus_model, (list, tuple)):
+        if len(ocropus_model) != n:
+            raise ValueError("a list of models needs one entry per page")
+        recs = [_recognizer_for(m) for m in ocropus_model]
+    else:
+        recs = [_recognizer_for(ocropus_model)] * n
+    groups = {}
+    for k, r in enumerate(recs):
+        groups.setdefault(id(r), (r, []))[1].append(k)
+    if not groups:
+        groups[0] = (_recognizer_for(ocropus_model), [])
     # pages that still need the preprocessing kernels (page images) take larger chunks: their line finding waits for the
     # device several times per batch of pages, and those waits queue behind a previous chunk's recogniser
     # (measured at 64 pages, chunks of 8 / 16 / 32: normalised strips 1 410 / 1 515 / 1 515 pages/s, raw strips -- whose
@@ -428,40 +442,71 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     # whatever the chunk)
     images = any(not isinstance(pg, page_mod.PreparedPage) for pg in pages)
     raw = not images and any(st.prepared is None for pg in pages for st in getattr(pg, "strips", ()))
-    n = len(pages)
     C = PIPELINE_CHUNK_PAGES_IMAGES if images else (PIPELINE_CHUNK_PAGES_RAW if raw else PIPELINE_CHUNK_PAGES)
-    if n <= C + C // 2:
-        ctx = _pb_begin(rec, pages, transcripts, seq_align_params, parallel)
+    chunks = []
+    for rec, ks in groups.values():
+        a = 0
+        while True:
+            b = len(ks) if len(ks) - (a + C) < C // 2 else min(a + C, len(ks))   # (no sliver of a last chunk)
+            chunks.append((rec, ks[a:b]))
+            a = b
+            if a >= len(ks):
+                break
+    out_res, out_idx, out_arr = [None] * n, [None] * n, [None] * n
+
+    def begin(job):
+        rec, ks = job
+        ctx = _pb_begin(rec, [pages[k] for k in ks], [transcripts[k] for k in ks], seq_align_params, parallel)
+        ctx["page_ids"] = ks
+        return ctx
+
+    def collect(ctx):
+        idx, arr = [], []
+        res = _pb_finish_b(ctx, idx, arr)
+        for j, k in enumerate(ctx["page_ids"]):
+            out_res[k] = res[j]
+            out_idx[k] = idx[j] if j < len(idx) else None
+            out_arr[k] = arr[j] if j < len(arr) else None
+
+    def deliver():
+        if indices_out is not None:
+            indices_out.extend(v for v in out_idx if v is not None)
+        if arrays_out is not None and all(v is not None for v in out_arr):
+            arrays_out.extend(out_arr)               # (the object path hands over no arrays: all pages or none)
+        return out_res
+    if len(chunks) == 1:
+        ctx = begin(chunks[0])
         _pb_launch(ctx)
-        return _pb_finish(ctx, indices_out, arrays_out)
+        _pb_finish_a(ctx)
+        collect(ctx)
+        return deliver()
     # chunk k + 1's strips are copied to the staging buffer by the pool while this thread finishes chunk k - 1 and the
     # device runs chunk k; at most two chunks are in flight
     import torch
-    results, flight = [], []
-    streams = _ocr_streams(rec.device)
-    caller = torch.cuda.current_stream(rec.device)
+    flight = []
+    device = chunks[0][0].device
+    streams = _ocr_streams(device)
+    caller = torch.cuda.current_stream(device)
     for st_ in streams:
         st_.wait_stream(caller)                                  # whatever the caller enqueued before this call
-    for a in range(0, n, C):
-        b = n if n - (a + C) < C // 2 else min(a + C, n)        # (no sliver of a last chunk)
-        ctx = _pb_begin(rec, pages[a:b], transcripts[a:b], seq_align_params, parallel)
+    for c, job in enumerate(chunks):
+        ctx = begin(job)
         oldest = flight.pop(0) if len(flight) == 2 else None
         if oldest is not None:
             _pb_finish_a(oldest)                                 # ... its NW launch runs under the next chunk's launch
             if not _SPLIT_FINISH:
-                results.extend(_pb_finish_b(oldest, indices_out, arrays_out))
-        with torch.cuda.stream(streams[(a // C) % 2] if _TWO_STREAMS else caller):
+                collect(oldest)
+        with torch.cuda.stream(streams[c % 2] if _TWO_STREAMS else caller):
             _pb_launch(ctx)
         flight.append(ctx)
         if oldest is not None and _SPLIT_FINISH:
-            results.extend(_pb_finish_b(oldest, indices_out, arrays_out))
-        if b == n:
-            break
+            collect(oldest)
     for st_ in streams:
         caller.wait_stream(st_)
     for ctx in flight:
-        results.extend(_pb_finish(ctx, indices_out, arrays_out))
-    return results
+        _pb_finish_a(ctx)
+        collect(ctx)
+    return deliver()
 
 
 def _pb_begin(rec, pages, transcripts, seq_align_params, workers):
