@@ -549,11 +549,6 @@ def _pb_launch(ctx):
     ctx["done"].record()
 
 
-def _pb_finish(ctx, indices_out, arrays_out):
-    _pb_finish_a(ctx)
-    return _pb_finish_b(ctx, indices_out, arrays_out)
-
-
 def _pb_finish_a(ctx):
     """second stage, first half: characters and boxes of every line, abbreviations, ONE NW launch for the chunk's pages
     and the download of its alignment columns STARTED"""

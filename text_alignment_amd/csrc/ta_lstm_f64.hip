@@ -19,7 +19,10 @@
 //                             kept in LDS (float64) and read into registers once per step; per step the accumulators
 //                             start from Gx (the loads are issued a step ahead) and take 25 k-steps of
 //                             v_mfma_f64_16x16x4_f64; cell state and gate functions in float64 (own exp: range
-//                             reduction + degree-10 polynomial, 3e-13).
+//                             reduction + degree-9 polynomial, 1.9e-14).
+//  Kr4 lstm_seq4_f64_kernel   (round 5; the product's choice) the same recurrence, bit for bit, on groups of FOUR lines:
+//                             eight waves (two per SIMD, 256 registers each), v_mfma_f64_4x4x4_4b_f64, the gates of a cell
+//                             brought into one lane by the gfx950 row swaps -- see the comment at the kernel.
 //
 // Tiling of the 400 pre-activations of a step: 25 tiles of 16 = (4 units) x (4 gates).  The WEIGHTS are the A operand
 // (M = 16 tile rows, row i = 4 * gate + unit-in-tile), the 16 lines the B operand's columns.  The f64 MFMA returns
