@@ -1,5 +1,7 @@
 """Ad-hoc fuzz of the recogniser's launch shapes against each other: groups of 4 / 16 lines, one launch each or
-per length class -- LSTM outputs, summaries and decode must be equal to the bit.  python tools/fuzz_ocr_kernels.py [rounds] [seed]"""
+per length class -- LSTM outputs, summaries and decode must be equal to the bit.
+    python tools/fuzz_ocr_kernels.py [rounds] [seed] [f64 | f32 | split]
+(float64: lstm_seq4_f64_kernel against lstm_seq_f64_kernel; f32: lstm_seq4_kernel against lstm_seq_kernel; split has one group size)"""
 import os
 import sys
 
@@ -11,15 +13,16 @@ from text_alignment_amd import ocr
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+precision = sys.argv[3] if len(sys.argv) > 3 else ocr.DEFAULT_PRECISION
 bad = 0
 for rnd in range(rounds):
     no = int(rng.choice([3, 17, 40, 96, 128]))
-    rec = ocr.LineRecognizer(ocr.LineModel.random(int(rng.integers(1, 10 ** 6)), no=no))
+    rec = ocr.LineRecognizer(ocr.LineModel.random(int(rng.integers(1, 10 ** 6)), no=no), precision=precision)
     n = int(rng.choice([1, 3, 4, 5, 31, 64, 65, 400, 700]))
     hi = int(rng.choice([3, 40, 300, 900]))
     lines = [(rng.random((int(rng.integers(1, hi + 1)), 48)) < rng.uniform(0.05, 0.6)).astype(np.float32) for _ in range(n)]
     ref = None
-    for G in (4, 16):
+    for G in ((16,) if precision == "split" else (4, 16)):
         for split in (False, True):
             ocr.FORCE_GROUP = G
             st = rec.prepare(lines)
