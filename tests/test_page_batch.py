@@ -157,3 +157,23 @@ def test_syllable_span_fast_path_equals_sequential_search():
     assert pb._syllable_spans_fast("do mi", ["dom", "i"]) is None
     assert pb._syllable_spans_fast("do\tmi", ["do", "mi"]) is None
     assert pb._syllable_spans_fast("", []) is None
+
+
+def test_chunk_plan_of_the_page_pipeline():
+    """alignToOCR.plan_chunks: pages grouped by recogniser, runs of C pages, no sliver at the end of a group, every page
+    exactly once and in order within its group"""
+    from text_alignment_amd import alignToOCR as atocr
+    for n_a, n_b, C in [(64, 0, 16), (32, 32, 16), (20, 0, 16), (24, 0, 16), (25, 7, 16), (1, 1, 16), (0, 0, 16), (100, 3, 32)]:
+        groups = [("A", list(range(0, 2 * n_a, 2)))] + ([("B", list(range(1, 2 * n_b, 2)))] if n_b else [])
+        chunks = atocr.plan_chunks(groups, C)
+        for name, ks in groups:
+            mine = [c for c in chunks if c[0] == name]
+            assert [k for _, c in mine for k in c] == ks                       # all pages, in order, once
+            sizes = [len(c) for _, c in mine]
+            assert all(s == C for s in sizes[:-1]) or len(sizes) == 1 or sizes[:-2] == [C] * (len(sizes) - 2)
+            if ks:
+                assert sizes[-1] >= min(len(ks), C // 2) and max(sizes) < C + C // 2 + (C % 2 == 0)
+            else:
+                assert sizes == [0]
+        # groups are not interleaved: the pipeline changes recogniser once per group
+        assert [c[0] for c in chunks] == sorted([c[0] for c in chunks])

@@ -408,6 +408,22 @@ def _nw_stream(device):
     return _side_streams[key]
 
 
+def plan_chunks(groups, C):
+    """[(recogniser, page indices)] in pipeline order: every group of pages (one recogniser each, in order of first
+    appearance) cut into runs of C pages; a last run shorter than C / 2 joins the run before it (no sliver of a chunk
+    whose kernels would not cover the next chunk's host stage)"""
+    chunks = []
+    for rec, ks in groups:
+        a = 0
+        while True:
+            b = len(ks) if len(ks) - (a + C) < C // 2 else min(a + C, len(ks))
+            chunks.append((rec, ks[a:b]))
+            a = b
+            if a >= len(ks):
+                break
+    return chunks
+
+
 def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indices_out=None,
                   parallel=parallel, arrays_out=None):
     """`process` for many pages at once: the strips of ALL pages go through the line recogniser
@@ -443,15 +459,7 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     images = any(not isinstance(pg, page_mod.PreparedPage) for pg in pages)
     raw = not images and any(st.prepared is None for pg in pages for st in getattr(pg, "strips", ()))
     C = PIPELINE_CHUNK_PAGES_IMAGES if images else (PIPELINE_CHUNK_PAGES_RAW if raw else PIPELINE_CHUNK_PAGES)
-    chunks = []
-    for rec, ks in groups.values():
-        a = 0
-        while True:
-            b = len(ks) if len(ks) - (a + C) < C // 2 else min(a + C, len(ks))   # (no sliver of a last chunk)
-            chunks.append((rec, ks[a:b]))
-            a = b
-            if a >= len(ks):
-                break
+    chunks = plan_chunks(list(groups.values()), C)
     out_res, out_idx, out_arr = [None] * n, [None] * n, [None] * n
 
     def begin(job):
