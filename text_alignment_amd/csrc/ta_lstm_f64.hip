@@ -654,8 +654,16 @@ __device__ __forceinline__ void seq4_f64_body(const Seq64G4Args& a, double (&hs)
         unsigned long long q1;                                       // (g0 as an input: the stamp follows the MFMAs)
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(q1) : "v"(g0), "v"(g2) : "memory");
 #endif
+        // The next step's accumulators take their Gx values HERE, before this step's hout store is issued.  Left to itself
+        // the compiler sinks these copies to the top of the next iteration, where the loads and the store are both
+        // pending; with mixed kinds outstanding it cannot count and waits with vmcnt(0) -- i.e. for the store's
+        // acknowledgement by the L2, every step, exposed on the wave whose cell update is the last thing in the step
+        // (~800 of 4 200 cycles).  Here only the loads (issued a whole step ago) are outstanding: the wait is free.
 #pragma unroll
-        for (int s = 0; s < 3; ++s) acc[s] = gn[s];
+        for (int s = 0; s < 3; ++s) {
+            acc[s] = gn[s];
+            asm volatile("" : "+v"(acc[s]));
+        }
         // (accumulator a, row b) -> (accumulator b, row a): row r then holds gates 0..3 of tile slot r in g0..g3
         swap_rows16(g0, g1);
         swap_rows16(g2, g3);
@@ -686,7 +694,11 @@ __device__ __forceinline__ void seq4_f64_body(const Seq64G4Args& a, double (&hs)
 #endif
         wop_t = wop;
         if (has_cell) {
+#if defined(TA_F64_ABL) && (TA_F64_ABL & 4)       // timing ablation: the cell update runs, but the MFMAs see a constant operand
+            hs[nxt][unit][j] = h * 0.0 + 0.001 * (lane & 3);
+#else
             hs[nxt][unit][j] = h;
+#endif
             if (t < myT) *hptr = (float)h;
         }
         hptr += hstep;
