@@ -243,6 +243,7 @@ CLASS_SPLIT_MIN_LINES = 384     # below this (a few pages) the recurrence's tail
 GROUP4_MAX_LINES = 2048         # exact-f32 mode: batches up to this size run in groups of 4 lines (see prepare)
 F64_GROUP4_MAX_LINES = 1 << 30  # float64 mode: groups of 4 lines (lstm_seq4_f64_kernel) up to this batch size
 F64_GX_MAX_ROWS = 3200000       # float64 mode: rows whose hoisted input projection (6 400 B per row) is held at once: 20 GB
+F64_GX_KEEP_BYTES = 6 << 30     # ... and a scratch buffer larger than this is not kept by the recogniser between batches
 # float64 mode: runs of this many groups (16 lines each) or more are pipelined per length class (forward_f64); cuts as
 # shares of the run's groups.  Measured (tools/f64_time.py, lines of 800 .. 2000 columns): two halves 17.3 ms per 1 920
 # lines against 19.0 one after the other (384 / 960 / 3 840 / 5 760 lines: 14.1 / 15.6 / 33.3 / 54.3 against 14.4 / 16.2 /
@@ -577,6 +578,7 @@ class LineRecognizer(object):
             projection of the shorter class runs on the CUs that recurrence has not claimed.  Same kernels on the
             same rows: results are bit for bit those of the one-after-the-other order."""
             grow = st["group_row_host"]
+            gx_buf = None
             # (groups of four lines leave the projection no idle CUs to hide under: measured no gain, so no side streams)
             piped = F64_CLASS_PIPELINE and stream_ == stream and G != 4
             a = g0
@@ -619,6 +621,11 @@ class LineRecognizer(object):
                 for sd in used:                                      # (also orders the reuse of the buffer)
                     cs.wait_stream(sd)
                 a = b
+            # a large batch's scratch goes back to torch's caching allocator (it stays cached there: the next large batch
+            # gets it back at once, and meanwhile other tensors may use the memory); small ones are kept by the recogniser
+            if gx_buf is not None and gx_buf.numel() * 8 > F64_GX_KEEP_BYTES:
+                gx_buf.record_stream(cs)
+                self._gx.pop(stream, None)
 
         # (h0 / c0 / tstart of a continuation are indexed by LINE id, not by position in the launch: a launch over
         # groups g0 .. g1 passes the whole arrays, un-offset, whichever run of groups it covers)
