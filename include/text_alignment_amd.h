@@ -67,8 +67,8 @@ extern "C" {
 #define TA_NW_TBWAVES(w) (((uint32_t)(w) & 0x7u) << TA_NW_TBWAVES_SHIFT)
 #define TA_NW_NO_PROFILE 64u
 /* ta_nw2_batch, debug guard for the two caller assertions above (TA_NW_CODES8: ids < 255; TA_NW_ALPHABET(a): ids < a):
- * with this bit the call first checks every token id of the batch on the device, WAITS for the result (one stream
- * synchronisation: not for timed code) and returns TA_EINVAL -- nothing else launched -- if an id breaks an assertion
+ * with this bit the call first checks every token id of the batch on the device, WAITS for the result (one synchronisation
+ * of `stream` -- its scratch word is a stream-ordered allocation, so other streams of the device run on: not for timed code) and returns TA_EINVAL -- nothing else launched -- if an id breaks an assertion
  * the flags make.  Without it a violated assertion gives silently wrong alignments. */
 #define TA_NW_CHECK_IDS 128u
 #define TA_NW_WAVES_SHIFT 16
@@ -256,24 +256,27 @@ int ta_lstm_forward(const float* x, const int64_t* row_off, const int32_t* T,
  *   [dir 2][wave 4][slot 7][k-step 25][lane 64] = W_gate(i / 4)[unit 4 tile + i % 4][49 + 4 kstep + lane / 16],
  *   tile = 6 wave + slot for slots 0..5 and 24 for slot 6 (the tile the waves split along k); peep = double[2][3][100]: WIP, WFP, WOP per direction.
  *   hout [rows][200] float (the float64 outputs rounded once).  h0 / c0 (double[lines][2][100]) / tstart as in
- *   ta_lstm_forward.
+ *   ta_lstm_forward.  status (optional, [dev] one int32 the caller zeroes): the kernel ORs TA_LSTM_F64_PARTS_LATE into
+ *   it if a workgroup's bounded wait for the partial sums of the tile its waves share ever runs out (the outputs of
+ *   that group are NaN from there on); the launch itself still returns TA_OK -- read the word back with the results.
  * ta_lstm_forward_f64_g4: the same recurrence, bit for bit the same outputs, over groups of FOUR lines (group_lines =
  *   int32[ngroups][4]) on v_mfma_f64_4x4x4_4b_f64: a quarter of the cost per step, for batches whose 16-line groups
  *   would not fill the GPU or would wait for their longest line.  wh4 = ta_lstm_f64_weight_doubles(3) doubles
  *   [dir 2][tile 25][k-step 25][lane 64] = W_gate(lane % 4)[unit 4 tile + (lane / 4) % 4][49 + 4 kstep + lane / 16];
  *   every other argument as in ta_lstm_forward_f64.
  */
+#define TA_LSTM_F64_PARTS_LATE 1
 int64_t ta_lstm_f64_weight_doubles(int32_t which);
 int64_t ta_lstm_f64_gx_bytes(int64_t rows);
 int ta_lstm_xproj_f64(const float* x, int64_t rows, const double* wx, double* gx, void* stream);
 int ta_lstm_forward_f64(const double* gx, int64_t gx_row0, int64_t gx_rows, const int64_t* row_off,
                         const int32_t* T, const int32_t* group_lines, int32_t ngroups, const double* wh,
                         const double* peep, float* hout, const double* h0, const double* c0,
-                        const int32_t* tstart, void* stream);
+                        const int32_t* tstart, int32_t* status, void* stream);
 int ta_lstm_forward_f64_g4(const double* gx, int64_t gx_row0, int64_t gx_rows, const int64_t* row_off,
                            const int32_t* T, const int32_t* group_lines, int32_t ngroups, const double* wh4,
                            const double* peep, float* hout, const double* h0, const double* c0,
-                           const int32_t* tstart, void* stream);
+                           const int32_t* tstart, int32_t* status, void* stream);
 int ta_lstm_output(const float* y, int64_t rows, const float* w2p, int32_t no,
                    float* probs, float* logits, float* summary, void* stream);
 int64_t ta_lstm_output_split_weight_bytes(int32_t no);
@@ -287,6 +290,16 @@ int ta_decode(const float* probs, const int64_t* row_off, const int32_t* T,
               int32_t nlines, int32_t no, float threshold,
               int32_t* dec_t, int32_t* dec_c, int32_t* dec_n, const int64_t* dec_off,
               void* stream);
+
+/*
+ * ta_rows_gather: prepared rows that already lie in device memory into the recogniser's row layout -- line b's T[b]
+ *   rows of 48 floats are copied from the device ADDRESS src[b] (16-byte aligned; any allocation, e.g. the device copy
+ *   of a page-locked block of rows that ONE transfer brought over as it was) to rows dst_row[b] .. of x.  max_T >= every
+ *   T[b].  All pointers [dev].  It stands where the reference writes each strip to a PNG file for the recogniser
+ *   (alignToOCR.py:131-132): the hand-over of a batch's line images, without a host-side copy per line.
+ */
+int ta_rows_gather(const int64_t* src, const int64_t* dst_row, const int32_t* T, int32_t nlines,
+                   int32_t max_T, float* x, void* stream);
 
 /*
  * Line normaliser: what `ocropus-rpred` does to each PNG strip of alignToOCR.py:131-147 before the

@@ -270,3 +270,9 @@ def test_token_encoding_and_list_rebuild_fast_paths_equal_the_token_by_token_for
         assert tsc.ops_to_alignment(np.array(ops, dtype=np.uint8), t, o) == rebuild(ops, t, o)
     assert tsc.ops_to_alignment(np.zeros(0, np.uint8), [], []) == ([], [])
     assert tsc.encode_tokens([], [])[0][0].tolist() == []
+    # tokens the code-point pass cannot encode (a lone surrogate: UnicodeEncodeError, a ValueError) go token by token
+    # like any other hashable, and a generator is read once, by whichever path numbers it
+    (a, b), ids = tsc.encode_tokens(list(u"ab\ud800a"), iter(u"ba"))
+    assert (a.tolist(), b.tolist(), ids) == ([0, 1, 2, 0], [1, 0], {u"a": 0, u"b": 1, u"\ud800": 2})
+    (a, b), ids = tsc.encode_tokens((c for c in "abca"), (c for c in ("bc", "a")))
+    assert (a.tolist(), b.tolist()) == ([0, 1, 2, 0], [3, 0])

@@ -305,7 +305,7 @@ def test_f64_mode_group_edges_continuation_and_chunks(monkeypatch):
     _native.check(_native.lib.ta_lstm_forward_f64(gx.data_ptr(), 0, rows, args[0].data_ptr(), args[1].data_ptr(),
                                                   args[2].data_ptr(), ngroups, rec.wh64.data_ptr(), rec.peep64.data_ptr(),
                                                   st["hout"].data_ptr(), args[3].data_ptr(), args[4].data_ptr(),
-                                                  args[5].data_ptr(), stream), "forward_f64")
+                                                  args[5].data_ptr(), None, stream), "forward_f64")
     torch.cuda.synchronize()
     hout = st["hout"].cpu().numpy()
     for b, xs in enumerate(lines):
@@ -506,7 +506,7 @@ def test_f64_four_line_groups_equal_sixteen_line_groups(monkeypatch):
         st["hout"].zero_()
         _native.check(fn(gx.data_ptr(), 0, rows, common[0].data_ptr(), common[1].data_ptr(), gld.data_ptr(), ngroups,
                          wh.data_ptr(), rec.peep64.data_ptr(), st["hout"].data_ptr(), common[2].data_ptr(),
-                         common[3].data_ptr(), common[4].data_ptr(), stream), "forward_f64 G=%d" % G)
+                         common[3].data_ptr(), common[4].data_ptr(), None, stream), "forward_f64 G=%d" % G)
         torch.cuda.synchronize()
         seg[G] = st["hout"].clone()
     assert torch.equal(seg[4], seg[16])

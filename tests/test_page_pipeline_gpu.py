@@ -1,0 +1,233 @@
+"""The PIPELINED page path (alignToOCR.process_batch over several chunks) under the checkers, at the shape bench.py
+times and the ranks of an 8-GPU job run: chunks of >= 160 lines, so that the strips are copied by the pool threads, the
+rows' transfer is issued from the pool on the upload stream, consecutive chunks run on two compute streams and the two
+page-locked staging slots are reused -- everything that the small-page tests (tests/test_page_gpu.py) never reach
+together.  The contract is the reference's per-page one (alignToOCR.py:187-330): a page's result does not depend on
+what else is in the batch."""
+import threading
+
+import numpy as np
+import pytest
+
+from test_page_gpu import VOCAB, _expected, _page
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+PARAMS = [8, -1, -9, -9, -4, -4]
+
+
+def _two_models():
+    from oracle import ocr_ref_f64 as R
+    from text_alignment_amd import ocr
+    oms, recs = [], []
+    for seed, no in ((7001, 96), (7002, 64)):
+        om = R.synthetic_model(seed, no=no)
+        om.W2[0, 0] += 4.0
+        om.W2[30:, :] *= 0.25                       # mostly the first classes come out: text-like strings
+        oms.append(om)
+        recs.append(ocr.LineRecognizer(ocr.LineModel(om.fwd, om.rev, om.W2, om.codec)))      # the default mode
+    return oms, recs
+
+
+def _as_row_blocks(pages, kind, page_mod, per_block=8):
+    """the same pages with their prepared rows in RowBlocks (`per_block` pages each; the lines of a page in REVERSE
+    order inside the block and a few unused rows between pages, so that neither the order nor the density is the
+    recogniser's)"""
+    out, blocks = [], []
+    for a in range(0, len(pages), per_block):
+        group = pages[a:a + per_block]
+        total = sum(s.prepared.shape[0] for pg in group for s in pg.strips) + 40 * len(group)
+        block = page_mod.RowBlock(total, kind=kind)
+        blocks.append(block)
+        for pg in group:
+            spans = [None] * len(pg.strips)
+            for k in reversed(range(len(pg.strips))):
+                xs = pg.strips[k].prepared
+                sp = block.take(xs.shape[0])
+                if kind == "pinned":
+                    block.host[sp.start:sp.stop] = xs
+                else:
+                    block.tensor[sp.start:sp.stop] = torch.from_numpy(np.ascontiguousarray(xs, dtype=np.float32)).to(block.tensor.device)
+                spans[k] = sp
+            block.take(40)
+            boxes = [(s.offset_x, s.offset_y, s.height, s.width) for s in pg.strips]
+            out.append(page_mod.PreparedPage.from_rows((pg.image.dim.ncols, pg.image.dim.nrows), (pg.dim.ncols, pg.dim.nrows),
+                                                       pg.angle, block, spans, boxes, pg.lines_peak_locs))
+    return out, blocks
+
+
+def _json(atocr, res):
+    return [atocr.to_JSON_dict(r[0], r[2]) for r in res]
+
+
+@pytest.mark.parametrize("rows_in", ["numpy", "pinned_block", "device_block"])
+def test_pipelined_batch_at_the_timed_shape_equals_process_and_the_checkers(rows_in, monkeypatch):
+    """64 pages x 12 lines of 150 .. 420 columns, two models: four chunks of 16 pages = 192 lines each.
+    Every page's JSON equals process() of that page alone; three pages equal the checker pipeline (float64 recogniser
+    restatement + C aligner + reference-pinned glue); a SECOND call on the same recognisers returns the same bytes
+    (staging slots and scratch reused across calls).  rows_in: the strips' prepared rows as pageable numpy arrays (pool
+    copies into page-locked staging), or inside page-locked / device RowBlocks (no host copy: csrc/ta_rows.hip)."""
+    from oracle import nw_oracle, ocr_ref_f64 as R
+    from text_alignment_amd import alignToOCR as atocr, ocr, page as page_mod
+    oms, recs = _two_models()
+    plain, trs = zip(*[_page(900 + k, 12, R, page_mod) for k in range(64)])
+    plain, trs = list(plain), list(trs)
+    models = [recs[k % 2] for k in range(64)]
+    pages, blocks = (plain, []) if rows_in == "numpy" else _as_row_blocks(plain, rows_in.split("_")[0], page_mod)
+
+    # what the call actually exercises: count the transfers the pool issues and the streams the chunks launch on
+    seen = {"pool_uploads": 0, "threads": set(), "lanes": set(), "gathers": 0}
+    issue = ocr.LineRecognizer._issue_upload
+
+    def counting_issue(self, copies, rows, slot):
+        if copies:
+            seen["pool_uploads"] += 1
+            seen["threads"].add(threading.current_thread().name)
+        return issue(self, copies, rows, slot)
+    monkeypatch.setattr(ocr.LineRecognizer, "_issue_upload", counting_issue)
+    launch = atocr._pb_launch
+
+    def counting_launch(ctx):
+        seen["lanes"].add(torch.cuda.current_stream().cuda_stream)
+        assert len(ctx["lines"]) >= 160
+        return launch(ctx)
+    monkeypatch.setattr(atocr, "_pb_launch", counting_launch)
+    span_begin = ocr.LineRecognizer._span_rows_begin
+
+    def counting_spans(self, lines, rows):
+        seen["gathers"] += 1
+        return span_begin(self, lines, rows)
+    monkeypatch.setattr(ocr.LineRecognizer, "_span_rows_begin", counting_spans)
+
+    idx1, arr1 = [], []
+    first = atocr.process_batch(pages, trs, models, PARAMS, indices_out=idx1, arrays_out=arr1)
+    torch.cuda.synchronize()
+    assert len(seen["lanes"]) == 2                                   # two compute streams in turn
+    if rows_in == "numpy":
+        assert seen["pool_uploads"] == 4 and seen["gathers"] == 0    # every chunk's rows: pool copies + pool-issued transfer
+        assert all(name != threading.current_thread().name for name in seen["threads"])
+    else:
+        assert seen["pool_uploads"] == 0 and seen["gathers"] == 4    # ... or no host copy at all
+    got = _json(atocr, first)
+    assert len(idx1) == len(arr1) == 64 and all(len(i) == len(a) == len(g["syl_boxes"]) for i, a, g in zip(idx1, arr1, got))
+    assert sum(len(g["syl_boxes"]) for g in got) > 1500
+
+    # a second call: same bytes (slots, scratch buffers and streams of the first call reused)
+    idx2, arr2 = [], []
+    second = atocr.process_batch(pages, trs, models, PARAMS, indices_out=idx2, arrays_out=arr2)
+    assert _json(atocr, second) == got and idx2 == idx1
+    assert all(np.array_equal(a, b) for a, b in zip(arr1, arr2))
+    monkeypatch.undo()
+
+    # every page alone through process() (plain numpy rows: one batch of 12 lines, no pipeline)
+    for k in range(64):
+        res = atocr.process(plain[k], trs[k], models[k], seq_align_params=PARAMS)
+        assert got[k] == atocr.to_JSON_dict(res[0], res[2]), k
+    # three pages from the checkers alone
+    for k in (0, 21, 63):
+        want, _ = _expected(plain[k], trs[k], oms[k % 2], R, nw_oracle, PARAMS, rec=recs[k % 2])
+        assert got[k] == want, k
+    del blocks
+
+
+def test_pipelined_raw_strips_over_three_chunks_equal_process(monkeypatch):
+    """Raw uint8 strips (what the reference hands the recogniser, alignToOCR.py:131-132) through more than two chunks of
+    the pipeline: the device normaliser's kernels, the metadata uploads and the zero-fill of the decoder's outputs are
+    enqueued by the chunk's first stage on the CALLER's stream, the recogniser runs on a compute stream of the
+    pipeline -- which has to take that work in first.  Per page the result equals process() of the page alone."""
+    from test_lineest_gpu import _strip
+    from text_alignment_amd import alignToOCR as atocr, page as page_mod
+    _, recs = _two_models()
+    rng = np.random.default_rng(77)
+    pages, trs = [], []
+    for k in range(40):
+        strips = [page_mod.Strip(40 + int(rng.integers(0, 20)), 100 + 120 * q, 60,
+                                 pixels=_strip(rng, int(rng.integers(40, 70)), int(rng.integers(200, 520)), wobble=2.0 * (q % 2)))
+                  for q in range(6)]
+        pages.append(page_mod.PreparedPage((2200, 3300), (2200, 3300), 0, strips, [130 + 120 * q for q in range(7)]))
+        trs.append(" ".join(VOCAB[int(i)] for i in rng.integers(0, len(VOCAB), size=30)))
+    monkeypatch.setattr(atocr, "PIPELINE_CHUNK_PAGES_RAW", 6)
+    chunks = []
+    launch = atocr._pb_launch
+    monkeypatch.setattr(atocr, "_pb_launch", lambda ctx: (chunks.append(len(ctx["pages"])), launch(ctx))[1])
+    models = [recs[k % 2] for k in range(40)]
+    got = _json(atocr, atocr.process_batch(pages, trs, models, PARAMS))
+    assert len(chunks) >= 6                                           # 20 pages per model, chunks of six
+    again = _json(atocr, atocr.process_batch(pages, trs, models, PARAMS))
+    assert again == got
+    monkeypatch.undo()
+    for k in range(40):
+        res = atocr.process(pages[k], trs[k], models[k], seq_align_params=PARAMS)
+        assert got[k] == atocr.to_JSON_dict(res[0], res[2]), k
+    assert sum(len(g["syl_boxes"]) for g in got) > 200
+
+
+def test_pipelined_page_images_over_three_chunks_equal_process(monkeypatch):
+    """Whole page images (preprocessing + line finding + normaliser on the device, all enqueued by a chunk's first stage on
+    the caller's stream) through three chunks of the pipeline: per page the result of process()."""
+    from test_preproc_gpu import _noisy_page
+    from text_alignment_amd import alignToOCR as atocr
+    _, recs = _two_models()
+    rng = np.random.default_rng(5)
+    pages = [_noisy_page(40 + k, nlines=5 + k % 3, angle=float(rng.uniform(-2, 2))) for k in range(9)]
+    trs = [" ".join(VOCAB[int(i)] for i in rng.integers(0, len(VOCAB), size=24)) for _ in pages]
+    monkeypatch.setattr(atocr, "PIPELINE_CHUNK_PAGES_IMAGES", 3)
+    chunks = []
+    launch = atocr._pb_launch
+    monkeypatch.setattr(atocr, "_pb_launch", lambda ctx: (chunks.append(len(ctx["pages"])), launch(ctx))[1])
+    got = _json(atocr, atocr.process_batch(pages, trs, recs[0], PARAMS))
+    assert chunks == [3, 3, 3]
+    monkeypatch.undo()
+    for k, pg in enumerate(pages):
+        res = atocr.process(pg, trs[k], recs[0], seq_align_params=PARAMS)
+        assert got[k] == atocr.to_JSON_dict(res[0], res[2]), k
+    assert sum(len(g["syl_boxes"]) for g in got) > 20
+
+
+def test_rows_gather_moves_every_line_to_its_rows():
+    """csrc/ta_rows.hip through the C ABI: lines scattered over two device allocations land, row for row, where dst_row says"""
+    from text_alignment_amd import _native
+    rng = np.random.default_rng(3)
+    T = rng.integers(1, 300, size=37).astype(np.int32)
+    T[5], T[6] = 1, 64
+    pool = [torch.from_numpy(rng.random((int(T.sum()) + 500, 48), dtype=np.float32)).cuda() for _ in range(2)]
+    src, starts, pos = np.zeros(len(T), np.int64), [], [0, 0]
+    for b, t in enumerate(T):
+        which = b % 2
+        pos[which] += int(rng.integers(0, 9))
+        starts.append((which, pos[which]))
+        src[b] = pool[which].data_ptr() + 192 * pos[which]
+        pos[which] += int(t)
+    order = rng.permutation(len(T))
+    dst = np.zeros(len(T), np.int64)
+    dst[order] = np.cumsum(T[order]) - T[order]
+    x = torch.full((int(T.sum()), 48), -1.0, dtype=torch.float32, device="cuda")
+    d_src, d_dst, d_T = (torch.from_numpy(a).cuda() for a in (src, dst, T))
+    _native.check(_native.lib.ta_rows_gather(d_src.data_ptr(), d_dst.data_ptr(), d_T.data_ptr(), len(T), int(T.max()),
+                                             x.data_ptr(), torch.cuda.current_stream().cuda_stream), "ta_rows_gather")
+    got = x.cpu().numpy()
+    hosts = [p.cpu().numpy() for p in pool]
+    for b, t in enumerate(T):
+        which, a = starts[b]
+        assert np.array_equal(got[dst[b]:dst[b] + t], hosts[which][a:a + t]), b
+
+
+def test_device_status_word_is_checked_on_the_host():
+    """The float64 recurrence reports a wait that ran out in a status word behind the decoder's counts
+    (TA_LSTM_F64_PARTS_LATE, include/text_alignment_amd.h): decoded() and the page pipeline raise on it instead of
+    handing back characters decoded from NaN outputs.  (The wait cannot be made to run out on demand; the host side is
+    exercised by setting the word.)"""
+    from oracle import ocr_ref_f64 as R
+    from text_alignment_amd import ocr
+    om = R.synthetic_model(7001, no=40)
+    rec = ocr.LineRecognizer(ocr.LineModel(om.fwd, om.rev, om.W2, om.codec))
+    lines = [R.synthetic_line(50 + k, width=80 + 10 * k) for k in range(5)]
+    st = rec.prepare(lines)
+    rec.run(st)
+    assert st["dec_n"].numel() == len(lines) + 1 and int(st["dec_n"][-1]) == 0
+    good = rec.decoded(st)
+    assert len(good) == 5
+    st["dec_n"][-1] = 1
+    with pytest.raises(RuntimeError, match="status"):
+        rec.decoded(st)

@@ -379,12 +379,13 @@ def _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, 
 # process_batch runs batches larger than this as a two-stage pipeline over chunks of PIPELINE_CHUNK_PAGES pages: while
 # the recogniser kernels of chunk k run, the host copies the strips of chunk k + 1 into its staging buffer and finishes
 # chunk k - 1 (characters, alignment, syllable boxes).  One host thread; results are those of the unchunked call.
-PIPELINE_CHUNK_PAGES = int(os.environ.get("TA_PAGE_CHUNK", "16"))          # (the variable: timing experiments)
-PIPELINE_CHUNK_PAGES_RAW = int(os.environ.get("TA_PAGE_CHUNK_RAW", "32"))    # raw strips: the device normaliser in front
-PIPELINE_CHUNK_PAGES_IMAGES = int(os.environ.get("TA_PAGE_CHUNK_IMAGES", "64"))
+# (Plain module attributes: this module reads no environment variables; tools/switches.py sets them for timing experiments.)
+PIPELINE_CHUNK_PAGES = 16
+PIPELINE_CHUNK_PAGES_RAW = 32        # raw strips: the device normaliser in front
+PIPELINE_CHUNK_PAGES_IMAGES = 64
 _side_streams = {}
-_SPLIT_FINISH = os.environ.get("TA_PB_SPLIT_FINISH", "1") != "0"      # (timing experiments)
-_TWO_STREAMS = os.environ.get("TA_PB_TWO_STREAMS", "1") != "0"
+SPLIT_FINISH = True                  # the second stage of a chunk split around the next chunk's launch
+TWO_STREAMS = True                   # consecutive chunks' recogniser kernels on two compute streams
 
 
 def _ocr_streams(device):
@@ -473,14 +474,15 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
         res = _pb_finish_b(ctx, idx, arr)
         for j, k in enumerate(ctx["page_ids"]):
             out_res[k] = res[j]
-            out_idx[k] = idx[j] if j < len(idx) else None
-            out_arr[k] = arr[j] if j < len(arr) else None
+            out_idx[k], out_arr[k] = idx[j], arr[j]
 
     def deliver():
+        # one entry per page, in page order, whichever path each chunk took (a chunk whose alignment does not fit the
+        # integer kernels goes object by object on its own; callers zip these lists with the pages)
         if indices_out is not None:
-            indices_out.extend(v for v in out_idx if v is not None)
-        if arrays_out is not None and all(v is not None for v in out_arr):
-            arrays_out.extend(out_arr)               # (the object path hands over no arrays: all pages or none)
+            indices_out.extend(out_idx)
+        if arrays_out is not None:
+            arrays_out.extend(out_arr)
         return out_res
     if len(chunks) == 1:
         ctx = begin(chunks[0])
@@ -502,12 +504,20 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
         oldest = flight.pop(0) if len(flight) == 2 else None
         if oldest is not None:
             _pb_finish_a(oldest)                                 # ... its NW launch runs under the next chunk's launch
-            if not _SPLIT_FINISH:
+            if not SPLIT_FINISH:
                 collect(oldest)
-        with torch.cuda.stream(streams[c % 2] if _TWO_STREAMS else caller):
+        lane = streams[c % 2] if TWO_STREAMS else caller
+        # begin() ran on the CALLER's stream: for raw strips and page images it enqueued device work there (the normaliser's
+        # kernels write the rows, the metadata uploads, the zero-fill of the decoder's outputs) that this chunk's recogniser
+        # reads -- the chunk's compute stream takes it all in before its first kernel.  (Host rows: nothing was enqueued
+        # there and the wait is on an idle stream.)  Nothing else is ever put on the caller's stream inside this loop,
+        # so this never orders a chunk behind another chunk's kernels.
+        if lane is not caller:
+            lane.wait_stream(caller)
+        with torch.cuda.stream(lane):
             _pb_launch(ctx)
         flight.append(ctx)
-        if oldest is not None and _SPLIT_FINISH:
+        if oldest is not None and SPLIT_FINISH:
             collect(oldest)
     for st_ in streams:
         caller.wait_stream(st_)
@@ -575,6 +585,7 @@ def _pb_finish_a(ctx):
     ctx["done"].synchronize()
     dec_t = ctx["host"]["dec_t"].numpy()
     dec_c = ctx["host"]["dec_c"].numpy()
+    rec.check_status(ctx["host"]["dec_n"].numpy())       # the device's status word travels behind the counts
     dec_n = ctx["host"]["dec_n"].numpy()[:nlines].astype(np.int64) if nlines else np.zeros(0, np.int64)
     x_min = np.array([s.offset_x for s in all_strips], dtype=np.int64)
     y_min = np.array([s.offset_y for s in all_strips], dtype=np.int64)
@@ -617,8 +628,12 @@ def _pb_finish_b(ctx, indices_out, arrays_out):
     lines, widths, st, syls_all = ctx["lines"], ctx["widths"], ctx["st"], ctx["syls_all"]
     if ctx["nw"] is None:                 # a scoring callable / non-integral numbers / a multi-character codec / too large
         rec._last_state, rec.last_T = st, st["T_host"]
-        return _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, widths,
-                                      transcripts, seq_align_params, indices_out)
+        res = _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, widths,
+                                     transcripts, seq_align_params, indices_out)
+        if arrays_out is not None:            # the same [k, 4] arrays as the array path hands over: one entry per page
+            for r in res:
+                arrays_out.append(np.array([[b.ulx, b.uly, b.lrx, b.lry] for b in r[0]], dtype=np.int64).reshape(-1, 4))
+        return res
     all_ops = ctx["nw"].results()
     ctx["nw"] = None
     texts, idxs, boxes = ctx["texts"], ctx["idxs"], ctx["boxes"]

@@ -244,6 +244,7 @@ struct Seq64Args {
     const double* h0;          // optional [lines][2][100]: outputs before the first step
     const double* c0;          // optional [lines][2][100]: cell states before the first step
     const int32_t* tstart;     // optional [lines][2]: steps of the sequence already done
+    int32_t* status;           // optional: one word, OR-ed with TA_LSTM_F64_PARTS_LATE if a wait for the split tile's parts runs out
 };
 
 // The f64 MFMA holds the SIMD's vector issue for its 64 cycles: any VALU instruction between two MFMAs of a chain
@@ -404,7 +405,10 @@ __device__ __forceinline__ void seq_f64_body(const Seq64Args& a, double (&hs)[2]
             for (int spin = 0; spin < (1 << 22) && !arrived; ++spin)
                 arrived = __hip_atomic_load(&part_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            if (!arrived) accs[0] = __builtin_nan("");         // a wait that ran out must show: NaN outputs, not plausible ones
+            if (!arrived) {                                    // a wait that ran out must show: NaN outputs, not plausible ones,
+                accs[0] = __builtin_nan("");                   // and a word the host reads with the decoder's counts
+                if (a.status && lane == 0) atomicOr(a.status, TA_LSTM_F64_PARTS_LATE);
+            }
 #pragma unroll
             for (int w = 0; w < kW - 1; ++w)
 #pragma unroll
@@ -512,6 +516,7 @@ struct Seq64G4Args {
     const double* h0;
     const double* c0;
     const int32_t* tstart;
+    int32_t* status;           // as Seq64Args
 };
 
 __device__ __forceinline__ void swap_rows16(double& a, double& b) {       // a.row1 <-> b.row0, a.row3 <-> b.row2
@@ -678,7 +683,10 @@ __device__ __forceinline__ void seq4_f64_body(const Seq64G4Args& a, double (&hs)
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             const double* pl = &part[0][lane & 15];
             double v[4] = {gs01[0], gs01[1], gs23[0], gs23[1]};
-            if (!arrived) v[0] = __builtin_nan("");            // a wait that ran out must show: NaN outputs, not plausible ones
+            if (!arrived) {                                    // a wait that ran out must show: NaN outputs, not plausible ones,
+                v[0] = __builtin_nan("");                      // and a word the host reads with the decoder's counts
+                if (a.status && lane == 0) atomicOr(a.status, TA_LSTM_F64_PARTS_LATE);
+            }
 #pragma unroll
             for (int w = 0; w < 3; ++w)                              // Kr's order: Gx, then the parts of k-steps 0..8, 9..16, 17..24
 #pragma unroll
@@ -808,14 +816,14 @@ extern "C" int ta_lstm_xproj_f64(const float* x, int64_t rows, const double* wx,
 extern "C" int ta_lstm_forward_f64(const double* gx, int64_t gx_row0, int64_t gx_rows, const int64_t* row_off,
                                    const int32_t* T, const int32_t* group_lines, int32_t ngroups, const double* wh,
                                    const double* peep, float* hout, const double* h0, const double* c0,
-                                   const int32_t* tstart, void* stream) {
+                                   const int32_t* tstart, int32_t* status, void* stream) {
     if (ngroups < 0 || gx_rows < 0 || gx_row0 < 0) return ta_fail(TA_EINVAL, "negative count");
     if (ngroups == 0) return TA_OK;
     if (!gx || !row_off || !T || !group_lines || !wh || !peep || !hout)
         return ta_fail(TA_EINVAL, "null pointer argument");
     if ((h0 != nullptr) != (c0 != nullptr) || (h0 != nullptr) != (tstart != nullptr))
         return ta_fail(TA_EINVAL, "h0, c0 and tstart go together (all null, or all given)");
-    Seq64Args a{gx, gx_row0, gx_rows, row_off, T, group_lines, wh, peep, hout, h0, c0, tstart};
+    Seq64Args a{gx, gx_row0, gx_rows, row_off, T, group_lines, wh, peep, hout, h0, c0, tstart, status};
     hipLaunchKernelGGL(lstm_seq_f64_kernel, dim3(2 * ngroups), dim3(kW * 64), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     hipError_t e = hipGetLastError();
@@ -826,14 +834,14 @@ extern "C" int ta_lstm_forward_f64(const double* gx, int64_t gx_row0, int64_t gx
 extern "C" int ta_lstm_forward_f64_g4(const double* gx, int64_t gx_row0, int64_t gx_rows, const int64_t* row_off,
                                       const int32_t* T, const int32_t* group_lines, int32_t ngroups, const double* wh4,
                                       const double* peep, float* hout, const double* h0, const double* c0,
-                                      const int32_t* tstart, void* stream) {
+                                      const int32_t* tstart, int32_t* status, void* stream) {
     if (ngroups < 0 || gx_rows < 0 || gx_row0 < 0) return ta_fail(TA_EINVAL, "negative count");
     if (ngroups == 0) return TA_OK;
     if (!gx || !row_off || !T || !group_lines || !wh4 || !peep || !hout)
         return ta_fail(TA_EINVAL, "null pointer argument");
     if ((h0 != nullptr) != (c0 != nullptr) || (h0 != nullptr) != (tstart != nullptr))
         return ta_fail(TA_EINVAL, "h0, c0 and tstart go together (all null, or all given)");
-    Seq64G4Args a{gx, gx_row0, gx_rows, row_off, T, group_lines, wh4, peep, hout, h0, c0, tstart};
+    Seq64G4Args a{gx, gx_row0, gx_rows, row_off, T, group_lines, wh4, peep, hout, h0, c0, tstart, status};
     hipLaunchKernelGGL(lstm_seq4_f64_kernel, dim3(2 * ngroups), dim3(kW4 * 64), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     hipError_t e = hipGetLastError();

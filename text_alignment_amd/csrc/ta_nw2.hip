@@ -1955,9 +1955,11 @@ static int check_ids(const NwArgs& a, uint32_t flags, hipStream_t st) {
     if (flags & TA_NW_CODES8) bound = 255;
     const int alpha = (int)((flags >> TA_NW_ALPHABET_SHIFT) & 0xFFu);
     if (alpha > 0 && !(flags & TA_NW_NO_PROFILE)) bound = alpha < bound ? alpha : bound;
+    // stream-ordered allocation: hipMalloc / hipFree would synchronise the whole DEVICE (the page pipeline's other streams
+    // included), this call waits for `st` alone
     int* bad = nullptr;
-    hipError_t e = hipMalloc(&bad, sizeof(int));
-    if (e != hipSuccess) return ta_fail_hip(e, "TA_NW_CHECK_IDS: hipMalloc");
+    hipError_t e = hipMallocAsync(reinterpret_cast<void**>(&bad), sizeof(int), st);
+    if (e != hipSuccess) return ta_fail_hip(e, "TA_NW_CHECK_IDS: hipMallocAsync");
     int host_bad = 0;
     e = hipMemsetAsync(bad, 0, sizeof(int), st);
     if (e == hipSuccess) {
@@ -1965,8 +1967,8 @@ static int check_ids(const NwArgs& a, uint32_t flags, hipStream_t st) {
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&host_bad, bad, sizeof(int), hipMemcpyDeviceToHost, st);
+    (void)hipFreeAsync(bad, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(bad);
     if (e != hipSuccess) return ta_fail_hip(e, "TA_NW_CHECK_IDS");
     if (host_bad) return ta_fail(TA_EINVAL, "a token id is outside the range the flags assert (TA_NW_CODES8 / TA_NW_ALPHABET)");
     return TA_OK;

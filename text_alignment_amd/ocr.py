@@ -9,8 +9,6 @@ lines are sorted by length, grouped 16 to a workgroup, and run through K3 (BiLST
 (output layer + softmax) and K5 (decode) behind the C ABI (`ta_lstm_forward`,
 `ta_lstm_output` / `ta_lstm_output_split`, `ta_decode`).
 """
-import os
-
 import numpy as np
 import torch
 
@@ -235,10 +233,10 @@ def _copy_pool():
     return _pool
 
 
-# Overrides for tests and timing tools, read ONCE at import (TA_OCR_GROUP=4|16, TA_OCR_CLASS_SPLIT=0|1); the tests
-# patch the attributes.  None = the product's own choice.
-FORCE_GROUP = int(os.environ["TA_OCR_GROUP"]) if os.environ.get("TA_OCR_GROUP") in ("4", "16") else None
-FORCE_CLASS_SPLIT = (os.environ["TA_OCR_CLASS_SPLIT"] == "1") if os.environ.get("TA_OCR_CLASS_SPLIT") in ("0", "1") else None
+# Overrides for tests and timing tools: plain module attributes (this module reads no environment variables; the tools
+# under tools/ translate their TA_* variables into these, tools/switches.py).  None = the product's own choice.
+FORCE_GROUP = None              # 4 | 16: lines per workgroup of the recurrence (f32 / f64 modes)
+FORCE_CLASS_SPLIT = None        # True | False: split mode, K3 + K4 per length class on side streams
 CLASS_SPLIT_MIN_LINES = 384     # below this (a few pages) the recurrence's tail has nothing worth hiding
 GROUP4_MAX_LINES = 2048         # exact-f32 mode: batches up to this size run in groups of 4 lines (see prepare)
 F64_GROUP4_MAX_LINES = 1 << 30  # float64 mode: groups of 4 lines (lstm_seq4_f64_kernel) up to this batch size
@@ -248,10 +246,10 @@ F64_GX_KEEP_BYTES = 6 << 30     # ... and a scratch buffer larger than this is n
 # shares of the run's groups.  Measured (tools/f64_time.py, lines of 800 .. 2000 columns): two halves 17.3 ms per 1 920
 # lines against 19.0 one after the other (384 / 960 / 3 840 / 5 760 lines: 14.1 / 15.6 / 33.3 / 54.3 against 14.4 / 16.2 /
 # 34.4 / 55.7); three or four classes are SLOWER (20 .. 21 ms: the projection of the last class is left a third of the
-# CUs), and so are unequal halves (0.45 or 0.55: 19.3).  TA_OCR_F64_PIPE=0 switches it off, TA_OCR_F64_CUTS=a,b sets the cuts (timing).
-F64_CLASS_PIPELINE = os.environ.get("TA_OCR_F64_PIPE", "1") != "0"
+# CUs), and so are unequal halves (0.45 or 0.55: 19.3).
+F64_CLASS_PIPELINE = True
 F64_CLASS_MIN_GROUPS = 16
-F64_CLASS_CUTS = tuple(float(v) for v in os.environ.get("TA_OCR_F64_CUTS", "0.5").split(",") if v)[:3]
+F64_CLASS_CUTS = (0.5,)
 # class-split state: the side streams per device, and the verdict of the one-off timing check per (device, mode)
 # (a recogniser on another GPU or in another mode is timed for itself); guarded by a lock -- page threads share it
 _split_state = {"streams": {}, "ok": {}, "times_ms": {}}
@@ -276,7 +274,7 @@ def _class_streams(device):
 
 
 def _class_split_wanted(rec, st):
-    """FORCE_CLASS_SPLIT (TA_OCR_CLASS_SPLIT=0 / 1 at import) decides; otherwise batches of CLASS_SPLIT_MIN_LINES lines or more take the
+    """FORCE_CLASS_SPLIT decides; otherwise batches of CLASS_SPLIT_MIN_LINES lines or more take the
     class split unless the one-off check below found it SLOWER in this process (another user of the
     high-priority queues): the first eligible batch is run both ways once, timed with events."""
     if FORCE_CLASS_SPLIT is not None:
@@ -433,6 +431,55 @@ class LineRecognizer(object):
         """All prepared lines as one [rows, 48] float32 device tensor (line k at rows row_start[k] ...)."""
         return self._stage_rows_end(self._stage_rows_begin(lines, row_start, rows))
 
+    SPAN_MERGE_GAP = 256        # rows: two lines of a page-locked block this close go over in one transfer (<= 48 KB idle)
+
+    def _span_rows_begin(self, lines, rows):
+        """Lines that are RowSpans (page.RowBlock: rows in page-locked or device memory): nothing is copied on the host.
+        Every run of neighbouring spans of a page-locked block crosses PCIe as it lies, in one asynchronous transfer
+        issued HERE on the upload stream (a chunk of the page pipeline: under the previous chunk's kernels); spans of a
+        device block are read where they are.  Returns the per-line source ADDRESSES for ta_rows_gather and what has to
+        stay alive until the gather has run."""
+        if rows == 0:
+            return None
+        dev = self.device
+        src = np.zeros(len(lines), dtype=np.int64)
+        by_block = {}
+        for k, ln in enumerate(lines):
+            by_block.setdefault(id(ln.block), (ln.block, []))[1].append(k)
+        keep, done = [], None
+        up = self._upload_stream()
+        for block, ks in by_block.values():
+            t = block.tensor
+            if block.kind == "device":
+                if t.device != dev:
+                    raise ValueError("a device RowBlock must live on the recogniser's device (%s, not %s)" % (dev, t.device))
+                base = t.data_ptr()
+                for k in ks:
+                    src[k] = base + 4 * NI * lines[k].start
+                keep.append(t)
+                continue
+            ks = sorted(ks, key=lambda k: lines[k].start)
+            runs, a, b, members = [], lines[ks[0]].start, lines[ks[0]].stop, [ks[0]]
+            for k in ks[1:]:
+                if lines[k].start - b <= self.SPAN_MERGE_GAP:
+                    b = max(b, lines[k].stop)
+                    members.append(k)
+                else:
+                    runs.append((a, b, members))
+                    a, b, members = lines[k].start, lines[k].stop, [k]
+            runs.append((a, b, members))
+            with torch.cuda.stream(up):
+                for a, b, members in runs:
+                    d = torch.empty((b - a, NI), dtype=torch.float32, device=dev)
+                    d.copy_(t[a:b], non_blocking=True)
+                    keep.append(d)
+                    base = d.data_ptr()
+                    for k in members:
+                        src[k] = base + 4 * NI * (lines[k].start - a)
+                done = torch.cuda.Event()
+                done.record(up)
+        return {"src": src, "keep": keep, "done": done, "rows": rows}
+
     # ---- batched device pass -------------------------------------------------------------
     def prepare(self, lines, defer=False):
         """Upload lines and allocate outputs.  A line is either a prepared (T, 48) float array
@@ -440,6 +487,11 @@ class LineRecognizer(object):
         on the device), which is normalised on the device (lineest_gpu, csrc/ta_lineest.hip) without a
         host round trip.  defer = True (host lines only): the staging copies are started and the call returns;
         `complete(st)` -- or `run(st)` -- waits for them and does the device part."""
+        from .page import RowSpan
+        nspans = sum(1 for ln in lines if isinstance(ln, RowSpan))
+        if 0 < nspans < len(lines):         # a mixed batch: the spans go the way of host arrays (a device span is downloaded)
+            lines = [ln.numpy() if isinstance(ln, RowSpan) else ln for ln in lines]
+            nspans = 0
         raw = [k for k, ln in enumerate(lines) if _is_raw_strip(ln)]
         n = len(lines)
         T = np.zeros(n, dtype=np.int64)
@@ -486,7 +538,10 @@ class LineRecognizer(object):
         raw_set = set(raw)
         host = [k for k in range(n) if k not in raw_set]
         pending = None
-        if not raw:
+        if nspans:
+            pending = self._span_rows_begin(lines, rows)
+            x_dev = None
+        elif not raw:
             pending = self._stage_rows_begin(lines, row_start, rows)
             x_dev = None
         elif not host:
@@ -521,20 +576,36 @@ class LineRecognizer(object):
         pending, x_dev, group_lines, nlines = st.pop("_pending")
         n, rows, T, row_start = st["n"], st["rows"], st["T_host"], st["row_start_host"]
         lines = [None] * nlines
-        if x_dev is None:
+        spans = pending if isinstance(pending, dict) else None
+        if x_dev is None and spans is None:
             x_dev = self._stage_rows_end(pending)
         dev = self.device
+        meta = [row_start if n else np.zeros(1, np.int64), T.astype(np.int32) if len(lines) else np.zeros(1, np.int32),
+                group_lines]
+        if spans is not None:
+            meta.append(spans["src"])
+        up = _native.upload_packed(meta, dev)
+        st["row_off"], st["T"], st["group_lines"] = up[:3]
+        if spans is not None:
+            # the permutation into the recogniser's row order, on the compute stream, behind the blocks' transfers
+            main = torch.cuda.current_stream(dev)
+            if spans["done"] is not None:
+                main.wait_event(spans["done"])
+            x_dev = torch.empty((rows, NI), dtype=torch.float32, device=dev)
+            _native.check(_native.lib.ta_rows_gather(up[3].data_ptr(), st["row_off"].data_ptr(), st["T"].data_ptr(), n,
+                                                     int(T.max()), x_dev.data_ptr(), main.cuda_stream), "ta_rows_gather")
+            for t in spans["keep"]:
+                t.record_stream(main)           # (allocated on the upload stream, or the caller's block: read by this one)
         st["x"] = x_dev
-        st["row_off"], st["T"], st["group_lines"] = _native.upload_packed(
-            [row_start if n else np.zeros(1, np.int64), T.astype(np.int32) if len(lines) else np.zeros(1, np.int32),
-             group_lines], dev)
         st["hout"] = torch.empty((max(rows, 1), 2 * NS), dtype=torch.float32, device=dev)
         st["probs"] = None            # full probabilities only on request (tests, inspection)
         st["logits"] = None
         st["summary"] = torch.empty((max(rows, 1), 4), dtype=torch.float32, device=dev)
         st["dec_t"] = torch.zeros(max(rows, 1), dtype=torch.int32, device=dev)
         st["dec_c"] = torch.zeros(max(rows, 1), dtype=torch.int32, device=dev)
-        st["dec_n"] = torch.zeros(max(len(lines), 1), dtype=torch.int32, device=dev)
+        # dec_n[k] = decoded characters of line k; ONE more word at the end is the batch's device status (zero; the float64
+        # recurrence ORs TA_LSTM_F64_PARTS_LATE into it): it comes back with the counts and check_status() raises on it
+        st["dec_n"] = torch.zeros(max(len(lines), 1) + 1, dtype=torch.int32, device=dev)
         return st
 
     def run(self, st, want_logits=False, lstm=True, output=True, decode=True, from_probs=False, class_split=None):
@@ -617,7 +688,8 @@ class LineRecognizer(object):
                         gx, c0, c1 - c0, st["row_off"].data_ptr(), st["T"].data_ptr(),
                         st["group_lines"].data_ptr() + 4 * G * ca, cb - ca, (self.wh64g4 if G == 4 else self.wh64).data_ptr(), self.peep64.data_ptr(),
                         st["hout"].data_ptr(), cont[0].data_ptr() if cont else None, cont[1].data_ptr() if cont else None,
-                        cont[2].data_ptr() if cont else None, seq_stream), "ta_lstm_forward_f64")
+                        cont[2].data_ptr() if cont else None, st["dec_n"].data_ptr() + 4 * (st["dec_n"].numel() - 1),
+                        seq_stream), "ta_lstm_forward_f64")
                 for sd in used:                                      # (also orders the reuse of the buffer)
                     cs.wait_stream(sd)
                 a = b
@@ -683,6 +755,17 @@ class LineRecognizer(object):
                 THRESHOLD, st["dec_t"].data_ptr(), st["dec_c"].data_ptr(),
                 st["dec_n"].data_ptr(), st["row_off"].data_ptr(), stream), "ta_decode_summary")
 
+    @staticmethod
+    def check_status(dec_n_host):
+        """dec_n as it came back from the device (counts + the status word, see complete()): a batch whose recurrence
+        reported trouble has no usable result -- its outputs are NaN from the step it happened -- and says so HERE, instead
+        of handing back whatever the decoder made of them."""
+        word = int(dec_n_host[-1])
+        if word != 0:
+            raise RuntimeError("line recogniser: the device reported status %#x for this batch (bit 0: a workgroup of the "
+                               "float64 recurrence gave up waiting for the partial sums its waves exchange; its outputs "
+                               "are NaN from that step on) -- the batch's characters are not usable" % word)
+
     def decoded(self, st):
         """Host lists [(t, class), ...] per line (translate_back order)."""
         if st["n"] == 0:
@@ -690,6 +773,7 @@ class LineRecognizer(object):
         dt = st["dec_t"].cpu().numpy()
         dc = st["dec_c"].cpu().numpy()
         dn = st["dec_n"].cpu().numpy()
+        self.check_status(dn)
         out = []
         for b in range(st["n"]):
             o = int(st["row_start_host"][b])

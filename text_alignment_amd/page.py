@@ -22,12 +22,94 @@ class Image(object):
         self.ncols, self.nrows = self.dim.ncols, self.dim.nrows
 
 
+class RowBlock(object):
+    """Prepared rows ((T, 48) float32, ink = 1, padded -- what `Strip.prepared` holds) of MANY text lines in ONE block
+    of memory the GPU reads where it lies: page-locked host memory (kind "pinned": a batch's rows cross PCIe in one DMA
+    transfer per block, straight from here, no staging copy) or device memory (kind "device": nothing moves at all).
+    A loader that decodes / normalises strips fills `block.host[a:b]` (pinned) or `block.tensor[a:b]` (device) and
+    hands `block.span(a, b)` to the strip.  The recogniser gathers the lines into its own row order on the device
+    (csrc/ta_rows.hip); results are those of the same rows passed as numpy arrays.
+
+    The caller keeps the rows unchanged until the call that consumes them has returned (as with any input array)."""
+    WIDTH = 48
+
+    def __init__(self, rows, kind="pinned", device=None):
+        import torch
+        rows = max(int(rows), 1)
+        if kind == "pinned":
+            self.tensor = torch.empty((rows, self.WIDTH), dtype=torch.float32, pin_memory=True)
+            self.host = self.tensor.numpy()
+        elif kind == "device":
+            dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+            self.tensor = torch.empty((rows, self.WIDTH), dtype=torch.float32, device=dev)
+            self.host = None
+        else:
+            raise ValueError("a RowBlock is 'pinned' (page-locked host memory) or 'device'")
+        self.kind, self.rows, self.used = kind, rows, 0
+
+    @classmethod
+    def from_lines(cls, lines, kind="pinned", device=None):
+        """(block, spans): the given (T, 48) arrays laid out one after the other in a new block"""
+        import torch
+        total = sum(int(ln.shape[0]) for ln in lines)
+        block = cls(total, kind, device)
+        spans = []
+        for ln in lines:
+            sp = block.take(int(ln.shape[0]))
+            if kind == "pinned":
+                block.host[sp.start:sp.stop] = ln
+            else:
+                block.tensor[sp.start:sp.stop] = torch.from_numpy(np.ascontiguousarray(ln, dtype=np.float32)).to(block.tensor.device)
+            spans.append(sp)
+        return block, spans
+
+    def take(self, nrows):
+        """the next `nrows` unused rows of the block as a span"""
+        if self.used + nrows > self.rows:
+            raise ValueError("RowBlock of %d rows is full" % self.rows)
+        self.used += int(nrows)
+        return RowSpan(self, self.used - int(nrows), self.used)
+
+    def span(self, start, stop):
+        if not 0 <= start <= stop <= self.rows:
+            raise ValueError("rows %d..%d are outside the block" % (start, stop))
+        return RowSpan(self, int(start), int(stop))
+
+
+class RowSpan(object):
+    """rows [start, stop) of a RowBlock: one text line's prepared (T, 48) rows.  Looks like an array where the host glue
+    looks (shape, ndim, dtype, np.asarray -- which DOWNLOADS a device span)."""
+    __slots__ = ("block", "start", "stop")
+    ndim = 2
+    dtype = np.dtype(np.float32)
+
+    def __init__(self, block, start, stop):
+        self.block, self.start, self.stop = block, start, stop
+
+    @property
+    def shape(self):
+        return (self.stop - self.start, RowBlock.WIDTH)
+
+    def numpy(self):
+        if self.block.kind == "pinned":
+            return self.block.host[self.start:self.stop]
+        return self.block.tensor[self.start:self.stop].cpu().numpy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __len__(self):
+        return self.stop - self.start
+
+
 class Strip(object):
     """One text-line strip: position on the (deskewed) page plus its pixels.
 
     offset_x, offset_y, height: as the reference reads them (alignToOCR.py:160-162).
     prepared: (T, 48) float array, ink = 1, normalised to height 48 and padded by 16 columns on
-        each side (what ocropus-rpred feeds its network); or
+        each side (what ocropus-rpred feeds its network) -- or a RowSpan: those rows
+        inside a RowBlock (page-locked or device memory), taken by the recogniser where they lie; or
     pixels: raw (H, W) uint8 strip with white background, normalised on the device (lineest_gpu); or
     device_pixels: the same strip as a 2-D uint8 tensor that already lives on the GPU (what the device
         preprocessing cuts, preproc_gpu.identify_text_lines_batch) -- `.pixels` then downloads it on
@@ -37,7 +119,7 @@ class Strip(object):
 
     def __init__(self, offset_x, offset_y, height, width=None, prepared=None, pixels=None, device_pixels=None):
         self.offset_x, self.offset_y, self.height = int(offset_x), int(offset_y), int(height)
-        self.prepared = None if prepared is None else np.asarray(prepared)
+        self.prepared = prepared if (prepared is None or isinstance(prepared, RowSpan)) else np.asarray(prepared)
         self._pixels = None if pixels is None else np.asarray(pixels)
         self.device_pixels = device_pixels
         if width is None:
@@ -72,6 +154,17 @@ class PreparedPage(object):
         self.strips = list(strips)
         self.lines_peak_locs = list(lines_peak_locs)
         self.image._page = self
+
+    @classmethod
+    def from_rows(cls, image_dim, raw_dim, angle, block, spans, boxes, lines_peak_locs):
+        """A page whose text lines' prepared rows lie in a RowBlock: spans[k] = (first row, end row) of line k in
+        `block` (or a RowSpan), boxes[k] = (offset_x, offset_y, height, raw width in pixels) of its strip."""
+        strips = []
+        for sp, (ox, oy, h, w) in zip(spans, boxes):
+            if not isinstance(sp, RowSpan):
+                sp = block.span(int(sp[0]), int(sp[1]))
+            strips.append(Strip(ox, oy, h, width=w, prepared=sp))
+        return cls(image_dim, raw_dim, angle, strips, lines_peak_locs)
 
 
 def preprocess_images(raw_image):
@@ -108,7 +201,7 @@ def prepared_line(strip):
     if the strip carries one, else its raw uint8 pixels (host array or device tensor; normalised on the
     device, csrc/ta_lineest.hip) -- and its raw pixel width."""
     if getattr(strip, "prepared", None) is not None:
-        xs = np.asarray(strip.prepared)
+        xs = strip.prepared if isinstance(strip.prepared, RowSpan) else np.asarray(strip.prepared)
         return xs, int(getattr(strip, "width", xs.shape[0] - 32))
     dp = getattr(strip, "device_pixels", None)
     if dp is not None:                  # cut on the GPU: stays there (an empty or constant one is refused by

@@ -56,6 +56,7 @@ def encode_tokens(*seqs):
     (the aligner only ever compares tokens with ==, textSeqCompare.py:32).  Sequences of single characters -- what
     alignToOCR.py:273 passes, `list(transcript)` -- are encoded by their code points in one numpy pass; anything else
     (the bigrams of textSeqCompare.py:185-186, numbers, tuples) token by token through a dict."""
+    seqs = [seq if isinstance(seq, (list, tuple, str)) else list(seq) for seq in seqs]    # an iterator is read ONCE
     try:
         if all(type(tok) is str for seq in seqs for tok in seq) and \
                 all(len(seq) == 0 or max(map(len, seq)) == 1 == min(map(len, seq)) for seq in seqs):
@@ -67,7 +68,7 @@ def encode_tokens(*seqs):
             out = [rank[np.searchsorted(alphabet, c)] if len(c) else np.zeros(0, np.int32) for c in cps]
             ids = {chr(int(c)): int(r) for c, r in zip(alphabet, rank)}
             return out, ids
-    except TypeError:
+    except (TypeError, ValueError):       # ValueError: UnicodeEncodeError -- a lone surrogate is a token like any other
         pass
     ids = {}
     out = []

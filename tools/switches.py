@@ -1,0 +1,51 @@
+"""Experiment switches of the timing / profiling tools.
+
+The product modules read no environment variables: their tunables are plain module attributes
+(text_alignment_amd.ocr.FORCE_GROUP, .F64_CLASS_PIPELINE, ...; alignToOCR.PIPELINE_CHUNK_PAGES, ...).
+The tools under tools/ are run under rocprofv3 and from shell scripts (tools/profile_round.sh), where the
+environment is the only handle -- so THEY translate it, once, after importing the product:
+
+    TA_OCR_GROUP=4|16          ocr.FORCE_GROUP            lines per workgroup of the recurrence (f32 / f64 modes)
+    TA_OCR_CLASS_SPLIT=0|1     ocr.FORCE_CLASS_SPLIT      split mode: K3 + K4 per length class on side streams
+    TA_OCR_F64_PIPE=0|1        ocr.F64_CLASS_PIPELINE     f64 mode: projection / recurrence pipelined per length class
+    TA_OCR_F64_CUTS=a,b        ocr.F64_CLASS_CUTS         ... its cuts (shares of the groups)
+    TA_PAGE_CHUNK=n            alignToOCR.PIPELINE_CHUNK_PAGES          pages per pipeline chunk (normalised rows)
+    TA_PAGE_CHUNK_RAW=n        alignToOCR.PIPELINE_CHUNK_PAGES_RAW      ... raw strips
+    TA_PAGE_CHUNK_IMAGES=n     alignToOCR.PIPELINE_CHUNK_PAGES_IMAGES   ... page images
+    TA_PB_SPLIT_FINISH=0|1     alignToOCR.SPLIT_FINISH    second stage split around the next chunk's launch
+    TA_PB_TWO_STREAMS=0|1      alignToOCR.TWO_STREAMS     consecutive chunks on two compute streams
+"""
+import os
+
+
+def apply(environ=None):
+    """set the product modules' attributes from TA_* variables; returns what was set"""
+    env = os.environ if environ is None else environ
+    from text_alignment_amd import alignToOCR as atocr, ocr
+    done = {}
+
+    def put(mod, attr, value):
+        setattr(mod, attr, value)
+        done["%s.%s" % (mod.__name__.rsplit(".", 1)[-1], attr)] = value
+    v = env.get("TA_OCR_GROUP")
+    if v in ("4", "16"):
+        put(ocr, "FORCE_GROUP", int(v))
+    v = env.get("TA_OCR_CLASS_SPLIT")
+    if v in ("0", "1"):
+        put(ocr, "FORCE_CLASS_SPLIT", v == "1")
+    v = env.get("TA_OCR_F64_PIPE")
+    if v in ("0", "1"):
+        put(ocr, "F64_CLASS_PIPELINE", v == "1")
+    v = env.get("TA_OCR_F64_CUTS")
+    if v:
+        put(ocr, "F64_CLASS_CUTS", tuple(float(x) for x in v.split(",") if x)[:3])
+    for var, attr in (("TA_PAGE_CHUNK", "PIPELINE_CHUNK_PAGES"), ("TA_PAGE_CHUNK_RAW", "PIPELINE_CHUNK_PAGES_RAW"),
+                      ("TA_PAGE_CHUNK_IMAGES", "PIPELINE_CHUNK_PAGES_IMAGES")):
+        v = env.get(var)
+        if v and v.isdigit() and int(v) > 0:
+            put(atocr, attr, int(v))
+    for var, attr in (("TA_PB_SPLIT_FINISH", "SPLIT_FINISH"), ("TA_PB_TWO_STREAMS", "TWO_STREAMS")):
+        v = env.get(var)
+        if v in ("0", "1"):
+            put(atocr, attr, v == "1")
+    return done
