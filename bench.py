@@ -42,11 +42,20 @@ P1_VALU_PER_BLOCK = 382        # nw_score_kernel, score profile + one gap open: 
 P1_NS_PER_VALU = 1.72          # measured issue interval of that instruction mix (profiles/r05_valu_issue_rates.txt: 1.722 at 8 waves per SIMD; round 2: 1.72)
 
 
-def _profile_file(*names):
-    for name in names:
-        path = os.path.join(REPO, "profiles", name)
-        if os.path.exists(path):
-            return name, path
+def _profile_file(*stems):
+    """(name, path) of the NEWEST round's copy of a profile summary: for each stem ("nw2_hbm_traffic.json", ...) the file
+    profiles/rNN_<stem> with the highest NN present -- the line never cites an older round than profiles/ holds
+    (tests/test_bench_profiles.py).  Several stems: the first that exists in any round."""
+    import re
+    try:
+        listing = os.listdir(os.path.join(REPO, "profiles"))
+    except OSError:
+        return None, None
+    for stem in stems:
+        rounds = sorted((int(m.group(1)), f) for f in listing for m in [re.match(r"r(\d+)_" + re.escape(stem) + "$", f)] if m)
+        if rounds:
+            name = rounds[-1][1]
+            return name, os.path.join(REPO, "profiles", name)
     return None, None
 
 
@@ -55,7 +64,7 @@ def measured_traffic(batch, n, m, kernel):
     profiles/ (WRITE_SIZE + 2 x FETCH_SIZE, MI355X_MICROARCH.md HBM section) -- a number read from
     that file, not measured in this run; (None, None) for configs that were not profiled."""
     stem = "nw2_hbm_traffic.json" if kernel == "nw_score_kernel" else "nw_hbm_traffic.json"
-    name, path = _profile_file("r04_" + stem, "r03_" + stem, "r02_" + stem, "r01_" + stem)
+    name, path = _profile_file(stem)
     try:
         with open(path) as f:
             d = json.load(f)
@@ -71,8 +80,7 @@ def measured_traffic(batch, n, m, kernel):
 def measured_mfma_busy(kernel):
     """MFMA pipe utilisation of a recogniser kernel from the counter pass kept under profiles/
     (SQ_VALU_MFMA_BUSY_CYCLES over all SIMD-cycles, 1920-line workload); (None, None) if absent."""
-    name, path = _profile_file("r04_ocr_pmc_mfma.json", "r03_ocr_pmc_mfma.json", "r02_ocr_pmc_mfma.json",
-                               "r01_ocr_pmc_mfma.json")
+    name, path = _profile_file("ocr_pmc_mfma.json")
     try:
         with open(path) as f:
             for k, v in json.load(f)["kernels"].items():
@@ -302,7 +310,7 @@ def bench_ocr(args, rank, precision=None, nlines=None):
 def measured_ocr_traffic(nlines, precision, group):
     """HBM bytes of one pass of the recurrence kernels of a mode (float64: projection + recurrence) from the separate
     --pmc WRITE_SIZE / FETCH_SIZE passes kept under profiles/ (tools/profile_round.sh); read, not measured in this run."""
-    name, path = _profile_file("r05_ocr_hbm_traffic.json", "r05_ocr_f64_hbm_traffic.json")
+    name, path = _profile_file("ocr_hbm_traffic.json", "ocr_f64_hbm_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -322,7 +330,7 @@ def measured_ocr_traffic(nlines, precision, group):
 def ocr_mode_agreement():
     """Free-running agreement of the recogniser's modes (f32, split, f64) with oracle/ocr_ref_f64.py, as measured by
     tools/ocr_mode_agreement.py on the GPU box and kept under profiles/ (read, not measured here)."""
-    name, path = _profile_file("r05_ocr_mode_agreement.json", "r04_ocr_mode_agreement.json")
+    name, path = _profile_file("ocr_mode_agreement.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -362,8 +370,8 @@ def nw_roofline(batch, kname, fill_ms, tb_ms, traffic, traffic_src):
         floor_ms = cells / 4096.0 * P1_VALU_PER_BLOCK * P1_NS_PER_VALU * 1e-6 / 1024.0
         roof.update({"binding_unit": "valu-issue", "valu_issue_floor_ms": floor_ms,
                      "valu_issue_frac": floor_ms / fill_ms,
-                     "valu_issue_source": "profiles/r05_valu_issue_rates.txt; %d VALU per 64 cells x 64 lanes at "
-                                          "%.2f ns per wave-instruction per SIMD" % (P1_VALU_PER_BLOCK, P1_NS_PER_VALU)})
+                     "valu_issue_source": "profiles/%s; %d VALU per 64 cells x 64 lanes at %.2f ns per wave-instruction "
+                                          "per SIMD" % (_profile_file("valu_issue_rates.txt")[0], P1_VALU_PER_BLOCK, P1_NS_PER_VALU)})
     return roof
 
 
@@ -534,8 +542,16 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group even at world size 1 (rehearses the RCCL path)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--no-bind", action="store_true", help="leave the process's cpu affinity as started (A/B of the NUMA binding)")
+    ap.add_argument("--page-rows", default="pinned", choices=["pinned", "numpy", "device"],
+                    help="pages_sharded leg: where the strips' prepared rows lie (tools/pages_bench.ROWS_INPUT)")
+    ap.add_argument("--pages-only", action="store_true",
+                    help="rehearsals: a minimal NW step, no OCR / config legs -- the pages_sharded leg is what is looked at")
     args = ap.parse_args()
 
+    if args.pages_only:
+        args.batch, args.steps, args.warmup = min(args.batch, 8), 1, 0
+        args.no_ocr = args.no_configs = args.no_cpu_baseline = True
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
 
@@ -546,6 +562,12 @@ def main():
     ndev = torch.cuda.device_count()
     dev_index = local if local < ndev else local % max(ndev, 1)
     torch.cuda.set_device(dev_index)
+    # before the first kernel launch: this rank -- and every thread it starts -- onto the host cores next to its GPU,
+    # torch's intra-op pool down to one thread (text_alignment_amd.sharding.bind_to_gpu_node; silent where the host
+    # does not name a NUMA node for the device)
+    from text_alignment_amd import sharding as _sh
+    placement = {"bound": False, "reason": "--no-bind"} if args.no_bind else _sh.bind_to_gpu_node(
+        dev_index, local_rank=local, local_world=int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     dist = None
     if world > 1 or (args.force_dist and "RANK" in os.environ):
         import torch.distributed as dist
@@ -604,15 +626,34 @@ def main():
     sharded = None
     if args.pages > 0:
         from tools import pages_bench
-        job = pages_bench.setup_sharded(args.pages, rank, world, seed0=100)
-        sh_all = []
+        job = pages_bench.setup_sharded(args.pages, rank, world, seed0=100, rows=args.page_rows)
+        sh_all, mine_s, gather_s, cpu_s = [], [], [], []
         for _ in range(10):         # median of ten passes, each barrier to barrier over every rank incl. the gather
             barrier()
-            t1 = time.perf_counter()
-            allrec = pages_bench.run_sharded(job)
+            tm = {}
+            c1, t1 = time.process_time(), time.perf_counter()
+            allrec = pages_bench.run_sharded(job, timings=tm)
+            cpu_s.append(time.process_time() - c1)
             barrier()
             sh_all.append(reduce_max(time.perf_counter() - t1))
+            mine_s.append(tm["pages_s"])
+            gather_s.append(tm["gather_s"])
         sh_dt = float(np.median(sh_all))
+        # per-rank diagnosis, after the timed passes: one pass under the device profiler (every rank: the gather is collective)
+        # and ONE all_gather of a fixed vector per rank -- a straggler or a starved rank must be readable from this line
+        busy_ms = pages_bench._device_busy_ms(lambda: pages_bench.run_sharded(job))
+        cpus_now = sorted(os.sched_getaffinity(0))
+        vec = [float(np.median(mine_s)), float(np.median(gather_s)), 1e3 * float(np.median(cpu_s)) / max(len(job["ids"]), 1),
+               (busy_ms * 1e-3 / float(np.median(mine_s))) if busy_ms else -1.0, float(len(cpus_now)), float(cpus_now[0]),
+               float(cpus_now[-1]), float(-1 if placement.get("numa_node") is None else placement["numa_node"]),
+               1.0 if placement.get("bound") else 0.0, float(len(job["ids"])), float(dev_index)]
+        mine_t = torch.tensor(vec, dtype=torch.float64, device=red_dev)
+        if dist is not None:
+            every = torch.zeros(world * len(vec), dtype=torch.float64, device=red_dev)
+            dist.all_gather_into_tensor(every, mine_t)
+            every = every.cpu().numpy().reshape(world, len(vec))
+        else:
+            every = mine_t.cpu().numpy().reshape(1, len(vec))
         if rank == 0:
             import hashlib
             heads = allrec[allrec[:, 1] == sharding.HEADER]
@@ -630,8 +671,32 @@ def main():
                                          and int(heads[:, 4].sum()) == boxes),
                        "timing": "median of 10 barrier-to-barrier passes (max over ranks each); shortest %.4f s, longest %.4f s"
                                  % (min(sh_all), max(sh_all)),
+                       "input": job["input"],
+                       "rank_seconds": {"min": float(every[:, 0].min()), "median": float(np.median(every[:, 0])),
+                                        "max": float(every[:, 0].max()),
+                                        "is": "each rank's own share (process_batch, results on the host), median of its 10 passes"},
+                       "gather_seconds": {"min": float(every[:, 1].min()), "median": float(np.median(every[:, 1])),
+                                          "max": float(every[:, 1].max()),
+                                          "is": "pack + the ONE gather + unpack on rank 0, per rank; includes waiting for the slowest rank to arrive"},
+                       "per_rank": [{"rank": r, "device": int(every[r, 10]), "pages": int(every[r, 9]), "seconds": float(every[r, 0]),
+                                     "gather_seconds": float(every[r, 1]), "host_cpu_ms_per_page": float(every[r, 2]),
+                                     "gpu_busy_frac": (float(every[r, 3]) if every[r, 3] >= 0 else None),
+                                     "cpus": "%d in %d..%d" % (every[r, 4], every[r, 5], every[r, 6]),
+                                     "numa_node": (int(every[r, 7]) if every[r, 7] >= 0 else None), "bound": bool(every[r, 8])}
+                                    for r in range(world)],
+                       "placement_rank0": placement,
                        "note": "sharding.process_shard: process_batch per model on this rank's pages + ONE "
                                "gather of [page, syllable, ulx, uly, lrx, lry] records to rank 0"}
+            # the timed output under the checkers: two of rank 0's own pages (one per model) rebuilt from the float64
+            # recogniser restatement, the C aligner and the reference-pinned glue -- after the timed region
+            from tools import pages_check
+            got = sharding.records_to_json(allrec, {k: t for k, t in enumerate(job["all_transcripts"])})
+            local = {gid: j for j, gid in enumerate(job["ids"])}
+            which = [job["ids"][0], job["ids"][min(1, len(job["ids"]) - 1)]]
+            chk = pages_check.check_pages({g: got[g] for g in which}, {g: job["pages"][local[g]] for g in which},
+                                          {g: job["transcripts"][local[g]] for g in which},
+                                          {g: job["models"][local[g]].model for g in which}, pages_bench.PARAMS, sorted(set(which)))
+            sharded.update({"pages_checked": chk["pages_checked"], "pages_equal_to_oracle": chk["pages_equal_to_oracle"], "check": chk})
         del job
 
     ocr_res = None

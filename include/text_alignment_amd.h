@@ -76,6 +76,10 @@ extern "C" {
 
 int ta_version(void);
 const char* ta_last_error(void);
+/* PCI address ("0000:c1:00.0", NUL-terminated, len >= 13) of HIP device `device` -- the key under /sys/bus/pci/devices/
+ * from which a rank of the page-sharded job (the loop of alignToOCR.py:407-438, one process per GPU) reads the NUMA node
+ * of its GPU to bind itself next to it.  [host] */
+int ta_device_pci_bus_id(int32_t device, char* out, int32_t len);
 
 /*
  * Affine-gap Needleman-Wunsch, replaces textSeqCompare.perform_alignment

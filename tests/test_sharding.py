@@ -281,6 +281,43 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert ps2["gather_ok"] and ps1["gather_ok"]
     assert ps2["syllable_boxes"] == ps1["syllable_boxes"] > 0
     assert ps2["records_sha16"] == ps1["records_sha16"]
+    # the timed output under the checkers, and the per-rank diagnosis the single line of an 8-GPU run has to carry
+    assert ps2["pages_checked"] >= 1 and ps2["pages_equal_to_oracle"] == ps2["pages_checked"]
+    assert ps1["pages_checked"] >= 1 and ps1["pages_equal_to_oracle"] == ps1["pages_checked"]
+    assert "page-locked" in ps2["input"]
+    assert [r["rank"] for r in ps2["per_rank"]] == [0, 1] and sum(r["pages"] for r in ps2["per_rank"]) == 8
+    for r in ps2["per_rank"]:
+        assert 0 < r["seconds"] <= ps2["rank_seconds"]["max"] and r["gather_seconds"] >= 0 and r["host_cpu_ms_per_page"] > 0
+        assert r["gpu_busy_frac"] is None or 0 < r["gpu_busy_frac"] <= 1.5
+        assert set(r) >= {"device", "cpus", "numa_node", "bound"}
+    assert ps2["rank_seconds"]["min"] <= ps2["rank_seconds"]["median"] <= ps2["rank_seconds"]["max"] <= ps2["seconds"] * 1.5
+    assert set(ps2["placement_rank0"]) >= {"bound", "numa_node", "cpus", "ncpus", "reason"}
+
+
+def test_binding_plan_slices_a_numa_node_among_its_ranks():
+    """sharding.plan_binding (pure): the cpus of the GPU's NUMA node that the process may use, an equal contiguous slice per
+    local rank on that node; the whole node when a slice would be too small; None when the host names no node."""
+    from text_alignment_amd import sharding as sh
+    node_of = {0: 0, 1: 0, 2: 0, 3: 0, 4: 1, 5: 1, 6: 1, 7: 1}
+    cpus_of = {0: set(range(0, 64)) | set(range(128, 192)), 1: set(range(64, 128)) | set(range(192, 256))}
+    every = set(range(256))
+    got = [sh.plan_binding(node_of, cpus_of, every, r, 8) for r in range(8)]
+    assert all(len(g) == 32 for g in got)
+    assert set().union(*got[:4]) == cpus_of[0] and set().union(*got[4:]) == cpus_of[1]
+    assert all(not (set(got[a]) & set(got[b])) for a in range(8) for b in range(a))
+    # a container that owns 16 cpus of node 0 only: ranks on node 0 share them (slices of 4 are the floor), node 1 has none
+    few = set(range(0, 12))
+    assert sh.plan_binding(node_of, cpus_of, few, 1, 8) == sorted(few)
+    assert sh.plan_binding(node_of, cpus_of, few, 5, 8) is None
+    assert sh.plan_binding({0: None}, {}, every, 0, 1) is None
+    assert sh._fmt_cpus({0, 1, 2, 3, 8, 9, 11}) == "0-3,8-9,11" and sh._cpulist("0-3,8-9,11\n") == {0, 1, 2, 3, 8, 9, 11}
+    # no GPU here: the helper says so and leaves the mask alone
+    import os
+    before = os.sched_getaffinity(0)
+    import torch
+    if not torch.cuda.is_available():
+        out = sh.bind_to_gpu_node()
+        assert out["bound"] is False and out["reason"] == "no GPU" and os.sched_getaffinity(0) == before
 
 
 @pytest.mark.gpu

@@ -18,3 +18,12 @@ int ta_fail_hip(hipError_t e, const char* where) {
 extern "C" int ta_version(void) { return 100; }   // 0.1.0
 
 extern "C" const char* ta_last_error(void) { return g_err; }
+
+// PCI address ("0000:c1:00.0") of HIP device `device`: the key under /sys/bus/pci/devices/ from which a rank reads the
+// NUMA node of its GPU (text_alignment_amd.sharding.bind_to_gpu_node)
+extern "C" int ta_device_pci_bus_id(int32_t device, char* out, int32_t len) {
+    if (!out || len < 13) return ta_fail(TA_EINVAL, "ta_device_pci_bus_id needs a buffer of at least 13 bytes");
+    const hipError_t e = hipDeviceGetPCIBusId(out, len, device);
+    if (e != hipSuccess) return ta_fail_hip(e, "hipDeviceGetPCIBusId");
+    return TA_OK;
+}

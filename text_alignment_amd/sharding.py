@@ -16,6 +16,128 @@ import torch
 RECORD_FIELDS = 6        # page_id, syl_index, ulx, uly, lrx, lry
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Host placement of a rank.  A rank of the page-sharded job is HOST-bound as often as device-bound: per page it
+# lays out ~8 MB of rows, decodes characters and assembles boxes while its GPU runs the previous chunk.  Eight ranks on a
+# two-socket host that the scheduler is free to migrate share caches, memory channels and -- with rows staged through the
+# copy pool -- cross the socket link twice per byte.  Each rank therefore pins itself (and thereby every thread it
+# starts: the copy pool, torch's helper threads) to the cores of the NUMA node its GPU hangs off, an equal slice of them
+# per rank when several ranks share the node.
+def _cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_node(device_index, sysfs="/sys/bus/pci/devices"):
+    """(numa node, cpus of that node) of HIP device `device_index`, from its PCI address; (None, None) if the host does
+    not say (no sysfs entry, node -1: a single-node box or a VM that hides the topology)."""
+    import ctypes
+    import os
+    from . import _native
+    buf = ctypes.create_string_buffer(64)
+    if _native.lib.ta_device_pci_bus_id(int(device_index), buf, 64) != 0:
+        return None, None
+    bdf = buf.value.decode("ascii", "replace").lower()
+    try:
+        with open(os.path.join(sysfs, bdf, "numa_node")) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None, None
+        with open(os.path.join(sysfs, bdf, "local_cpulist")) as f:
+            cpus = _cpulist(f.read())
+    except (OSError, ValueError):
+        return None, None
+    return node, cpus
+
+
+def plan_binding(node_of_device, cpus_of_node, allowed, local_rank, local_world, min_slice=4):
+    """The cpus rank `local_rank` binds to (pure function; tests/test_sharding.py): the cpus of its GPU's NUMA node that
+    the process may use at all (`allowed`: the affinity mask it was started with, i.e. the container's share), cut into
+    equal contiguous slices among the local ranks whose GPUs sit on the same node -- unless a slice would be smaller than
+    `min_slice` cpus (the main thread, the copy pool, the runtime's helper threads), in which case the ranks of a node
+    share all of it.  None: no binding (unknown topology, or nothing left after the intersection)."""
+    node = node_of_device.get(local_rank)
+    if node is None or node not in cpus_of_node:
+        return None
+    cpus = sorted(set(cpus_of_node[node]) & set(allowed))
+    if not cpus:
+        return None
+    peers = sorted(r for r in range(local_world) if node_of_device.get(r) == node)
+    share = len(cpus) // max(len(peers), 1)
+    if len(peers) <= 1 or share < min_slice:
+        return cpus
+    at = peers.index(local_rank)
+    return cpus[at * share:(at + 1) * share]
+
+
+def bind_to_gpu_node(device_index=None, local_rank=None, local_world=None, num_threads=1):
+    """Bind THIS process to host cores next to its GPU and stop torch's intra-op pool from spreading (`num_threads`;
+    the glue's numpy / torch calls are small and a pool of idle spinners per rank is exactly the contention to avoid).
+    Call it before the first kernel launch of the rank -- threads started later inherit the mask.
+    device_index: the rank's HIP device (default: torch's current one); local_rank / local_world: its place among the
+    ranks of this host (default: LOCAL_RANK / LOCAL_WORLD_SIZE of the launcher, else 0 / 1).  Devices that do not exist
+    (a rehearsal with more ranks than GPUs) count as sharing the device they wrap to.
+    Returns a dict saying what was done: {"bound": bool, "numa_node", "cpus": "a-b,c", "ncpus", "reason"}; never raises
+    for a host that cannot say or will not let us."""
+    import os
+    out = {"bound": False, "numa_node": None, "cpus": _fmt_cpus(os.sched_getaffinity(0)), "ncpus": len(os.sched_getaffinity(0)),
+           "torch_threads": None, "reason": None}
+    try:
+        if num_threads:
+            torch.set_num_threads(int(num_threads))
+        out["torch_threads"] = torch.get_num_threads()
+    except RuntimeError as exc:                      # (set after parallel work has started)
+        out["reason"] = "torch.set_num_threads: %s" % exc
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        out["reason"] = "no GPU"
+        return out
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    node_of, cpus_of = {}, {}
+    for r in range(local_world):
+        dev = device_index if r == local_rank else r % ndev
+        node, cpus = gpu_numa_node(dev)
+        node_of[r] = node
+        if node is not None:
+            cpus_of[node] = cpus
+    out["numa_node"] = node_of.get(local_rank)
+    want = plan_binding(node_of, cpus_of, os.sched_getaffinity(0), local_rank, local_world)
+    if want is None:
+        out["reason"] = "the host does not name a NUMA node for this GPU (or none of its cpus is ours): affinity left as started"
+        return out
+    try:
+        os.sched_setaffinity(0, want)
+    except OSError as exc:
+        out["reason"] = "sched_setaffinity refused: %s" % exc
+        return out
+    now = os.sched_getaffinity(0)
+    out.update(bound=True, cpus=_fmt_cpus(now), ncpus=len(now))
+    return out
+
+
+def _fmt_cpus(cpus):
+    """{0,1,2,3,8,9} -> '0-3,8-9'"""
+    cpus = sorted(cpus)
+    parts, a = [], None
+    for k, c in enumerate(cpus):
+        if a is None:
+            a = c
+        if k + 1 == len(cpus) or cpus[k + 1] != c + 1:
+            parts.append("%d" % a if a == c else "%d-%d" % (a, c))
+            a = None
+    return ",".join(parts)
+
+
 def page_cost(line_widths, n_transcript, n_ocr_estimate=None):
     """Work estimate of one page: LSTM timesteps + DP cells."""
     m = n_transcript if n_ocr_estimate is None else n_ocr_estimate
@@ -212,14 +334,18 @@ def _page_errors():
 
 
 def process_shard(my_pages, my_transcripts, my_ids, my_models, capacity, seq_align_params=None,
-                  group=None, dst=0, device=None):
+                  group=None, dst=0, device=None, timings=None):
     """This rank's pages (global indices `my_ids`) through alignToOCR.process_batch, one batch per
     distinct recogniser model, then THE collective of the path: one fixed-capacity gather of the
     box records to rank `dst`.  `capacity` must be the same on every rank (shard_plan).  Returns
-    the concatenated records on `dst`, None elsewhere."""
+    the concatenated records on `dst`, None elsewhere.  timings (a dict, optional) receives this rank's
+    wall seconds of the two parts: "pages_s" (its share, results on the host) and "gather_s" (packing, the
+    collective, unpacking on `dst` -- including the wait for the slowest rank to arrive)."""
     from . import alignToOCR as atocr
+    import time
     import torch.distributed as dist
     import warnings
+    t_start = time.perf_counter()
     recs = []
     by_model = {}
     for k, mdl in enumerate(my_models):
@@ -294,6 +420,7 @@ def process_shard(my_pages, my_transcripts, my_ids, my_models, capacity, seq_ali
                         fatal = exc1
                     recs.append(page_failed(my_ids[k]))
     local = np.concatenate(recs, axis=0) if recs else np.zeros((0, RECORD_FIELDS), np.int32)
+    t_pages = time.perf_counter()
     if device is None:
         nccl = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
         device = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
@@ -307,7 +434,13 @@ def process_shard(my_pages, my_transcripts, my_ids, my_models, capacity, seq_ali
         raise fatal
     if local.shape[0] > capacity:
         raise ValueError("more records (%d) than the agreed capacity (%d)" % (local.shape[0], capacity))
-    return None if out is None else unpack_gathered(out)
+    res = None if out is None else unpack_gathered(out)
+    if timings is not None:
+        if out is None and device.type == "cuda":
+            torch.cuda.current_stream(device).synchronize()      # (a sender's part of the gather is over when its stream is)
+        timings["pages_s"] = t_pages - t_start
+        timings["gather_s"] = time.perf_counter() - t_pages
+    return res
 
 
 def process_pages(pages, transcripts, ocropus_model, seq_align_params=None, group=None, dst=0):

@@ -14,6 +14,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench                                            # noqa: E402
 from text_alignment_amd import _native, ocr            # noqa: E402
+from tools import switches                               # noqa: E402
+
+switches.apply()             # TA_* environment variables -> the product modules' attributes
 
 
 def main():

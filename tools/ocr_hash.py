@@ -9,6 +9,9 @@ import numpy as np
 import torch
 
 from text_alignment_amd import ocr
+from tools import switches                               # noqa: E402
+
+switches.apply()             # TA_* environment variables -> the product modules' attributes
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(77)

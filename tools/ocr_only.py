@@ -8,6 +8,9 @@ import torch
 
 from bench import synthetic_lines
 from text_alignment_amd import ocr
+from tools import switches                               # noqa: E402
+
+switches.apply()             # TA_* environment variables -> the product modules' attributes
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
 prec = sys.argv[2] if len(sys.argv) > 2 else ocr.DEFAULT_PRECISION

@@ -10,6 +10,9 @@ import torch
 
 from bench import synthetic_lines
 from text_alignment_amd import _native, ocr
+from tools import switches                               # noqa: E402
+
+switches.apply()             # TA_* environment variables -> the product modules' attributes
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
 fr = [float(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0.125, 0.125, 0.25, 0.5]

@@ -1,0 +1,53 @@
+"""A/B of process_batch on synthetic pages by where the prepared rows lie: pageable numpy arrays (staged through the
+copy pool), page-locked RowBlocks, device RowBlocks.   python tools/pages_ab.py [npages] [reps]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from tools import pages_bench as pb, switches
+from text_alignment_amd import alignToOCR as atocr
+
+print("switches:", switches.apply())
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+rec = pb.make_recognizer()
+seeds = [100 + k for k in range(n)]
+inputs = {"numpy": tuple(zip(*[pb.make_page(sd) for sd in seeds]))}
+for kind in ("pinned", "device"):
+    pages, trs, blocks = pb.make_pages_in_blocks(seeds, kind)
+    inputs[kind] = (pages, trs, blocks)
+ref = None
+for name, inp in inputs.items():
+    pages, trs = list(inp[0]), list(inp[1])
+    for _ in range(3):
+        atocr.process_batch(pages, trs, rec, pb.PARAMS)
+    torch.cuda.synchronize()
+    ts, cpu = [], []
+    for _ in range(reps):
+        c0, t0 = time.process_time(), time.perf_counter()
+        res = atocr.process_batch(pages, trs, rec, pb.PARAMS)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+        cpu.append(time.process_time() - c0)
+    js = [atocr.to_JSON_dict(r[0], r[2]) for r in res]
+    if ref is None:
+        ref = js
+    busy = pb._device_busy_ms(lambda: atocr.process_batch(pages, trs, rec, pb.PARAMS))
+    dt = float(np.median(ts))
+    print("%-7s %7.1f pages/s  median %.2f ms (min %.2f)  host cpu %.2f ms/page  gpu busy %.1f ms (%.2f)  equal=%s"
+          % (name, n / dt, 1e3 * dt, 1e3 * min(ts), 1e3 * float(np.median(cpu)) / n, busy or -1, (busy or 0) * 1e-3 / dt, js == ref))
+if "--profile" in sys.argv:
+    import cProfile
+    import pstats
+    kind = sys.argv[sys.argv.index("--profile") + 1]
+    pages, trs = list(inputs[kind][0]), list(inputs[kind][1])
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(5):
+        atocr.process_batch(pages, trs, rec, pb.PARAMS)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(45)

@@ -25,8 +25,9 @@ def page_meta(seed, nlines=30):
     return widths, tr
 
 
-def make_page(seed, nlines=30, raw=False):
-    """raw = False: strips carry already-normalised (T, 48) rows (SURVEY 8d's OCR input);
+def make_page(seed, nlines=30, raw=False, block=None):
+    """raw = False: strips carry already-normalised (T, 48) rows (SURVEY 8d's OCR input) -- as pageable numpy arrays,
+    or, with `block` (a page.RowBlock, page-locked or device memory), as spans of that block (same values);
     raw = True: strips are 60-row uint8 images as the page cutter saves them (device normaliser)."""
     from text_alignment_amd import page as page_mod
     widths, tr = page_meta(seed, nlines)
@@ -41,9 +42,34 @@ def make_page(seed, nlines=30, raw=False):
             continue
         xs = np.zeros((w + 32, 48), dtype=np.float32)
         xs[16:16 + w] = (rng.random((w, 48), dtype=np.float32) < 0.15) * rng.random((w, 48), dtype=np.float32)
+        if block is not None:
+            sp = block.take(w + 32)
+            if block.kind == "pinned":
+                block.host[sp.start:sp.stop] = xs
+            else:
+                import torch
+                block.tensor[sp.start:sp.stop] = torch.from_numpy(xs).to(block.tensor.device)
+            xs = sp
         strips.append(page_mod.Strip(40, 100 + 120 * k, 60, width=2 * w, prepared=xs))
     peaks = [130 + 120 * k for k in range(nlines + 1)]
     return page_mod.PreparedPage((2200, 3300), (2200, 3300), 0, strips, peaks), tr
+
+
+def make_pages_in_blocks(seeds, kind="pinned", pages_per_block=16, nlines=30):
+    """make_page for every seed, the rows of `pages_per_block` consecutive pages in one RowBlock of `kind`;
+    returns (pages, transcripts, blocks)"""
+    from text_alignment_amd import page as page_mod
+    pages, trs, blocks = [], [], []
+    for a in range(0, len(seeds), pages_per_block):
+        part = seeds[a:a + pages_per_block]
+        rows = sum(sum(w + 32 for w in page_meta(sd, nlines)[0]) for sd in part)
+        block = page_mod.RowBlock(rows, kind=kind)
+        blocks.append(block)
+        for sd in part:
+            pg, tr = make_page(sd, nlines, block=block)
+            pages.append(pg)
+            trs.append(tr)
+    return pages, trs, blocks
 
 
 def make_page_image(seed, nlines=30):
@@ -83,11 +109,19 @@ def make_recognizer(seed=7001, no=40, precision=None):
     return ocr.LineRecognizer(model, precision=precision or ocr.DEFAULT_PRECISION)
 
 
-def setup_sharded(pages_per_rank, rank, world, seed0=100):
+ROWS_INPUT = {
+    "numpy": "prepared rows as pageable numpy arrays, one per strip (copied into page-locked staging by the copy pool)",
+    "pinned": "prepared rows in page-locked RowBlocks of 16 pages (text_alignment_amd.page.RowBlock): one DMA transfer per "
+              "block and chunk straight from where the loader wrote them, lines permuted on the device (csrc/ta_rows.hip)",
+    "device": "prepared rows in device-resident RowBlocks of 16 pages: nothing crosses PCIe"}
+
+
+def setup_sharded(pages_per_rank, rank, world, seed0=100, rows="pinned"):
     """BASELINE configs[4]: `pages_per_rank` x world synthetic pages, half read with a
     Salzinnes-shaped model (96 classes), half with a St-Gall-shaped one (64), sharded over the
     ranks by sharding.shard_plan.  Every rank builds only its own pages (the plan needs strip
-    widths and transcripts only).  Returns the arguments of sharding.process_shard + the transcripts."""
+    widths and transcripts only).  rows: where the strips' prepared rows lie (ROWS_INPUT).
+    Returns the arguments of sharding.process_shard + the transcripts."""
     import torch
     from text_alignment_amd import sharding
     total = pages_per_rank * world
@@ -97,9 +131,13 @@ def setup_sharded(pages_per_rank, rank, world, seed0=100):
     shards, capacity = sharding.shard_plan(costs, transcripts, world)
     mine = shards[rank]
     recs = [make_recognizer(7001, 96), make_recognizer(7002, 64)]
-    job = {"pages": [make_page(seed0 + k)[0] for k in mine], "transcripts": [transcripts[k] for k in mine],
+    if rows == "numpy":
+        pages, blocks = [make_page(seed0 + k)[0] for k in mine], []
+    else:
+        pages, _, blocks = make_pages_in_blocks([seed0 + k for k in mine], rows)
+    job = {"pages": pages, "transcripts": [transcripts[k] for k in mine], "blocks": blocks,
            "ids": mine, "models": [recs[k % 2] for k in mine], "capacity": capacity,
-           "all_transcripts": transcripts, "total_pages": total}
+           "all_transcripts": transcripts, "total_pages": total, "rows": rows, "input": ROWS_INPUT[rows]}
     for _ in range(3):                    # warm-up at full size (collective: every rank); the first calls of a process
         sharding.process_shard(job["pages"], job["transcripts"], mine, job["models"],      # pay for stream / queue
                                capacity, PARAMS)                                           # creation and allocator growth
@@ -107,12 +145,12 @@ def setup_sharded(pages_per_rank, rank, world, seed0=100):
     return job
 
 
-def run_sharded(job):
+def run_sharded(job, timings=None):
     """one timed pass: this rank's share through process_batch (one batch per model) and the single
     gather; returns the gathered records on rank 0, None elsewhere"""
     from text_alignment_amd import sharding
     return sharding.process_shard(job["pages"], job["transcripts"], job["ids"], job["models"],
-                                  job["capacity"], PARAMS)
+                                  job["capacity"], PARAMS, timings=timings)
 
 
 def _device_busy_ms(fn):
@@ -166,6 +204,27 @@ def run(npages, seed0=100):
     torch.cuda.synchronize()
     dt, res, cpu_s = median_of(10, list(pages), list(trs))
     busy_ms = _device_busy_ms(lambda: atocr.process_batch(list(pages), list(trs), rec, PARAMS))
+    # the same pages with their rows where a GPU-side loader puts them: page-locked blocks (no host copy), device blocks
+    from tools import pages_check
+    in_place = {}
+    for kind in ("pinned", "device"):
+        bpages, btrs, blocks = make_pages_in_blocks([seed0 + k for k in range(npages)], kind)
+        for _ in range(3):
+            atocr.process_batch(bpages, btrs, rec, PARAMS)
+        torch.cuda.synchronize()
+        bdt, bres, bcpu = median_of(10, bpages, btrs)
+        bbusy = _device_busy_ms(lambda: atocr.process_batch(bpages, btrs, rec, PARAMS))
+        in_place[kind] = {"input": ROWS_INPUT[kind], "pages_per_s": npages / bdt, "seconds": bdt,
+                          "host": {"cpu_ms_per_page": 1e3 * bcpu / npages, "cpu_over_wall": bcpu / bdt,
+                                   "gpu_busy_ms_per_pass": bbusy, "gpu_busy_frac": (bbusy * 1e-3 / bdt) if bbusy else None},
+                          "equal_to_numpy_input": [atocr.to_JSON_dict(r[0], r[2]) for r in bres] ==
+                                                  [atocr.to_JSON_dict(r[0], r[2]) for r in res]}
+        if kind == "pinned":
+            in_place[kind].update(pages_check.check_pages(
+                [atocr.to_JSON_dict(r[0], r[2]) for r in bres], bpages, btrs, [rec.model] * npages, PARAMS, [1, npages - 1]))
+        del bpages, bres, blocks
+    checked = pages_check.check_pages([atocr.to_JSON_dict(r[0], r[2]) for r in res], pages, trs, [rec.model] * npages,
+                                      PARAMS, [0, npages // 2])
     # BASELINE configs[2]: one page end to end (30 strips + one NW problem), latency of a lone call
     import gc
     gc.collect()                               # a generation-2 collection in mid-call costs ~20 ms
@@ -205,7 +264,9 @@ def run(npages, seed0=100):
     torch.cuda.synchronize()
     img_dt, _, img_cpu = median_of(10, ipages, itrs)
     out = {"pages": npages, "precision": {0: "f32", 1: "split", 3: "f64"}[rec.mode], "seconds": dt,
+           "input": ROWS_INPUT["numpy"],
            "pages_per_s": npages / dt, "lines_per_s": npages * 30 / dt,
+           "pinned_rows": in_place["pinned"], "device_rows": in_place["device"],
            "single_page_ms": lat_ms,
            "host": {"cpu_ms_per_page": 1e3 * cpu_s / npages, "cpu_s_per_pass": cpu_s,
                     "cpu_over_wall": cpu_s / dt, "threads_alive": threading.active_count(),
@@ -220,6 +281,8 @@ def run(npages, seed0=100):
            "raw_strips": {"pages_per_s": npages / raw_dt, "seconds": raw_dt, "host_cpu_ms_per_page": 1e3 * raw_cpu / npages,
                           "note": "strips as 60-row uint8 images, normalised by csrc/ta_lineest.hip"},
            "syllable_boxes": sum(len(r[0]) for r in res),
+           "pages_checked": checked["pages_checked"], "pages_equal_to_oracle": checked["pages_equal_to_oracle"],
+           "check": checked,
            "timing": "median of 10 passes after warm-up, each a whole process_batch call incl. the final synchronize",
            "note": "process_batch end to end: host upload + K3/K4/K5 + NW + host glue (numpy arrays, page_batch.py), "
                    "chunks of pages pipelined (host stage of one chunk under the device stage of the next)"}
@@ -229,6 +292,8 @@ def run(npages, seed0=100):
 
 
 if __name__ == "__main__":
+    from tools import switches
+    switches.apply()             # TA_* environment variables -> the product modules' attributes
     n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 64
     print(run(n))
     if "--profile" in sys.argv:

@@ -11,6 +11,9 @@ from text_alignment_amd import alignToOCR as atocr
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 from text_alignment_amd import textAlignPreprocessing as preproc
+from tools import switches                               # noqa: E402
+
+switches.apply()             # TA_* environment variables -> the product modules' attributes
 if len(sys.argv) > 2:
     preproc.PAGES_PER_BATCH = int(sys.argv[2])
 if len(sys.argv) > 3:

@@ -9,6 +9,9 @@ import torch
 
 from tools import pages_bench as pb
 from text_alignment_amd import alignToOCR as atocr
+from tools import switches                               # noqa: E402
+
+switches.apply()             # TA_* environment variables -> the product modules' attributes
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 rec = pb.make_recognizer()
