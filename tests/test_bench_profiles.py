@@ -33,7 +33,7 @@ def test_no_round_is_spelled_out_in_bench_py():
     with open(os.path.join(REPO, "bench.py")) as f:
         src = f.read()
     code = "\n".join(re.sub(r"\s+# .*$", "", ln) for ln in src.splitlines() if not ln.lstrip().startswith("#"))
-    hits = re.findall(r"[\"']r0\d_[a-z0-9_]+\.(?:json|txt|csv)", code) + re.findall(r"profiles/r0\d_", code)
+    hits = re.findall(r"[\"']r0\d_[a-z0-9_]+\.(?:json|txt|csv)", code) + re.findall(r"profiles/r0\d_[a-z0-9_]+", code)
     # (peak_is strings name the microbenchmark records that established a hardware rate: documentation, not data read here)
     hits = [h for h in hits if "mfma_f64" not in h]
     assert not hits, hits
