@@ -627,7 +627,7 @@ def main():
     if args.pages > 0:
         from tools import pages_bench
         job = pages_bench.setup_sharded(args.pages, rank, world, seed0=100, rows=args.page_rows)
-        sh_all, mine_s, gather_s, cpu_s = [], [], [], []
+        sh_all, mine_s, gather_s, cpu_s, wait_s = [], [], [], [], []
         for _ in range(10):         # median of ten passes, each barrier to barrier over every rank incl. the gather
             barrier()
             tm = {}
@@ -638,6 +638,7 @@ def main():
             sh_all.append(reduce_max(time.perf_counter() - t1))
             mine_s.append(tm["pages_s"])
             gather_s.append(tm["gather_s"])
+            wait_s.append(tm["device_wait_s"])
         sh_dt = float(np.median(sh_all))
         # per-rank diagnosis, after the timed passes: one pass under the device profiler (every rank: the gather is collective)
         # and ONE all_gather of a fixed vector per rank -- a straggler or a starved rank must be readable from this line
@@ -646,7 +647,8 @@ def main():
         vec = [float(np.median(mine_s)), float(np.median(gather_s)), 1e3 * float(np.median(cpu_s)) / max(len(job["ids"]), 1),
                (busy_ms * 1e-3 / float(np.median(mine_s))) if busy_ms else -1.0, float(len(cpus_now)), float(cpus_now[0]),
                float(cpus_now[-1]), float(-1 if placement.get("numa_node") is None else placement["numa_node"]),
-               1.0 if placement.get("bound") else 0.0, float(len(job["ids"])), float(dev_index)]
+               1.0 if placement.get("bound") else 0.0, float(len(job["ids"])), float(dev_index),
+               1e3 * float(np.median(np.array(mine_s) - np.array(wait_s))) / max(len(job["ids"]), 1)]
         mine_t = torch.tensor(vec, dtype=torch.float64, device=red_dev)
         if dist is not None:
             every = torch.zeros(world * len(vec), dtype=torch.float64, device=red_dev)
@@ -680,10 +682,14 @@ def main():
                                           "is": "pack + the ONE gather + unpack on rank 0, per rank; includes waiting for the slowest rank to arrive"},
                        "per_rank": [{"rank": r, "device": int(every[r, 10]), "pages": int(every[r, 9]), "seconds": float(every[r, 0]),
                                      "gather_seconds": float(every[r, 1]), "host_cpu_ms_per_page": float(every[r, 2]),
+                                     "host_work_ms_per_page": float(every[r, 11]),
                                      "gpu_busy_frac": (float(every[r, 3]) if every[r, 3] >= 0 else None),
                                      "cpus": "%d in %d..%d" % (every[r, 4], every[r, 5], every[r, 6]),
                                      "numa_node": (int(every[r, 7]) if every[r, 7] >= 0 else None), "bound": bool(every[r, 8])}
                                     for r in range(world)],
+                       "per_rank_is": "seconds: the rank's own share; host_work_ms_per_page: (that - the main thread's waits for its GPU) "
+                                      "/ pages -- the figure that must stay flat as ranks are added; host_cpu_ms_per_page: process CPU "
+                                      "time of ALL threads (runtime helpers and any spin-waiting included)",
                        "placement_rank0": placement,
                        "note": "sharding.process_shard: process_batch per model on this rank's pages + ONE "
                                "gather of [page, syllable, ulx, uly, lrx, lry] records to rank 0"}

@@ -305,6 +305,11 @@ def test_binding_plan_slices_a_numa_node_among_its_ranks():
     assert all(len(g) == 32 for g in got)
     assert set().union(*got[:4]) == cpus_of[0] and set().union(*got[4:]) == cpus_of[1]
     assert all(not (set(got[a]) & set(got[b])) for a in range(8) for b in range(a))
+    # with the core map, a slice is whole cores: cpu c and its SMT sibling c + 128 always land in the same rank's slice
+    core_of = {c: c % 128 for c in range(256)}
+    smt = [sh.plan_binding(node_of, cpus_of, every, r, 8, core_of=core_of) for r in range(8)]
+    assert all(len(g) == 32 and {c % 128 for c in g} == {c % 128 for c in g if c < 128} and len({c % 128 for c in g}) == 16 for g in smt)
+    assert all(not (set(smt[a]) & set(smt[b])) for a in range(8) for b in range(a))
     # a container that owns 16 cpus of node 0 only: ranks on node 0 share them (slices of 4 are the floor), node 1 has none
     few = set(range(0, 12))
     assert sh.plan_binding(node_of, cpus_of, few, 1, 8) == sorted(few)

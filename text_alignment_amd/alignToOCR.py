@@ -384,6 +384,10 @@ PIPELINE_CHUNK_PAGES = 16
 PIPELINE_CHUNK_PAGES_RAW = 32        # raw strips: the device normaliser in front
 PIPELINE_CHUNK_PAGES_IMAGES = 64
 _side_streams = {}
+WAIT_SECONDS = [0.0]                 # wall seconds the calling thread has spent WAITING for the device inside process_batch (a
+                                     # running total: callers take differences): a pass's wall time minus this is its host work
+BLOCKING_WAITS = True                # the pipeline's waits for the device SLEEP (hipEventBlockingSync) instead of spinning: eight
+                                     # ranks on one host do not each burn a core while their GPU works (and host-CPU figures count work)
 SPLIT_FINISH = True                  # the second stage of a chunk split around the next chunk's launch
 TWO_STREAMS = True                   # consecutive chunks' recogniser kernels on two compute streams
 
@@ -527,6 +531,13 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     return deliver()
 
 
+def _timed_wait(event):
+    import time
+    t0 = time.perf_counter()
+    event.synchronize()
+    WAIT_SECONDS[0] += time.perf_counter() - t0
+
+
 def _pb_begin(rec, pages, transcripts, seq_align_params, workers):
     """first stage of process_batch for one chunk, host part: line finding, the layout of the chunk's rows, the staging
     copies STARTED (pool threads), and the host work that needs no OCR result"""
@@ -563,7 +574,7 @@ def _pb_launch(ctx):
         host[key] = torch.empty(st[key].shape, dtype=st[key].dtype, pin_memory=True)
         host[key].copy_(st[key], non_blocking=True)
     ctx["host"] = host
-    ctx["done"] = torch.cuda.Event()
+    ctx["done"] = torch.cuda.Event(blocking=BLOCKING_WAITS)
     ctx["done"].record()
 
 
@@ -582,7 +593,7 @@ def _pb_finish_a(ctx):
 
     # ---- every character of every line: code points + boxes (alignToOCR.py:160-182) ----
     nlines = len(all_strips)
-    ctx["done"].synchronize()
+    _timed_wait(ctx["done"])
     dec_t = ctx["host"]["dec_t"].numpy()
     dec_c = ctx["host"]["dec_c"].numpy()
     rec.check_status(ctx["host"]["dec_n"].numpy())       # the device's status word travels behind the counts
@@ -613,7 +624,7 @@ def _pb_finish_a(ctx):
                                 [np.searchsorted(alphabet, a).astype(np.int32) for a in o_cp],
                                 [int(v) for v in params])
             batch.run()
-            batch.fetch_begin()
+            batch.fetch_begin(blocking=BLOCKING_WAITS)
             ctx["nw"] = batch
         except OverflowError:
             pass
@@ -634,6 +645,8 @@ def _pb_finish_b(ctx, indices_out, arrays_out):
             for r in res:
                 arrays_out.append(np.array([[b.ulx, b.uly, b.lrx, b.lry] for b in r[0]], dtype=np.int64).reshape(-1, 4))
         return res
+    if getattr(ctx["nw"], "_fetched", None) is not None:
+        _timed_wait(ctx["nw"]._fetched)
     all_ops = ctx["nw"].results()
     ctx["nw"] = None
     texts, idxs, boxes = ctx["texts"], ctx["idxs"], ctx["boxes"]

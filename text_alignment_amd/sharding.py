@@ -55,12 +55,26 @@ def gpu_numa_node(device_index, sysfs="/sys/bus/pci/devices"):
     return node, cpus
 
 
-def plan_binding(node_of_device, cpus_of_node, allowed, local_rank, local_world, min_slice=4):
+def cpu_cores(cpus, sysfs="/sys/devices/system/cpu"):
+    """cpu -> the lowest-numbered hardware thread of its physical core (thread_siblings_list); {} where sysfs is silent"""
+    import os
+    out = {}
+    for c in cpus:
+        try:
+            with open(os.path.join(sysfs, "cpu%d" % c, "topology", "thread_siblings_list")) as f:
+                out[c] = min(_cpulist(f.read()))
+        except (OSError, ValueError):
+            pass
+    return out
+
+
+def plan_binding(node_of_device, cpus_of_node, allowed, local_rank, local_world, min_slice=4, core_of=None):
     """The cpus rank `local_rank` binds to (pure function; tests/test_sharding.py): the cpus of its GPU's NUMA node that
     the process may use at all (`allowed`: the affinity mask it was started with, i.e. the container's share), cut into
     equal contiguous slices among the local ranks whose GPUs sit on the same node -- unless a slice would be smaller than
     `min_slice` cpus (the main thread, the copy pool, the runtime's helper threads), in which case the ranks of a node
-    share all of it.  None: no binding (unknown topology, or nothing left after the intersection)."""
+    share all of it.  core_of (cpu -> id of its physical core, `cpu_cores()`): slices are cut along cores, SMT siblings
+    together.  None: no binding (unknown topology, or nothing left after the intersection)."""
     node = node_of_device.get(local_rank)
     if node is None or node not in cpus_of_node:
         return None
@@ -71,8 +85,12 @@ def plan_binding(node_of_device, cpus_of_node, allowed, local_rank, local_world,
     share = len(cpus) // max(len(peers), 1)
     if len(peers) <= 1 or share < min_slice:
         return cpus
+    # whole CORES per rank: the hardware threads of a core stay together (cpu 64 and its sibling 192 in one slice), so that
+    # two ranks' main threads never time-share one core's pipelines
+    core = core_of or {}
+    cpus.sort(key=lambda c: (core.get(c, c), c))
     at = peers.index(local_rank)
-    return cpus[at * share:(at + 1) * share]
+    return sorted(cpus[at * share:(at + 1) * share])
 
 
 def bind_to_gpu_node(device_index=None, local_rank=None, local_world=None, num_threads=1):
@@ -111,7 +129,8 @@ def bind_to_gpu_node(device_index=None, local_rank=None, local_world=None, num_t
         if node is not None:
             cpus_of[node] = cpus
     out["numa_node"] = node_of.get(local_rank)
-    want = plan_binding(node_of, cpus_of, os.sched_getaffinity(0), local_rank, local_world)
+    want = plan_binding(node_of, cpus_of, os.sched_getaffinity(0), local_rank, local_world,
+                        core_of=cpu_cores(os.sched_getaffinity(0)))
     if want is None:
         out["reason"] = "the host does not name a NUMA node for this GPU (or none of its cpus is ours): affinity left as started"
         return out
@@ -340,12 +359,13 @@ def process_shard(my_pages, my_transcripts, my_ids, my_models, capacity, seq_ali
     box records to rank `dst`.  `capacity` must be the same on every rank (shard_plan).  Returns
     the concatenated records on `dst`, None elsewhere.  timings (a dict, optional) receives this rank's
     wall seconds of the two parts: "pages_s" (its share, results on the host) and "gather_s" (packing, the
-    collective, unpacking on `dst` -- including the wait for the slowest rank to arrive)."""
+    collective, unpacking on `dst` -- including the wait for the slowest rank to arrive), and "device_wait_s": the part
+    of pages_s this thread spent waiting for its GPU (pages_s minus it = the share's host work)."""
     from . import alignToOCR as atocr
     import time
     import torch.distributed as dist
     import warnings
-    t_start = time.perf_counter()
+    t_start, w_start = time.perf_counter(), atocr.WAIT_SECONDS[0]
     recs = []
     by_model = {}
     for k, mdl in enumerate(my_models):
@@ -439,6 +459,7 @@ def process_shard(my_pages, my_transcripts, my_ids, my_models, capacity, seq_ali
         if out is None and device.type == "cuda":
             torch.cuda.current_stream(device).synchronize()      # (a sender's part of the gather is over when its stream is)
         timings["pages_s"] = t_pages - t_start
+        timings["device_wait_s"] = atocr.WAIT_SECONDS[0] - w_start
         timings["gather_s"] = time.perf_counter() - t_pages
     return res
 
