@@ -70,17 +70,27 @@ def _line_kernels(h):
     return _kernels[h]
 
 
-def normalize_strips(strips, device="cuda", want_debug=False, layout=None):
-    """strips: list of 2-D uint8 images (white background), each a host array or a tensor already on
-    the device.  Returns (x, T, debug): x = float32
-    device tensor [sum T, 48] (line b owns rows sum(T[:b]) .. + T[b]; or, with `layout`, rows
-    layout(T)[b] .. + T[b] -- a permutation of those ranges, for a caller that wants the lines in an order of
-    its own: the output widths are only known in here), T = int64 array of timesteps (normalised width + 32)."""
+class MeasuredStrips(object):
+    """State between the two passes of the normaliser: the strips' pixels and the measuring pass's results on the device,
+    the output widths on the host (`wo`; T = wo + 32 timesteps).  resample_strips() turns any run of strips [a, b) of it
+    into recogniser rows without another wait for the device."""
+    __slots__ = ("n", "dev", "d_pix", "d_pix_off", "d_hh", "d_ww", "d_col_off", "center", "minmax", "r", "wout",
+                 "arg", "col_off", "wo", "T")
+
+
+def measure_strips(strips, device="cuda"):
+    """First pass (ta_linenorm_measure) over `strips` -- 2-D uint8 images (white background), each a host array or a
+    tensor already on the device: centre line, band height and OUTPUT WIDTH of every strip.  The widths are
+    data-dependent and the caller sizes its buffers with them, so this pass ends with the one wait for the device the
+    normaliser needs; a caller with many chunks of strips (alignToOCR.process_batch) measures all of them here, once."""
     dev = torch.device(device)
     lib = _native.lib
     n = len(strips)
+    ms = MeasuredStrips()
+    ms.n, ms.dev = n, dev
     if n == 0:
-        return torch.zeros((0, TARGET_HEIGHT), dtype=torch.float32, device=dev), np.zeros(0, np.int64), {}
+        ms.wo = ms.T = np.zeros(0, np.int64)
+        return ms
     hh = np.zeros(n, np.int32); ww = np.zeros(n, np.int32)
     on_device = [isinstance(s, torch.Tensor) for s in strips]
     for k, s in enumerate(strips):
@@ -118,42 +128,76 @@ def normalize_strips(strips, device="cuda", want_debug=False, layout=None):
         d_pix = _upload_host_strips(strips, pix_off, dev)
     else:
         d_pix = torch.cat([s.reshape(-1) if on_device[k] else up(np.asarray(s).ravel()) for k, s in enumerate(strips)])
-    d_pix_off, d_hh, d_ww = up(pix_off[:-1].copy()), up(hh), up(ww)
-    d_gw, d_gw_off, d_gr, d_col_off = up(gw), up(gw_off), up(gr), up(col_off[:-1].copy())
-    d_ws_off = up(3 * pix_off[:-1])
+    # the batch's metadata in one transfer (nine small arrays: a `.to(device)` from pageable memory each was 2 ms of host time)
+    (ms.d_pix_off, ms.d_hh, ms.d_ww, d_gw, d_gw_off, d_gr, ms.d_col_off, d_ws_off) = _native.upload_packed(
+        [pix_off[:-1].copy(), hh, ww, gw, gw_off, gr, col_off[:-1].copy(), 3 * pix_off[:-1]], dev)
     ws = torch.empty(3 * int(pix_off[-1]), dtype=torch.float64, device=dev)
-    arg = torch.empty(int(col_off[-1]), dtype=torch.int32, device=dev)
-    center = torch.empty_like(arg)
-    minmax = torch.empty(2 * n, dtype=torch.int32, device=dev)
-    r = torch.empty(n, dtype=torch.int32, device=dev)
-    wout = torch.empty(n, dtype=torch.int32, device=dev)
+    ms.arg = torch.empty(int(col_off[-1]), dtype=torch.int32, device=dev)
+    ms.center = torch.empty_like(ms.arg)
+    sizes = torch.empty(3 * n, dtype=torch.int32, device=dev)          # wout [n] | minmax [2 n]: read back in one piece
+    ms.wout, ms.minmax = sizes[:n], sizes[n:]
+    ms.r = torch.empty(n, dtype=torch.int32, device=dev)
+    ms.d_pix, ms.col_off = d_pix, col_off
     stream = torch.cuda.current_stream(dev).cuda_stream
     _native.check(lib.ta_linenorm_measure(
-        d_pix.data_ptr(), d_pix_off.data_ptr(), d_hh.data_ptr(), d_ww.data_ptr(), n,
+        d_pix.data_ptr(), ms.d_pix_off.data_ptr(), ms.d_hh.data_ptr(), ms.d_ww.data_ptr(), n,
         d_gw.data_ptr(), d_gw_off.data_ptr(), d_gr.data_ptr(), ws.data_ptr(), d_ws_off.data_ptr(),
-        arg.data_ptr(), center.data_ptr(), d_col_off.data_ptr(), minmax.data_ptr(),
-        r.data_ptr(), wout.data_ptr(), stream), "ta_linenorm_measure")
-    sized = torch.cat([wout, minmax]).cpu().numpy()       # output sizes are data-dependent: one small sync
-    wo = sized[:n].astype(np.int64)
+        ms.arg.data_ptr(), ms.center.data_ptr(), ms.d_col_off.data_ptr(), ms.minmax.data_ptr(),
+        ms.r.data_ptr(), ms.wout.data_ptr(), stream), "ta_linenorm_measure")
+    sized = sizes.cpu().numpy()                           # output sizes are data-dependent: THE wait of the normaliser
+    ms.wo = sized[:n].astype(np.int64)
     if bool((sized[n::2] == sized[n + 1::2]).any()):      # the measuring pass found a strip's minimum = its maximum
         raise ValueError("empty or constant text-line image")
     del ws
-    T = wo + 2 * PAD
+    ms.T = ms.wo + 2 * PAD
+    return ms
+
+
+def resample_strips(ms, a=0, b=None, layout=None):
+    """Second pass (ta_linenorm_resample) over strips [a, b) of a measured batch: (x, T) with x = float32 device tensor
+    [sum T, 48] -- strip a + k owns rows sum(T[:k]) .. + T[k], or, with `layout`, rows layout(T)[k] .. + T[k] (a
+    permutation of those ranges, for a caller that wants the lines in an order of its own).  Enqueues on torch's current
+    stream and waits for nothing: every size is known from the measuring pass."""
+    b = ms.n if b is None else b
+    n = b - a
+    dev = ms.dev
+    if n <= 0:
+        return torch.zeros((0, TARGET_HEIGHT), dtype=torch.float32, device=dev), np.zeros(0, np.int64)
+    wo, T = ms.wo[a:b], ms.T[a:b]
     row_off = np.zeros(n + 1, np.int64); np.cumsum(T, out=row_off[1:])
     row_start = row_off[:-1].copy() if layout is None else np.ascontiguousarray(layout(T), dtype=np.int64)
     tmp_off = np.zeros(n + 1, np.int64); np.cumsum(wo * TARGET_HEIGHT, out=tmp_off[1:])
     tmp = torch.empty(max(int(tmp_off[-1]), 1), dtype=torch.float32, device=dev)
     omax = torch.empty(n, dtype=torch.int32, device=dev)
     x = torch.empty((int(row_off[-1]), TARGET_HEIGHT), dtype=torch.float32, device=dev)
-    d_tmp_off, d_row_off = up(tmp_off[:-1].copy()), up(row_start)     # named: they must outlive the launch
-    _native.check(lib.ta_linenorm_resample(
-        d_pix.data_ptr(), d_pix_off.data_ptr(), d_hh.data_ptr(), d_ww.data_ptr(), n,
-        center.data_ptr(), d_col_off.data_ptr(), minmax.data_ptr(), r.data_ptr(), wout.data_ptr(),
-        tmp.data_ptr(), d_tmp_off.data_ptr(), omax.data_ptr(), x.data_ptr(),
+    d_tmp_off, d_row_off = _native.upload_packed([tmp_off[:-1].copy(), row_start], dev)     # named: they must outlive the launch
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    # the per-strip arrays of the measured batch, from strip `a` on (their offsets into pix / center are absolute)
+    _native.check(_native.lib.ta_linenorm_resample(
+        ms.d_pix.data_ptr(), ms.d_pix_off.data_ptr() + 8 * a, ms.d_hh.data_ptr() + 4 * a, ms.d_ww.data_ptr() + 4 * a, n,
+        ms.center.data_ptr(), ms.d_col_off.data_ptr() + 8 * a, ms.minmax.data_ptr() + 8 * a, ms.r.data_ptr() + 4 * a,
+        ms.wout.data_ptr() + 4 * a, tmp.data_ptr(), d_tmp_off.data_ptr(), omax.data_ptr(), x.data_ptr(),
         d_row_off.data_ptr(), stream), "ta_linenorm_resample")
+    return x, T
+
+
+def normalize_strips(strips, device="cuda", want_debug=False, layout=None):
+    """strips: list of 2-D uint8 images (white background), each a host array or a tensor already on
+    the device.  Returns (x, T, debug): x = float32
+    device tensor [sum T, 48] (line b owns rows sum(T[:b]) .. + T[b]; or, with `layout`, rows
+    layout(T)[b] .. + T[b] -- a permutation of those ranges, for a caller that wants the lines in an order of
+    its own: the output widths are only known in here), T = int64 array of timesteps (normalised width + 32).
+    measure_strips + resample_strips over the whole list."""
+    dev = torch.device(device)
+    n = len(strips)
+    if n == 0:
+        return torch.zeros((0, TARGET_HEIGHT), dtype=torch.float32, device=dev), np.zeros(0, np.int64), {}
+    ms = measure_strips(strips, dev)
+    x, T = resample_strips(ms, 0, n, layout)
     debug = {}
     if want_debug:
-        c = center.cpu().numpy()
-        debug = {"center": [c[col_off[k]:col_off[k + 1]] for k in range(n)], "r": r.cpu().numpy(),
-                 "arg": [arg.cpu().numpy()[col_off[k]:col_off[k + 1]] for k in range(n)]}
+        c = ms.center.cpu().numpy()
+        col_off = ms.col_off
+        debug = {"center": [c[col_off[k]:col_off[k + 1]] for k in range(n)], "r": ms.r.cpu().numpy(),
+                 "arg": [ms.arg.cpu().numpy()[col_off[k]:col_off[k + 1]] for k in range(n)]}
     return x, T, debug

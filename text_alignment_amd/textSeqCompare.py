@@ -233,17 +233,16 @@ class NWBatch(object):
         return {1: "nw_trace2_kernel", 2: "nw_trace2w_kernel<2>", 4: "nw_trace2w_kernel<4>", 3: "nw_trace2h_kernel",
                 5: "nw_trace2hw_kernel<2>", 6: "nw_trace2hw_kernel<4>"}[w]
 
-    def fetch_begin(self, blocking=False):
+    def fetch_begin(self):
         """start the download of the alignment columns (pinned buffers, an event on the current stream); `results()` then
-        only waits for that event -- a caller with other host work puts it in between.  blocking: the wait SLEEPS instead
-        of spinning (a rank of a multi-process job does not burn a core while its GPU works)"""
+        only waits for that event -- a caller with other host work puts it in between"""
         if self.nprob == 0:
             return
         self._host_ops = torch.empty(self.ops.shape, dtype=self.ops.dtype, pin_memory=True)
         self._host_len = torch.empty(self.ops_len.shape, dtype=self.ops_len.dtype, pin_memory=True)
         self._host_ops.copy_(self.ops, non_blocking=True)
         self._host_len.copy_(self.ops_len, non_blocking=True)
-        self._fetched = torch.cuda.Event(blocking=bool(blocking))
+        self._fetched = torch.cuda.Event()
         self._fetched.record()
 
     def results(self):

@@ -14,7 +14,6 @@ environment is the only handle -- so THEY translate it, once, after importing th
     TA_PAGE_CHUNK_IMAGES=n     alignToOCR.PIPELINE_CHUNK_PAGES_IMAGES   ... page images
     TA_PB_SPLIT_FINISH=0|1     alignToOCR.SPLIT_FINISH    second stage split around the next chunk's launch
     TA_PB_TWO_STREAMS=0|1      alignToOCR.TWO_STREAMS     consecutive chunks on two compute streams
-    TA_PB_BLOCKING=0|1         alignToOCR.BLOCKING_WAITS  the pipeline's device waits sleep instead of spinning
 """
 import os
 
@@ -45,7 +44,7 @@ def apply(environ=None):
         v = env.get(var)
         if v and v.isdigit() and int(v) > 0:
             put(atocr, attr, int(v))
-    for var, attr in (("TA_PB_SPLIT_FINISH", "SPLIT_FINISH"), ("TA_PB_TWO_STREAMS", "TWO_STREAMS"), ("TA_PB_BLOCKING", "BLOCKING_WAITS")):
+    for var, attr in (("TA_PB_SPLIT_FINISH", "SPLIT_FINISH"), ("TA_PB_TWO_STREAMS", "TWO_STREAMS")):
         v = env.get(var)
         if v in ("0", "1"):
             put(atocr, attr, v == "1")
