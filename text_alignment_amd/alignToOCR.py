@@ -464,26 +464,9 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     C = PIPELINE_CHUNK_PAGES_IMAGES if images else (PIPELINE_CHUNK_PAGES_RAW if raw else PIPELINE_CHUNK_PAGES)
     chunks = plan_chunks(list(groups.values()), C)
     out_res, out_idx, out_arr = [None] * n, [None] * n, [None] * n
-    # Raw strips: the normaliser's output widths are data-dependent, and reading them back is a wait for the device that,
-    # taken chunk by chunk, queues behind the previous chunk's recurrence.  So the MEASURING pass (ta_linenorm_measure,
-    # ~0.04 ms per strip) runs for the strips of many chunks at once, before their pipeline starts -- one wait per
-    # MEASURE_MAX_PIXELS of strips, not one per chunk -- and every chunk then resamples its own strips on its own
-    # compute stream with all sizes known.
-    premeasured = {}
-    if raw and len(chunks) > 1 and all(st.prepared is None for pg in pages for st in pg.strips):
-        premeasured = _plan_measure_groups(chunks, pages)
-
     def begin(job):
         rec, ks = job
-        pre = None
-        grp = premeasured.get(id(job))
-        if grp is not None:
-            if grp["ms"] is None:
-                from . import lineest_gpu
-                grp["ms"] = lineest_gpu.measure_strips(grp["lines"], device=rec.device)
-            a, b = grp["range"][id(job)]
-            pre = {"ms": grp["ms"], "a": a, "b": b, "lines": grp["lines"][a:b], "widths": grp["widths"][a:b]}
-        ctx = _pb_begin(rec, [pages[k] for k in ks], [transcripts[k] for k in ks], seq_align_params, parallel, pre)
+        ctx = _pb_begin(rec, [pages[k] for k in ks], [transcripts[k] for k in ks], seq_align_params, parallel)
         ctx["page_ids"] = ks
         return ctx
 
@@ -545,29 +528,6 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     return deliver()
 
 
-MEASURE_MAX_PIXELS = 400 << 20       # strips measured per wait: the measuring pass holds 24 bytes of float64 scratch per pixel
-
-
-def _plan_measure_groups(chunks, pages):
-    """{id(chunk): group}: consecutive chunks whose raw strips are measured together (up to MEASURE_MAX_PIXELS per group);
-    group = {"lines": raw pixel arrays in chunk order, "widths", "range": {id(chunk): (first, end) strip}, "ms": None
-    until the group's first chunk begins}"""
-    out, grp, npix = {}, None, 0
-    for job in chunks:
-        strips = [st for k in job[1] for st in pages[k].strips]
-        prepared = page_mod.prepared_lines(strips)
-        px = sum(int(ln.shape[0]) * int(ln.shape[1]) for ln, _ in prepared)
-        if grp is None or npix + px > MEASURE_MAX_PIXELS:
-            grp, npix = {"lines": [], "widths": [], "range": {}, "ms": None}, 0
-        a = len(grp["lines"])
-        grp["lines"] += [ln for ln, _ in prepared]
-        grp["widths"] += [w for _, w in prepared]
-        grp["range"][id(job)] = (a, len(grp["lines"]))
-        npix += px
-        out[id(job)] = grp
-    return out
-
-
 def _timed_wait(event):
     import time
     t0 = time.perf_counter()
@@ -575,24 +535,18 @@ def _timed_wait(event):
     WAIT_SECONDS[0] += time.perf_counter() - t0
 
 
-def _pb_begin(rec, pages, transcripts, seq_align_params, workers, pre=None):
+def _pb_begin(rec, pages, transcripts, seq_align_params, workers):
     """first stage of process_batch for one chunk, host part: line finding, the layout of the chunk's rows, the staging
-    copies STARTED (pool threads), and the host work that needs no OCR result.  pre: the chunk's raw strips as
-    process_batch measured them beforehand (their pixel arrays, widths and place in a lineest_gpu.MeasuredStrips)"""
+    copies STARTED (pool threads), and the host work that needs no OCR result"""
     from . import page_batch as pb
     raw_dims = [_raw_dim(pg) for pg in pages]            # bad page types fail before any GPU work
     found = find_lines_all(list(pages), workers=workers)
     strips_per_page = [f[3] for f in found]
     all_strips = [st for strips in strips_per_page for st in strips]
-    if pre is not None:
-        lines, widths = pre["lines"], pre["widths"]
-        assert len(lines) == len(all_strips)
-        st = rec.prepare(lines, defer=True, measured=(pre["ms"], pre["a"], pre["b"]))
-    else:
-        prepared = page_mod.prepared_lines(all_strips, workers=workers)
-        lines = [xs for xs, _ in prepared]
-        widths = [w for _, w in prepared]
-        st = rec.prepare(lines, defer=True)
+    prepared = page_mod.prepared_lines(all_strips, workers=workers)
+    lines = [xs for xs, _ in prepared]
+    widths = [w for _, w in prepared]
+    st = rec.prepare(lines, defer=True)
     syls_all = [latsyl.syllabify_text(tr) for tr in transcripts]
     t_cp = [np.frombuffer(tr.encode('utf-32-le'), dtype='<u4').astype(np.int64) for tr in transcripts]
     return {"rec": rec, "pages": pages, "transcripts": transcripts, "params": seq_align_params, "raw_dims": raw_dims,

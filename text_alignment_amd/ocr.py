@@ -481,15 +481,12 @@ class LineRecognizer(object):
         return {"src": src, "keep": keep, "done": done, "rows": rows}
 
     # ---- batched device pass -------------------------------------------------------------
-    def prepare(self, lines, defer=False, measured=None):
+    def prepare(self, lines, defer=False):
         """Upload lines and allocate outputs.  A line is either a prepared (T, 48) float array
         (ink = 1, padded) or a raw 2-D uint8 strip (white background; a host array or a tensor already
         on the device), which is normalised on the device (lineest_gpu, csrc/ta_lineest.hip) without a
         host round trip.  defer = True (host lines only): the staging copies are started and the call returns;
-        `complete(st)` -- or `run(st)` -- waits for them and does the device part.
-        measured = (lineest_gpu.MeasuredStrips, a, b): `lines` are raw strips a .. b of a batch whose measuring pass has
-        run already (alignToOCR.process_batch measures all chunks' strips at once): their sizes are known, nothing is
-        waited for, and with defer the resampling too is left to complete()."""
+        `complete(st)` -- or `run(st)` -- waits for them and does the device part."""
         from .page import RowSpan
         nspans = sum(1 for ln in lines if isinstance(ln, RowSpan))
         if 0 < nspans < len(lines):         # a mixed batch: the spans go the way of host arrays (a device span is downloaded)
@@ -507,12 +504,7 @@ class LineRecognizer(object):
             start[order_] = np.cumsum(Tl[order_]) - Tl[order_]
             return start
         x_raw, T_raw = None, None
-        if measured is not None:
-            ms, ma, mb = measured
-            if len(raw) != n or mb - ma != n:
-                raise ValueError("`measured` covers exactly the raw strips of this call")
-            T[:] = ms.T[ma:mb]
-        elif raw:
+        if raw:
             from . import lineest_gpu
             x_raw, T_raw, _ = lineest_gpu.normalize_strips([lines[k] for k in raw], device=self.device,
                                                            layout=layout if len(raw) == n else None)
@@ -546,10 +538,7 @@ class LineRecognizer(object):
         raw_set = set(raw)
         host = [k for k in range(n) if k not in raw_set]
         pending = None
-        if measured is not None:
-            pending = {"measured": measured}                # resampled in complete(), on the stream that runs the recogniser
-            x_dev = None
-        elif nspans:
+        if nspans:
             pending = self._span_rows_begin(lines, rows)
             x_dev = None
         elif not raw:
@@ -576,7 +565,7 @@ class LineRecognizer(object):
         st = {"n": n, "rows": rows, "T_host": T, "row_start_host": row_start, "ngroups": ngroups,
               "group_row_host": group_row, "group_size": G,
               "_pending": (pending, x_dev, group_lines, len(lines))}
-        if not (defer and (not raw or measured is not None)):
+        if not (defer and not raw):
             self.complete(st)
         return st
 
@@ -587,12 +576,8 @@ class LineRecognizer(object):
         pending, x_dev, group_lines, nlines = st.pop("_pending")
         n, rows, T, row_start = st["n"], st["rows"], st["T_host"], st["row_start_host"]
         lines = [None] * nlines
-        spans = pending if isinstance(pending, dict) and "src" in pending else None
-        if isinstance(pending, dict) and "measured" in pending:
-            from . import lineest_gpu
-            ms, ma, mb = pending["measured"]
-            x_dev, _ = lineest_gpu.resample_strips(ms, ma, mb, layout=lambda T_: row_start)
-        elif x_dev is None and spans is None:
+        spans = pending if isinstance(pending, dict) else None
+        if x_dev is None and spans is None:
             x_dev = self._stage_rows_end(pending)
         dev = self.device
         meta = [row_start if n else np.zeros(1, np.int64), T.astype(np.int32) if len(lines) else np.zeros(1, np.int32),

@@ -20,6 +20,8 @@ inputs = {"numpy": tuple(zip(*[pb.make_page(sd) for sd in seeds]))}
 for kind in ("pinned", "device"):
     pages, trs, blocks = pb.make_pages_in_blocks(seeds, kind)
     inputs[kind] = (pages, trs, blocks)
+if "--raw" in sys.argv:
+    inputs = {"raw": tuple(zip(*[pb.make_page(sd + 5000, raw=True) for sd in seeds]))}
 ref = None
 for name, inp in inputs.items():
     pages, trs = list(inp[0]), list(inp[1])

@@ -13,9 +13,10 @@ from tools import switches                               # noqa: E402
 
 switches.apply()             # TA_* environment variables -> the product modules' attributes
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 64
 rec = pb.make_recognizer()
-pages, trs = zip(*[pb.make_page(100 + k) for k in range(n)])
+raw = "--raw" in sys.argv
+pages, trs = zip(*[pb.make_page(100 + k + (5000 if raw else 0), raw=raw) for k in range(n)])
 for _ in range(3):
     atocr.process_batch(list(pages), list(trs), rec, pb.PARAMS)
 torch.cuda.synchronize()
