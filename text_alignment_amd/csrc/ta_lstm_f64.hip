@@ -77,10 +77,22 @@ __device__ __forceinline__ unsigned long long prof_now() {
 // the four gates of one (row, unit) and moves them with two 16-byte accesses; the four lanes of a row's tile make each
 // access a contiguous 64-byte piece.
 __host__ __device__ constexpr int gx_index(int unit, int gate) { return 16 * (unit / 4) + 8 * (gate / 2) + 2 * (unit % 4) + (gate % 2); }
-// the projection's column tiles per wave: 0..6, 7..12, 13..18, 19..24 (giving the waves the 25th in turn, row tile by
-// row tile, measured SLOWER: 6.1 against 5.4 ms per 2.76 M rows -- the kernel waits on its stores, not on the MFMAs)
-__host__ __device__ constexpr int tile0_of(int wave) { return wave == 0 ? 0 : 1 + 6 * wave; }
-__host__ __device__ constexpr int ntiles_of(int wave) { return wave == 0 ? 7 : 6; }
+// The projection's column tiles per wave: 0..6, 7..12, 13..18, 19..24 -- four waves, one per SIMD, 284 registers each.
+// (Giving the waves the 25th tile in turn, row tile by row tile, measured SLOWER: 6.1 against 5.4 ms per 2.76 M rows.
+// Round 6, -DTA_XPROJ_WAVES=8: EIGHT waves of 4 / 3 tiles at 180 registers, two per SIMD, so that one wave's row stores
+// could issue under its SIMD partner's MFMAs -- bit-identical Gx, 6.25 against 5.17 ms: slower.  A wave then writes
+// 384 .. 512 contiguous bytes of a row instead of 896 and every row tile's x values are fetched and converted by twice
+// as many waves; the kernel is bound by what the memory system takes for this write pattern (3.4 TB/s of the 4.7 TB/s
+// a plain fill reaches), not by its own issue port.  The switch stays for A/B builds: tools/f64_variants.sh.)
+#ifndef TA_XPROJ_WAVES
+#define TA_XPROJ_WAVES 4
+#endif
+#ifndef TA_XPROJ_ORDER
+#define TA_XPROJ_ORDER 1
+#endif
+constexpr int kXW = TA_XPROJ_WAVES;
+__host__ __device__ constexpr int tile0_of(int wave) { return kXW == 8 ? (wave == 0 ? 0 : 1 + 3 * wave) : (wave == 0 ? 0 : 1 + 6 * wave); }
+__host__ __device__ constexpr int ntiles_of(int wave) { return kXW == 8 ? (wave == 0 ? 4 : 3) : (wave == 0 ? 7 : 6); }
 
 // ---------------------------------------------------------------------------------------------
 // float64 gate functions.  exp: x = n ln2 + r, |r| <= ln2 / 2; e^r by a degree-9 polynomial (the interpolant at the
@@ -197,6 +209,52 @@ __device__ __forceinline__ void xproj_body(const XprojArgs& a, int dir, int wave
     };
     float A[kKX], An[kKX];
     load_tile(blockIdx.x, A);
+#if TA_XPROJ_ORDER == 1
+    // Column tile by column tile: the 13 k-steps of ONE tile (a dependent chain: 64 cycles per MFMA all the same), then the
+    // four row stores of the tile BEFORE it -- issued in the shadow of the chain's last MFMA, so a wave's stores are spread
+    // over its MFMA stream (4 per 832 cycles) instead of coming as 28 in a burst when all four waves of the CU have
+    // finished a row tile together and the matrix pipes idle until the shared store path has drained.
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        load_tile(tile + gridDim.x, An);                       // flies under this tile's MFMAs
+        double Ad[kKX];
+#pragma unroll
+        for (int kk = 0; kk < kKX; ++kk) Ad[kk] = (double)A[kk];
+        double* orow[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            // rows past the end are CLAMPED here as in load_tile: such a lane computes the last row's values again and writes
+            // them to the last row again -- no branch around any store
+            const int64_t row = min(tile * 16 + 4 * r + kq, a.rows - 1);
+            orow[r] = gxd + row * kCols + 16 * tile0 + li;
+        }
+        f64x4 prev = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < NT; ++s) {
+            f64x4 cur = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < kKX; ++kk)
+#if defined(TA_XPROJ_ABL) && (TA_XPROJ_ABL & 2)       // timing ablation: one MFMA per tile instead of 13
+                if (kk == 0)
+#endif
+                cur = __builtin_amdgcn_mfma_f64_16x16x4f64(Ad[kk], Bx[s][kk], cur, 0, 0, 0);
+#if defined(TA_XPROJ_ABL) && (TA_XPROJ_ABL & 1)       // timing ablation: no stores (one that never happens keeps the values alive)
+            if (s > 0 && a.rows < 0) {
+#else
+            if (s > 0) {
+#endif
+#pragma unroll
+                for (int r = 0; r < 4; ++r) orow[r][16 * (s - 1)] = prev[r];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            prev = cur;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) orow[r][16 * (NT - 1)] = prev[r];
+#pragma unroll
+        for (int kk = 0; kk < kKX; ++kk) A[kk] = An[kk];
+    }
+    return;
+#endif
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         load_tile(tile + gridDim.x, An);                       // flies under this tile's MFMAs
         f64x4 acc[NT];
@@ -222,11 +280,11 @@ __device__ __forceinline__ void xproj_body(const XprojArgs& a, int dir, int wave
     }
 }
 
-__global__ __launch_bounds__(kW * 64) void lstm_xproj_f64_kernel(XprojArgs a) {
+__global__ __launch_bounds__(kXW * 64) void lstm_xproj_f64_kernel(XprojArgs a) {
     const int dir = blockIdx.y, lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) xproj_body<7>(a, dir, wave, lane);
-    else xproj_body<6>(a, dir, wave, lane);
+    if (wave == 0) xproj_body<ntiles_of(0)>(a, dir, wave, lane);
+    else xproj_body<ntiles_of(1)>(a, dir, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -807,7 +865,7 @@ extern "C" int ta_lstm_xproj_f64(const float* x, int64_t rows, const double* wx,
     XprojArgs a{x, rows, wx, gx};
     const int64_t ntiles = (rows + 15) / 16;
     const dim3 grid((unsigned)(ntiles < 1024 ? ntiles : 1024), 2);
-    hipLaunchKernelGGL(lstm_xproj_f64_kernel, grid, dim3(kW * 64), 0, reinterpret_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(lstm_xproj_f64_kernel, grid, dim3(kXW * 64), 0, reinterpret_cast<hipStream_t>(stream), a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ta_fail_hip(e, "lstm_xproj_f64_kernel launch");
     return TA_OK;

@@ -8,12 +8,15 @@ cd "$(dirname "$0")/../text_alignment_amd/csrc"
 out=../../tools/ubench/abl
 mkdir -p $out
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function"
-others="ta_common.o ta_nw.o ta_nw2.o ta_nw_general.o ta_lstm.o ta_lineest.o ta_preproc.o"
+others="ta_common.o ta_nw.o ta_nw2.o ta_nw_general.o ta_lstm.o ta_rows.o ta_lineest.o ta_preproc.o"
 build() {
     name=$1; shift
     /opt/rocm/bin/hipcc $FLAGS "$@" -c ta_lstm_f64.hip -o $out/ta_lstm_f64_$name.o
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out/libta_f64_$name.so $others $out/ta_lstm_f64_$name.o
     echo built $out/libta_f64_$name.so
 }
-build prof -DTA_F64_PROFILE
-for kv in "$@"; do build "${kv%%=*}" -DTA_F64_PROFILE ${kv#*=}; done
+# NOPROF=1: plain timing builds (no cycle counters in the kernels)
+PROF=-DTA_F64_PROFILE
+[ -n "$NOPROF" ] && PROF=
+[ -z "$NOPROF" ] && build prof -DTA_F64_PROFILE
+for kv in "$@"; do build "${kv%%=*}" $PROF ${kv#*=}; done
