@@ -95,40 +95,106 @@ __host__ __device__ constexpr int tile0_of(int wave) { return kXW == 8 ? (wave =
 __host__ __device__ constexpr int ntiles_of(int wave) { return kXW == 8 ? (wave == 0 ? 4 : 3) : (wave == 0 ? 7 : 6); }
 
 // ---------------------------------------------------------------------------------------------
-// float64 gate functions.  exp: x = n ln2 + r, |r| <= ln2 / 2; e^r by a degree-9 polynomial (the interpolant at the
-// Chebyshev nodes of the interval: 1.9e-14 relative, round 5 -- the degree-10 Taylor polynomial it replaces had 3e-13),
-// scaled by 2^n with v_ldexp_f64.  |x| <= 40 here (the callers clamp), so n ln2 is exact enough with ln2 as ONE double
-// (|n| <= 58: 1.3e-15).  SCALE = 2 evaluates e^(2 x') from x' = x / 2 (the tanh's e^(-2 c)): the same reduction on
-// r / 2 with the coefficients scaled by powers of two, which is exact -- no instruction for the doubling.
+// float64 gate functions.  exp: x = n ln2 + r, |r| <= ln2 / 2; e^r by a degree-7 polynomial -- the interpolant at the
+// Chebyshev nodes of the interval, 5.5e-11 relative (round 6; rounds 4-5 carried degree 9 / 10 at 1.9e-14 / 3e-13).  What the
+// path is asked for is logits within 1e-3 of the float64 restatement; this model amplifies a perturbation of the recurrence
+// by up to 1e4 over a line, so 5.5e-11 reaches the logits as < 1e-6 -- below the 1e-5 the float32 output
+// layer contributes -- and two multiply-adds fewer per exponential are ten fewer float64 VALU instructions per cell, on a
+// SIMD whose f64 MFMAs and f64 VALU do not overlap.  |x| <= 40 where the scaled result is built by hand (the callers
+// clamp), so n ln2 is exact enough with ln2 as ONE double (|n| <= 58: 1.3e-15).  SCALE = 2 evaluates e^(2 x') from
+// x' = x / 2 (the tanh's e^(-2 |c|)): the same reduction on r / 2 with the coefficients scaled by powers of two, which is
+// exact -- no instruction for the doubling.
 #ifndef TA_F64_RCP_NEWTON
 #define TA_F64_RCP_NEWTON 1
 #endif
-template <int SCALE>
-__device__ __forceinline__ double exp_scaled_f64(double xs) {                // e^(SCALE xs), |SCALE xs| <= 40
-#pragma clang fp contract(off)
-    // n = rint(SCALE xs log2 e) by the magic-number add: the integer lands in the low mantissa bits of t
-    const double kMagic = 6755399441055744.0;                             // 1.5 * 2^52
-    const double t = __builtin_fma(xs, SCALE * 1.4426950408889634074, kMagic);
-    const double n = t - kMagic;
-    const double r = __builtin_fma(n, -0.69314718055994530942 / SCALE, xs); // = (SCALE xs - n ln2) / SCALE
-    constexpr double s1 = SCALE, s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1, s6 = s4 * s2, s7 = s4 * s3,
-                     s8 = s4 * s4, s9 = s8 * s1;
-    double p = 2.763264057801236e-06 * s9;
-    p = __builtin_fma(p, r, 2.488445976576625e-05 * s8);
-    p = __builtin_fma(p, r, 0.00019841190647903092 * s7);
-    p = __builtin_fma(p, r, 0.0013888801749630082 * s6);
-    p = __builtin_fma(p, r, 0.008333333367311192 * s5);
-    p = __builtin_fma(p, r, 0.041666667040552045 * s4);
-    p = __builtin_fma(p, r, 0.16666666666615648 * s3);
-    p = __builtin_fma(p, r, 0.4999999999943859 * s2);
-    p = __builtin_fma(p, r, 1.0000000000000013 * s1);
-    p = __builtin_fma(p, r, 1.0000000000000135);
-    return __builtin_ldexp(p, (int)__builtin_bit_cast(long long, t));     // low dword of t = n (two's complement)
+// The cell update is a LATENCY chain, not an instruction count: a float64 VALU instruction issues in 4 cycles but its
+// result is ready for a dependent one after ~8, the exponentials are Horner chains, and while a wave updates its cells its
+// SIMD partner is in its MFMA phase (which holds the vector issue) -- nobody fills the bubbles.  Round 5's 160 instructions
+// took 680 cycles on a wave alone; cutting them to 129 in the same order took 704 (tools/ubench/cell_f64.hip,
+// profiles/r06_cell_f64.txt).  So the three exponentials that do not depend on each other (input gate, forget gate, tanh of
+// the candidate) are evaluated IN LOCKSTEP, level by level -- three independent instructions per level cover the latency --
+// and so are the two of the output half (tanh of the new state, output gate).  Each level is one asm block: the order is
+// the point, and left to itself the compiler emits the chains one after the other.
+struct ExpConsts {                   // c_k S^k of the degree-7 interpolant, for SCALE = S
+    double c0, c1, c2, c3, c4, c5, c6, c7, log2e_s, mln2_s;
+};
+template <int SCALE> __device__ __forceinline__ constexpr ExpConsts exp_consts() {
+    constexpr double s1 = SCALE, s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2, s5 = s4 * s1, s6 = s4 * s2, s7 = s4 * s3;
+    return {0.9999999999595618, 0.999999999995509 * s1, 0.5000000107729166 * s2, 0.16666666786308587 * s3,
+            0.041666218319291945 * s4, 0.008333283538708528 * s5, 0.0013948578326459795 * s6, 0.00019907569310848288 * s7,
+            SCALE * 1.4426950408889634074, -0.69314718055994530942 / SCALE};
 }
-__device__ __forceinline__ double exp_f64(double x) { return exp_scaled_f64<1>(x); }
+constexpr double kExpMagic = 6755399441055744.0;                          // 1.5 * 2^52: t = x log2e + magic has n = rint(..) in its low dword
+// One level for THREE chains (A with the SCALE = 2 constant, B and C with the SCALE = 1 one): d = d * r + c
+#define TA_LEVEL3(da, db, dc, ra, rb, rc, ca, cbc)                                                                        \
+    asm("v_fma_f64 %0, %0, %3, %6\n\tv_fma_f64 %1, %1, %4, %7\n\tv_fma_f64 %2, %2, %5, %7"                               \
+        : "+v"(da), "+v"(db), "+v"(dc) : "v"(ra), "v"(rb), "v"(rc), "s"(ca), "s"(cbc))
+#define TA_LEVEL2(da, db, ra, rb, ca, cb)                                                                                 \
+    asm("v_fma_f64 %0, %0, %2, %4\n\tv_fma_f64 %1, %1, %3, %5" : "+v"(da), "+v"(db) : "v"(ra), "v"(rb), "s"(ca), "s"(cb))
+// 2^n into the exponent field of p (p in [0.70, 1.42], |n| <= 29: a clamped sigmoid argument) with ONE 32-bit instruction
+__device__ __forceinline__ double scale_small_f64(double p, double t) {
+    const unsigned long long pb = __builtin_bit_cast(unsigned long long, p);
+    unsigned hi;
+    asm("v_lshl_add_u32 %0, %1, 20, %2" : "=v"(hi) : "v"((unsigned)__builtin_bit_cast(unsigned long long, t)), "v"((unsigned)(pb >> 32)));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (pb & 0xffffffffull));
+}
+// ea = e^(2 xa) for ANY xa <= 0 (the tanh's argument: unclamped, the hardware scales, underflow included);
+// eb = e^xb, ec = e^xc for |xb|, |xc| <= 20 (clamped sigmoid arguments)
+__device__ __forceinline__ void exp3_f64(double xa, double xb, double xc, double& ea, double& eb, double& ec) {
+    constexpr ExpConsts A = exp_consts<2>(), B = exp_consts<1>();
+    double magic = kExpMagic, ta, tb, tc;
+    asm("v_fma_f64 %0, %3, %6, %8\n\tv_fma_f64 %1, %4, %7, %8\n\tv_fma_f64 %2, %5, %7, %8"
+        : "=&v"(ta), "=&v"(tb), "=&v"(tc) : "v"(xa), "v"(xb), "v"(xc), "s"(A.log2e_s), "s"(B.log2e_s), "v"(magic));
+    double na, nb, nc;
+    asm("v_add_f64 %0, %3, %6\n\tv_add_f64 %1, %4, %6\n\tv_add_f64 %2, %5, %6"
+        : "=&v"(na), "=&v"(nb), "=&v"(nc) : "v"(ta), "v"(tb), "v"(tc), "s"(-kExpMagic));
+    double ra, rb, rc;                                                      // r = (S x - n ln2) / S
+    asm("v_fma_f64 %0, %3, %9, %6\n\tv_fma_f64 %1, %4, %10, %7\n\tv_fma_f64 %2, %5, %10, %8"
+        : "=&v"(ra), "=&v"(rb), "=&v"(rc) : "v"(na), "v"(nb), "v"(nc), "v"(xa), "v"(xb), "v"(xc), "s"(A.mln2_s), "s"(B.mln2_s));
+    double c6a = A.c6, c6b = B.c6, pa, pb, pc;
+    asm("v_fma_f64 %0, %3, %6, %8\n\tv_fma_f64 %1, %4, %7, %9\n\tv_fma_f64 %2, %5, %7, %9"
+        : "=&v"(pa), "=&v"(pb), "=&v"(pc) : "v"(ra), "v"(rb), "v"(rc), "s"(A.c7), "s"(B.c7), "v"(c6a), "v"(c6b));
+    TA_LEVEL3(pa, pb, pc, ra, rb, rc, A.c5, B.c5);
+    TA_LEVEL3(pa, pb, pc, ra, rb, rc, A.c4, B.c4);
+    TA_LEVEL3(pa, pb, pc, ra, rb, rc, A.c3, B.c3);
+    TA_LEVEL3(pa, pb, pc, ra, rb, rc, A.c2, B.c2);
+    TA_LEVEL3(pa, pb, pc, ra, rb, rc, A.c1, B.c1);
+    TA_LEVEL3(pa, pb, pc, ra, rb, rc, A.c0, B.c0);
+    ea = __builtin_ldexp(pa, (int)__builtin_bit_cast(long long, ta));
+    eb = scale_small_f64(pb, tb);
+    ec = scale_small_f64(pc, tc);
+}
+// the same for the two exponentials of the output half: ea = e^(2 xa), xa <= 0 unclamped; eb = e^xb, |xb| <= 20
+__device__ __forceinline__ void exp2_f64(double xa, double xb, double& ea, double& eb) {
+    constexpr ExpConsts A = exp_consts<2>(), B = exp_consts<1>();
+    double magic = kExpMagic, ta, tb;
+    asm("v_fma_f64 %0, %2, %4, %6\n\tv_fma_f64 %1, %3, %5, %6"
+        : "=&v"(ta), "=&v"(tb) : "v"(xa), "v"(xb), "s"(A.log2e_s), "s"(B.log2e_s), "v"(magic));
+    double na, nb;
+    asm("v_add_f64 %0, %2, %4\n\tv_add_f64 %1, %3, %4" : "=&v"(na), "=&v"(nb) : "v"(ta), "v"(tb), "s"(-kExpMagic));
+    double ra, rb;
+    asm("v_fma_f64 %0, %2, %6, %4\n\tv_fma_f64 %1, %3, %7, %5"
+        : "=&v"(ra), "=&v"(rb) : "v"(na), "v"(nb), "v"(xa), "v"(xb), "s"(A.mln2_s), "s"(B.mln2_s));
+    double c6a = A.c6, c6b = B.c6, pa, pb;
+    asm("v_fma_f64 %0, %2, %4, %6\n\tv_fma_f64 %1, %3, %5, %7"
+        : "=&v"(pa), "=&v"(pb) : "v"(ra), "v"(rb), "s"(A.c7), "s"(B.c7), "v"(c6a), "v"(c6b));
+    TA_LEVEL2(pa, pb, ra, rb, A.c5, B.c5);
+    TA_LEVEL2(pa, pb, ra, rb, A.c4, B.c4);
+    TA_LEVEL2(pa, pb, ra, rb, A.c3, B.c3);
+    TA_LEVEL2(pa, pb, ra, rb, A.c2, B.c2);
+    TA_LEVEL2(pa, pb, ra, rb, A.c1, B.c1);
+    TA_LEVEL2(pa, pb, ra, rb, A.c0, B.c0);
+    ea = __builtin_ldexp(pa, (int)__builtin_bit_cast(long long, ta));
+    eb = scale_small_f64(pb, tb);
+}
+// e^x alone (tools/ubench/cell_f64.hip checks it against long double; the cell update itself uses the lockstep forms)
+__device__ __forceinline__ double exp_f64(double x) {
+    double ea, eb;
+    exp2_f64(-1.0, x, ea, eb);
+    return eb;
+}
 // 1 / d for d in [1, 1e40]: the hardware reciprocal (measured 4.5e-8 relative: tools/ubench/cell_f64.hip,
-// profiles/r05_cell_f64.txt) refined by ONE Newton step (quadratic: 2e-15; the cell update's error against long double
-// arithmetic is 2.1e-14 with one step or two -- the exponentials' polynomial)
+// profiles/r05_cell_f64.txt) refined by ONE Newton step (quadratic: 2e-15)
 __device__ __forceinline__ double rcp_f64(double d) {
 #pragma clang fp contract(off)
     double y = __builtin_amdgcn_rcp(d);
@@ -141,31 +207,33 @@ __device__ __forceinline__ double rcp_f64(double d) {
 }
 __device__ __forceinline__ double clamp20(double v) { return __builtin_fmin(__builtin_fmax(v, -20.0), 20.0); }
 // ocropy's sigmoid is 1 / (1 + exp(clip(-x, -20, 20)))   -- in float64 the clip is visible
-// (sigma(-25) = 2.06e-9 with it, 1.4e-11 without), so it is kept; tanh(x) = (1 - e) / (1 + e) with e = exp(-2x), |x|
-// clamped to 20 (tanh(20) = 1 - 8e-18 rounds to 1).
+// (sigma(-25) = 2.06e-9 with it, 1.4e-11 without), so it is kept.  tanh(x) = sign(x) (1 - e) / (1 + e) with e = exp(-2 |x|):
+// e <= 1 for every x, so nothing needs clamping (numpy's tanh is not clipped either; round 5 clamped |x| to 20 at two
+// float64 min / max per tanh, and the compiler added a canonicalising v_max_f64 in front of each); the sign goes onto the
+// numerator with one v_bfi_b32.
 
 // One LSTM cell update (`forward_py`) from the four pre-activations of a (line, unit) pair.
 // c: the cell state, ZERO before the first step of a sequence (the input / forget peepholes and the old state's share then
 // vanish by themselves); wop_t: the output peephole, zero at the first step of the whole sequence (skipped at t = 0).
 // Every operation is spelled out (no contraction left to the compiler): the 16-line and the 4-line kernel round alike.
+// A NaN in ci_pre (how a wait that ran out poisons a cell, see the kernels) reaches c and h: that path has no min / max.
 __device__ __forceinline__ double lstm_cell_f64(double gi, double gf, double go, double ci_pre, double& c,
                                                 double wip, double wfp, double wop_t) {
 #pragma clang fp contract(off)
     // every gate is a ratio with denominator 1 + e^z; the three of the cell-state update share ONE reciprocal
-    // (of the product of their denominators, at most (1 + e^40) (1 + e^20)^2 ~ 1e35), the two of the output another
+    // (of the product of their denominators, at most 2 (1 + e^20)^2 ~ 5e17), the two of the output another
     const double cp = c;
-    const double ea = exp_scaled_f64<2>(-clamp20(ci_pre));                       // tanh(ci_pre) = (1 - ea) / (1 + ea)
-    const double eb = exp_f64(clamp20(-__builtin_fma(wip, cp, gi)));             // sigma = 1 / (1 + eb), ocropy's clip
-    const double ef = exp_f64(clamp20(-__builtin_fma(wfp, cp, gf)));
+    double ea, eb, ef;     // tanh(ci_pre) = sign (1 - ea) / (1 + ea);  sigma = 1 / (1 + e^clip(-z)), ocropy's clip
+    exp3_f64(-__builtin_fabs(ci_pre), clamp20(-__builtin_fma(wip, cp, gi)), clamp20(-__builtin_fma(wfp, cp, gf)), ea, eb, ef);
     const double da = 1.0 + ea;
     const double pa = __builtin_fma(da, eb, da), pf = 1.0 + ef;                  // (1 + ea) (1 + eb)
     const double r3 = rcp_f64(pa * pf);
-    const double cn = __builtin_fma((1.0 - ea) * pf, r3, (pa * r3) * cp);        // ci * gi + gf * c
-    const double ec = exp_scaled_f64<2>(-clamp20(cn));
-    const double eo = exp_f64(clamp20(-__builtin_fma(wop_t, cn, go)));
+    const double cn = __builtin_fma(__builtin_copysign(1.0 - ea, ci_pre) * pf, r3, (pa * r3) * cp);   // ci * gi + gf * c
+    double ec, eo;
+    exp2_f64(-__builtin_fabs(cn), clamp20(-__builtin_fma(wop_t, cn, go)), ec, eo);
     const double dc = 1.0 + ec;
     c = cn;
-    return (1.0 - ec) * rcp_f64(__builtin_fma(dc, eo, dc));                      // tanh(c) * go
+    return __builtin_copysign(1.0 - ec, cn) * rcp_f64(__builtin_fma(dc, eo, dc));                     // tanh(c) * go
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -464,7 +532,8 @@ __device__ __forceinline__ void seq_f64_body(const Seq64Args& a, double (&hs)[2]
                 arrived = __hip_atomic_load(&part_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             if (!arrived) {                                    // a wait that ran out must show: NaN outputs, not plausible ones,
-                accs[0] = __builtin_nan("");                   // and a word the host reads with the decoder's counts
+                accs[3] = __builtin_nan("");                   // (ci_pre: the one pre-activation no min / max stands behind), and a
+                                                               // word the host reads with the decoder's counts
                 if (a.status && lane == 0) atomicOr(a.status, TA_LSTM_F64_PARTS_LATE);
             }
 #pragma unroll
@@ -742,7 +811,8 @@ __device__ __forceinline__ void seq4_f64_body(const Seq64G4Args& a, double (&hs)
             const double* pl = &part[0][lane & 15];
             double v[4] = {gs01[0], gs01[1], gs23[0], gs23[1]};
             if (!arrived) {                                    // a wait that ran out must show: NaN outputs, not plausible ones,
-                v[0] = __builtin_nan("");                      // and a word the host reads with the decoder's counts
+                v[3] = __builtin_nan("");                      // (ci_pre: the one pre-activation no min / max stands behind), and a
+                                                               // word the host reads with the decoder's counts
                 if (a.status && lane == 0) atomicOr(a.status, TA_LSTM_F64_PARTS_LATE);
             }
 #pragma unroll
