@@ -16,7 +16,10 @@ switches.apply()             # TA_* environment variables -> the product modules
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 64
 rec = pb.make_recognizer()
 raw = "--raw" in sys.argv
-pages, trs = zip(*[pb.make_page(100 + k + (5000 if raw else 0), raw=raw) for k in range(n)])
+if "--rows" in sys.argv:
+    pages, trs, _blocks = pb.make_pages_in_blocks([100 + k for k in range(n)], sys.argv[sys.argv.index("--rows") + 1])
+else:
+    pages, trs = zip(*[pb.make_page(100 + k + (5000 if raw else 0), raw=raw) for k in range(n)])
 for _ in range(3):
     atocr.process_batch(list(pages), list(trs), rec, pb.PARAMS)
 torch.cuda.synchronize()
@@ -28,6 +31,6 @@ ev.sort(key=lambda e: e.time_range.start)
 t0 = ev[0].time_range.start
 for e in ev:
     d = e.time_range.end - e.time_range.start
-    if d >= 50:
+    if d >= 30:
         print("%9.3f ms  +%8.3f ms  %s" % ((e.time_range.start - t0) / 1e3, d / 1e3, e.name[:70]))
 print("span %.3f ms" % ((max(e.time_range.end for e in ev) - t0) / 1e3))
