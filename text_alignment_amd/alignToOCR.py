@@ -386,7 +386,6 @@ PIPELINE_CHUNK_PAGES_IMAGES = 64
 _side_streams = {}
 WAIT_SECONDS = [0.0]                 # wall seconds the calling thread has spent WAITING for the device inside process_batch (a
                                      # running total: callers take differences): a pass's wall time minus this is its host work
-SPLIT_FINISH = True                  # the second stage of a chunk split around the next chunk's launch
 TWO_STREAMS = True                   # consecutive chunks' recogniser kernels on two compute streams
 
 
@@ -501,16 +500,20 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     caller = torch.cuda.current_stream(device)
     for st_ in streams:
         st_.wait_stream(caller)                                  # whatever the caller enqueued before this call
+    # Three stages per chunk: (1) begin + launch -- the recogniser's kernels enqueued; (2) _pb_finish_a, once the chunk's
+    # characters are back: abbreviations and the chunk's ONE aligner launch; (3) collect, once the alignment columns are
+    # back: syllable boxes.  The device must never run dry, so a new chunk is launched BEFORE any second stage of the
+    # iteration, and neither later stage may make the host wait: stage 2 is taken for the chunk launched two iterations
+    # ago (its recogniser is over by the time the chunk before this one is running), stage 3 for the chunk whose aligner
+    # launch was made one iteration ago (small kernels that slip onto CUs the recurrences leave free).
+    # (Round 5's order -- stage 2 of the oldest chunk, THEN this chunk's launch, stage 3 behind it -- left the GPU idle for
+    # ~2 ms per chunk while the host did stage 2: timeline in profiles/r06_pages_timeline_pinned.txt.)
+    # The first stage's host half of chunk c + 1 (row layout, the pool's staging copies STARTED) is taken right behind
+    # chunk c's launch: the copies then run under this iteration's later stages and the next launch finds them done.
+    aligned = []                                                 # chunks whose stage 2 is done, oldest first
+    nxt = begin(chunks[0])
     for c, job in enumerate(chunks):
-        ctx = begin(job)
-        oldest = flight.pop(0) if len(flight) == 2 else None
-        # (Launching THIS chunk before the oldest chunk's second stage -- possible when its rows need no staging copy --
-        # measured slower, 1 860 against 1 960 pages/s on pinned rows: the oldest chunk's aligner launch then queues behind
-        # this chunk's recurrence and the host waits for it; a high-priority aligner stream did not change that.)
-        if oldest is not None:
-            _pb_finish_a(oldest)                                 # ... its NW launch runs under the next chunk's launch
-            if not SPLIT_FINISH:
-                collect(oldest)
+        ctx = nxt
         lane = streams[c % 2] if TWO_STREAMS else caller
         # begin() ran on the CALLER's stream: for raw strips and page images it enqueued device work there (the normaliser's
         # kernels write the rows, the metadata uploads, the zero-fill of the decoder's outputs) that this chunk's recogniser
@@ -521,15 +524,23 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
             lane.wait_stream(caller)
         with torch.cuda.stream(lane):
             _pb_launch(ctx)
+        nxt = begin(chunks[c + 1]) if c + 1 < len(chunks) else None
         _pb_transcripts(ctx)
         flight.append(ctx)
-        if oldest is not None and SPLIT_FINISH:
-            collect(oldest)
+        if aligned:
+            collect(aligned.pop(0))
+        if len(flight) > 2:
+            oldest = flight.pop(0)
+            _pb_finish_a(oldest)
+            aligned.append(oldest)
     for st_ in streams:
         caller.wait_stream(st_)
-    for ctx in flight:                                            # both aligner launches first: the second runs under the
-        _pb_finish_a(ctx)                                         # first chunk's box assembly
-    for ctx in flight:
+    for ctx in flight:                                            # the drain: every aligner launch as soon as its characters are
+        _pb_finish_a(ctx)                                         # back, the box assembly of a chunk under the next one's launch
+        if aligned:
+            collect(aligned.pop(0))
+        aligned.append(ctx)
+    for ctx in aligned:
         collect(ctx)
     return deliver()
 

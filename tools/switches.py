@@ -12,7 +12,6 @@ environment is the only handle -- so THEY translate it, once, after importing th
     TA_PAGE_CHUNK=n            alignToOCR.PIPELINE_CHUNK_PAGES          pages per pipeline chunk (normalised rows)
     TA_PAGE_CHUNK_RAW=n        alignToOCR.PIPELINE_CHUNK_PAGES_RAW      ... raw strips
     TA_PAGE_CHUNK_IMAGES=n     alignToOCR.PIPELINE_CHUNK_PAGES_IMAGES   ... page images
-    TA_PB_SPLIT_FINISH=0|1     alignToOCR.SPLIT_FINISH    second stage split around the next chunk's launch
     TA_PB_TWO_STREAMS=0|1      alignToOCR.TWO_STREAMS     consecutive chunks on two compute streams
 """
 import os
@@ -44,7 +43,7 @@ def apply(environ=None):
         v = env.get(var)
         if v and v.isdigit() and int(v) > 0:
             put(atocr, attr, int(v))
-    for var, attr in (("TA_PB_SPLIT_FINISH", "SPLIT_FINISH"), ("TA_PB_TWO_STREAMS", "TWO_STREAMS")):
+    for var, attr in (("TA_PB_TWO_STREAMS", "TWO_STREAMS"),):
         v = env.get(var)
         if v in ("0", "1"):
             put(atocr, attr, v == "1")
