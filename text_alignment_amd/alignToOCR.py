@@ -680,7 +680,7 @@ def _pb_finish_b(ctx, indices_out, arrays_out):
     results = []
     for k, (raw_dim, f, tr) in enumerate(zip(raw_dims, found, transcripts)):
         image, angle, lp = f[0], f[2], f[4]
-        chars_seq = pb.BoxSeq(list(texts[k]), boxes[idxs[k]], CharBox)
+        chars_seq = pb.BoxSeq(texts[k], boxes[idxs[k]], CharBox)          # (a str is a sequence of its characters)
         if k in batched:
             which, sb = batched[k]
             named = [s for s in syls_all[k] if len(s) >= 1]

@@ -492,7 +492,7 @@ class LineRecognizer(object):
         if 0 < nspans < len(lines):         # a mixed batch: the spans go the way of host arrays (a device span is downloaded)
             lines = [ln.numpy() if isinstance(ln, RowSpan) else ln for ln in lines]
             nspans = 0
-        raw = [k for k, ln in enumerate(lines) if _is_raw_strip(ln)]
+        raw = [] if nspans else [k for k, ln in enumerate(lines) if _is_raw_strip(ln)]
         n = len(lines)
         T = np.zeros(n, dtype=np.int64)
 
@@ -509,12 +509,16 @@ class LineRecognizer(object):
             x_raw, T_raw, _ = lineest_gpu.normalize_strips([lines[k] for k in raw], device=self.device,
                                                            layout=layout if len(raw) == n else None)
             T[raw] = T_raw
-        for k, ln in enumerate(lines):
-            if _is_raw_strip(ln):
-                continue
-            if ln.ndim != 2 or ln.shape[1] != NI:
-                raise ValueError("a prepared line must have shape (T, 48)")
-            T[k] = ln.shape[0]
+        if nspans:                                   # spans of RowBlocks: (T, 48) by construction
+            T[:] = [ln.stop - ln.start for ln in lines]
+        else:
+            raw_set = set(raw)
+            for k, ln in enumerate(lines):
+                if k in raw_set:
+                    continue
+                if ln.ndim != 2 or ln.shape[1] != NI:
+                    raise ValueError("a prepared line must have shape (T, 48)")
+                T[k] = ln.shape[0]
         if n and T.max() > MAX_T:
             raise RecognitionError("input too large for LSTM model")
         order = np.argsort(-T, kind="stable")

@@ -173,12 +173,9 @@ def syllable_boxes_arrays(transcript, syls, ops, box_of_ocr):
     # keep the boxes on that line only (alignToOCR.py:318-320)
     # syllable of each column: +1 at a syllable's first column, -1 after its last (ranges are disjoint
     # and in order), running sum > 0 inside; the syllable's index is the number of starts so far - 1
-    mark = np.zeros(ncol + 2, dtype=np.int64)
-    np.add.at(mark, starts, 1)
-    np.add.at(mark, ends, -1)
+    begun = np.bincount(starts, minlength=ncol + 2)                # (np.add.at costs 0.2 ms per call on 3 000 indices)
+    mark = begun - np.bincount(ends, minlength=ncol + 2)
     inside = np.cumsum(mark)[:ncol + 1] > 0
-    begun = np.zeros(ncol + 2, dtype=np.int64)
-    np.add.at(begun, starts, 1)
     seg_of_col = np.cumsum(begun)[:ncol + 1] - 1
     on_line = inside & (uly_max == low[np.maximum(seg_of_col, 0)])
     big, small = np.iinfo(np.int64).max, np.iinfo(np.int64).min
@@ -283,12 +280,9 @@ def syllable_boxes_batch(transcripts, syls_list, ops_list, idx_list, boxes, angl
     bounds = np.stack([starts, ends], axis=1).reshape(-1)
     low = np.maximum.reduceat(uly_max, bounds)[0::2]
     present = low > small
-    mark = np.zeros(ncol + 2, dtype=np.int64)
-    np.add.at(mark, starts, 1)
-    np.add.at(mark, ends, -1)
+    begun = np.bincount(starts, minlength=ncol + 2)                # (np.add.at costs 0.2 ms per call on 3 000 indices)
+    mark = begun - np.bincount(ends, minlength=ncol + 2)
     inside = np.cumsum(mark)[:ncol + 1] > 0
-    begun = np.zeros(ncol + 2, dtype=np.int64)
-    np.add.at(begun, starts, 1)
     seg_of_col = np.cumsum(begun)[:ncol + 1] - 1
     on_line = inside & (uly_max == low[np.maximum(seg_of_col, 0)])
     out = np.stack([np.minimum.reduceat(np.where(on_line, ulx, big), bounds)[0::2],
