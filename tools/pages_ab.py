@@ -20,6 +20,9 @@ inputs = {"numpy": tuple(zip(*[pb.make_page(sd) for sd in seeds]))}
 for kind in ("pinned", "device"):
     pages, trs, blocks = pb.make_pages_in_blocks(seeds, kind)
     inputs[kind] = (pages, trs, blocks)
+if "--only" in sys.argv:
+    only = sys.argv[sys.argv.index("--only") + 1]
+    inputs = {only: inputs[only]}
 if "--raw" in sys.argv:
     inputs = {"raw": tuple(zip(*[pb.make_page(sd + 5000, raw=True) for sd in seeds]))}
 ref = None

@@ -12,7 +12,7 @@
 # 4. matrix-pipe counters of the recogniser kernels (1920 lines, both modes) -> <round>_ocr_pmc_mfma.json
 # then (where gpurun_out/ was merged back): python3 tools/profile_summarise.py <round> gpurun_out/prof_<round>
 set -eo pipefail
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 PART=${2:-all}           # traces | pmc | all (a gpurun call is limited to 20 minutes: run the two parts in two calls)
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$ROUND
@@ -59,6 +59,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/
 echo "ocr 1920 split (length classes) kernel trace done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_pages_images" -o pg -- python3 "$REPO/tools/pages_img_time.py" 32 8 1 > "$OUT/kt_pages_images.log" 2>&1
 echo "page images kernel trace done"
+# the page pipeline on 64 pages whose rows lie in page-locked RowBlocks (round 6: no staging copy, csrc/ta_rows.hip)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_pages_pinned" -o pg -- python3 "$REPO/tools/pages_ab.py" 64 10 --only pinned > "$OUT/kt_pages_pinned.log" 2>&1
+echo "pinned pages kernel trace done"
 # BASELINE configs[1] (1024 x 2048^2) and the grid search (2187 x 800 x 900, per-problem systems): kernel traces
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_nw_c2" -o nw -- python3 "$REPO/tools/p1_time.py" profile auto 1024 2048 2048 > "$OUT/kt_nw_c2.log" 2>&1
 echo "C2 kernel trace done"
