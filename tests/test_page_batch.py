@@ -177,3 +177,15 @@ def test_chunk_plan_of_the_page_pipeline():
                 assert sizes == [0]
         # groups are not interleaved: the pipeline changes recogniser once per group
         assert [c[0] for c in chunks] == sorted([c[0] for c in chunks])
+        # a half-size LEADING chunk (round 6): taken from the first group only, and only while more than a chunk and a half
+        # of it remains; every page still exactly once and in order
+        led = atocr.plan_chunks(groups, C, (C // 2,))
+        for name, ks in groups:
+            assert [k for nm, c in led if nm == name for k in c] == ks
+        if n_a > C + C // 2:
+            assert len(led[0][1]) == C // 2 and led[0][0] == "A"
+            assert [len(c) for _, c in led[1:]] == [len(c) for _, c in atocr.plan_chunks(
+                [("A", groups[0][1][C // 2:])] + groups[1:], C)]
+        else:
+            assert [len(c) for _, c in led] == [len(c) for _, c in chunks]
+    assert [len(c) for _, c in atocr.plan_chunks([("A", list(range(64)))], 16, (8,))] == [8, 16, 16, 16, 8]

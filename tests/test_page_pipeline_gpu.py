@@ -63,7 +63,8 @@ def _json(atocr, res):
 
 @pytest.mark.parametrize("rows_in", ["numpy", "pinned_block", "device_block"])
 def test_pipelined_batch_at_the_timed_shape_equals_process_and_the_checkers(rows_in, monkeypatch):
-    """64 pages x 12 lines of 150 .. 420 columns, two models: four chunks of 16 pages = 192 lines each.
+    """64 pages x 20 lines of 150 .. 420 columns, two models: five chunks -- 8, 16, 8 pages of the first model (the call's
+    first chunk is half a chunk), 16, 16 of the second -- of 160 or 320 lines each.
     Every page's JSON equals process() of that page alone; three pages equal the checker pipeline (float64 recogniser
     restatement + C aligner + reference-pinned glue); a SECOND call on the same recognisers returns the same bytes
     (staging slots and scratch reused across calls).  rows_in: the strips' prepared rows as pageable numpy arrays (pool
@@ -71,13 +72,13 @@ def test_pipelined_batch_at_the_timed_shape_equals_process_and_the_checkers(rows
     from oracle import nw_oracle, ocr_ref_f64 as R
     from text_alignment_amd import alignToOCR as atocr, ocr, page as page_mod
     oms, recs = _two_models()
-    plain, trs = zip(*[_page(900 + k, 12, R, page_mod) for k in range(64)])
+    plain, trs = zip(*[_page(900 + k, 20, R, page_mod) for k in range(64)])
     plain, trs = list(plain), list(trs)
     models = [recs[k % 2] for k in range(64)]
     pages, blocks = (plain, []) if rows_in == "numpy" else _as_row_blocks(plain, rows_in.split("_")[0], page_mod)
 
     # what the call actually exercises: count the transfers the pool issues and the streams the chunks launch on
-    seen = {"pool_uploads": 0, "threads": set(), "lanes": set(), "gathers": 0}
+    seen = {"pool_uploads": 0, "threads": set(), "lanes": set(), "gathers": 0, "chunks": []}
     issue = ocr.LineRecognizer._issue_upload
 
     def counting_issue(self, copies, rows, slot):
@@ -90,7 +91,7 @@ def test_pipelined_batch_at_the_timed_shape_equals_process_and_the_checkers(rows
 
     def counting_launch(ctx):
         seen["lanes"].add(torch.cuda.current_stream().cuda_stream)
-        assert len(ctx["lines"]) >= 160
+        seen["chunks"].append(len(ctx["lines"]))
         return launch(ctx)
     monkeypatch.setattr(atocr, "_pb_launch", counting_launch)
     span_begin = ocr.LineRecognizer._span_rows_begin
@@ -104,14 +105,15 @@ def test_pipelined_batch_at_the_timed_shape_equals_process_and_the_checkers(rows
     first = atocr.process_batch(pages, trs, models, PARAMS, indices_out=idx1, arrays_out=arr1)
     torch.cuda.synchronize()
     assert len(seen["lanes"]) == 2                                   # two compute streams in turn
+    assert seen["chunks"] == [160, 320, 160, 320, 320]               # every chunk large enough for the pooled copies
     if rows_in == "numpy":
-        assert seen["pool_uploads"] == 4 and seen["gathers"] == 0    # every chunk's rows: pool copies + pool-issued transfer
+        assert seen["pool_uploads"] == 5 and seen["gathers"] == 0    # every chunk's rows: pool copies + pool-issued transfer
         assert all(name != threading.current_thread().name for name in seen["threads"])
     else:
-        assert seen["pool_uploads"] == 0 and seen["gathers"] == 4    # ... or no host copy at all
+        assert seen["pool_uploads"] == 0 and seen["gathers"] == 5    # ... or no host copy at all
     got = _json(atocr, first)
     assert len(idx1) == len(arr1) == 64 and all(len(i) == len(a) == len(g["syl_boxes"]) for i, a, g in zip(idx1, arr1, got))
-    assert sum(len(g["syl_boxes"]) for g in got) > 1500
+    assert sum(len(g["syl_boxes"]) for g in got) > 2500
 
     # a second call: same bytes (slots, scratch buffers and streams of the first call reused)
     idx2, arr2 = [], []

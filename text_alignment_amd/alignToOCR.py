@@ -410,13 +410,27 @@ def _nw_stream(device):
     return _side_streams[key]
 
 
-def plan_chunks(groups, C):
+# The call's FIRST chunk is half a chunk: nothing can be finished on the host before the first chunk's characters are back,
+# so its latency stands in front of the whole pipeline (a 16-page chunk: ~12 ms until decoded, an 8-page one ~6).  Measured
+# on 64 pages of page-locked rows: chunks 8, 16, 16, 16, 8 give 2 125-2 140 pages/s against 1 937 for 4 x 16 (device rows
+# 2 223-2 239 against 2 095-2 111; pageable rows the same within their noise); a first chunk of 4 pages is too small to
+# fill the chip (1 790), halving the last chunk as well gains nothing (profiles/r06_lead_chunk.txt).
+LEAD_CHUNK_DIVISOR = 2
+
+
+def plan_chunks(groups, C, lead=()):
     """[(recogniser, page indices)] in pipeline order: every group of pages (one recogniser each, in order of first
     appearance) cut into runs of C pages; a last run shorter than C / 2 joins the run before it (no sliver of a chunk
-    whose kernels would not cover the next chunk's host stage)"""
+    whose kernels would not cover the next chunk's host stage).  lead: sizes of the call's FIRST chunks (taken from the
+    first group while more than C pages of it remain)"""
     chunks = []
+    lead = list(lead)
     for rec, ks in groups:
         a = 0
+        while lead and len(ks) - a > C + lead[0]:
+            chunks.append((rec, ks[a:a + lead[0]]))
+            a += lead.pop(0)
+        lead = []
         while True:
             b = len(ks) if len(ks) - (a + C) < C // 2 else min(a + C, len(ks))
             chunks.append((rec, ks[a:b]))
@@ -461,7 +475,8 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     images = any(not isinstance(pg, page_mod.PreparedPage) for pg in pages)
     raw = not images and any(st.prepared is None for pg in pages for st in getattr(pg, "strips", ()))
     C = PIPELINE_CHUNK_PAGES_IMAGES if images else (PIPELINE_CHUNK_PAGES_RAW if raw else PIPELINE_CHUNK_PAGES)
-    chunks = plan_chunks(list(groups.values()), C)
+    lead = (C // LEAD_CHUNK_DIVISOR,) if LEAD_CHUNK_DIVISOR > 1 and not (images or raw) else ()
+    chunks = plan_chunks(list(groups.values()), C, lead)
     out_res, out_idx, out_arr = [None] * n, [None] * n, [None] * n
     def begin(job):
         rec, ks = job

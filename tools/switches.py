@@ -13,6 +13,7 @@ environment is the only handle -- so THEY translate it, once, after importing th
     TA_PAGE_CHUNK_RAW=n        alignToOCR.PIPELINE_CHUNK_PAGES_RAW      ... raw strips
     TA_PAGE_CHUNK_IMAGES=n     alignToOCR.PIPELINE_CHUNK_PAGES_IMAGES   ... page images
     TA_PB_TWO_STREAMS=0|1      alignToOCR.TWO_STREAMS     consecutive chunks on two compute streams
+    TA_PB_LEAD_DIVISOR=n       alignToOCR.LEAD_CHUNK_DIVISOR   the call's first chunk is 1/n of a chunk (1: a whole one)
 """
 import os
 
@@ -47,4 +48,7 @@ def apply(environ=None):
         v = env.get(var)
         if v in ("0", "1"):
             put(atocr, attr, v == "1")
+    v = env.get("TA_PB_LEAD_DIVISOR")
+    if v and v.isdigit():
+        put(atocr, "LEAD_CHUNK_DIVISOR", int(v))
     return done
