@@ -92,7 +92,7 @@ def test_line_normaliser_checker_shapes_and_polarity():
 
 def test_prepared_lines_hand_raw_strips_to_the_device_normaliser():
     """page.prepared_lines: strips that carry `.prepared` pass through; raw strips are handed on as 2-D
-    uint8 images (bool: True = ink -> black on white) for the device normaliser; blank strips and
+    uint8 images (bool: True = ink -> black on white) for the device normaliser; empty strips and
     pixel types the reference's PNG seam never saw are refused on the host, before any GPU work."""
     from text_alignment_amd import page as page_mod
     rng = np.random.default_rng(3)
@@ -105,7 +105,9 @@ def test_prepared_lines_hand_raw_strips_to_the_device_normaliser():
     assert got[1][0] is ready and got[1][1] == 136
     assert got[2][0].dtype == np.uint8 and np.array_equal(got[2][0], raw.pixels)
     with pytest.raises(ValueError, match="empty or constant"):
-        page_mod.prepared_lines([page_mod.Strip(0, 0, 40, pixels=np.full((40, 100), 255, np.uint8))])
+        page_mod.prepared_lines([page_mod.Strip(0, 0, 40, pixels=np.zeros((0, 100), np.uint8))])
+    # (a CONSTANT strip passes here and is refused, with the same error, by the device normaliser's measuring pass:
+    # tests/test_lineest_gpu.py::test_device_normaliser_rejects_what_the_checker_rejects)
     # a strip whose pixels live in a tensor (on the GPU, after the device preprocessing): handed on as it is,
     # `.pixels` reads it back once; assigning pixels drops the tensor
     import torch

@@ -381,7 +381,8 @@ def _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, 
 # chunk k - 1 (characters, alignment, syllable boxes).  One host thread; results are those of the unchunked call.
 # (Plain module attributes: this module reads no environment variables; tools/switches.py sets them for timing experiments.)
 PIPELINE_CHUNK_PAGES = 16
-PIPELINE_CHUNK_PAGES_RAW = 32        # raw strips: the device normaliser in front
+PIPELINE_CHUNK_PAGES_RAW = 16        # raw strips: the device normaliser in front (32 while every chunk's first stage WAITED for
+                                     # its measuring pass; round 6 enqueues it and waits a stage later: 16 is faster, 970 against 885)
 PIPELINE_CHUNK_PAGES_IMAGES = 64
 _side_streams = {}
 WAIT_SECONDS = [0.0]                 # wall seconds the calling thread has spent WAITING for the device inside process_batch (a
@@ -475,7 +476,7 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     images = any(not isinstance(pg, page_mod.PreparedPage) for pg in pages)
     raw = not images and any(st.prepared is None for pg in pages for st in getattr(pg, "strips", ()))
     C = PIPELINE_CHUNK_PAGES_IMAGES if images else (PIPELINE_CHUNK_PAGES_RAW if raw else PIPELINE_CHUNK_PAGES)
-    lead = (C // LEAD_CHUNK_DIVISOR,) if LEAD_CHUNK_DIVISOR > 1 and not (images or raw) else ()
+    lead = (C // LEAD_CHUNK_DIVISOR,) if LEAD_CHUNK_DIVISOR > 1 and not (images or raw) else ()   # (raw strips: measured, no gain)
     chunks = plan_chunks(list(groups.values()), C, lead)
     out_res, out_idx, out_arr = [None] * n, [None] * n, [None] * n
     def begin(job):

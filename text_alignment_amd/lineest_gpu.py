@@ -75,19 +75,26 @@ class MeasuredStrips(object):
     the output widths on the host (`wo`; T = wo + 32 timesteps).  resample_strips() turns any run of strips [a, b) of it
     into recogniser rows without another wait for the device."""
     __slots__ = ("n", "dev", "d_pix", "d_pix_off", "d_hh", "d_ww", "d_col_off", "center", "minmax", "r", "wout",
-                 "arg", "col_off", "wo", "T")
+                 "arg", "col_off", "wo", "T", "_sizes_host", "_sizes_ready")
 
 
 def measure_strips(strips, device="cuda"):
     """First pass (ta_linenorm_measure) over `strips` -- 2-D uint8 images (white background), each a host array or a
     tensor already on the device: centre line, band height and OUTPUT WIDTH of every strip.  The widths are
     data-dependent and the caller sizes its buffers with them, so this pass ends with the one wait for the device the
-    normaliser needs; a caller with many chunks of strips (alignToOCR.process_batch) measures all of them here, once."""
+    normaliser needs.  measure_strips_begin + measure_strips_end: a caller with other host work puts it in between."""
+    return measure_strips_end(measure_strips_begin(strips, device))
+
+
+def measure_strips_begin(strips, device="cuda"):
+    """the measuring pass ENQUEUED on torch's current stream -- upload, kernels, the read-back of the sizes into
+    page-locked memory behind an event -- and nothing waited for: measure_strips_end(ms) does that"""
     dev = torch.device(device)
     lib = _native.lib
     n = len(strips)
     ms = MeasuredStrips()
     ms.n, ms.dev = n, dev
+    ms._sizes_host = ms._sizes_ready = None
     if n == 0:
         ms.wo = ms.T = np.zeros(0, np.int64)
         return ms
@@ -144,12 +151,30 @@ def measure_strips(strips, device="cuda"):
         d_gw.data_ptr(), d_gw_off.data_ptr(), d_gr.data_ptr(), ws.data_ptr(), d_ws_off.data_ptr(),
         ms.arg.data_ptr(), ms.center.data_ptr(), ms.d_col_off.data_ptr(), ms.minmax.data_ptr(),
         ms.r.data_ptr(), ms.wout.data_ptr(), stream), "ta_linenorm_measure")
-    sized = sizes.cpu().numpy()                           # output sizes are data-dependent: THE wait of the normaliser
+    # output sizes are data-dependent: they come back through page-locked memory behind an event (a plain .cpu() would
+    # make the host wait HERE, for kernels that may be queued behind another batch's recogniser)
+    ms._sizes_host = torch.empty(3 * n, dtype=torch.int32, pin_memory=True)
+    ms._sizes_host.copy_(sizes, non_blocking=True)
+    ms._sizes_ready = torch.cuda.Event()
+    ms._sizes_ready.record()
+    ws.record_stream(torch.cuda.current_stream(dev))       # (freed below while the kernels that use it may still be queued)
+    del ws
+    ms.wo = ms.T = None
+    return ms
+
+
+def measure_strips_end(ms):
+    """THE wait of the normaliser: the measured sizes on the host (ms.wo, ms.T); ValueError for a constant strip"""
+    if ms.wo is not None:
+        return ms
+    ms._sizes_ready.synchronize()
+    n = ms.n
+    sized = ms._sizes_host.numpy()
     ms.wo = sized[:n].astype(np.int64)
     if bool((sized[n::2] == sized[n + 1::2]).any()):      # the measuring pass found a strip's minimum = its maximum
         raise ValueError("empty or constant text-line image")
-    del ws
     ms.T = ms.wo + 2 * PAD
+    ms._sizes_host = ms._sizes_ready = None
     return ms
 
 

@@ -481,12 +481,15 @@ class LineRecognizer(object):
         return {"src": src, "keep": keep, "done": done, "rows": rows}
 
     # ---- batched device pass -------------------------------------------------------------
-    def prepare(self, lines, defer=False):
+    def prepare(self, lines, defer=False, _measured=None):
         """Upload lines and allocate outputs.  A line is either a prepared (T, 48) float array
         (ink = 1, padded) or a raw 2-D uint8 strip (white background; a host array or a tensor already
         on the device), which is normalised on the device (lineest_gpu, csrc/ta_lineest.hip) without a
-        host round trip.  defer = True (host lines only): the staging copies are started and the call returns;
-        `complete(st)` -- or `run(st)` -- waits for them and does the device part."""
+        host round trip.  defer = True: what can be STARTED is started and the call returns; `complete(st)` -- or
+        `run(st)` -- waits for it and does the rest.  Host rows: the staging copies are started.  Raw strips (all lines
+        raw): the normaliser's measuring pass is enqueued -- its output widths are data-dependent, so the batch's layout
+        itself waits for it; a caller with other host work (alignToOCR.process_batch: the second stages of older chunks)
+        does it before complete(), instead of waiting here for kernels queued behind the previous chunk's recogniser."""
         from .page import RowSpan
         nspans = sum(1 for ln in lines if isinstance(ln, RowSpan))
         if 0 < nspans < len(lines):         # a mixed batch: the spans go the way of host arrays (a device span is downloaded)
@@ -506,8 +509,14 @@ class LineRecognizer(object):
         x_raw, T_raw = None, None
         if raw:
             from . import lineest_gpu
-            x_raw, T_raw, _ = lineest_gpu.normalize_strips([lines[k] for k in raw], device=self.device,
-                                                           layout=layout if len(raw) == n else None)
+            if len(raw) == n and (defer or _measured is not None):
+                if _measured is None:
+                    return {"_raw": (lines, lineest_gpu.measure_strips_begin(lines, device=self.device))}
+                lineest_gpu.measure_strips_end(_measured)                       # the wait; sizes known from here on
+                x_raw, T_raw = lineest_gpu.resample_strips(_measured, 0, n, layout=layout)
+            else:
+                x_raw, T_raw, _ = lineest_gpu.normalize_strips([lines[k] for k in raw], device=self.device,
+                                                               layout=layout if len(raw) == n else None)
             T[raw] = T_raw
         if nspans:                                   # spans of RowBlocks: (T, 48) by construction
             T[:] = [ln.stop - ln.start for ln in lines]
@@ -575,6 +584,10 @@ class LineRecognizer(object):
 
     def complete(self, st):
         """the device part of prepare(): the rows' transfer, the batch's metadata, the output buffers"""
+        if "_raw" in st:                        # raw strips whose measuring pass was enqueued by prepare(defer=True)
+            lines, ms = st.pop("_raw")
+            st.update(self.prepare(lines, defer=False, _measured=ms))
+            return st
         if "_pending" not in st:
             return st
         pending, x_dev, group_lines, nlines = st.pop("_pending")

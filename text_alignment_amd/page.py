@@ -184,16 +184,19 @@ def raw_strip_pixels(strip):
     """The 2-D uint8 greyscale image of a raw strip (white background), as the PNG the reference
     saves for ocropus-rpred (alignToOCR.py:131-132: Gamera writes onebit / greyscale PNGs).  A bool
     strip (True = ink) becomes black on white.  Anything else -- colour, float -- is not something
-    the reference's seam ever saw and is refused: convert it to uint8 greyscale first."""
+    the reference's seam ever saw and is refused: convert it to uint8 greyscale first.  An EMPTY strip is refused here; a
+    constant (blank) one by the device normaliser's measuring pass, with the same ValueError -- it reduces every strip
+    to its minimum and maximum anyway, and the host's own look at 1 920 strips per pass was 10 % of a raw page's host time."""
     px = np.asarray(strip.pixels)
     if px.dtype == bool and px.ndim == 2:
         px = np.where(px, 0, 255).astype(np.uint8)
     if px.dtype != np.uint8 or px.ndim != 2:
         raise TypeError("a raw text-line strip is a 2-D uint8 greyscale image (bool: True = ink); got %s, %d-D"
                         % (px.dtype, px.ndim))
-    if px.size == 0 or _is_constant(px):
+    if px.size == 0:
         raise ValueError("empty or constant text-line image")
-    return px
+    return px               # (a CONSTANT strip is found by the normaliser's measuring pass, which reduces every strip to its
+                            # minimum and maximum anyway, and raises the same error: lineest_gpu.measure_strips_end)
 
 
 def prepared_line(strip):
@@ -208,16 +211,6 @@ def prepared_line(strip):
         return dp, int(dp.shape[1])     # the normaliser, which measures it anyway)
     px = raw_strip_pixels(strip)
     return px, int(px.shape[1])
-
-
-def _is_constant(px):
-    """px.max() == px.min(), decided from ~64 samples whenever they already differ (two full
-    reductions per strip were 10 % of a page's host time)"""
-    flat = px.reshape(-1)
-    probe = flat[::max(1, flat.size // 64)]
-    if probe.min() != probe.max():
-        return False
-    return bool(px.max() == px.min())
 
 
 def prepared_lines(strips, workers=1):

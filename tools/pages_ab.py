@@ -49,6 +49,7 @@ if "--profile" in sys.argv:
     import cProfile
     import pstats
     kind = sys.argv[sys.argv.index("--profile") + 1]
+    kind = kind if kind in inputs else next(iter(inputs))
     pages, trs = list(inputs[kind][0]), list(inputs[kind][1])
     pr = cProfile.Profile()
     pr.enable()
