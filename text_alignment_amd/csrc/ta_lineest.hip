@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kLnThreads) void ln_gauss_kernel(LnArgs a) {
 // per thread: the two tap windows x[j + jj .. j + jj + 3] and x[j - jj .. j - jj + 3] slide by one
 // element per tap pair, so each pair costs two new loads for NO outputs.  Every output still sums
 // its own products in scipy's order.
-template <int SRC, int DST, int WSEL>
+template <int SRC, int DST, int WSEL, bool ONLY_WIDE>
 __global__ __launch_bounds__(kLnThreads) void ln_gauss_row_kernel(LnArgs a) {
     constexpr int NO = TA_LN_ROW_NO;
     const int line = blockIdx.x;
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(kLnThreads) void ln_gauss_row_kernel(LnArgs a) {
     const double* wc = a.gw + a.gw_off[3 * line + WSEL];
     const int rad = a.gr[3 * line + WSEL];
     const int reach = min(rad, w - 1);
+    if (ONLY_WIDE && reach <= 640) return;                  // (kRowMaxReach: those strips are ln_gauss_row_lds_kernel's)
     const int per_row = (w + NO - 1) / NO;
     const int64_t ngroups = (int64_t)h * per_row;
     for (int64_t gidx = (int64_t)blockIdx.y * kLnThreads + threadIdx.x; gidx < ngroups;
@@ -149,6 +150,73 @@ __global__ __launch_bounds__(kLnThreads) void ln_gauss_row_kernel(LnArgs a) {
 #pragma unroll
         for (int q = 0; q < NO; ++q)
             if (j0 + q < w) D[(int64_t)i * w + j0 + q] = t[q];
+    }
+}
+
+// Round 6: the same row correlation with the row staged in LDS.  The kernel above runs at a fifth of the float64 VALU
+// rate: a thread's two new window elements per tap pair are 8-byte loads at a lane stride of 64 bytes -- 64 cache lines per
+// load instruction -- and the texture path, not the arithmetic, sets the pace (6.6-7.0 ms per 960 strips of 60 x 800..2000
+// at sigma = 60: 481 taps).  Here a workgroup copies a tile of a row (its outputs + `reach` elements either side, zeros
+// outside the strip: no bounds test in the tap loop) into LDS with coalesced loads, and the windows slide over LDS.  FIVE
+// adjacent outputs per thread: an odd lane stride in doubles (40 bytes) puts the 16 lanes of a quarter-wave on 16 different
+// pairs of banks -- no conflicts, no padding.  Every output still sums its own products in scipy's order (centre tap, then the
+// pairs from the outermost inwards, explicit non-fused operations): results equal to the bit, checked by the same tests.
+// Strips whose reach exceeds the tile's halo (taller than 160 rows) take the kernel above.
+constexpr int kRowNO = 5;
+constexpr int kRowTile = kLnThreads * kRowNO;       // 1280 outputs per pass
+constexpr int kRowMaxReach = 640;                   // 4 sigma + 0.5 at sigma = h = 160
+template <int SRC, int DST, int WSEL>
+__global__ __launch_bounds__(kLnThreads) void ln_gauss_row_lds_kernel(LnArgs a) {
+    constexpr int NO = kRowNO;
+    __shared__ double L[kRowTile + 2 * kRowMaxReach + NO];
+    const int line = blockIdx.x, tid = threadIdx.x;
+    const int h = a.hh[line], w = a.ww[line];
+    const int64_t n = (int64_t)h * w;
+    const double* S = a.ws + a.ws_off[line] + (int64_t)SRC * n;
+    double* D = a.ws + a.ws_off[line] + (int64_t)DST * n;
+    const double* wc = a.gw + a.gw_off[3 * line + WSEL];
+    const int rad = a.gr[3 * line + WSEL];
+    const int reach = min(rad, w - 1);
+    if (reach > kRowMaxReach) return;                       // (such strips are done by ln_gauss_row_kernel, launched beside this one)
+    const int span = kRowTile + 2 * reach + NO;
+    for (int i = blockIdx.y; i < h; i += gridDim.y) {
+        const double* row = S + (int64_t)i * w;
+        for (int jt = 0; jt < w; jt += kRowTile) {
+            __syncthreads();                                // the tile before this one has been read
+            for (int k = tid; k < span; k += kLnThreads) {
+                const int src = jt - reach + k;
+                L[k] = (src >= 0 && src < w) ? row[src] : 0.0;
+            }
+            __syncthreads();
+            const int j0 = jt + NO * tid;
+            if (j0 < w) {
+                const double* C = L + reach + NO * tid;     // C[k] = X(j0 + k)
+                double t[NO], lo[NO], hi[NO];
+#pragma unroll
+                for (int q = 0; q < NO; ++q) {
+                    t[q] = dmul(C[q], wc[0]);
+                    lo[q] = C[q - reach];
+                    hi[q] = C[q + reach];
+                }
+                for (int jb = -reach; jb < 0; jb += NO) {   // ring windows, as in the kernel above
+#pragma unroll
+                    for (int u = 0; u < NO; ++u) {
+                        const int jj = jb + u;
+                        if (jj < 0) {
+                            const double wj = wc[jj];
+#pragma unroll
+                            for (int q = 0; q < NO; ++q)
+                                t[q] = dadd(t[q], dmul(dadd(lo[(q + u) % NO], hi[(q - u + NO) % NO]), wj));
+                            lo[u % NO] = C[jj + NO];
+                            hi[(NO - 1 - u) % NO] = C[-jj - 1];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NO; ++q)
+                    if (j0 + q < w) D[(int64_t)i * w + j0 + q] = t[q];
+            }
+        }
     }
 }
 
@@ -431,7 +499,8 @@ extern "C" int ta_linenorm_measure(const uint8_t* pix, const int64_t* pix_off, c
     hipLaunchKernelGGL(ln_minmax_kernel, one, dim3(kLnThreads), 0, st, a);
     hipLaunchKernelGGL(ln_temp_kernel, wide, dim3(kLnThreads), 0, st, a);
     hipLaunchKernelGGL((ln_gauss_col_kernel<0, 1, 0>), wide, dim3(kLnThreads), 0, st, a);     // plane 0 -> 1
-    hipLaunchKernelGGL((ln_gauss_row_kernel<1, 2, 1>), wide, dim3(kLnThreads), 0, st, a);     // plane 1 -> 2
+    hipLaunchKernelGGL((ln_gauss_row_lds_kernel<1, 2, 1>), wide, dim3(kLnThreads), 0, st, a);     // plane 1 -> 2
+    hipLaunchKernelGGL((ln_gauss_row_kernel<1, 2, 1, true>), dim3(nlines, 8), dim3(kLnThreads), 0, st, a);   // ... strips taller than 160 rows
     hipLaunchKernelGGL((ln_uniform_kernel<0, 2, 0>), cols, dim3(kLnThreads), 0, st, a);       // plane 2 -> 0
     hipLaunchKernelGGL((ln_uniform_kernel<1, 0, 1>), one, dim3(kLnThreads), 0, st, a);        // plane 0 -> 1
     hipLaunchKernelGGL((ln_argmax_kernel<2, 1>), cols, dim3(kLnThreads), 0, st, a);
