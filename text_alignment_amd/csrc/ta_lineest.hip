@@ -224,11 +224,12 @@ __global__ __launch_bounds__(kLnThreads) void ln_gauss_row_lds_kernel(LnArgs a) 
 // vertically adjacent outputs per thread with the same sliding tap windows -- a thread's loads per tap pair go
 // from eight to two, and the threads of a wave sit on neighbouring columns, so every load is one coalesced row
 // segment.  Every output sums its own products in scipy's order.
-template <int SRC, int DST, int WSEL>
+template <int SRC, int DST, int WSEL, bool ONLY_TALL>
 __global__ __launch_bounds__(kLnThreads) void ln_gauss_col_kernel(LnArgs a) {
     constexpr int NO = 4;
     const int line = blockIdx.x;
     const int h = a.hh[line], w = a.ww[line];
+    if (ONLY_TALL && h <= 96) return;                       // (kColMaxH: those strips are ln_gauss_col_lds_kernel's)
     const int64_t n = (int64_t)h * w;
     const double* S = a.ws + a.ws_off[line] + (int64_t)SRC * n;
     double* D = a.ws + a.ws_off[line] + (int64_t)DST * n;
@@ -265,6 +266,65 @@ __global__ __launch_bounds__(kLnThreads) void ln_gauss_col_kernel(LnArgs a) {
 #pragma unroll
         for (int q = 0; q < NO; ++q)
             if (i0 + q < h) D[(int64_t)(i0 + q) * w + j] = t[q];
+    }
+}
+
+// Round 6: the column correlation over an LDS tile -- all h rows of 64 neighbouring columns (h <= kColMaxH; taller strips
+// take the kernel above).  A workgroup's four waves take the groups of four rows in turn; a lane owns one column, so every
+// LDS access of a wave is 64 consecutive doubles (no bank conflicts), and rows outside the strip are ONE row of zeros
+// the index is clamped to.  Same operations per output, in the same order: results equal to the bit.
+constexpr int kColTile = 64;
+constexpr int kColMaxH = 96;                        // (96 + 1 zero row) x 64 x 8 B = 49 664 B of LDS: three workgroups per CU
+template <int SRC, int DST, int WSEL>
+__global__ __launch_bounds__(kLnThreads) void ln_gauss_col_lds_kernel(LnArgs a) {
+    constexpr int NO = 4;
+    __shared__ double L[(kColMaxH + 1) * kColTile];
+    const int line = blockIdx.x, tid = threadIdx.x;
+    const int h = a.hh[line], w = a.ww[line];
+    if (h > kColMaxH) return;                               // (done by ln_gauss_col_kernel, launched beside this one)
+    const int64_t n = (int64_t)h * w;
+    const double* S = a.ws + a.ws_off[line] + (int64_t)SRC * n;
+    double* D = a.ws + a.ws_off[line] + (int64_t)DST * n;
+    const double* wc = a.gw + a.gw_off[3 * line + WSEL];
+    const int rad = a.gr[3 * line + WSEL];
+    const int reach = min(rad, h - 1);
+    const int c = tid & (kColTile - 1), wave = tid >> 6;
+    for (int jt = blockIdx.y * kColTile; jt < w; jt += gridDim.y * kColTile) {
+        __syncthreads();                                    // the tile before this one has been read
+        for (int e = tid; e < (h + 1) * kColTile; e += kLnThreads) {
+            const int r = e / kColTile, cc = e % kColTile;
+            L[e] = (r < h && jt + cc < w) ? S[(int64_t)r * w + jt + cc] : 0.0;      // row h: the zeros outside the strip
+        }
+        __syncthreads();
+        if (jt + c >= w) continue;
+        const double* col = L + c;
+        auto X = [&](int k) -> double { return col[((unsigned)k < (unsigned)h ? k : h) * kColTile]; };
+        for (int i0 = NO * wave; i0 < h; i0 += NO * (kLnThreads / 64)) {
+            double t[NO], lo[NO], hi[NO];
+#pragma unroll
+            for (int q = 0; q < NO; ++q) {
+                t[q] = dmul(X(i0 + q), wc[0]);
+                lo[q] = X(i0 - reach + q);
+                hi[q] = X(i0 + reach + q);
+            }
+            for (int jb = -reach; jb < 0; jb += NO) {       // ring windows, as in the kernels above
+#pragma unroll
+                for (int u = 0; u < NO; ++u) {
+                    const int jj = jb + u;
+                    if (jj < 0) {
+                        const double wj = wc[jj];
+#pragma unroll
+                        for (int q = 0; q < NO; ++q)
+                            t[q] = dadd(t[q], dmul(dadd(lo[(q + u) % NO], hi[(q - u + NO) % NO]), wj));
+                        lo[u % NO] = X(i0 + jj + NO);
+                        hi[(NO - 1 - u) % NO] = X(i0 - jj - 1);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NO; ++q)
+                if (i0 + q < h) D[(int64_t)(i0 + q) * w + jt + c] = t[q];
+        }
     }
 }
 
@@ -498,7 +558,8 @@ extern "C" int ta_linenorm_measure(const uint8_t* pix, const int64_t* pix_off, c
     const dim3 one(nlines), wide(nlines, 32), cols(nlines, 8);
     hipLaunchKernelGGL(ln_minmax_kernel, one, dim3(kLnThreads), 0, st, a);
     hipLaunchKernelGGL(ln_temp_kernel, wide, dim3(kLnThreads), 0, st, a);
-    hipLaunchKernelGGL((ln_gauss_col_kernel<0, 1, 0>), wide, dim3(kLnThreads), 0, st, a);     // plane 0 -> 1
+    hipLaunchKernelGGL((ln_gauss_col_lds_kernel<0, 1, 0>), wide, dim3(kLnThreads), 0, st, a); // plane 0 -> 1
+    hipLaunchKernelGGL((ln_gauss_col_kernel<0, 1, 0, true>), dim3(nlines, 8), dim3(kLnThreads), 0, st, a);   // ... strips taller than 96 rows
     hipLaunchKernelGGL((ln_gauss_row_lds_kernel<1, 2, 1>), wide, dim3(kLnThreads), 0, st, a);     // plane 1 -> 2
     hipLaunchKernelGGL((ln_gauss_row_kernel<1, 2, 1, true>), dim3(nlines, 8), dim3(kLnThreads), 0, st, a);   // ... strips taller than 160 rows
     hipLaunchKernelGGL((ln_uniform_kernel<0, 2, 0>), cols, dim3(kLnThreads), 0, st, a);       // plane 2 -> 0
