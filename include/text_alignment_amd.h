@@ -80,6 +80,10 @@ const char* ta_last_error(void);
  * from which a rank of the page-sharded job (the loop of alignToOCR.py:407-438, one process per GPU) reads the NUMA node
  * of its GPU to bind itself next to it.  [host] */
 int ta_device_pci_bus_id(int32_t device, char* out, int32_t len);
+/* n host arrays into one staging buffer in one call: nbytes[k] bytes from src[k] to dst + dst_off[k] (memcpy; all pointers
+ * [host]).  How a chunk's text-line strips reach the page-locked buffer they cross PCIe from -- where the reference writes
+ * each strip to a PNG file for the recogniser (alignToOCR.py:131-132) -- without the interpreter lock being taken per strip. */
+int ta_host_copy_pieces(void* dst, const void* const* src, const int64_t* dst_off, const int64_t* nbytes, int32_t n);
 
 /*
  * Affine-gap Needleman-Wunsch, replaces textSeqCompare.perform_alignment

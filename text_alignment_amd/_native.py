@@ -95,6 +95,8 @@ def _load():
     lib.ta_decode.argtypes = [vp, vp, vp, i32, i32, f32, vp, vp, vp, vp, vp]
     lib.ta_device_pci_bus_id.restype = ctypes.c_int
     lib.ta_device_pci_bus_id.argtypes = [i32, ctypes.c_char_p, i32]
+    lib.ta_host_copy_pieces.restype = ctypes.c_int
+    lib.ta_host_copy_pieces.argtypes = [vp, vp, vp, vp, i32]
     lib.ta_rows_gather.restype = ctypes.c_int
     lib.ta_rows_gather.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.ta_linenorm_measure.restype = ctypes.c_int
@@ -120,7 +122,7 @@ def _load():
 
 lib = _load()
 
-EXPORTS = ["ta_version", "ta_last_error", "ta_device_pci_bus_id", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_max_m", "ta_nw2_batch", "ta_nw2_phase1_plan", "ta_nw2_phase1_plan_batch", "ta_nw2_traceback_plan",
+EXPORTS = ["ta_version", "ta_last_error", "ta_device_pci_bus_id", "ta_host_copy_pieces", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_max_m", "ta_nw2_batch", "ta_nw2_phase1_plan", "ta_nw2_phase1_plan_batch", "ta_nw2_traceback_plan",
            "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general", "ta_nw_general_batch",
            "ta_lstm_packed_weight_floats", "ta_lstm_forward", "ta_lstm_f64_weight_doubles", "ta_lstm_f64_gx_bytes", "ta_lstm_xproj_f64", "ta_lstm_forward_f64", "ta_lstm_forward_f64_g4", "ta_lstm_output", "ta_lstm_output_split_weight_bytes", "ta_lstm_output_split", "ta_decode",
            "ta_decode_summary", "ta_rows_gather", "ta_linenorm_measure", "ta_linenorm_resample",
@@ -167,3 +169,19 @@ def upload_packed(arrays, device):
         t = dev[off:off + a.nbytes].view(getattr(torch, a.dtype.name))
         out.append(t.reshape(a.shape))
     return out
+
+
+def host_copy_pieces(dst_view, pieces, dst_off_bytes):
+    """pieces (C-contiguous numpy arrays) -> dst_view (a writable, C-contiguous numpy array, e.g. the view of a page-locked
+    tensor) at byte offsets dst_off_bytes[k], in ONE native call that holds no interpreter lock (ta_host_copy_pieces)."""
+    import numpy as np
+    n = len(pieces)
+    if n == 0:
+        return
+    src = np.fromiter((p.ctypes.data for p in pieces), dtype=np.uint64, count=n)
+    nb = np.fromiter((p.nbytes for p in pieces), dtype=np.int64, count=n)
+    off = np.ascontiguousarray(dst_off_bytes, dtype=np.int64)
+    end = int((off + nb).max())
+    if end > dst_view.nbytes or int(off.min()) < 0:
+        raise ValueError("a piece does not fit the staging buffer")
+    check(lib.ta_host_copy_pieces(dst_view.ctypes.data, src.ctypes.data, off.ctypes.data, nb.ctypes.data, n), "ta_host_copy_pieces")

@@ -2,6 +2,7 @@
 #include "ta_common.h"
 
 #include <cstdio>
+#include <cstring>
 
 static thread_local char g_err[256] = "";
 
@@ -25,5 +26,19 @@ extern "C" int ta_device_pci_bus_id(int32_t device, char* out, int32_t len) {
     if (!out || len < 13) return ta_fail(TA_EINVAL, "ta_device_pci_bus_id needs a buffer of at least 13 bytes");
     const hipError_t e = hipDeviceGetPCIBusId(out, len, device);
     if (e != hipSuccess) return ta_fail_hip(e, "hipDeviceGetPCIBusId");
+    return TA_OK;
+}
+
+// Many small host arrays into one (page-locked) staging buffer in ONE native call: piece k = nbytes[k] bytes from src[k]
+// to dst + dst_off[k].  The page pipeline's copy threads stage a chunk's strips / rows with it (275 KB per text line, 480
+// lines per chunk): a Python loop of slice assignments takes and drops the interpreter lock once per piece and fights the
+// pipeline's own thread for it; one foreign call holds no lock at all.  [host only: no device work]
+extern "C" int ta_host_copy_pieces(void* dst, const void* const* src, const int64_t* dst_off, const int64_t* nbytes, int32_t n) {
+    if (n < 0) return ta_fail(TA_EINVAL, "negative piece count");
+    if (n == 0) return TA_OK;
+    if (!dst || !src || !dst_off || !nbytes) return ta_fail(TA_EINVAL, "null pointer argument");
+    char* base = static_cast<char*>(dst);
+    for (int32_t k = 0; k < n; ++k)
+        if (nbytes[k] > 0) std::memcpy(base + dst_off[k], src[k], (size_t)nbytes[k]);
     return TA_OK;
 }

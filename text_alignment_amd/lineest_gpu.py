@@ -35,8 +35,14 @@ def _upload_host_strips(strips, pix_off, dev):
             st = _stage["buf"] = torch.empty(int(total * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
         view = st.numpy()
 
+        plain = all(isinstance(s_, np.ndarray) and s_.flags.c_contiguous for s_ in strips)
+
         def copy(span):
-            for k in range(*span):
+            a, b = span
+            if plain:                                    # one native call, no interpreter lock (ta_host_copy_pieces)
+                _native.host_copy_pieces(view, strips[a:b], pix_off[a:b])
+                return
+            for k in range(a, b):
                 view[pix_off[k]:pix_off[k + 1]] = np.asarray(strips[k]).reshape(-1)
         n = len(strips)
         nthreads = min(8, max(1, total >> 22))           # ~4 MB per thread at least

@@ -377,9 +377,16 @@ class LineRecognizer(object):
             slot["buf"] = None
             slot["buf"] = torch.empty((int(rows * 1.25) + 1024, NI), dtype=torch.float32, pin_memory=True)
         view = slot["buf"].numpy()
+        # float32 rows as they are: one native call per thread and no interpreter lock (ta_host_copy_pieces); anything that
+        # needs converting (float64 rows, non-contiguous views) goes through numpy's assignment, line by line
+        plain = all(ln.dtype == np.float32 and ln.flags.c_contiguous for ln in lines)
 
         def copy(span):
-            for k in range(*span):
+            a, b = span
+            if plain:
+                _native.host_copy_pieces(view, lines[a:b], 4 * NI * np.asarray(row_start[a:b], dtype=np.int64))
+                return
+            for k in range(a, b):
                 view[row_start[k]:row_start[k] + lines[k].shape[0]] = lines[k]
         nthreads = min(COPY_THREADS, max(1, len(lines) // 64))
         if nthreads == 1:
