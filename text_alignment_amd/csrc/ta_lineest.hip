@@ -157,31 +157,23 @@ __global__ __launch_bounds__(kLnThreads) void ln_gauss_row_kernel(LnArgs a) {
 // rate: a thread's two new window elements per tap pair are 8-byte loads at a lane stride of 64 bytes -- 64 cache lines per
 // load instruction -- and the texture path, not the arithmetic, sets the pace (6.6-7.0 ms per 960 strips of 60 x 800..2000
 // at sigma = 60: 481 taps).  Here a workgroup copies a tile of a row (its outputs + `reach` elements either side, zeros
-// outside the strip: no bounds test in the tap loop) into LDS with coalesced loads, and the windows slide over LDS.  FIVE
-// adjacent outputs per thread: an odd lane stride in doubles (40 bytes) puts the 16 lanes of a quarter-wave on 16 different
-// pairs of banks -- no conflicts, no padding.  Every output still sums its own products in scipy's order (centre tap, then the
+// outside the strip: no bounds test in the tap loop) into LDS with coalesced loads, and the windows slide over LDS.  An ODD
+// number of adjacent outputs per thread: an odd lane stride in doubles (40 bytes at five) puts the 16 lanes of a quarter-wave
+// on 16 different pairs of banks -- no conflicts, no padding.  Every output still sums its own products in scipy's order (centre tap, then the
 // pairs from the outermost inwards, explicit non-fused operations): results equal to the bit, checked by the same tests.
 // Strips whose reach exceeds the tile's halo (taller than 160 rows) take the kernel above.
-constexpr int kRowNO = 5;
-constexpr int kRowTile = kLnThreads * kRowNO;       // 1280 outputs per pass
+// The outputs per thread follow the row's width -- 5 up to 1 280 columns, 7 up to 1 792, 9 beyond -- so that one pass of the
+// workgroup covers the row (a second pass over a 120-column rest costs as much as the first); all three odd.
+constexpr int kRowMaxNO = 9;
 constexpr int kRowMaxReach = 640;                   // 4 sigma + 0.5 at sigma = h = 160
-template <int SRC, int DST, int WSEL>
-__global__ __launch_bounds__(kLnThreads) void ln_gauss_row_lds_kernel(LnArgs a) {
-    constexpr int NO = kRowNO;
-    __shared__ double L[kRowTile + 2 * kRowMaxReach + NO];
-    const int line = blockIdx.x, tid = threadIdx.x;
-    const int h = a.hh[line], w = a.ww[line];
-    const int64_t n = (int64_t)h * w;
-    const double* S = a.ws + a.ws_off[line] + (int64_t)SRC * n;
-    double* D = a.ws + a.ws_off[line] + (int64_t)DST * n;
-    const double* wc = a.gw + a.gw_off[3 * line + WSEL];
-    const int rad = a.gr[3 * line + WSEL];
-    const int reach = min(rad, w - 1);
-    if (reach > kRowMaxReach) return;                       // (such strips are done by ln_gauss_row_kernel, launched beside this one)
-    const int span = kRowTile + 2 * reach + NO;
+template <int NO>
+__device__ __forceinline__ void gauss_row_lds_body(const double* S, double* D, const double* wc, int h, int w, int reach, double* L) {
+    constexpr int kTile = kLnThreads * NO;
+    const int tid = threadIdx.x;
+    const int span = kTile + 2 * reach + NO;
     for (int i = blockIdx.y; i < h; i += gridDim.y) {
         const double* row = S + (int64_t)i * w;
-        for (int jt = 0; jt < w; jt += kRowTile) {
+        for (int jt = 0; jt < w; jt += kTile) {
             __syncthreads();                                // the tile before this one has been read
             for (int k = tid; k < span; k += kLnThreads) {
                 const int src = jt - reach + k;
@@ -218,6 +210,23 @@ __global__ __launch_bounds__(kLnThreads) void ln_gauss_row_lds_kernel(LnArgs a) 
             }
         }
     }
+}
+
+template <int SRC, int DST, int WSEL>
+__global__ __launch_bounds__(kLnThreads) void ln_gauss_row_lds_kernel(LnArgs a) {
+    __shared__ double L[kLnThreads * kRowMaxNO + 2 * kRowMaxReach + kRowMaxNO];       // 28.7 KB
+    const int line = blockIdx.x;
+    const int h = a.hh[line], w = a.ww[line];
+    const int64_t n = (int64_t)h * w;
+    const double* S = a.ws + a.ws_off[line] + (int64_t)SRC * n;
+    double* D = a.ws + a.ws_off[line] + (int64_t)DST * n;
+    const double* wc = a.gw + a.gw_off[3 * line + WSEL];
+    const int rad = a.gr[3 * line + WSEL];
+    const int reach = min(rad, w - 1);
+    if (reach > kRowMaxReach) return;                       // (such strips are done by ln_gauss_row_kernel, launched beside this one)
+    if (w <= kLnThreads * 5) gauss_row_lds_body<5>(S, D, wc, h, w, reach, L);
+    else if (w <= kLnThreads * 7) gauss_row_lds_body<7>(S, D, wc, h, w, reach, L);
+    else gauss_row_lds_body<9>(S, D, wc, h, w, reach, L);
 }
 
 // The correlation down the columns (AXIS 0 of ln_gauss_kernel; reach = h - 1: every row of the strip), four
