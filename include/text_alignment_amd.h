@@ -84,6 +84,16 @@ int ta_device_pci_bus_id(int32_t device, char* out, int32_t len);
  * [host]).  How a chunk's text-line strips reach the page-locked buffer they cross PCIe from -- where the reference writes
  * each strip to a PNG file for the recogniser (alignToOCR.py:131-132) -- without the interpreter lock being taken per strip. */
 int ta_host_copy_pieces(void* dst, const void* const* src, const int64_t* dst_off, const int64_t* nbytes, int32_t n);
+/* Characters and boxes of every decoded line of a batch -- the loop of alignToOCR.py:160-182 over all lines at once, host
+ * arithmetic: entry i of line b is (dec_t, dec_c)[dec_off[b] + i], i < dec_n[b]; its position x = (t - pad) * raw_w[b] /
+ * (T[b] - 2 pad) goes through the `.llocs` text's one decimal ("%.1f") and int(np.round(x + x_min[b])) (half to even); a box
+ * runs from the previous character's position (x_min[b] for the first) to its own, between y_min[b] and y_max[b]; classes
+ * with cps[c] < 0 ('~' and '', alignToOCR.py:175) are dropped but still move the edge.  Outputs have capacity sum(dec_n):
+ * out_line, out_cp, out_boxes [k][4] = ulx, uly, lrx, lry; *out_count = characters kept.  All pointers [host]. */
+int ta_host_chars_of_batch(const int32_t* dec_t, const int32_t* dec_c, const int64_t* dec_n, const int64_t* dec_off,
+                           const int64_t* T, const int64_t* raw_w, const int64_t* x_min, const int64_t* y_min,
+                           const int64_t* y_max, const int64_t* cps, int32_t ncps, int32_t pad, int32_t nlines,
+                           int64_t* out_line, int64_t* out_cp, int64_t* out_boxes, int64_t* out_count);
 
 /*
  * Affine-gap Needleman-Wunsch, replaces textSeqCompare.perform_alignment

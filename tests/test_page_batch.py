@@ -61,7 +61,47 @@ def test_chars_of_batch_matches_reference_llocs():
                                             np.array(ymax), cps, 16)
         got = [[chr(int(a)), [int(b[0]), int(b[1])], [int(b[2]), int(b[3])]] for a, b in zip(cp, boxes)]
         assert got == c["chars"]
+        # the array form (rounds 3-5) against the same fixture
+        line2, cp2, boxes2 = pb.chars_of_batch_numpy(np.array(dec_t), np.array(dec_c), np.array(dec_n, dtype=np.int64), off,
+                                                    np.array(T), np.full(len(T), 10000), np.array(xmin), np.array(ymin),
+                                                    np.array(ymax), cps, 16)
+        assert np.array_equal(line, line2) and np.array_equal(cp, cp2) and np.array_equal(boxes, boxes2)
     assert pb.codec_code_points(["", " ", "~", "ab"]) is None
+
+
+def test_native_character_loop_equals_the_array_form_on_random_batches():
+    """ta_host_chars_of_batch (one native call) against chars_of_batch_numpy on random decoder outputs: ragged lines, empty
+    lines, dropped classes at line starts and ends, negative positions (t < pad), scales that put x on .x5 boundaries
+    (where the reference's "%.1f" decides) and on exact halves after the offset (round half to even)"""
+    from text_alignment_amd import page_batch as pb
+    rng = np.random.default_rng(17)
+    for trial in range(60):
+        nlines = int(rng.integers(0, 40))
+        dec_n = rng.integers(0, 30, size=nlines).astype(np.int64)
+        if trial % 5 == 0 and nlines:
+            dec_n[rng.integers(0, nlines)] = 0
+        cap = dec_n + rng.integers(0, 5, size=nlines)
+        dec_off = np.concatenate([[0], np.cumsum(cap)[:-1]]).astype(np.int64) if nlines else np.zeros(0, np.int64)
+        total = int(cap.sum()) if nlines else 0
+        T = rng.integers(40, 3000, size=nlines).astype(np.int64)
+        dec_t = np.zeros(max(total, 1), np.int32); dec_c = np.zeros(max(total, 1), np.int32)
+        ncls = 12
+        for b in range(nlines):
+            ts = np.sort(rng.integers(0, T[b], size=dec_n[b]))
+            dec_t[dec_off[b]:dec_off[b] + dec_n[b]] = ts
+            dec_c[dec_off[b]:dec_off[b] + dec_n[b]] = rng.integers(0, ncls, size=dec_n[b])
+        # widths that make (t - 16) * raw_w / (T - 32) land on multiples of 0.05 and 0.25 often
+        raw_w = np.where(rng.random(nlines) < 0.5, (T - 32) * rng.integers(1, 4, size=nlines) // rng.choice([1, 2, 4, 20], size=nlines),
+                         rng.integers(10, 4000, size=nlines)).astype(np.int64)
+        raw_w = np.maximum(raw_w, 1)
+        x_min = rng.integers(-5, 300, size=nlines).astype(np.int64)
+        y_min = rng.integers(0, 3000, size=nlines).astype(np.int64)
+        y_max = y_min + rng.integers(20, 90, size=nlines)
+        cps = rng.integers(97, 123, size=ncls).astype(np.int64)
+        cps[[0, 2]] = -1                                                   # '' and '~'
+        a = pb.chars_of_batch(dec_t, dec_c, dec_n, dec_off, T, raw_w, x_min, y_min, y_max, cps, 16)
+        b_ = pb.chars_of_batch_numpy(dec_t, dec_c, dec_n, dec_off, T, raw_w, x_min, y_min, y_max, cps, 16)
+        assert all(np.array_equal(u, v) for u, v in zip(a, b_)), trial
 
 
 def test_array_glue_equals_object_glue_on_random_pages():

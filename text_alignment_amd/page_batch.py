@@ -79,7 +79,30 @@ def codec_code_points(codec):
 
 
 def chars_of_batch(dec_t, dec_c, dec_n, dec_off, T, raw_w, x_min, y_min, y_max, cps, pad):
-    """All characters of all lines, reading order (line, then position).
+    """All characters of all lines, reading order (line, then position): (line of each character, code point, boxes
+    [k, 4]) with the dropped classes removed -- ONE native call (ta_host_chars_of_batch, host arithmetic in the library;
+    chars_of_batch_numpy below is the same in array operations and its cross-check, tests/test_page_batch.py)."""
+    from . import _native
+    nlines = len(dec_n)
+    dec_n = np.ascontiguousarray(dec_n, dtype=np.int64)
+    total = int(dec_n.sum()) if nlines else 0
+    if total == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros((0, 4), np.int64)
+    i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)            # noqa: E731
+    dec_t, dec_c = np.ascontiguousarray(dec_t, dtype=np.int32), np.ascontiguousarray(dec_c, dtype=np.int32)
+    dec_off, T, raw_w, x_min, y_min, y_max, cps = (i64(a) for a in (dec_off, T, raw_w, x_min, y_min, y_max, cps))
+    line, cp, boxes = np.empty(total, np.int64), np.empty(total, np.int64), np.empty((total, 4), np.int64)
+    count = np.zeros(1, np.int64)
+    _native.check(_native.lib.ta_host_chars_of_batch(
+        dec_t.ctypes.data, dec_c.ctypes.data, dec_n.ctypes.data, dec_off.ctypes.data, T.ctypes.data, raw_w.ctypes.data,
+        x_min.ctypes.data, y_min.ctypes.data, y_max.ctypes.data, cps.ctypes.data, len(cps), int(pad), nlines,
+        line.ctypes.data, cp.ctypes.data, boxes.ctypes.data, count.ctypes.data), "ta_host_chars_of_batch")
+    k = int(count[0])
+    return line[:k], cp[:k], boxes[:k]
+
+
+def chars_of_batch_numpy(dec_t, dec_c, dec_n, dec_off, T, raw_w, x_min, y_min, y_max, cps, pad):
+    """chars_of_batch in numpy array operations (the form rounds 3-5 ran; kept as the native loop's cross-check).
 
     dec_*: the decoder's output arrays (entry i of line b at dec_off[b] + i, dec_n[b] entries);
     T, raw_w, x_min, y_min, y_max: per line.  Returns (line of each character, code point, boxes

@@ -25,6 +25,8 @@ if "--only" in sys.argv:
     inputs = {only: inputs[only]}
 if "--raw" in sys.argv:
     inputs = {"raw": tuple(zip(*[pb.make_page(sd + 5000, raw=True) for sd in seeds]))}
+if "--images" in sys.argv:
+    inputs = {"images": ([pb.RawPage(pb.make_page_image(9100 + k)) for k in range(n)], inputs[next(iter(inputs))][1])}
 ref = None
 for name, inp in inputs.items():
     pages, trs = list(inp[0]), list(inp[1])
