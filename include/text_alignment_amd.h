@@ -90,6 +90,16 @@ int ta_host_copy_pieces(void* dst, const void* const* src, const int64_t* dst_of
  * runs from the previous character's position (x_min[b] for the first) to its own, between y_min[b] and y_max[b]; classes
  * with cps[c] < 0 ('~' and '', alignToOCR.py:175) are dropped but still move the edge.  Outputs have capacity sum(dec_n):
  * out_line, out_cp, out_boxes [k][4] = ulx, uly, lrx, lry; *out_count = characters kept.  All pointers [host]. */
+/* Union of the OCR character boxes under every syllable of a batch of pages (alignToOCR.py:285-324 after the alignment;
+ * host arithmetic).  ops: uint8 alignment columns of all pages end to end (0 pair, 1 transcript character over a gap, 2 gap
+ * over an OCR character); idx[nidx]: row of boxes ([nboxes][4] = ulx, uly, lrx, lry) of the character of every OCR-carrying
+ * column, in order; syllable s = transcript characters first_t[s] .. last_t[s] of the concatenated transcripts (ranges
+ * disjoint, ascending).  out_low[s] = largest uly under the syllable (INT64_MIN: no OCR character under it -- the reference
+ * skips it, :313-314); out_box[s][4] = union of the boxes whose uly is that value (the lower of two text lines, :318-320).
+ * All pointers [host]. */
+int ta_host_syllable_boxes(const uint8_t* ops, int64_t ncol, const int64_t* idx, int64_t nidx, const int64_t* boxes,
+                           int64_t nboxes, const int64_t* first_t, const int64_t* last_t, int64_t nsyl,
+                           int64_t* out_low, int64_t* out_box);
 int ta_host_chars_of_batch(const int32_t* dec_t, const int32_t* dec_c, const int64_t* dec_n, const int64_t* dec_off,
                            const int64_t* T, const int64_t* raw_w, const int64_t* x_min, const int64_t* y_min,
                            const int64_t* y_max, const int64_t* cps, int32_t ncps, int32_t pad, int32_t nlines,

@@ -2,6 +2,7 @@
 reference's own outputs (tests/golden/glue.json, llocs.json) and against the object-by-object
 functions of alignToOCR.py.  CPU only: the aligner here is oracle/nw_oracle.py."""
 import numpy as np
+import pytest
 
 from conftest import load_golden
 
@@ -229,3 +230,37 @@ def test_chunk_plan_of_the_page_pipeline():
         else:
             assert [len(c) for _, c in led] == [len(c) for _, c in chunks]
     assert [len(c) for _, c in atocr.plan_chunks([("A", list(range(64)))], 16, (8,))] == [8, 16, 16, 16, 8]
+
+
+def test_native_syllable_union_equals_the_array_form():
+    """ta_host_syllable_boxes against page_batch._syllable_union_numpy on random alignments: gaps on both sides, syllables
+    with no OCR character under them, syllables spanning two text lines (the lower line's boxes only), several pages end to end"""
+    from text_alignment_amd import page_batch as pb
+    rng = np.random.default_rng(23)
+    for trial in range(40):
+        ncol = int(rng.integers(5, 400))
+        ops = rng.choice([0, 0, 0, 1, 2], size=ncol).astype(np.uint8)
+        nt, no = int((ops != 2).sum()), int((ops != 1).sum())
+        if nt == 0:
+            continue
+        nboxes = no + 7
+        boxes = np.zeros((nboxes, 4), np.int64)
+        boxes[:, 0] = rng.integers(0, 2000, nboxes); boxes[:, 2] = boxes[:, 0] + rng.integers(1, 60, nboxes)
+        boxes[:, 1] = rng.choice([90, 210, 330], nboxes); boxes[:, 3] = boxes[:, 1] + 40
+        idx = rng.permutation(nboxes)[:no].astype(np.int64)
+        # disjoint ascending syllable ranges over the transcript characters
+        cuts = np.sort(rng.choice(np.arange(nt + 1), size=min(nt + 1, int(rng.integers(2, 30))), replace=False))
+        first = cuts[:-1][::2].astype(np.int64)
+        last = (cuts[1:][::2] - 1).astype(np.int64)
+        keep = last >= first
+        first, last = first[keep], last[keep]
+        if len(first) == 0:
+            continue
+        low_a, box_a = pb._syllable_union(ops, idx, boxes, first, last)
+        low_b, box_b = pb._syllable_union_numpy(ops, idx, boxes, first, last)
+        assert np.array_equal(low_a, low_b), trial
+        present = low_a > np.iinfo(np.int64).min
+        assert np.array_equal(box_a[present], box_b[present]), trial
+    with pytest.raises(AssertionError, match="not same length"):
+        pb._syllable_union(np.array([0, 0, 1], np.uint8), np.array([0], np.int64), np.zeros((3, 4), np.int64),
+                           np.array([0], np.int64), np.array([1], np.int64))

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 static thread_local char g_err[256] = "";
 
@@ -94,5 +95,61 @@ extern "C" int ta_host_chars_of_batch(const int32_t* dec_t, const int32_t* dec_c
         }
     }
     *out_count = k;
+    return TA_OK;
+}
+
+// Union of the OCR character boxes under every syllable of a batch of pages (reference alignToOCR.py:285-324, after the
+// alignment): host arithmetic.  ops: the alignment columns of all pages laid end to end (0 pair, 1 transcript character
+// over a gap, 2 gap over an OCR character); idx: for every OCR-carrying column, in order, the row of `boxes` ([.][4] =
+// ulx, uly, lrx, lry) of its character; syllable s covers the transcript characters first_t[s] .. last_t[s] (positions in
+// the concatenated transcripts; ranges disjoint and ascending), i.e. the columns from the one of its first character to
+// the one of its last.  Per syllable: out_low[s] = the largest uly under it (INT64_MIN if no OCR character is: the
+// reference skips such a syllable, :313-314) and out_box[s] = union of the boxes whose uly IS that value (a syllable
+// that spans two text lines keeps the lower one, :318-320).
+extern "C" int ta_host_syllable_boxes(const uint8_t* ops, int64_t ncol, const int64_t* idx, int64_t nidx, const int64_t* boxes,
+                                      int64_t nboxes, const int64_t* first_t, const int64_t* last_t, int64_t nsyl,
+                                      int64_t* out_low, int64_t* out_box) {
+    if (ncol < 0 || nidx < 0 || nsyl < 0 || nboxes < 0) return ta_fail(TA_EINVAL, "negative count");
+    if (nsyl == 0) return TA_OK;
+    if (!ops || !first_t || !last_t || !out_low || !out_box || (nidx > 0 && (!idx || !boxes)))
+        return ta_fail(TA_EINVAL, "null pointer argument");
+    std::vector<int64_t> col_of_t, o_at((size_t)ncol, -1);
+    col_of_t.reserve((size_t)ncol);
+    int64_t no = 0;
+    for (int64_t c = 0; c < ncol; ++c) {
+        if (ops[c] != 2) col_of_t.push_back(c);
+        if (ops[c] != 1) o_at[(size_t)c] = no++;
+    }
+    if (no != nidx) return ta_fail(TA_EINVAL, "all_chars not same length as alignment");
+    const int64_t nt = (int64_t)col_of_t.size();
+    const int64_t kMin = INT64_MIN, kMax = INT64_MAX;
+    for (int64_t s = 0; s < nsyl; ++s) {
+        if (first_t[s] < 0 || last_t[s] < first_t[s] || last_t[s] >= nt) return ta_fail(TA_EINVAL, "a syllable lies outside the transcript");
+        const int64_t c0 = col_of_t[(size_t)first_t[s]], c1 = col_of_t[(size_t)last_t[s]] + 1;
+        int64_t low = kMin;
+        for (int64_t c = c0; c < c1; ++c) {
+            const int64_t o = o_at[(size_t)c];
+            if (o < 0) continue;
+            const int64_t r = idx[o];
+            if (r < 0 || r >= nboxes) return ta_fail(TA_EINVAL, "a character index is outside the box table");
+            const int64_t uly = boxes[4 * r + 1];
+            if (uly > low) low = uly;
+        }
+        int64_t ulx = kMax, uly_ = kMax, lrx = kMin, lry = kMin;
+        if (low != kMin) {
+            for (int64_t c = c0; c < c1; ++c) {
+                const int64_t o = o_at[(size_t)c];
+                if (o < 0) continue;
+                const int64_t* b = boxes + 4 * idx[o];
+                if (b[1] != low) continue;
+                if (b[0] < ulx) ulx = b[0];
+                if (b[1] < uly_) uly_ = b[1];
+                if (b[2] > lrx) lrx = b[2];
+                if (b[3] > lry) lry = b[3];
+            }
+        }
+        out_low[s] = low;
+        out_box[4 * s] = ulx; out_box[4 * s + 1] = uly_; out_box[4 * s + 2] = lrx; out_box[4 * s + 3] = lry;
+    }
     return TA_OK;
 }

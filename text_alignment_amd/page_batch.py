@@ -247,23 +247,13 @@ def _syllable_spans_fast(tr, syls):
     return first, last
 
 
-def syllable_boxes_batch(transcripts, syls_list, ops_list, idx_list, boxes, angles, image_dims, raw_dims):
-    """syllable_boxes_arrays + rotate_boxes for MANY pages in one set of array operations (the
-    per-page versions spend their time in numpy's per-call overhead on 2000-element arrays): the
-    alignment columns of all pages are laid end to end, a syllable is a column range, and one
-    reduceat per quantity serves every syllable of every page.  idx_list[k]: indices into `boxes`
-    of page k's (expanded) OCR characters.  Returns per page (which, boxes [k, 4])."""
-    npages = len(transcripts)
-    if npages == 0:
-        return []
-    ops = np.concatenate([np.asarray(o) for o in ops_list]) if ops_list else np.zeros(0, np.uint8)
-    idx_all = np.concatenate(idx_list) if idx_list else np.zeros(0, np.int64)
+def _syllable_union_numpy(ops, idx_all, boxes, first_t, last_t):
+    """(low, box [k, 4]) per syllable in array operations -- the form rounds 3-5 ran, kept as the cross-check of the native
+    loop (ta_host_syllable_boxes): the alignment columns of all pages are laid end to end, a syllable is a column range,
+    and one reduceat per quantity serves every syllable of every page"""
     has_t = ops != 2
     has_o = ops != 1
-    col_of_t = np.flatnonzero(has_t)                     # global column of global transcript character
-    toff = np.zeros(npages + 1, dtype=np.int64)
-    np.cumsum([len(t) for t in transcripts], out=toff[1:])
-    assert len(col_of_t) == toff[-1] and int(has_o.sum()) == len(idx_all), 'all_chars not same length as alignment'
+    col_of_t = np.flatnonzero(has_t)
     ncol = len(ops)
     big, small = np.iinfo(np.int64).max, np.iinfo(np.int64).min
     ulx = np.full(ncol + 1, big, dtype=np.int64)
@@ -274,6 +264,52 @@ def syllable_boxes_batch(transcripts, syls_list, ops_list, idx_list, boxes, angl
     cols = np.flatnonzero(has_o)
     b = boxes[idx_all]
     ulx[cols], uly_min[cols], lrx[cols], lry[cols], uly_max[cols] = b[:, 0], b[:, 1], b[:, 2], b[:, 3], b[:, 1]
+    starts, ends = col_of_t[first_t], col_of_t[last_t] + 1
+    bounds = np.stack([starts, ends], axis=1).reshape(-1)
+    low = np.maximum.reduceat(uly_max, bounds)[0::2]
+    begun = np.bincount(starts, minlength=ncol + 2)                # (np.add.at costs 0.2 ms per call on 3 000 indices)
+    mark = begun - np.bincount(ends, minlength=ncol + 2)
+    inside = np.cumsum(mark)[:ncol + 1] > 0
+    seg_of_col = np.cumsum(begun)[:ncol + 1] - 1
+    on_line = inside & (uly_max == low[np.maximum(seg_of_col, 0)])
+    out = np.stack([np.minimum.reduceat(np.where(on_line, ulx, big), bounds)[0::2],
+                    np.minimum.reduceat(np.where(on_line, uly_min, big), bounds)[0::2],
+                    np.maximum.reduceat(np.where(on_line, lrx, small), bounds)[0::2],
+                    np.maximum.reduceat(np.where(on_line, lry, small), bounds)[0::2]], axis=1)
+    return low, out
+
+
+def _syllable_union(ops, idx_all, boxes, first_t, last_t):
+    """(low, box [k, 4]) per syllable: ONE native call (ta_host_syllable_boxes, host arithmetic in the library)"""
+    from . import _native
+    ops = np.ascontiguousarray(ops, dtype=np.uint8)
+    idx_all = np.ascontiguousarray(idx_all, dtype=np.int64)
+    boxes = np.ascontiguousarray(boxes, dtype=np.int64).reshape(-1, 4)
+    first_t, last_t = np.ascontiguousarray(first_t, dtype=np.int64), np.ascontiguousarray(last_t, dtype=np.int64)
+    k = len(first_t)
+    low, out = np.empty(k, np.int64), np.empty((k, 4), np.int64)
+    rc = _native.lib.ta_host_syllable_boxes(ops.ctypes.data, len(ops), idx_all.ctypes.data, len(idx_all), boxes.ctypes.data,
+                                            len(boxes), first_t.ctypes.data, last_t.ctypes.data, k, low.ctypes.data, out.ctypes.data)
+    if rc != 0 and b"not same length" in _native.lib.ta_last_error():
+        raise AssertionError('all_chars not same length as alignment')      # the reference's assert, alignToOCR.py:291
+    _native.check(rc, "ta_host_syllable_boxes")
+    return low, out
+
+
+def syllable_boxes_batch(transcripts, syls_list, ops_list, idx_list, boxes, angles, image_dims, raw_dims):
+    """syllable_boxes_arrays + rotate_boxes for MANY pages at once (the per-page versions spend their time in numpy's
+    per-call overhead on 2000-element arrays): the alignment columns of all pages are laid end to end, a syllable is a
+    range of transcript characters, and one native loop serves every syllable of every page (_syllable_union).
+    idx_list[k]: indices into `boxes` of page k's (expanded) OCR characters.  Returns per page (which, boxes [k, 4])."""
+    npages = len(transcripts)
+    if npages == 0:
+        return []
+    ops = np.concatenate([np.asarray(o) for o in ops_list]) if ops_list else np.zeros(0, np.uint8)
+    idx_all = np.concatenate(idx_list) if idx_list else np.zeros(0, np.int64)
+    toff = np.zeros(npages + 1, dtype=np.int64)
+    np.cumsum([len(t) for t in transcripts], out=toff[1:])
+    assert int((ops != 2).sum()) == toff[-1] and int((ops != 1).sum()) == len(idx_all), 'all_chars not same length as alignment'
+    small = np.iinfo(np.int64).min
     first_t, last_t, which, page = [], [], [], []
     for k, (tr, syls) in enumerate(zip(transcripts, syls_list)):
         base = int(toff[k])
@@ -299,19 +335,8 @@ def syllable_boxes_batch(transcripts, syls_list, ops_list, idx_list, boxes, angl
     if len(which) == 0:
         return list(empty)
     page, first_t, last_t = np.concatenate(page), np.concatenate(first_t), np.concatenate(last_t)
-    starts, ends = col_of_t[first_t], col_of_t[last_t] + 1
-    bounds = np.stack([starts, ends], axis=1).reshape(-1)
-    low = np.maximum.reduceat(uly_max, bounds)[0::2]
+    low, out = _syllable_union(ops, idx_all, boxes, first_t, last_t)
     present = low > small
-    begun = np.bincount(starts, minlength=ncol + 2)                # (np.add.at costs 0.2 ms per call on 3 000 indices)
-    mark = begun - np.bincount(ends, minlength=ncol + 2)
-    inside = np.cumsum(mark)[:ncol + 1] > 0
-    seg_of_col = np.cumsum(begun)[:ncol + 1] - 1
-    on_line = inside & (uly_max == low[np.maximum(seg_of_col, 0)])
-    out = np.stack([np.minimum.reduceat(np.where(on_line, ulx, big), bounds)[0::2],
-                    np.minimum.reduceat(np.where(on_line, uly_min, big), bounds)[0::2],
-                    np.maximum.reduceat(np.where(on_line, lrx, small), bounds)[0::2],
-                    np.maximum.reduceat(np.where(on_line, lry, small), bounds)[0::2]], axis=1)
     which, page, out = which[present], page[present], out[present]
     # un-rotation (rotate_bbox, alignToOCR.py:90-125) with each box's own page geometry
     px = np.array([d.ncols // 2 for d in image_dims], dtype=np.int64)[page]
