@@ -88,7 +88,8 @@ int ta_host_copy_pieces(void* dst, const void* const* src, const int64_t* dst_of
  * arithmetic: entry i of line b is (dec_t, dec_c)[dec_off[b] + i], i < dec_n[b]; its position x = (t - pad) * raw_w[b] /
  * (T[b] - 2 pad) goes through the `.llocs` text's one decimal ("%.1f") and int(np.round(x + x_min[b])) (half to even); a box
  * runs from the previous character's position (x_min[b] for the first) to its own, between y_min[b] and y_max[b]; classes
- * with cps[c] < 0 ('~' and '', alignToOCR.py:175) are dropped but still move the edge.  Outputs have capacity sum(dec_n):
+ * with cps[c] < 0 ('~' and '', alignToOCR.py:175) are dropped but still move the edge.  dec_len = entries in dec_t / dec_c (a
+ * line whose dec_off + dec_n exceeds it is refused: TA_EINVAL).  Outputs have capacity sum(dec_n):
  * out_line, out_cp, out_boxes [k][4] = ulx, uly, lrx, lry; *out_count = characters kept.  All pointers [host]. */
 /* Union of the OCR character boxes under every syllable of a batch of pages (alignToOCR.py:285-324 after the alignment;
  * host arithmetic).  ops: uint8 alignment columns of all pages end to end (0 pair, 1 transcript character over a gap, 2 gap
@@ -103,7 +104,7 @@ int ta_host_syllable_boxes(const uint8_t* ops, int64_t ncol, const int64_t* idx,
 int ta_host_chars_of_batch(const int32_t* dec_t, const int32_t* dec_c, const int64_t* dec_n, const int64_t* dec_off,
                            const int64_t* T, const int64_t* raw_w, const int64_t* x_min, const int64_t* y_min,
                            const int64_t* y_max, const int64_t* cps, int32_t ncps, int32_t pad, int32_t nlines,
-                           int64_t* out_line, int64_t* out_cp, int64_t* out_boxes, int64_t* out_count);
+                           int64_t dec_len, int64_t* out_line, int64_t* out_cp, int64_t* out_boxes, int64_t* out_count);
 
 /*
  * Affine-gap Needleman-Wunsch, replaces textSeqCompare.perform_alignment

@@ -103,6 +103,11 @@ def test_native_character_loop_equals_the_array_form_on_random_batches():
         a = pb.chars_of_batch(dec_t, dec_c, dec_n, dec_off, T, raw_w, x_min, y_min, y_max, cps, 16)
         b_ = pb.chars_of_batch_numpy(dec_t, dec_c, dec_n, dec_off, T, raw_w, x_min, y_min, y_max, cps, 16)
         assert all(np.array_equal(u, v) for u, v in zip(a, b_)), trial
+    # counts that point outside the decoder's arrays (they come from the device) are refused, not read
+    from text_alignment_amd import _native
+    with pytest.raises(_native.NativeArgumentError, match="outside the decoder"):
+        pb.chars_of_batch(np.zeros(4, np.int32), np.zeros(4, np.int32), np.array([3, 9]), np.array([0, 3]), np.array([100, 100]),
+                          np.array([50, 50]), np.zeros(2, np.int64), np.zeros(2, np.int64), np.ones(2, np.int64), np.array([97]), 16)
 
 
 def test_array_glue_equals_object_glue_on_random_pages():

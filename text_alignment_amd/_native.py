@@ -98,7 +98,7 @@ def _load():
     lib.ta_host_copy_pieces.restype = ctypes.c_int
     lib.ta_host_copy_pieces.argtypes = [vp, vp, vp, vp, i32]
     lib.ta_host_chars_of_batch.restype = ctypes.c_int
-    lib.ta_host_chars_of_batch.argtypes = [vp] * 10 + [i32, i32, i32] + [vp] * 4
+    lib.ta_host_chars_of_batch.argtypes = [vp] * 10 + [i32, i32, i32, i64] + [vp] * 4
     lib.ta_host_syllable_boxes.restype = ctypes.c_int
     lib.ta_host_syllable_boxes.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, vp]
     lib.ta_rows_gather.restype = ctypes.c_int

@@ -67,7 +67,7 @@ static inline int64_t ta_edge_position(double x, double x_min) {
 extern "C" int ta_host_chars_of_batch(const int32_t* dec_t, const int32_t* dec_c, const int64_t* dec_n, const int64_t* dec_off,
                                       const int64_t* T, const int64_t* raw_w, const int64_t* x_min, const int64_t* y_min,
                                       const int64_t* y_max, const int64_t* cps, int32_t ncps, int32_t pad, int32_t nlines,
-                                      int64_t* out_line, int64_t* out_cp, int64_t* out_boxes, int64_t* out_count) {
+                                      int64_t dec_len, int64_t* out_line, int64_t* out_cp, int64_t* out_boxes, int64_t* out_count) {
     if (nlines < 0 || ncps < 0) return ta_fail(TA_EINVAL, "negative count");
     if (!out_count) return ta_fail(TA_EINVAL, "null pointer argument");
     *out_count = 0;
@@ -76,6 +76,9 @@ extern "C" int ta_host_chars_of_batch(const int32_t* dec_t, const int32_t* dec_c
         return ta_fail(TA_EINVAL, "null pointer argument");
     int64_t k = 0;
     for (int32_t b = 0; b < nlines; ++b) {
+        // (the counts come from the device: a line that claims more entries than the arrays hold is refused, not read)
+        if (dec_n[b] < 0 || dec_off[b] < 0 || dec_off[b] + dec_n[b] > dec_len)
+            return ta_fail(TA_EINVAL, "a line's decoded entries lie outside the decoder's arrays");
         const double scale = (double)raw_w[b] / (double)(T[b] - 2 * pad);
         const double xm = (double)x_min[b];
         int64_t left = x_min[b];

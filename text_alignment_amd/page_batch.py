@@ -96,7 +96,7 @@ def chars_of_batch(dec_t, dec_c, dec_n, dec_off, T, raw_w, x_min, y_min, y_max, 
     _native.check(_native.lib.ta_host_chars_of_batch(
         dec_t.ctypes.data, dec_c.ctypes.data, dec_n.ctypes.data, dec_off.ctypes.data, T.ctypes.data, raw_w.ctypes.data,
         x_min.ctypes.data, y_min.ctypes.data, y_max.ctypes.data, cps.ctypes.data, len(cps), int(pad), nlines,
-        line.ctypes.data, cp.ctypes.data, boxes.ctypes.data, count.ctypes.data), "ta_host_chars_of_batch")
+        min(len(dec_t), len(dec_c)), line.ctypes.data, cp.ctypes.data, boxes.ctypes.data, count.ctypes.data), "ta_host_chars_of_batch")
     k = int(count[0])
     return line[:k], cp[:k], boxes[:k]
 

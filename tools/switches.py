@@ -9,6 +9,7 @@ environment is the only handle -- so THEY translate it, once, after importing th
     TA_OCR_CLASS_SPLIT=0|1     ocr.FORCE_CLASS_SPLIT      split mode: K3 + K4 per length class on side streams
     TA_OCR_F64_PIPE=0|1        ocr.F64_CLASS_PIPELINE     f64 mode: projection / recurrence pipelined per length class
     TA_OCR_F64_CUTS=a,b        ocr.F64_CLASS_CUTS         ... its cuts (shares of the groups)
+    TA_OCR_COPY_THREADS=n      ocr.COPY_THREADS           pool threads that stage pageable rows (before the pool's first use)
     TA_PAGE_CHUNK=n            alignToOCR.PIPELINE_CHUNK_PAGES          pages per pipeline chunk (normalised rows)
     TA_PAGE_CHUNK_RAW=n        alignToOCR.PIPELINE_CHUNK_PAGES_RAW      ... raw strips
     TA_PAGE_CHUNK_IMAGES=n     alignToOCR.PIPELINE_CHUNK_PAGES_IMAGES   ... page images
@@ -48,6 +49,9 @@ def apply(environ=None):
         v = env.get(var)
         if v in ("0", "1"):
             put(atocr, attr, v == "1")
+    v = env.get("TA_OCR_COPY_THREADS")
+    if v and v.isdigit() and int(v) > 0:
+        put(ocr, "COPY_THREADS", int(v))
     v = env.get("TA_PB_LEAD_DIVISOR")
     if v and v.isdigit():
         put(atocr, "LEAD_CHUNK_DIVISOR", int(v))
