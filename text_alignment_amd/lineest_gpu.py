@@ -209,6 +209,13 @@ def resample_strips(ms, a=0, b=None, layout=None):
         ms.center.data_ptr(), ms.d_col_off.data_ptr() + 8 * a, ms.minmax.data_ptr() + 8 * a, ms.r.data_ptr() + 4 * a,
         ms.wout.data_ptr() + 4 * a, tmp.data_ptr(), d_tmp_off.data_ptr(), omax.data_ptr(), x.data_ptr(),
         d_row_off.data_ptr(), stream), "ta_linenorm_resample")
+    # The measuring pass may have run on ANOTHER stream than this one (process_batch: a chunk's first stage measures on
+    # the caller's stream, its launch resamples on the chunk's compute stream): what the resampling reads must not go back
+    # to the other stream's allocator -- and from there into the next chunk's measuring pass -- before this stream has
+    # read it, however early the last reference to `ms` is dropped.
+    here = torch.cuda.current_stream(dev)
+    for t in (ms.d_pix, ms.d_pix_off, ms.d_hh, ms.d_ww, ms.center, ms.d_col_off, ms.minmax, ms.r, ms.wout):
+        t.record_stream(here)
     return x, T
 
 
