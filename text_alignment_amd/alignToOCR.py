@@ -376,9 +376,10 @@ def _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, 
     return results
 
 
-# process_batch runs batches larger than this as a two-stage pipeline over chunks of PIPELINE_CHUNK_PAGES pages: while
-# the recogniser kernels of chunk k run, the host copies the strips of chunk k + 1 into its staging buffer and finishes
-# chunk k - 1 (characters, alignment, syllable boxes).  One host thread; results are those of the unchunked call.
+# process_batch runs batches larger than this as a pipeline over chunks of PIPELINE_CHUNK_PAGES pages (three stages per chunk,
+# see the loop): while the recogniser kernels of chunk k run, the copy pool stages the rows of chunk k + 1 and this thread
+# does the later stages of chunks k - 2 and k - 3 (characters and the aligner launch; syllable boxes).  One host thread
+# besides the copy pool; results are those of the unchunked call.
 # (Plain module attributes: this module reads no environment variables; tools/switches.py sets them for timing experiments.)
 PIPELINE_CHUNK_PAGES = 16
 PIPELINE_CHUNK_PAGES_RAW = 16        # raw strips: the device normaliser in front (32 while every chunk's first stage WAITED for
@@ -507,8 +508,6 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
         _pb_finish_a(ctx)
         collect(ctx)
         return deliver()
-    # chunk k + 1's strips are copied to the staging buffer by the pool while this thread finishes chunk k - 1 and the
-    # device runs chunk k; at most two chunks are in flight
     import torch
     flight = []
     device = chunks[0][0].device
