@@ -627,6 +627,9 @@ def main():
     if args.pages > 0:
         from tools import pages_bench
         job = pages_bench.setup_sharded(args.pages, rank, world, seed0=100, rows=args.page_rows)
+        import gc
+        gc.collect()
+        gc.freeze()                  # the job's pages and blocks out of the collector's way for the timed passes
         sh_all, mine_s, gather_s, cpu_s, wait_s = [], [], [], [], []
         for _ in range(10):         # median of ten passes, each barrier to barrier over every rank incl. the gather
             barrier()

@@ -186,6 +186,14 @@ def run(npages, seed0=100):
     rec = make_recognizer()
     pages, trs = zip(*[make_page(seed0 + k) for k in range(npages)])
 
+    import gc
+
+    def settle():
+        """before a timed loop: everything alive so far (pages, blocks, recognisers -- hundreds of thousands of objects) out
+        of the collector's way, so that a full collection in mid-pass costs what the pass itself allocated, not 20 ms"""
+        gc.collect()
+        gc.freeze()
+
     def median_of(n, pages_, trs_, rec_=None):
         """median of n passes (median of >= 10), each a whole process_batch call incl. the final
         synchronize; the host side of a pass -- numpy, uploads from pageable memory -- varies by +-20 % from call to
@@ -202,6 +210,7 @@ def run(npages, seed0=100):
     for _ in range(3):                       # warm-up at full size (staging buffers, streams, allocator)
         atocr.process_batch(list(pages), list(trs), rec, PARAMS)
     torch.cuda.synchronize()
+    settle()
     dt, res, cpu_s = median_of(10, list(pages), list(trs))
     busy_ms = _device_busy_ms(lambda: atocr.process_batch(list(pages), list(trs), rec, PARAMS))
     # the same pages with their rows where a GPU-side loader puts them: page-locked blocks (no host copy), device blocks
@@ -212,6 +221,7 @@ def run(npages, seed0=100):
         for _ in range(3):
             atocr.process_batch(bpages, btrs, rec, PARAMS)
         torch.cuda.synchronize()
+        settle()
         bdt, bres, bcpu = median_of(10, bpages, btrs)
         bbusy = _device_busy_ms(lambda: atocr.process_batch(bpages, btrs, rec, PARAMS))
         in_place[kind] = {"input": ROWS_INPUT[kind], "pages_per_s": npages / bdt, "seconds": bdt,
@@ -226,7 +236,6 @@ def run(npages, seed0=100):
     checked = pages_check.check_pages([atocr.to_JSON_dict(r[0], r[2]) for r in res], pages, trs, [rec.model] * npages,
                                       PARAMS, [0, npages // 2])
     # BASELINE configs[2]: one page end to end (30 strips + one NW problem), latency of a lone call
-    import gc
     gc.collect()                               # a generation-2 collection in mid-call costs ~20 ms
 
     def single_page(rec_):
