@@ -237,3 +237,27 @@ def test_bare_arrays_are_pages_too():
     assert [out[k] for k in range(2)] == want
     with pytest.raises(TypeError):
         atocr.process_batch([np.zeros(7)], ["dominus"], rec, params)
+
+
+def test_line_boxes_equal_the_per_line_loop():
+    """textAlignPreprocessing.line_boxes (one peaks x components table) against the reference's loop (:253-276): for
+    each peak the components that vertically_coincide with it, their union, lines without any left out -- on seeded
+    component sets with components straddling strips, touching strip edges, far outside, and with odd / fractional
+    median heights (the strip's half height is int(collision / 2))."""
+    from text_alignment_amd import textAlignPreprocessing as pp
+    rng = np.random.default_rng(77)
+    assert pp.line_boxes([], np.zeros((0, 4)), 10.0) == []
+    assert pp.line_boxes([5, 9], np.zeros((0, 4)), 10.0) == []
+    for case in range(60):
+        ncomp, npeaks = int(rng.integers(1, 120)), int(rng.integers(1, 40))
+        uly = rng.integers(0, 1500, ncomp)
+        ulx = rng.integers(0, 4000, ncomp)
+        comps = np.stack([ulx, uly, ulx + rng.integers(0, 60, ncomp), uly + rng.integers(0, 50, ncomp)], axis=1)
+        peaks = sorted(set(rng.integers(0, 1600, npeaks).tolist()))
+        collision = [np.float64(np.median(comps[:, 3] - comps[:, 1] + 1)), 7.0, 1.0, 2.5, 33.5][case % 5]
+        want = []
+        for loc in peaks:
+            hit = [c for c in comps.tolist() if pp.vertically_coincide(loc, c[1], c[3] - c[1] + 1, collision)]
+            if hit:
+                want.append([min(c[0] for c in hit), min(c[1] for c in hit), max(c[2] for c in hit), max(c[3] for c in hit)])
+        assert pp.line_boxes(peaks, comps, collision) == want, case

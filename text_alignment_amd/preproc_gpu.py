@@ -176,25 +176,29 @@ def rotation_angles_device(d, inks, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
         points.append(pts)
 
     def sweep(grids):
-        parts, keep = [], []
-        for k, ink in enumerate(inks):
-            g = grids[k]
+        # the angles' cosines / sines of all pages in ONE asynchronous upload, the histograms of all pages in one buffer
+        # and one download (a small `.to(device)` from pageable memory waits for everything the stream holds: per page
+        # it kept the host from ever running ahead of the device)
+        tables = []
+        for g in grids:
             cs = np.empty(2 * len(g), np.float64)
             rad = np.deg2rad(g)
             cs[0::2], cs[1::2] = np.cos(rad), np.sin(rad)
-            d_cs = torch.from_numpy(cs).to(d.dev)
-            keep.append(d_cs)
-            hist = torch.empty((len(g), hs[k]), dtype=torch.int32, device=d.dev)
+            tables.append(cs)
+        d_cs = _native.upload_packed(tables, d.dev)
+        sizes = [len(grids[k]) * hs[k] for k in range(n)]
+        hist = torch.empty(max(sum(sizes), 1), dtype=torch.int32, device=d.dev)
+        pos = 0
+        for k in range(n):
             _native.check(d.lib.ta_pp_angle_histograms_points(points[k].data_ptr(), counts[k:].data_ptr(), hs[k], ws[k],
-                                                              d_cs.data_ptr(), len(g), hist.data_ptr(), d.stream),
-                          "ta_pp_angle_histograms_points")
-            parts.append(hist.reshape(-1))
-        flat = torch.cat(parts).cpu().numpy()
+                                                              d_cs[k].data_ptr(), len(grids[k]), hist[pos:].data_ptr(),
+                                                              d.stream), "ta_pp_angle_histograms_points")
+            pos += sizes[k]
+        flat = hist.cpu().numpy()
         out, pos = [], 0
         for k in range(n):
-            m = len(grids[k]) * hs[k]
-            out.append(flat[pos:pos + m].reshape(len(grids[k]), hs[k]))
-            pos += m
+            out.append(flat[pos:pos + sizes[k]].reshape(len(grids[k]), hs[k]))
+            pos += sizes[k]
         return out
     grid = np.arange(lo, hi + 1e-9, coarse)
     hh = sweep([grid] * n)
@@ -210,12 +214,9 @@ def rotation_angle_device(d, ink, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
     return rotation_angles_device(d, [ink], lo, hi, coarse, fine)[0]
 
 
-def rotate_device(d, ink, angle):
-    """scipy.ndimage.rotate(float32(ink), angle, reshape=True, order=1) > 0.5, with scipy's own
-    geometry (ndimage/_interpolation.py rotate) computed here and the resampling on the device"""
-    if angle == 0:
-        return ink.clone()
-    h, w = ink.shape
+def _rotation_geometry(h, w, angle):
+    """scipy.ndimage.rotate's own geometry (ndimage/_interpolation.py rotate, reshape=True): the output shape and the
+    six numbers [matrix, offset] of the backward mapping"""
     c, s = special.cosdg(angle), special.sindg(angle)
     rot = np.array([[c, s], [-s, c]])
     out_bounds = rot @ [[0, 0, h, h], [0, w, 0, w]]
@@ -223,13 +224,32 @@ def rotate_device(d, ink, angle):
     out_center = rot @ ((out_shape - 1) / 2)
     in_center = (np.asarray([h, w]) - 1) / 2
     offset = in_center - out_center
-    mo = torch.from_numpy(np.array([rot[0, 0], rot[0, 1], rot[1, 0], rot[1, 1], offset[0], offset[1]],
-                                   np.float64)).to(d.dev)
-    oh, ow = int(out_shape[0]), int(out_shape[1])
-    out = torch.empty((oh, ow), dtype=torch.uint8, device=d.dev)
-    _native.check(d.lib.ta_pp_rotate(ink.data_ptr(), h, w, out.data_ptr(), oh, ow, mo.data_ptr(), d.stream),
-                  "ta_pp_rotate")
+    return (int(out_shape[0]), int(out_shape[1]),
+            np.array([rot[0, 0], rot[0, 1], rot[1, 0], rot[1, 1], offset[0], offset[1]], np.float64))
+
+
+def rotate_many(d, inks, angles):
+    """scipy.ndimage.rotate(float32(ink), angle, reshape=True, order=1) > 0.5 of every page, the resampling on the
+    device; the pages' mappings go up in one asynchronous transfer"""
+    geo = [None if a == 0 else _rotation_geometry(int(k.shape[0]), int(k.shape[1]), a) for k, a in zip(inks, angles)]
+    turned = [g for g in geo if g is not None]
+    maps = iter(_native.upload_packed([g[2] for g in turned], d.dev)) if turned else iter(())
+    out = []
+    for ink, g in zip(inks, geo):
+        if g is None:
+            out.append(ink.clone())
+            continue
+        h, w = ink.shape
+        oh, ow, _ = g
+        res = torch.empty((oh, ow), dtype=torch.uint8, device=d.dev)
+        _native.check(d.lib.ta_pp_rotate(ink.data_ptr(), h, w, res.data_ptr(), oh, ow, next(maps).data_ptr(), d.stream),
+                      "ta_pp_rotate")
+        out.append(res)
     return out
+
+
+def rotate_device(d, ink, angle):
+    return rotate_many(d, [ink], [angle])[0]
 
 
 def open_runs_device(d, ink, length, axis):
@@ -242,17 +262,29 @@ def open_runs_device(d, ink, length, axis):
     return out
 
 
+def _upload_pages(d, host_px):
+    """the pages of a batch on the device: gathered into ONE page-locked buffer by the library's host copy loop (no
+    interpreter lock held) and sent in one asynchronous transfer; the planes are views of one device buffer"""
+    sizes = [int(px.size) for px in host_px]
+    offs = np.concatenate(([0], np.cumsum([(sz + 255) // 256 * 256 for sz in sizes]))).astype(np.int64)
+    stage = torch.empty(max(int(offs[-1]), 1), dtype=torch.uint8, pin_memory=True)
+    _native.host_copy_pieces(stage.numpy(), host_px, offs[:-1])
+    dev = stage.to(d.dev, non_blocking=True)
+    return [dev[int(o):int(o) + sz].view(px.shape) for o, sz, px in zip(offs[:-1], sizes, host_px)]
+
+
 def preprocess_images_batch(pages, despeckle_amt=host.despeckle_amt, filter_runs=1, filter_runs_amt=2,
                             correct_rotation=True, device="cuda"):
     """[(ink, eroded, angle)] as uint8 device planes + the device handle: reference
     textAlignPreprocessing.py:160-195 for a list of uint8 greyscale pages"""
     d = _Dev(device)
-    imgs = []
+    host_px = []
     for pg in pages:
         px = np.asarray(getattr(pg, "pixels", pg))
         if px.dtype != np.uint8 or px.ndim != 2:
             raise TypeError("the device preprocessing takes 2-D uint8 pages")
-        imgs.append(torch.from_numpy(np.ascontiguousarray(px)).to(d.dev))
+        host_px.append(np.ascontiguousarray(px))
+    imgs = _upload_pages(d, host_px)
     thrs = otsu_thresholds_device(d, imgs)
     inks = []
     for img, thr in zip(imgs, thrs):
@@ -270,9 +302,9 @@ def preprocess_images_batch(pages, despeckle_amt=host.despeckle_amt, filter_runs
         d.filter(ink, lab, stats, max_height=host.sat_area_thresh)
     skews = rotation_angles_device(d, inks, -6, 6)
     out = []
+    if correct_rotation:
+        inks = rotate_many(d, inks, skews)
     for ink, skew in zip(inks, skews):
-        if correct_rotation:
-            ink = rotate_device(d, ink, skew)
         eroded = ink
         for _ in range(filter_runs):
             eroded = open_runs_device(d, eroded, filter_runs_amt, 0)
@@ -302,7 +334,7 @@ def identify_text_lines_batch(d, planes):
         _native.check(d.lib.ta_pp_row_sums(eroded.data_ptr(), h, w, s.data_ptr(), d.stream), "ta_pp_row_sums")
         sums.append(s)
     flat = torch.cat(sums).cpu().numpy().astype(np.int64) if n else np.zeros(0, np.int64)
-    smoothed_all, peaks_all, works, pos = [], [], [], 0
+    smoothed_all, peaks_all, works, pos, row_lists = [], [], [], 0, []
     for ink, eroded in planes:
         h, w = eroded.shape
         project = flat[pos:pos + h]
@@ -313,12 +345,15 @@ def identify_text_lines_batch(d, planes):
         for a, b in zip(peaks[:-1], peaks[1:]):
             idx = int(np.argmin(smoothed[a:b])) + a
             rows.extend(range(max(idx - 1, 0), idx + 1))          # 2-pixel white line
+        row_lists.append(np.array(sorted(set(rows)), dtype=np.int32))
+        smoothed_all.append(smoothed); peaks_all.append(peaks)
+    d_rows = _native.upload_packed(row_lists, d.dev) if n else []
+    for (ink, eroded), rows, dr in zip(planes, row_lists, d_rows):
         work = eroded.clone()
-        if rows:
-            d_rows = torch.tensor(sorted(set(rows)), dtype=torch.int32, device=d.dev)
-            _native.check(d.lib.ta_pp_clear_rows(work.data_ptr(), w, d_rows.data_ptr(), d_rows.numel(), d.stream),
+        if len(rows):
+            _native.check(d.lib.ta_pp_clear_rows(work.data_ptr(), eroded.shape[1], dr.data_ptr(), len(rows), d.stream),
                           "ta_pp_clear_rows")
-        smoothed_all.append(smoothed); peaks_all.append(peaks); works.append(work)
+        works.append(work)
     recs_all = d.components_many(d.label_many(works))
     boxes_all, total = [], 0
     for (ink, eroded), peaks, recs in zip(planes, peaks_all, recs_all):
@@ -330,24 +365,18 @@ def identify_text_lines_batch(d, planes):
             med = np.median(heights)
             comps = comps[heights < med * host.remove_capitals_scale]
             cc_median_height = np.median(comps[:, 3] - comps[:, 1] + 1)
-            for loc in peaks:
-                hit = comps[host.coincide_mask(loc, comps[:, 1], comps[:, 3] - comps[:, 1] + 1, cc_median_height)]
-                if not len(hit):
-                    continue
-                ulx, uly, lrx, lry = int(hit[:, 0].min()), int(hit[:, 1].min()), int(hit[:, 2].max()), int(hit[:, 3].max())
+            for ulx, uly, lrx, lry in host.line_boxes(peaks, comps, cc_median_height):
                 boxes.append((ulx, uly, lrx, lry, total))
                 total += (lry - uly + 1) * (lrx - ulx + 1)
         boxes_all.append(boxes)
     # cut the strips on the device (ink black on white, as the reference saves them) into one packed buffer
     # and leave them there: the recogniser's normaliser reads them where they are, `strip.pixels` downloads
     packed = torch.empty(max(total, 1), dtype=torch.uint8, device=d.dev)
-    keep = []
-    for (ink, eroded), boxes in zip(planes, boxes_all):
+    d_boxes = _native.upload_packed([np.array(boxes, dtype=np.int64).reshape(-1, 5) for boxes in boxes_all], d.dev) if n else []
+    for (ink, eroded), boxes, db in zip(planes, boxes_all, d_boxes):
         if boxes:
             h, w = ink.shape
-            d_boxes = torch.tensor(boxes, dtype=torch.int64).to(d.dev)
-            keep.append(d_boxes)
-            _native.check(d.lib.ta_pp_cut_strips(ink.data_ptr(), h, w, d_boxes.data_ptr(), len(boxes),
+            _native.check(d.lib.ta_pp_cut_strips(ink.data_ptr(), h, w, db.data_ptr(), len(boxes),
                                                  packed.data_ptr(), d.stream), "ta_pp_cut_strips")
     out = []
     for boxes, peaks, smoothed in zip(boxes_all, peaks_all, smoothed_all):

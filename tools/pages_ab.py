@@ -34,19 +34,23 @@ for name, inp in inputs.items():
         atocr.process_batch(pages, trs, rec, pb.PARAMS)
     torch.cuda.synchronize()
     ts, cpu = [], []
+    m0 = torch.cuda.memory_stats()
     for _ in range(reps):
         c0, t0 = time.process_time(), time.perf_counter()
         res = atocr.process_batch(pages, trs, rec, pb.PARAMS)
         torch.cuda.synchronize()
         ts.append(time.perf_counter() - t0)
         cpu.append(time.process_time() - c0)
+    m1 = torch.cuda.memory_stats()
+    mallocs = (m1.get("num_device_alloc", 0) - m0.get("num_device_alloc", 0)) / float(reps)     # hipMalloc calls per call
     js = [atocr.to_JSON_dict(r[0], r[2]) for r in res]
     if ref is None:
         ref = js
     busy = pb._device_busy_ms(lambda: atocr.process_batch(pages, trs, rec, pb.PARAMS))
     dt = float(np.median(ts))
-    print("%-7s %7.1f pages/s  median %.2f ms (min %.2f)  host cpu %.2f ms/page  gpu busy %.1f ms (%.2f)  equal=%s"
-          % (name, n / dt, 1e3 * dt, 1e3 * min(ts), 1e3 * float(np.median(cpu)) / n, busy or -1, (busy or 0) * 1e-3 / dt, js == ref))
+    print("%-7s %7.1f pages/s  median %.2f ms (min %.2f)  host cpu %.2f ms/page  gpu busy %.1f ms (%.2f)  hipMalloc/call %.1f  reserved %.1f GB  equal=%s"
+          % (name, n / dt, 1e3 * dt, 1e3 * min(ts), 1e3 * float(np.median(cpu)) / n, busy or -1, (busy or 0) * 1e-3 / dt, mallocs,
+             m1.get("reserved_bytes.all.current", 0) / 1e9, js == ref))
 if "--profile" in sys.argv:
     import cProfile
     import pstats
