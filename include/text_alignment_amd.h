@@ -421,6 +421,62 @@ int ta_pp_peak_prominence_args(const double* d, int32_t n, const int32_t* idx, i
 int ta_pp_cut_strips(const uint8_t* ink, int32_t h, int32_t w, const int64_t* boxes, int32_t nstrips,
                      uint8_t* out, void* stream);
 
+/*
+ * Whole STAGES of the page preprocessing for a batch of n pages, one call each: everything between two of the
+ * pipeline's data-dependent host decisions (Otsu threshold | skew sweeps | projection peaks | component selection |
+ * strips) -- reference textAlignPreprocessing.py:160-285, where every page pass is a Gamera call.  A page's stage is a
+ * dozen launches; made one by one from the host language they cost more host time than the kernels take.  Arguments
+ * named like arrays are [host] arrays of n [dev] pointers / sizes; everything is enqueued on `stream`, nothing is
+ * waited for; per page the kernels and their order are those of the single-page entry points above.
+ *
+ * ta_pp_histogram_batch: hist [dev] = uint32[n][256] of img[i][0..npix[i]).
+ * ta_pp_binarise_batch (:167-186): ink[i] = img[i] thresholded at thr[i], despeckled (components under `despeckle`
+ *   pixels; ink, then background), components taller than max_height rows dropped; points[i] / counts[i] [dev uint32[n]]
+ *   = ta_pp_ink_points of the page decimated by step[i].  lab[i] / stats[i]: h*w and 5*h*w int32 of scratch.
+ * ta_pp_angle_histograms_points_batch: ta_pp_angle_histograms_points per page (cos_sin[i]: 2*nang[i] doubles [dev],
+ *   hist[i]: uint32[nang[i]][hs[i]] [dev]).
+ * ta_pp_deskew_batch (:187-195, :212-215): out[i] (oh[i] x ow[i]) = ink[i] rotated through mo[i] (ta_pp_rotate;
+ *   mo[i] NULL: a copy, sizes equal); eroded[i] = out[i] opened with runs of runs_len pixels along the rows, then the
+ *   columns, `rounds` times (runs_len <= 1: a copy; tmp[i]: oh*ow bytes of scratch); sums[i][r] = ink of eroded row r.
+ * ta_pp_line_components_batch (:216-252): work[i] = eroded[i] with rows[i][0..nrows[i]) cleared, labelled (scratch as
+ *   above); page i's component table (ta_pp_components) at recs [dev] + i*cap*6, its true count in counts[i] [dev].
+ * ta_pp_cut_strips_batch: ta_pp_cut_strips per page into ONE packed buffer (the boxes carry their offsets).
+ */
+int ta_pp_histogram_batch(int32_t n, const uint8_t* const* img, const int64_t* npix, uint32_t* hist, void* stream);
+int ta_pp_binarise_batch(int32_t n, const uint8_t* const* img, const int32_t* h, const int32_t* w, const int32_t* thr,
+                         int32_t despeckle, int32_t max_height, uint8_t* const* ink, int32_t* const* lab,
+                         int32_t* const* stats, const int32_t* step, uint32_t* const* points, uint32_t* counts,
+                         void* stream);
+int ta_pp_angle_histograms_points_batch(int32_t n, const uint32_t* const* points, const uint32_t* counts,
+                                        const int32_t* hs, const int32_t* ws, const double* const* cos_sin,
+                                        const int32_t* nang, uint32_t* const* hist, void* stream);
+int ta_pp_deskew_batch(int32_t n, const uint8_t* const* ink, const int32_t* h, const int32_t* w,
+                       const double* const* mo, uint8_t* const* out, const int32_t* oh, const int32_t* ow,
+                       uint8_t* const* tmp, uint8_t* const* eroded, int32_t runs_len, int32_t rounds,
+                       int32_t* const* sums, void* stream);
+int ta_pp_line_components_batch(int32_t n, const uint8_t* const* eroded, const int32_t* h, const int32_t* w,
+                                const int32_t* const* rows, const int32_t* nrows, uint8_t* const* work,
+                                int32_t* const* lab, int32_t* const* stats, int32_t* recs, int32_t cap,
+                                int32_t* counts, void* stream);
+int ta_pp_cut_strips_batch(int32_t n, const uint8_t* const* ink, const int32_t* h, const int32_t* w,
+                           const int64_t* const* boxes, const int32_t* nstrips, uint8_t* packed, void* stream);
+
+/*
+ * Host arithmetic between the preprocessing stages ([host] pointers only, no device work): the per-page numpy passes
+ * of the reference's Python between two Gamera calls, as plain loops that hold no interpreter lock; each reproduces
+ * the numpy expression it replaces operation by operation (tests/test_preprocessing.py fuzzes them against numpy).
+ * ta_host_otsu_batch: Otsu's threshold (first maximum of the between-class variance) of n 256-bin histograms.
+ * ta_host_sharpest_rows: per page k the row of its nang[k] x hs[k] int32 histograms (at hist + off[k]) with the
+ *   largest np.var (numpy's pairwise summation), and whether the page has a count at all; var_out may be NULL.
+ * ta_host_line_boxes: per peak location the union of the components [ulx, uly, lrx, lry] that vertically coincide
+ *   with the strip of half height `half` around it (textAlignPreprocessing.py:38-56, :253-276).
+ */
+int ta_host_otsu_batch(const int32_t* hist, int32_t n, int32_t* thr);
+int ta_host_sharpest_rows(const int32_t* hist, const int64_t* off, const int32_t* nang, const int32_t* hs, int32_t n,
+                          int32_t* best, uint8_t* any, double* var_out);
+int ta_host_line_boxes(const int64_t* comps, int64_t ncomp, const int64_t* peaks, int64_t npeaks, int64_t half,
+                       int64_t* out_boxes, uint8_t* out_hit);
+
 #ifdef __cplusplus
 }
 #endif

@@ -261,3 +261,59 @@ def test_line_boxes_equal_the_per_line_loop():
             if hit:
                 want.append([min(c[0] for c in hit), min(c[1] for c in hit), max(c[2] for c in hit), max(c[3] for c in hit)])
         assert pp.line_boxes(peaks, comps, collision) == want, case
+        assert pp.line_boxes_numpy(peaks, comps, collision) == want, case
+
+
+def test_host_arithmetic_of_the_stages_equals_numpy():
+    """The library's host loops between the preprocessing stages against the numpy expressions they replace: Otsu
+    thresholds (preproc_gpu.otsu_from_histogram) and the skew sweep's choice -- np.var per histogram row TO THE LAST
+    BIT (numpy's pairwise summation restated in csrc/ta_common.cpp) and its argmax -- on flat, two-peaked, empty and
+    single-bin histograms and on rows of 1 .. 1400 counts."""
+    import ctypes
+    from text_alignment_amd import _native, preproc_gpu as pg
+    rng = np.random.default_rng(5)
+    hists = []
+    for trial in range(400):
+        kind = trial % 5
+        if kind == 0:
+            h = rng.integers(0, 70000, 256)
+        elif kind == 1:
+            h = np.zeros(256, np.int64)
+            h[rng.integers(0, 256, 3)] = rng.integers(1, 6000000, 3)
+        elif kind == 2:
+            x = np.clip(np.concatenate([rng.normal(60, 20, 3000), rng.normal(200, 15, 58000)]), 0, 255).astype(np.uint8)
+            h = np.bincount(x, minlength=256) * 100
+        elif kind == 3:
+            h = np.zeros(256, np.int64)
+        else:
+            h = rng.integers(0, 3, 256) * rng.integers(0, 2000000, 256)
+        hists.append(h.astype(np.int32))
+    assert pg.otsu_thresholds(np.stack(hists)).tolist() == [pg.otsu_from_histogram(h) for h in hists]
+    pages, nang, hs = [], [], []
+    for trial in range(300):
+        a_, h_ = int(rng.integers(1, 60)), int(rng.integers(1, 1400)) if trial % 7 else int(rng.integers(1, 140))
+        kind = trial % 4
+        if kind == 0:
+            H = rng.integers(0, 1400, (a_, h_))
+        elif kind == 1:
+            H = rng.poisson(3.0, (a_, h_))
+        elif kind == 2:
+            base = rng.integers(0, 900, h_)
+            H = np.stack([np.roll(base, int(sft)) for sft in rng.integers(0, 3, a_)])        # (ties between rows)
+        else:
+            H = np.zeros((a_, h_), np.int64)
+            H[:, rng.integers(0, h_)] = rng.integers(0, 5)
+        pages.append(H.astype(np.int32).ravel()); nang.append(a_); hs.append(h_)
+    offs = np.concatenate(([0], np.cumsum([len(p) for p in pages])))[:-1]
+    flat = np.concatenate(pages)
+    best, some = pg.sharpest_rows(flat, offs, nang, hs)
+    want_best, want_some = pg._sharpest_rows_numpy(flat, offs, nang, hs)
+    assert best.tolist() == want_best.tolist() and some.tolist() == want_some.tolist()
+    # the variances themselves, bit for bit
+    var = np.zeros(sum(nang))
+    b_, s_ = np.zeros(len(pages), np.int32), np.zeros(len(pages), np.uint8)
+    o64, a32, h32 = offs.astype(np.int64), np.array(nang, np.int32), np.array(hs, np.int32)
+    assert _native.lib.ta_host_sharpest_rows(flat.ctypes.data, o64.ctypes.data, a32.ctypes.data, h32.ctypes.data, len(pages),
+                                             b_.ctypes.data, s_.ctypes.data, var.ctypes.data) == 0
+    want = np.concatenate([np.var(p.reshape(a_, h_), axis=1) for p, a_, h_ in zip(pages, nang, hs)])
+    assert var.view(np.uint64).tolist() == want.view(np.uint64).tolist()

@@ -101,6 +101,12 @@ def _load():
     lib.ta_host_chars_of_batch.argtypes = [vp] * 10 + [i32, i32, i32, i64] + [vp] * 4
     lib.ta_host_syllable_boxes.restype = ctypes.c_int
     lib.ta_host_syllable_boxes.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, vp]
+    lib.ta_host_otsu_batch.restype = ctypes.c_int
+    lib.ta_host_otsu_batch.argtypes = [vp, i32, vp]
+    lib.ta_host_sharpest_rows.restype = ctypes.c_int
+    lib.ta_host_sharpest_rows.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
+    lib.ta_host_line_boxes.restype = ctypes.c_int
+    lib.ta_host_line_boxes.argtypes = [vp, i64, vp, i64, i64, vp, vp]
     lib.ta_rows_gather.restype = ctypes.c_int
     lib.ta_rows_gather.argtypes = [vp, vp, vp, i32, i32, vp, vp]
     lib.ta_linenorm_measure.restype = ctypes.c_int
@@ -117,7 +123,13 @@ def _load():
           "ta_pp_cut_strips": [vp, i32, i32, vp, i32, vp, vp],
           "ta_pp_peak_prominence_args": [vp, i32, vp, i32, ctypes.c_double, vp],
           "ta_pp_ink_points": [vp, i32, i32, i32, vp, vp, vp],
-          "ta_pp_angle_histograms_points": [vp, vp, i32, i32, vp, i32, vp, vp]}
+          "ta_pp_angle_histograms_points": [vp, vp, i32, i32, vp, i32, vp, vp],
+          "ta_pp_histogram_batch": [i32, vp, vp, vp, vp],
+          "ta_pp_binarise_batch": [i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+          "ta_pp_angle_histograms_points_batch": [i32, vp, vp, vp, vp, vp, vp, vp, vp],
+          "ta_pp_deskew_batch": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp],
+          "ta_pp_line_components_batch": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp],
+          "ta_pp_cut_strips_batch": [i32, vp, vp, vp, vp, vp, vp, vp]}
     for name, args in pp.items():
         getattr(lib, name).restype = ctypes.c_int
         getattr(lib, name).argtypes = args
@@ -126,14 +138,15 @@ def _load():
 
 lib = _load()
 
-EXPORTS = ["ta_version", "ta_last_error", "ta_device_pci_bus_id", "ta_host_copy_pieces", "ta_host_chars_of_batch", "ta_host_syllable_boxes", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_max_m", "ta_nw2_batch", "ta_nw2_phase1_plan", "ta_nw2_phase1_plan_batch", "ta_nw2_traceback_plan",
+EXPORTS = ["ta_version", "ta_last_error", "ta_device_pci_bus_id", "ta_host_copy_pieces", "ta_host_chars_of_batch", "ta_host_syllable_boxes", "ta_host_otsu_batch", "ta_host_sharpest_rows", "ta_host_line_boxes", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_max_m", "ta_nw2_batch", "ta_nw2_phase1_plan", "ta_nw2_phase1_plan_batch", "ta_nw2_traceback_plan",
            "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general", "ta_nw_general_batch",
            "ta_lstm_packed_weight_floats", "ta_lstm_forward", "ta_lstm_f64_weight_doubles", "ta_lstm_f64_gx_bytes", "ta_lstm_xproj_f64", "ta_lstm_forward_f64", "ta_lstm_forward_f64_g4", "ta_lstm_output", "ta_lstm_output_split_weight_bytes", "ta_lstm_output_split", "ta_decode",
            "ta_decode_summary", "ta_rows_gather", "ta_linenorm_measure", "ta_linenorm_resample",
            "ta_pp_histogram", "ta_pp_threshold", "ta_pp_label", "ta_pp_label_batch", "ta_pp_components", "ta_pp_filter_components",
            "ta_pp_invert", "ta_pp_angle_histograms", "ta_pp_rotate", "ta_pp_open_runs", "ta_pp_row_sums",
            "ta_pp_clear_rows", "ta_pp_cut_strips", "ta_pp_peak_prominence_args", "ta_pp_ink_points",
-           "ta_pp_angle_histograms_points"]
+           "ta_pp_angle_histograms_points", "ta_pp_histogram_batch", "ta_pp_binarise_batch",
+           "ta_pp_angle_histograms_points_batch", "ta_pp_deskew_batch", "ta_pp_line_components_batch", "ta_pp_cut_strips_batch"]
 
 
 class NativeArgumentError(ValueError):

@@ -386,7 +386,10 @@ PIPELINE_CHUNK_PAGES_RAW = 16        # raw strips: the device normaliser in fron
                                      # its measuring pass; round 6 enqueues it and waits a stage later: 16 is faster, 970 against 885)
 PIPELINE_CHUNK_PAGES_IMAGES = 16     # page images: preprocessing in front, itself in batches of 8 pages on two page threads (64 until
                                      # round 6: no faster -- 447-564 against 542-557 pages/s -- and its 1 920-line recogniser batch took a
-                                     # 17.7 GB scratch buffer from the caching allocator and gave it back on every call)
+                                     # 17.7 GB scratch buffer from the caching allocator and gave it back on every call).  Measured and
+                                     # not kept: the line finding of the NEXT chunks started ahead on a thread of its own -- with the
+                                     # stages' launches in the library (preproc_gpu) 551-575 pages/s against 625-636 without, same box:
+                                     # three threads of Python contend for one interpreter lock
 _side_streams = {}
 WAIT_SECONDS = [0.0]                 # wall seconds the calling thread has spent WAITING for the device inside process_batch (a
                                      # running total: callers take differences): a pass's wall time minus this is its host work
@@ -511,7 +514,6 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
         collect(ctx)
         return deliver()
     import torch
-    flight = []
     device = chunks[0][0].device
     streams = _ocr_streams(device)
     caller = torch.cuda.current_stream(device)
@@ -527,7 +529,13 @@ def process_batch(pages, transcripts, ocropus_model, seq_align_params=None, indi
     # ~2 ms per chunk while the host did stage 2: timeline in profiles/r06_pages_timeline_pinned.txt.)
     # The first stage's host half of chunk c + 1 (row layout, the pool's staging copies STARTED) is taken right behind
     # chunk c's launch: the copies then run under this iteration's later stages and the next launch finds them done.
-    aligned = []                                                 # chunks whose stage 2 is done, oldest first
+    return _pb_pipeline(chunks, begin, collect, deliver, streams, caller)
+
+
+def _pb_pipeline(chunks, begin, collect, deliver, streams, caller):
+    """the loop of process_batch over its chunks (see the comment there)"""
+    import torch
+    flight, aligned = [], []
     nxt = begin(chunks[0])
     for c, job in enumerate(chunks):
         ctx = nxt

@@ -156,3 +156,132 @@ extern "C" int ta_host_syllable_boxes(const uint8_t* ops, int64_t ncol, const in
     }
     return TA_OK;
 }
+
+// ---- host arithmetic of the page preprocessing (no device work): the per-page numpy passes between two stages of
+// csrc/ta_preproc.hip's pipeline, as plain loops that hold no interpreter lock.  Each reproduces the numpy expression
+// it replaces operation by operation (this file is compiled without FMA contraction); the Python forms stay in
+// preproc_gpu.py / textAlignPreprocessing.py as cross-checks (tests/test_preprocessing.py).
+
+// Otsu's threshold of n 256-bin histograms (preproc_gpu.otsu_from_histogram): first maximum over t of
+// (mean_all * cum[t] - mean_cum[t] * total)^2 / (cum[t] * (total - cum[t])), non-finite values counted as 0.
+extern "C" int ta_host_otsu_batch(const int32_t* hist, int32_t n, int32_t* thr) {
+    if (n < 0) return ta_fail(TA_EINVAL, "negative count");
+    if (n == 0) return TA_OK;
+    if (!hist || !thr) return ta_fail(TA_EINVAL, "null pointer argument");
+    for (int32_t k = 0; k < n; ++k) {
+        const int32_t* h = hist + (size_t)k * 256;
+        double cum[256], mean_cum[256], total = 0.0, c = 0.0, m = 0.0;
+        for (int t = 0; t < 256; ++t) {
+            const double v = (double)h[t];
+            c += v; cum[t] = c;                              // np.cumsum: left to right
+            m += v * (double)t; mean_cum[t] = m;
+        }
+        // hist.sum(): pairwise in numpy, but a sum of integers below 2^53 is exact in any order
+        total = cum[255];
+        const double mean_all = mean_cum[255];
+        int best = 0;
+        double best_v = -1.0;
+        for (int t = 0; t < 256; ++t) {
+            const double num = mean_all * cum[t] - mean_cum[t] * total;
+            double b = (num * num) / (cum[t] * (total - cum[t]));
+            if (!std::isfinite(b)) b = 0.0;
+            if (b > best_v) { best_v = b; best = t; }
+        }
+        thr[k] = best;
+    }
+    return TA_OK;
+}
+
+// numpy's pairwise summation of a contiguous float64 run (numpy/_core/src/umath/loops_utils.h.src, DOUBLE_pairwise_sum):
+// what np.add.reduce does along a contiguous axis, so that sums agree with numpy's to the last bit
+static double ta_np_pairwise_sum(const double* a, int64_t n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < n; ++i) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return ta_np_pairwise_sum(a, n2) + ta_np_pairwise_sum(a + n2, n - n2);
+}
+
+// The skew sweep's choice for n pages (preproc_gpu._skew_search): page k's histograms are hist + off[k], nang[k] rows of
+// hs[k] int32 counts; best[k] = int(np.argmax(np.var(rows, axis=1))) -- per row the mean (a sum of integers: exact),
+// the squared deviations, their pairwise sum over n -- and any[k] = whether the page has a count at all.
+// var_out (may be NULL): the variances, rows of all pages laid end to end.
+extern "C" int ta_host_sharpest_rows(const int32_t* hist, const int64_t* off, const int32_t* nang, const int32_t* hs, int32_t n,
+                                     int32_t* best, uint8_t* any, double* var_out) {
+    if (n < 0) return ta_fail(TA_EINVAL, "negative count");
+    if (n == 0) return TA_OK;
+    if (!hist || !off || !nang || !hs || !best || !any) return ta_fail(TA_EINVAL, "null pointer argument");
+    std::vector<double> sq;
+    int64_t vpos = 0;
+    for (int32_t k = 0; k < n; ++k) {
+        if (nang[k] < 0 || hs[k] < 0 || off[k] < 0) return ta_fail(TA_EINVAL, "negative size");
+        const int32_t* page = hist + off[k];
+        const int64_t len = hs[k];
+        sq.resize((size_t)len);
+        int b = 0;
+        double bv = 0.0;
+        bool some = false, first = true;
+        for (int32_t a = 0; a < nang[k]; ++a) {
+            const int32_t* row = page + (int64_t)a * len;
+            int64_t s = 0;
+            for (int64_t i = 0; i < len; ++i) { s += row[i]; some = some || row[i] != 0; }
+            double v;
+            if (len == 0) {
+                v = std::nan("");                            // (np.var of an empty row; argmax then stays at the first)
+            } else {
+                const double mean = (double)s / (double)len;
+                for (int64_t i = 0; i < len; ++i) { const double x = (double)row[i] - mean; sq[(size_t)i] = x * x; }
+                v = ta_np_pairwise_sum(sq.data(), len) / (double)len;
+            }
+            if (var_out) var_out[vpos++] = v;
+            // np.argmax: the first maximum, a NaN counting as one
+            if (first) { b = 0; bv = v; first = false; }
+            else if (v > bv || (std::isnan(v) && !std::isnan(bv))) { b = a; bv = v; }
+        }
+        best[k] = b;
+        any[k] = some ? 1 : 0;
+    }
+    return TA_OK;
+}
+
+// Bounding boxes of the text lines of a page (textAlignPreprocessing.line_boxes; reference :253-276): for every peak
+// location the union of the components [ulx, uly, lrx, lry] that vertically coincide with the strip of half height
+// `half` around it.  out_boxes [npeaks][4]; out_hit[p] = whether line p has a component at all.
+extern "C" int ta_host_line_boxes(const int64_t* comps, int64_t ncomp, const int64_t* peaks, int64_t npeaks, int64_t half,
+                                  int64_t* out_boxes, uint8_t* out_hit) {
+    if (ncomp < 0 || npeaks < 0) return ta_fail(TA_EINVAL, "negative count");
+    if (npeaks == 0) return TA_OK;
+    if (!peaks || !out_boxes || !out_hit || (ncomp > 0 && !comps)) return ta_fail(TA_EINVAL, "null pointer argument");
+    for (int64_t p = 0; p < npeaks; ++p) {
+        const int64_t st = peaks[p] - half, sb = peaks[p] + half;
+        int64_t ulx = INT64_MAX, uly = INT64_MAX, lrx = INT64_MIN, lry = INT64_MIN;
+        bool hit = false;
+        for (int64_t c = 0; c < ncomp; ++c) {
+            const int64_t* b = comps + 4 * c;
+            const int64_t top = b[1], bottom = b[1] + (b[3] - b[1] + 1);
+            const bool above = top < st && bottom < st, below = top > sb && bottom > sb;
+            if (above || below) continue;
+            hit = true;
+            if (b[0] < ulx) ulx = b[0];
+            if (b[1] < uly) uly = b[1];
+            if (b[2] > lrx) lrx = b[2];
+            if (b[3] > lry) lry = b[3];
+        }
+        out_hit[p] = hit ? 1 : 0;
+        out_boxes[4 * p] = ulx; out_boxes[4 * p + 1] = uly; out_boxes[4 * p + 2] = lrx; out_boxes[4 * p + 3] = lry;
+    }
+    return TA_OK;
+}

@@ -842,3 +842,196 @@ extern "C" int ta_pp_clear_rows(uint8_t* ink, int32_t w, const int32_t* rows, in
     PP_LAUNCH_CHECK("pp_clear_rows_kernel");
     return TA_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Whole STAGES of the preprocessing for a batch of pages, one call each: everything between two of the pipeline's
+// data-dependent host decisions (Otsu threshold | skew sweeps | projection peaks | component selection | strips).
+// A page's stage is a dozen launches; made one by one from the host language they cost more host time than the kernels
+// take (and a Python host holds its interpreter lock meanwhile, so the page threads could not run beside each other).
+// All pointer arguments named like arrays are HOST arrays (n entries) of DEVICE pointers / sizes; everything is
+// enqueued on `stream`, nothing is waited for.  Same kernels, same order per page as the single-page entry points.
+namespace {
+
+int pp_check_pages(int32_t n, const int32_t* h, const int32_t* w) {
+    if (n < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (n && (!h || !w)) return ta_fail(TA_EINVAL, "null pointer argument");
+    for (int i = 0; i < n; ++i) {
+        if (h[i] < 0 || w[i] < 0) return ta_fail(TA_EINVAL, "negative size");
+        if ((int64_t)h[i] * w[i] >= (1ll << 31)) return ta_fail(TA_ELIMIT, "page too large for 32-bit labels");
+    }
+    return TA_OK;
+}
+
+}  // namespace
+
+extern "C" int ta_pp_histogram_batch(int32_t n, const uint8_t* const* img, const int64_t* npix, uint32_t* hist,
+                                     void* stream) {
+    if (n < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (n == 0) return TA_OK;
+    if (!img || !npix || !hist) return ta_fail(TA_EINVAL, "null pointer argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)n * 256 * sizeof(uint32_t), st);
+    if (e != hipSuccess) return ta_fail_hip(e, "histogram memset");
+    for (int i = 0; i < n; ++i) {
+        if (npix[i] < 0) return ta_fail(TA_EINVAL, "negative size");
+        if (npix[i] == 0) continue;
+        if (!img[i]) return ta_fail(TA_EINVAL, "null pointer argument");
+        hipLaunchKernelGGL(pp_hist_kernel, dim3(pp_blocks(npix[i]) > 1024 ? 1024 : pp_blocks(npix[i])), dim3(kPpThreads), 0, st,
+                           img[i], npix[i], hist + (size_t)i * 256);
+    }
+    PP_LAUNCH_CHECK("pp_hist_kernel");
+    return TA_OK;
+}
+
+// greyscale pages -> cleaned ink planes + the ink points of the decimated pages (reference
+// textAlignPreprocessing.py:167-186): threshold at thr[i]; despeckle (components under `despeckle` pixels) the ink,
+// then the background (small holes), drop components taller than max_height rows; list the ink pixels of the page
+// decimated by step[i] (points[i], counts[i]: ta_pp_ink_points).  lab[i] / stats[i]: h*w and 5*h*w int32 of scratch.
+extern "C" int ta_pp_binarise_batch(int32_t n, const uint8_t* const* img, const int32_t* h, const int32_t* w,
+                                    const int32_t* thr, int32_t despeckle, int32_t max_height, uint8_t* const* ink,
+                                    int32_t* const* lab, int32_t* const* stats, const int32_t* step,
+                                    uint32_t* const* points, uint32_t* counts, void* stream) {
+    int rc = pp_check_pages(n, h, w);
+    if (rc != TA_OK) return rc;
+    if (n == 0) return TA_OK;
+    if (!img || !thr || !ink || !lab || !stats || !step || !points || !counts) return ta_fail(TA_EINVAL, "null pointer argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int i = 0; i < n; ++i) {
+        const int64_t np = (int64_t)h[i] * w[i];
+        if (step[i] < 1) return ta_fail(TA_EINVAL, "bad size");
+        if (np && (!img[i] || !ink[i] || !lab[i] || !stats[i] || !points[i])) return ta_fail(TA_EINVAL, "null pointer argument");
+        const int hs = (h[i] + step[i] - 1) / step[i], wsm = (w[i] + step[i] - 1) / step[i];
+        if (hs > 65535 || wsm > 65535) return ta_fail(TA_ELIMIT, "decimated page too large for 16-bit point coordinates");
+        if (np) hipLaunchKernelGGL(pp_threshold_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, img[i], np, thr[i], 0, ink[i]);
+    }
+    for (int round = 0; round < 3; ++round) {
+        rc = ta_pp_label_batch(n, ink, h, w, lab, stats, reinterpret_cast<int32_t*>(counts), stream);
+        if (rc != TA_OK) return rc;
+        for (int i = 0; i < n; ++i) {
+            const int64_t np = (int64_t)h[i] * w[i];
+            if (!np) continue;
+            hipLaunchKernelGGL(pp_filter_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, ink[i], lab[i], np, stats[i],
+                               stats[i] + 2 * np, stats[i] + 4 * np, round < 2 ? despeckle : 0, round < 2 ? (1 << 30) : max_height);
+            // round 0 works on the ink, round 1 on the background (inverted before and after), round 2 on the ink again
+            if (round < 2) hipLaunchKernelGGL(pp_invert_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, ink[i], np);
+        }
+    }
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)n * sizeof(uint32_t), st);
+    if (e != hipSuccess) return ta_fail_hip(e, "point count memset");
+    for (int i = 0; i < n; ++i) {
+        const int hs = (h[i] + step[i] - 1) / step[i], wsm = (w[i] + step[i] - 1) / step[i];
+        const int64_t np = (int64_t)hs * wsm;
+        if (np) hipLaunchKernelGGL(pp_ink_points_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, ink[i], h[i], w[i], step[i],
+                                   points[i], counts + i);
+    }
+    PP_LAUNCH_CHECK("binarise stage kernels");
+    return TA_OK;
+}
+
+// ta_pp_angle_histograms_points for every page: hist[i] = [nang[i]][hs[i]] uint32, cos_sin[i] = 2 * nang[i] doubles [dev]
+extern "C" int ta_pp_angle_histograms_points_batch(int32_t n, const uint32_t* const* points, const uint32_t* counts,
+                                                   const int32_t* hs, const int32_t* ws, const double* const* cos_sin,
+                                                   const int32_t* nang, uint32_t* const* hist, void* stream) {
+    if (n < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (n == 0) return TA_OK;
+    if (!points || !counts || !hs || !ws || !cos_sin || !nang || !hist) return ta_fail(TA_EINVAL, "null pointer argument");
+    for (int i = 0; i < n; ++i) {
+        const int rc = ta_pp_angle_histograms_points(points[i], counts + i, hs[i], ws[i], cos_sin[i], nang[i], hist[i], stream);
+        if (rc != TA_OK) return rc;
+    }
+    return TA_OK;
+}
+
+// deskew + run filters + row projection (reference :187-195, :212-215): out[i] = ink[i] rotated through mo[i]
+// (ta_pp_rotate; mo[i] NULL: a copy, oh / ow = h / w), eroded[i] = out[i] opened with runs of `runs_len` pixels along
+// the rows then the columns, `rounds` times (tmp[i]: oh*ow bytes of scratch), sums[i][r] = ink pixels of eroded row r
+extern "C" int ta_pp_deskew_batch(int32_t n, const uint8_t* const* ink, const int32_t* h, const int32_t* w,
+                                  const double* const* mo, uint8_t* const* out, const int32_t* oh, const int32_t* ow,
+                                  uint8_t* const* tmp, uint8_t* const* eroded, int32_t runs_len, int32_t rounds,
+                                  int32_t* const* sums, void* stream) {
+    int rc = pp_check_pages(n, h, w);
+    if (rc == TA_OK) rc = pp_check_pages(n, oh, ow);
+    if (rc != TA_OK) return rc;
+    if (n == 0) return TA_OK;
+    if (!ink || !mo || !out || !tmp || !eroded || !sums || rounds < 0) return ta_fail(TA_EINVAL, "bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int i = 0; i < n; ++i) {
+        const int64_t np = (int64_t)oh[i] * ow[i];
+        if (!np) continue;
+        if (!ink[i] || !out[i] || !tmp[i] || !eroded[i] || !sums[i]) return ta_fail(TA_EINVAL, "null pointer argument");
+        if (mo[i]) {
+            hipLaunchKernelGGL(pp_rotate_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, ink[i], h[i], w[i], out[i], oh[i], ow[i], mo[i]);
+        } else {
+            if (oh[i] != h[i] || ow[i] != w[i]) return ta_fail(TA_EINVAL, "a page that is not rotated keeps its size");
+            hipError_t e = hipMemcpyAsync(out[i], ink[i], (size_t)np, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return ta_fail_hip(e, "plane copy");
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const int64_t np = (int64_t)oh[i] * ow[i];
+        if (!np) continue;
+        const uint8_t* src = out[i];
+        if (runs_len > 1) {
+            for (int r = 0; r < rounds; ++r) {
+                hipLaunchKernelGGL(pp_open_runs_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, src, tmp[i], oh[i], ow[i], runs_len, 0);
+                hipLaunchKernelGGL(pp_open_runs_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, tmp[i], eroded[i], oh[i], ow[i], runs_len, 1);
+                src = eroded[i];
+            }
+        }
+        if (src != eroded[i]) {
+            hipError_t e = hipMemcpyAsync(eroded[i], out[i], (size_t)np, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return ta_fail_hip(e, "plane copy");
+        }
+        hipLaunchKernelGGL(pp_row_sums_kernel, dim3(oh[i]), dim3(kPpThreads), 0, st, eroded[i], oh[i], ow[i], sums[i]);
+    }
+    PP_LAUNCH_CHECK("deskew stage kernels");
+    return TA_OK;
+}
+
+// the components of the text lines (reference :216-252): work[i] = eroded[i] with the rows rows[i][0..nrows[i]) cleared
+// (the white lines between neighbouring text lines), labelled (lab[i] / stats[i] scratch as above), the component table
+// of page i collected into recs + i*cap*6 (ta_pp_components), its true count into counts[i]
+extern "C" int ta_pp_line_components_batch(int32_t n, const uint8_t* const* eroded, const int32_t* h, const int32_t* w,
+                                           const int32_t* const* rows, const int32_t* nrows, uint8_t* const* work,
+                                           int32_t* const* lab, int32_t* const* stats, int32_t* recs, int32_t cap,
+                                           int32_t* counts, void* stream) {
+    int rc = pp_check_pages(n, h, w);
+    if (rc != TA_OK) return rc;
+    if (n == 0) return TA_OK;
+    if (!eroded || !rows || !nrows || !work || !lab || !stats || !recs || !counts || cap < 0) return ta_fail(TA_EINVAL, "bad argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int i = 0; i < n; ++i) {
+        const int64_t np = (int64_t)h[i] * w[i];
+        if (!np) continue;
+        if (!eroded[i] || !work[i] || nrows[i] < 0 || (nrows[i] && !rows[i])) return ta_fail(TA_EINVAL, "bad argument");
+        hipError_t e = hipMemcpyAsync(work[i], eroded[i], (size_t)np, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return ta_fail_hip(e, "plane copy");
+        if (nrows[i]) hipLaunchKernelGGL(pp_clear_rows_kernel, dim3(nrows[i]), dim3(kPpThreads), 0, st, work[i], w[i], rows[i], nrows[i]);
+    }
+    rc = ta_pp_label_batch(n, work, h, w, lab, stats, counts, stream);
+    if (rc != TA_OK) return rc;
+    hipError_t e = hipMemsetAsync(counts, 0, (size_t)n * sizeof(int32_t), st);
+    if (e != hipSuccess) return ta_fail_hip(e, "component count memset");
+    for (int i = 0; i < n; ++i) {
+        const int64_t np = (int64_t)h[i] * w[i];
+        if (np) hipLaunchKernelGGL(pp_collect_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, lab[i], np, stats[i],
+                                   stats[i] + np, stats[i] + 2 * np, stats[i] + 3 * np, stats[i] + 4 * np,
+                                   recs + (size_t)i * cap * 6, cap, counts + i);
+    }
+    PP_LAUNCH_CHECK("line component stage kernels");
+    return TA_OK;
+}
+
+// ta_pp_cut_strips for every page, into ONE packed buffer (the boxes carry their offsets into it)
+extern "C" int ta_pp_cut_strips_batch(int32_t n, const uint8_t* const* ink, const int32_t* h, const int32_t* w,
+                                      const int64_t* const* boxes, const int32_t* nstrips, uint8_t* packed, void* stream) {
+    int rc = pp_check_pages(n, h, w);
+    if (rc != TA_OK) return rc;
+    if (n == 0) return TA_OK;
+    if (!ink || !boxes || !nstrips) return ta_fail(TA_EINVAL, "null pointer argument");
+    for (int i = 0; i < n; ++i) {
+        rc = ta_pp_cut_strips(ink[i], h[i], w[i], boxes[i], nstrips[i], packed, stream);
+        if (rc != TA_OK) return rc;
+    }
+    return TA_OK;
+}

@@ -46,6 +46,38 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+STAGE_CLOCK = None       # tools/pages_img_stages.py puts a list here: (thread, checkpoint name, perf_counter) per checkpoint
+
+
+def _mark(name):
+    if STAGE_CLOCK is not None:
+        import threading
+        import time
+        STAGE_CLOCK.append((threading.get_ident(), name, time.perf_counter()))
+
+
+def _carve(dev, counts, dtype):
+    """ONE device buffer with room for counts[k] elements of `dtype` per page, each page's piece 256-byte aligned:
+    (buffer, element offsets).  A stage's planes of a whole batch are one allocation instead of one per page."""
+    item = torch.empty(0, dtype=dtype).element_size()
+    unit = 256 // item
+    offs, total = [], 0
+    for c in counts:
+        offs.append(total)
+        total += (int(c) + unit - 1) // unit * unit
+    return torch.empty(max(total, 1), dtype=dtype, device=dev), offs
+
+
+def _addr(buf, offs):
+    """device addresses of the pieces of a carved buffer, as the library's stage functions take them (a host array)"""
+    base, item = buf.data_ptr(), buf.element_size()
+    return np.array([base + int(o) * item for o in offs], dtype=np.uint64)
+
+
+def _i32(values):
+    return np.array([int(v) for v in values], dtype=np.int32)
+
+
 class _Dev(object):
     def __init__(self, device="cuda"):
         self.dev = torch.device(device)
@@ -59,6 +91,7 @@ class _Dev(object):
         # handle lives for one batch, inside the caller's stream context; asking torch per launch was 0.15 ms
         # per page)
         self.stream = torch.cuda.current_stream(self.dev).cuda_stream
+        self.row_sums = None         # preprocess_images_batch leaves the eroded planes' row projections here (buffer, offsets)
 
     # ---- one image (kept for tests and tools) ------------------------------------------------
     def label(self, ink):
@@ -113,14 +146,20 @@ class _Dev(object):
             h, w = lab.shape
             _native.check(self.lib.ta_pp_components(lab.data_ptr(), stats.data_ptr(), h, w, recs[k].data_ptr(),
                                                     cap, counts[k:].data_ptr(), self.stream), "ta_pp_components")
+        return self.component_tables(n, labelled.__getitem__, recs, counts, cap)
+
+    def component_tables(self, n, labelled, recs, counts, cap):
+        """the download half of components_many: recs [n][cap][6] and counts [n] on the device -> sorted host tables
+        (labelled(k): the (lab, stats) planes of image k, asked for only when its table has to be collected again)"""
         cnt = counts.cpu().numpy()
         small = int(min(cap, max(int(cnt.max()), 1)))
         host_recs = recs[:, :small].cpu().numpy()
         out = []
-        for k, (lab, stats) in enumerate(labelled):
+        for k in range(n):
             c = int(cnt[k])
             if c > cap:                                    # rare: a page with thousands of components
                 big = torch.empty((c, 6), dtype=torch.int32, device=self.dev)
+                lab, stats = labelled(k)
                 h, w = lab.shape
                 _native.check(self.lib.ta_pp_components(lab.data_ptr(), stats.data_ptr(), h, w, big.data_ptr(),
                                                         c, self.count.data_ptr(), self.stream), "ta_pp_components")
@@ -144,6 +183,14 @@ def otsu_from_histogram(hist):
     return int(np.argmax(between))
 
 
+def otsu_thresholds(hists):
+    """otsu_from_histogram of every row of an int32 [n][256] array, in the library's host loop (ta_host_otsu_batch)"""
+    hists = np.ascontiguousarray(hists, dtype=np.int32).reshape(-1, 256)
+    thr = np.zeros(len(hists), np.int32)
+    _native.check(_native.lib.ta_host_otsu_batch(hists.ctypes.data, len(hists), thr.ctypes.data), "ta_host_otsu_batch")
+    return thr
+
+
 def otsu_threshold_device(d, img):
     return otsu_thresholds_device(d, [img])[0]
 
@@ -163,22 +210,34 @@ def rotation_angles_device(d, inks, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
     cy + (y - cy) cos a - (x - cx) sin a of the page decimated to <= 1200 rows / columns); one download
     per sweep for all pages.  A page without ink reports 0."""
     n = len(inks)
-    steps = [max(1, int(max(k.shape) / 1200)) for k in inks]
-    hs = [(int(k.shape[0]) + st - 1) // st for k, st in zip(inks, steps)]
-    ws = [(int(k.shape[1]) + st - 1) // st for k, st in zip(inks, steps)]
+    steps, hs, ws = _decimation([k.shape for k in inks])
     # the ink pixels of every decimated page, listed once for all angles of both sweeps (ta_pp_ink_points)
-    points, counts = [], torch.zeros(max(n, 1), dtype=torch.int32, device=d.dev)
+    pts, offs = _carve(d.dev, [a * b for a, b in zip(hs, ws)], torch.int32)
+    counts = torch.zeros(max(n, 1), dtype=torch.int32, device=d.dev)
     for k, ink in enumerate(inks):
-        pts = torch.empty(max(hs[k] * ws[k], 1), dtype=torch.int32, device=d.dev)
         h, w = ink.shape
-        _native.check(d.lib.ta_pp_ink_points(ink.data_ptr(), h, w, steps[k], pts.data_ptr(), counts[k:].data_ptr(),
+        _native.check(d.lib.ta_pp_ink_points(ink.data_ptr(), h, w, steps[k], pts[offs[k]:].data_ptr(), counts[k:].data_ptr(),
                                              d.stream), "ta_pp_ink_points")
-        points.append(pts)
+    return _skew_search(d, _addr(pts, offs), counts, hs, ws, lo, hi, coarse, fine, keep=pts)
 
-    def sweep(grids):
-        # the angles' cosines / sines of all pages in ONE asynchronous upload, the histograms of all pages in one buffer
-        # and one download (a small `.to(device)` from pageable memory waits for everything the stream holds: per page
-        # it kept the host from ever running ahead of the device)
+
+def _decimation(shapes):
+    steps = [max(1, int(max(sh) / 1200)) for sh in shapes]
+    hs = [(int(sh[0]) + st - 1) // st for sh, st in zip(shapes, steps)]
+    ws = [(int(sh[1]) + st - 1) // st for sh, st in zip(shapes, steps)]
+    return steps, hs, ws
+
+
+def _skew_search(d, points, counts, hs, ws, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05, keep=None):
+    """rotation_angles_device from the pages' point lists (device addresses `points`, device counts)"""
+    n = len(hs)
+    d_hs, d_ws = _i32(hs), _i32(ws)
+
+    def sharpest(grids):
+        """per page the index of the angle whose row histogram has the largest variance, and whether the page has ink"""
+        # the angles' cosines / sines of all pages in ONE asynchronous upload, the histograms of all pages in one buffer,
+        # one stage call and one download; the variances and their argmax in the library's host loop (numpy's np.var to
+        # the last bit -- _sharpest_rows_numpy is the expression it replaces -- without the interpreter lock)
         tables = []
         for g in grids:
             cs = np.empty(2 * len(g), np.float64)
@@ -186,28 +245,48 @@ def rotation_angles_device(d, inks, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
             cs[0::2], cs[1::2] = np.cos(rad), np.sin(rad)
             tables.append(cs)
         d_cs = _native.upload_packed(tables, d.dev)
-        sizes = [len(grids[k]) * hs[k] for k in range(n)]
-        hist = torch.empty(max(sum(sizes), 1), dtype=torch.int32, device=d.dev)
-        pos = 0
-        for k in range(n):
-            _native.check(d.lib.ta_pp_angle_histograms_points(points[k].data_ptr(), counts[k:].data_ptr(), hs[k], ws[k],
-                                                              d_cs[k].data_ptr(), len(grids[k]), hist[pos:].data_ptr(),
-                                                              d.stream), "ta_pp_angle_histograms_points")
-            pos += sizes[k]
+        nang = _i32([len(g) for g in grids])
+        sizes = [int(nang[k]) * hs[k] for k in range(n)]
+        hist, hoffs = _carve(d.dev, sizes, torch.int32)
+        cs_ptr = np.array([t.data_ptr() for t in d_cs], dtype=np.uint64)
+        hist_ptr = _addr(hist, hoffs)                                            # (host arrays: alive until the call returns)
+        _native.check(d.lib.ta_pp_angle_histograms_points_batch(
+            n, points.ctypes.data, counts.data_ptr(), d_hs.ctypes.data, d_ws.ctypes.data, cs_ptr.ctypes.data,
+            nang.ctypes.data, hist_ptr.ctypes.data, d.stream), "ta_pp_angle_histograms_points_batch")
+        _mark("sweep enqueued")
         flat = hist.cpu().numpy()
-        out, pos = [], 0
-        for k in range(n):
-            out.append(flat[pos:pos + sizes[k]].reshape(len(grids[k]), hs[k]))
-            pos += sizes[k]
-        return out
+        _mark("sweep back")
+        return sharpest_rows(flat, hoffs, nang, d_hs)
     grid = np.arange(lo, hi + 1e-9, coarse)
-    hh = sweep([grid] * n)
-    empty = [not bool(h.any()) for h in hh]
-    best = [grid[int(np.argmax(np.var(h, axis=1)))] for h in hh]          # np.var per row, bit for bit
-    fine_grids = [np.arange(b - coarse, b + coarse + 1e-9, fine) for b in best]
-    hh = sweep(fine_grids)
-    return [0.0 if e else float(np.round(g[int(np.argmax(np.var(h, axis=1)))], 3))
-            for e, g, h in zip(empty, fine_grids, hh)]
+    coarse_best, has_ink = sharpest([grid] * n)
+    fine_grids = [np.arange(grid[int(b_)] - coarse, grid[int(b_)] + coarse + 1e-9, fine) for b_ in coarse_best]
+    fine_best, _ = sharpest(fine_grids)
+    return [float(np.round(g[int(b_)], 3)) if ink else 0.0 for ink, g, b_ in zip(has_ink, fine_grids, fine_best)]
+
+
+def sharpest_rows(flat, offs, nang, hs):
+    """(best, any) per page: best[k] = int(np.argmax(np.var(H_k, axis=1))) of page k's histograms H_k = nang[k] rows of
+    hs[k] int32 counts at flat[offs[k]:], any[k] = H_k.any() -- ta_host_sharpest_rows"""
+    n = len(offs)
+    flat = np.ascontiguousarray(flat, dtype=np.int32)
+    off = np.array([int(o) for o in offs], dtype=np.int64)
+    nang, hs = np.ascontiguousarray(nang, dtype=np.int32), np.ascontiguousarray(hs, dtype=np.int32)
+    if n and int((off + nang.astype(np.int64) * hs).max()) > flat.size:
+        raise ValueError("a page's histograms lie outside the buffer")
+    best, some = np.zeros(n, np.int32), np.zeros(n, np.uint8)
+    _native.check(_native.lib.ta_host_sharpest_rows(flat.ctypes.data, off.ctypes.data, nang.ctypes.data, hs.ctypes.data, n,
+                                                    best.ctypes.data, some.ctypes.data, None), "ta_host_sharpest_rows")
+    return best, some.astype(bool)
+
+
+def _sharpest_rows_numpy(flat, offs, nang, hs):
+    """the numpy expressions sharpest_rows replaces (np.var per row, bit for bit): the cross-check of the tests"""
+    best, some = [], []
+    for o, a, h in zip(offs, nang, hs):
+        H = np.asarray(flat[int(o):int(o) + int(a) * int(h)]).reshape(int(a), int(h))
+        best.append(int(np.argmax(np.var(H, axis=1))))
+        some.append(bool(H.any()))
+    return np.array(best, np.int32), np.array(some, bool)
 
 
 def rotation_angle_device(d, ink, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
@@ -284,34 +363,68 @@ def preprocess_images_batch(pages, despeckle_amt=host.despeckle_amt, filter_runs
         if px.dtype != np.uint8 or px.ndim != 2:
             raise TypeError("the device preprocessing takes 2-D uint8 pages")
         host_px.append(np.ascontiguousarray(px))
+    n = len(host_px)
+    d.row_sums = None
+    if n == 0:
+        return d, []
+    lib, dev, st = d.lib, d.dev, d.stream
+    _mark("start")
     imgs = _upload_pages(d, host_px)
-    thrs = otsu_thresholds_device(d, imgs)
-    inks = []
-    for img, thr in zip(imgs, thrs):
-        ink = torch.empty_like(img)
-        _native.check(d.lib.ta_pp_threshold(img.data_ptr(), img.numel(), thr, 0, ink.data_ptr(), d.stream),
-                      "ta_pp_threshold")
-        inks.append(ink)
-    d.despeckle_many(inks, despeckle_amt)
-    for ink in inks:
-        d.invert(ink)                                        # fill small holes: despeckle the background
-    d.despeckle_many(inks, despeckle_amt)
-    for ink in inks:
-        d.invert(ink)
-    for ink, (lab, stats) in zip(inks, d.label_many(inks)):  # drop components taller than the threshold
-        d.filter(ink, lab, stats, max_height=host.sat_area_thresh)
-    skews = rotation_angles_device(d, inks, -6, 6)
+    _mark("pages staged")
+    hh, ww = _i32([px.shape[0] for px in host_px]), _i32([px.shape[1] for px in host_px])
+    npix = hh.astype(np.int64) * ww
+    img_ptr = np.array([t.data_ptr() for t in imgs], dtype=np.uint64)
+    # stage 1: grey-level histograms -> Otsu thresholds (host, as in the reference)
+    hist = torch.empty((n, 256), dtype=torch.int32, device=dev)
+    _native.check(lib.ta_pp_histogram_batch(n, img_ptr.ctypes.data, npix.ctypes.data, hist.data_ptr(), st), "ta_pp_histogram_batch")
+    _mark("histograms enqueued")
+    hist_host = hist.cpu().numpy()
+    _mark("histograms back")
+    thrs = otsu_thresholds(hist_host)
+    # stage 2: threshold, despeckle ink and background, drop tall components, list the decimated pages' ink points
+    inks, ink_off = _carve(dev, npix, torch.uint8)
+    lab, lab_off = _carve(dev, npix, torch.int32)
+    stats, stats_off = _carve(dev, 5 * npix, torch.int32)
+    steps, hs, ws = _decimation([px.shape for px in host_px])
+    pts, pts_off = _carve(dev, [a_ * b_ for a_, b_ in zip(hs, ws)], torch.int32)
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    ink_ptr, lab_ptr, stats_ptr, pts_ptr = _addr(inks, ink_off), _addr(lab, lab_off), _addr(stats, stats_off), _addr(pts, pts_off)
+    d_steps = _i32(steps)
+    _native.check(lib.ta_pp_binarise_batch(n, img_ptr.ctypes.data, hh.ctypes.data, ww.ctypes.data, thrs.ctypes.data,
+                                           int(despeckle_amt), int(host.sat_area_thresh), ink_ptr.ctypes.data,
+                                           lab_ptr.ctypes.data, stats_ptr.ctypes.data, d_steps.ctypes.data,
+                                           pts_ptr.ctypes.data, counts.data_ptr(), st), "ta_pp_binarise_batch")
+    _mark("binarise enqueued")
+    # stage 3: the skew search (two sweeps, a download each; variances and the choice on the host)
+    skews = _skew_search(d, pts_ptr, counts, hs, ws, -6, 6)
+    _mark("skews chosen")
+    # stage 4: rotation, run filters, row projection
+    geo = [_rotation_geometry(int(h), int(w), a_) if (correct_rotation and a_ != 0) else None
+           for h, w, a_ in zip(hh, ww, skews)]
+    oh = _i32([g[0] if g else h for g, h in zip(geo, hh)])
+    ow = _i32([g[1] if g else w for g, w in zip(geo, ww)])
+    turned = [g[2] for g in geo if g]
+    maps = iter(_native.upload_packed(turned, dev)) if turned else iter(())
+    keep_maps = [next(maps) if g else None for g in geo]
+    mo_ptr = np.array([t.data_ptr() if t is not None else 0 for t in keep_maps], dtype=np.uint64)
+    onp = oh.astype(np.int64) * ow
+    outs, out_off = _carve(dev, onp, torch.uint8)
+    tmp, tmp_off = _carve(dev, onp, torch.uint8)
+    eroded, er_off = _carve(dev, onp, torch.uint8)
+    sums, sums_off = _carve(dev, oh, torch.int32)
+    out_ptr, tmp_ptr, er_ptr, sums_ptr = _addr(outs, out_off), _addr(tmp, tmp_off), _addr(eroded, er_off), _addr(sums, sums_off)
+    _native.check(lib.ta_pp_deskew_batch(n, ink_ptr.ctypes.data, hh.ctypes.data, ww.ctypes.data, mo_ptr.ctypes.data,
+                                         out_ptr.ctypes.data, oh.ctypes.data, ow.ctypes.data, tmp_ptr.ctypes.data,
+                                         er_ptr.ctypes.data, int(filter_runs_amt), int(filter_runs), sums_ptr.ctypes.data, st),
+                  "ta_pp_deskew_batch")
+    _mark("deskew enqueued")
+    d.row_sums = (sums, sums_off)                                 # identify_text_lines_batch takes them from here
     out = []
-    if correct_rotation:
-        inks = rotate_many(d, inks, skews)
-    for ink, skew in zip(inks, skews):
-        eroded = ink
-        for _ in range(filter_runs):
-            eroded = open_runs_device(d, eroded, filter_runs_amt, 0)
-            eroded = open_runs_device(d, eroded, filter_runs_amt, 1)
-        if eroded is ink:
-            eroded = ink.clone()
-        out.append((ink, eroded, host.reported_angle(skew)))     # sign: see host.reported_angle
+    for k in range(n):
+        m = int(onp[k])
+        shape = (int(oh[k]), int(ow[k]))
+        out.append((outs[out_off[k]:out_off[k] + m].view(shape), eroded[er_off[k]:er_off[k] + m].view(shape),
+                    host.reported_angle(skews[k])))              # sign: see host.reported_angle
     return d, out
 
 
@@ -323,22 +436,32 @@ def preprocess_images(input_image, despeckle_amt=host.despeckle_amt, filter_runs
     return (d,) + out[0]
 
 
-def identify_text_lines_batch(d, planes):
+def identify_text_lines_batch(d, planes, row_sums=None):
     """text lines of preprocessed pages (reference textAlignPreprocessing.py:198-285) from their
-    (ink, eroded) device planes: [(line strips, peak locations, smoothed projection)]"""
+    (ink, eroded) device planes: [(line strips, peak locations, smoothed projection)].  row_sums: the carved buffer
+    (tensor, offsets) of the eroded planes' row projections when the deskew stage has made them already."""
     n = len(planes)
-    sums = []
-    for ink, eroded in planes:
-        h, w = eroded.shape
-        s = torch.empty(h, dtype=torch.int32, device=d.dev)
-        _native.check(d.lib.ta_pp_row_sums(eroded.data_ptr(), h, w, s.data_ptr(), d.stream), "ta_pp_row_sums")
-        sums.append(s)
-    flat = torch.cat(sums).cpu().numpy().astype(np.int64) if n else np.zeros(0, np.int64)
-    smoothed_all, peaks_all, works, pos, row_lists = [], [], [], 0, []
-    for ink, eroded in planes:
-        h, w = eroded.shape
-        project = flat[pos:pos + h]
-        pos += h
+    if n == 0:
+        return []
+    lib, dev, st = d.lib, d.dev, d.stream
+    hh, ww = _i32([e.shape[0] for _, e in planes]), _i32([e.shape[1] for _, e in planes])
+    npix = hh.astype(np.int64) * ww
+    er_ptr = np.array([e.data_ptr() for _, e in planes], dtype=np.uint64)
+    ink_ptr = np.array([i.data_ptr() for i, _ in planes], dtype=np.uint64)
+    if row_sums is None:
+        sums, sums_off = _carve(dev, hh, torch.int32)
+        for k, (ink, eroded) in enumerate(planes):
+            _native.check(lib.ta_pp_row_sums(eroded.data_ptr(), int(hh[k]), int(ww[k]), sums[sums_off[k]:].data_ptr(), st),
+                          "ta_pp_row_sums")
+    else:
+        sums, sums_off = row_sums
+    _mark("lines: start")
+    flat = sums.cpu().numpy().astype(np.int64)
+    _mark("projections back")
+    # peaks of the smoothed projections and the white lines between neighbouring text lines: host, as in the reference
+    smoothed_all, peaks_all, row_lists = [], [], []
+    for k in range(n):
+        project = flat[sums_off[k]:sums_off[k] + int(hh[k])]
         smoothed = host.moving_avg_filter(project, host.filter_size)
         peaks = host.find_peak_locations(smoothed)
         rows = []
@@ -347,18 +470,32 @@ def identify_text_lines_batch(d, planes):
             rows.extend(range(max(idx - 1, 0), idx + 1))          # 2-pixel white line
         row_lists.append(np.array(sorted(set(rows)), dtype=np.int32))
         smoothed_all.append(smoothed); peaks_all.append(peaks)
-    d_rows = _native.upload_packed(row_lists, d.dev) if n else []
-    for (ink, eroded), rows, dr in zip(planes, row_lists, d_rows):
-        work = eroded.clone()
-        if len(rows):
-            _native.check(d.lib.ta_pp_clear_rows(work.data_ptr(), eroded.shape[1], dr.data_ptr(), len(rows), d.stream),
-                          "ta_pp_clear_rows")
-        works.append(work)
-    recs_all = d.components_many(d.label_many(works))
+    _mark("peaks found")
+    # stage 5: clear those rows in a copy of the eroded plane, label it, collect the component tables
+    d_rows = _native.upload_packed(row_lists, dev)
+    rows_ptr = np.array([t.data_ptr() if len(r) else 0 for t, r in zip(d_rows, row_lists)], dtype=np.uint64)
+    nrows = _i32([len(r) for r in row_lists])
+    work, work_off = _carve(dev, npix, torch.uint8)
+    lab, lab_off = _carve(dev, npix, torch.int32)
+    stats, stats_off = _carve(dev, 5 * npix, torch.int32)
+    cap = 1 << 12
+    recs = torch.empty((n, cap, 6), dtype=torch.int32, device=dev)
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    work_ptr, lab_ptr, stats_ptr = _addr(work, work_off), _addr(lab, lab_off), _addr(stats, stats_off)
+    _native.check(lib.ta_pp_line_components_batch(n, er_ptr.ctypes.data, hh.ctypes.data, ww.ctypes.data, rows_ptr.ctypes.data,
+                                                  nrows.ctypes.data, work_ptr.ctypes.data, lab_ptr.ctypes.data,
+                                                  stats_ptr.ctypes.data, recs.data_ptr(), cap, counts.data_ptr(), st),
+                  "ta_pp_line_components_batch")
+    def labelled(k):
+        return (lab[lab_off[k]:lab_off[k] + int(npix[k])].view(int(hh[k]), int(ww[k])),
+                stats[stats_off[k]:stats_off[k] + 5 * int(npix[k])].view(5, int(hh[k]), int(ww[k])))
+    _mark("components enqueued")
+    recs_all = d.component_tables(n, labelled, recs, counts, cap)
+    _mark("components back")
     boxes_all, total = [], 0
-    for (ink, eroded), peaks, recs in zip(planes, peaks_all, recs_all):
+    for peaks, recs_k in zip(peaks_all, recs_all):
         boxes = []
-        big = recs[recs[:, 1] > host.noise_area_thresh]
+        big = recs_k[recs_k[:, 1] > host.noise_area_thresh]
         if len(big):
             comps = big[:, 2:6].astype(np.int64)                  # ulx, uly, lrx, lry
             heights = comps[:, 3] - comps[:, 1] + 1
@@ -369,23 +506,24 @@ def identify_text_lines_batch(d, planes):
                 boxes.append((ulx, uly, lrx, lry, total))
                 total += (lry - uly + 1) * (lrx - ulx + 1)
         boxes_all.append(boxes)
-    # cut the strips on the device (ink black on white, as the reference saves them) into one packed buffer
+    _mark("boxes chosen")
+    # stage 6: cut the strips on the device (ink black on white, as the reference saves them) into one packed buffer
     # and leave them there: the recogniser's normaliser reads them where they are, `strip.pixels` downloads
-    packed = torch.empty(max(total, 1), dtype=torch.uint8, device=d.dev)
-    d_boxes = _native.upload_packed([np.array(boxes, dtype=np.int64).reshape(-1, 5) for boxes in boxes_all], d.dev) if n else []
-    for (ink, eroded), boxes, db in zip(planes, boxes_all, d_boxes):
-        if boxes:
-            h, w = ink.shape
-            _native.check(d.lib.ta_pp_cut_strips(ink.data_ptr(), h, w, db.data_ptr(), len(boxes),
-                                                 packed.data_ptr(), d.stream), "ta_pp_cut_strips")
+    packed = torch.empty(max(total, 1), dtype=torch.uint8, device=dev)
+    d_boxes = _native.upload_packed([np.array(boxes, dtype=np.int64).reshape(-1, 5) for boxes in boxes_all], dev)
+    box_ptr = np.array([t.data_ptr() if boxes else 0 for t, boxes in zip(d_boxes, boxes_all)], dtype=np.uint64)
+    nboxes = _i32([len(boxes) for boxes in boxes_all])
+    _native.check(lib.ta_pp_cut_strips_batch(n, ink_ptr.ctypes.data, hh.ctypes.data, ww.ctypes.data, box_ptr.ctypes.data,
+                                             nboxes.ctypes.data, packed.data_ptr(), st), "ta_pp_cut_strips_batch")
     out = []
     for boxes, peaks, smoothed in zip(boxes_all, peaks_all, smoothed_all):
         strips = []
         for ulx, uly, lrx, lry, off in boxes:
-            hh, ww = lry - uly + 1, lrx - ulx + 1
-            strips.append(page_mod.Strip(ulx, uly, hh, width=ww,
-                                         device_pixels=packed[off:off + hh * ww].view(hh, ww)))
+            hh_, ww_ = lry - uly + 1, lrx - ulx + 1
+            strips.append(page_mod.Strip(ulx, uly, hh_, width=ww_,
+                                         device_pixels=packed[off:off + hh_ * ww_].view(hh_, ww_)))
         out.append((strips, peaks, smoothed))
+    _mark("strips made")
     return out
 
 
@@ -400,7 +538,7 @@ def find_lines_batch(pages, device="cuda"):
     if not pages:
         return []
     d, pre = preprocess_images_batch(pages, device=device)
-    lines = identify_text_lines_batch(d, [(ink, eroded) for ink, eroded, _ in pre])
+    lines = identify_text_lines_batch(d, [(ink, eroded) for ink, eroded, _ in pre], row_sums=d.row_sums)
     return [(DeviceBinImage(ink, d), DeviceBinImage(eroded, d), angle, strips, peaks)
             for (ink, eroded, angle), (strips, peaks, _) in zip(pre, lines)]
 

@@ -65,8 +65,22 @@ def coincide_mask(hline_position, comp_offsets, comp_nrows, collision):
 def line_boxes(peak_locs, comps, collision):
     """the bounding box of every text line of a page: for each peak location the union (ulx, uly, lrx, lry) of the
     components [ulx, uly, lrx, lry] that vertically_coincide with it, lines without a component left out (reference
-    :253-276, one line at a time there).  One (peaks x components) table instead of a mask and four reductions per
-    line: ~30 lines x ~300 components a page."""
+    :253-276, one line at a time there).  Integer comparisons in the library's host loop (ta_host_line_boxes; a page has
+    ~30 lines and up to a few thousand components); line_boxes_numpy is the same as one numpy table."""
+    comps = np.ascontiguousarray(comps, dtype=np.int64).reshape(-1, 4)
+    loc = np.ascontiguousarray(peak_locs, dtype=np.int64).reshape(-1)
+    if not len(loc) or not len(comps):
+        return []
+    from . import _native
+    half = int(collision * collision_strip_scale / 2)
+    boxes, hit = np.empty((len(loc), 4), np.int64), np.empty(len(loc), np.uint8)
+    _native.check(_native.lib.ta_host_line_boxes(comps.ctypes.data, len(comps), loc.ctypes.data, len(loc), half,
+                                                 boxes.ctypes.data, hit.ctypes.data), "ta_host_line_boxes")
+    return boxes[hit.astype(bool)].tolist()
+
+
+def line_boxes_numpy(peak_locs, comps, collision):
+    """line_boxes as one (peaks x components) numpy table: the cross-check of the native loop"""
     comps = np.asarray(comps, dtype=np.int64).reshape(-1, 4)
     loc = np.asarray(peak_locs, dtype=np.int64).reshape(-1, 1)
     if not len(loc) or not len(comps):

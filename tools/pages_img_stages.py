@@ -60,5 +60,21 @@ for rep in range(3):
     print("find_lines_all of %d pages: %.1f ms (threads %d, batch %d)" % (n, 1e3 * wall, preproc.PAGE_THREADS, preproc.PAGES_PER_BATCH))
     for tid, d in per.items():
         print("   thread %x: " % (tid & 0xffff) + ", ".join("%s %.1f" % (k, 1e3 * v) for k, v in sorted(d.items(), key=lambda kv: -kv[1])))
+# the checkpoints inside the two stage functions: wall time from each checkpoint to the next, summed per thread
+pg.STAGE_CLOCK = []
+atocr.find_lines_all(pages)
+torch.cuda.synchronize()
+clock, pg.STAGE_CLOCK = pg.STAGE_CLOCK, None
+spans = collections.defaultdict(lambda: collections.OrderedDict())
+last = {}
+for tid, name, t in clock:
+    if tid in last and name not in ("start", "lines: start"):
+        key = "%s -> %s" % (last[tid][0], name)
+        spans[tid][key] = spans[tid].get(key, 0.0) + t - last[tid][1]
+    last[tid] = (name, t)
+for tid, d_ in spans.items():
+    print("   thread %x, ms between checkpoints (summed over its batches):" % (tid & 0xffff))
+    for key, v in d_.items():
+        print("      %-46s %6.2f" % (key, 1e3 * v))
 busy = pb._device_busy_ms(lambda: atocr.find_lines_all(pages))
 print("device busy in one call: %.1f ms" % (busy or -1))

@@ -1,2 +1,5 @@
-for cfg in "8 2 0.005" "8 2 0.0005" "8 2 0.0001" "4 4 0.0005" "8 4 0.0005"; do python tools/pages_img_time.py 64 $cfg 2>&1 | tail -3; done
-for cfg in "8 2 0.005" "8 2 0.0005" "4 4 0.0005"; do TA_PAGE_CHUNK_IMAGES=16 python tools/pages_img_time.py 64 $cfg 2>&1 | tail -3; done
+export TA_PB_LINES_AHEAD=0
+for cfg in "16 8 2" "24 8 3" "32 8 4" "32 4 4" "64 8 4" "16 8 2" "24 8 3" "32 8 4"; do
+  set -- $cfg
+  echo -n "chunk $1 batch $2 threads $3: "; TA_PAGE_CHUNK_IMAGES=$1 TA_PP_BATCH=$2 TA_PP_THREADS=$3 python tools/pages_ab.py 64 8 --images 2>&1 | tail -1
+done
