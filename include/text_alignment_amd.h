@@ -471,6 +471,20 @@ int ta_pp_cut_strips_batch(int32_t n, const uint8_t* const* ink, const int32_t* 
  * ta_host_line_boxes: per peak location the union of the components [ulx, uly, lrx, lry] that vertically coincide
  *   with the strip of half height `half` around it (textAlignPreprocessing.py:38-56, :253-276).
  */
+/* The text-line peaks of a batch of pages in two calls with ONE numpy logarithm between them (numpy's float64 log is
+ * its own routine on AVX-512 hosts and differs from libm's in the last bit now and then, and the prominences are
+ * compared with a tolerance after a division: the logarithm stays numpy's).
+ * ta_host_peak_candidates: page k's row projection proj + off[k] (len[k] int64 sums) -> smoothed + off[k]
+ *   (moving_avg_filter, textAlignPreprocessing.py:147-157), its local maxima cand_idx + off[k] (cand_n[k] of them) and
+ *   the ARGUMENT of each one's logarithm cand_arg + off[k] (calculate_peak_prominence :59-110).
+ * ta_host_peak_select: with cand_log = log(cand_arg): peaks + off[k] (npeaks[k] rows whose prominence / the largest
+ *   exceeds tol >= 0, find_peak_locations :113-144) and the white rows between neighbouring peaks rows + 2 off[k]
+ *   (nrows[k], ascending; :222-232). */
+int ta_host_peak_candidates(const int64_t* proj, const int64_t* off, const int32_t* len, int32_t n, int32_t filter_size,
+                            double* smoothed, int32_t* cand_idx, double* cand_arg, int32_t* cand_n);
+int ta_host_peak_select(const double* smoothed, const int64_t* off, const int32_t* len, int32_t n, const int32_t* cand_idx,
+                        const double* cand_log, const int32_t* cand_n, double tol, int32_t* peaks, int32_t* npeaks,
+                        int32_t* rows, int32_t* nrows);
 int ta_host_otsu_batch(const int32_t* hist, int32_t n, int32_t* thr);
 int ta_host_sharpest_rows(const int32_t* hist, const int64_t* off, const int32_t* nang, const int32_t* hs, int32_t n,
                           int32_t* best, uint8_t* any, double* var_out);

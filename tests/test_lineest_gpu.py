@@ -78,6 +78,26 @@ def test_strips_already_on_the_device_are_normalised_where_they_are():
     st = page_mod.Strip(3, 4, 44, device_pixels=on_dev[0])
     assert st.width == 600 and page_mod.prepared_line(st)[0] is on_dev[0]
     assert np.array_equal(st.pixels, strips[0])
+    # DeviceStrips: pieces of packed buffers, as the page preprocessing leaves them -- neighbours in one buffer (taken
+    # as ONE slice), a gap between two, a second buffer, a tensor and a host strip in between
+    sizes = [s.size for s in strips]
+    buf_a = torch.cat([on_dev[0].reshape(-1), on_dev[1].reshape(-1), torch.zeros(100, dtype=torch.uint8, device="cuda"),
+                       on_dev[2].reshape(-1)])
+    buf_b = torch.cat([torch.zeros(7, dtype=torch.uint8, device="cuda"), on_dev[3].reshape(-1)])
+    ds = [page_mod.DeviceStrip(buf_a, 0, 44, 600), page_mod.DeviceStrip(buf_a, sizes[0], 50, 420),
+          page_mod.DeviceStrip(buf_a, sizes[0] + sizes[1] + 100, 61, 800), page_mod.DeviceStrip(buf_b, 7, 38, 256)]
+    for mix in (ds, [ds[0], ds[1]] + [on_dev[2], strips[3]], [strips[0], ds[1], ds[2], ds[3]]):
+        x1, T1, _ = lineest_gpu.normalize_strips(mix)
+        assert np.array_equal(T0, T1) and torch.equal(x0, x1)
+    x1, T1, _ = lineest_gpu.normalize_strips(ds[:2])                        # one slice, no copy
+    xa, Ta, _ = lineest_gpu.normalize_strips(strips[:2])
+    assert np.array_equal(Ta, T1) and torch.equal(xa, x1)
+    st = page_mod.Strip(3, 4, 50, device_pixels=ds[1])
+    assert st.width == 420 and page_mod.prepared_line(st)[0] is ds[1] and np.array_equal(st.pixels, strips[1])
+    with pytest.raises(ValueError, match="outside its buffer"):
+        lineest_gpu.normalize_strips([page_mod.DeviceStrip(buf_b, 8, 38, 256)])
+    with pytest.raises(TypeError):
+        lineest_gpu.normalize_strips([page_mod.DeviceStrip(buf_a.view(2, -1), 0, 44, 600)])
 
 
 def test_recogniser_takes_raw_strips():

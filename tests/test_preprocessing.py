@@ -317,3 +317,46 @@ def test_host_arithmetic_of_the_stages_equals_numpy():
                                              b_.ctypes.data, s_.ctypes.data, var.ctypes.data) == 0
     want = np.concatenate([np.var(p.reshape(a_, h_), axis=1) for p, a_, h_ in zip(pages, nang, hs)])
     assert var.view(np.uint64).tolist() == want.view(np.uint64).tolist()
+
+
+def test_batched_peaks_equal_the_per_page_functions():
+    """textAlignPreprocessing.peaks_of_projections (host loops of the library around one np.log) against
+    moving_avg_filter + find_peak_locations + the white rows between peaks page by page: smoothed projections bit for
+    bit, the same peaks, the same rows -- on the golden profiles' raw data, seeded text-like projections, flat-topped
+    peaks (equal prominences), short pages (no room for the filter) and constant pages."""
+    from text_alignment_amd import textAlignPreprocessing as pp
+    rng = np.random.default_rng(11)
+    pages = []
+    for c in load_golden("preproc.json")["profiles"]:
+        pages.append(np.array(c["data"], dtype=float).astype(np.int64))
+    for trial in range(120):
+        m = int(rng.integers(1, 5000)) if trial % 6 else int(rng.integers(1, 80))
+        kind = trial % 4
+        if kind == 0:                                     # text lines: humps on a noisy floor
+            y = rng.integers(0, 8, m).astype(np.int64)
+            for c0 in range(int(rng.integers(20, 90)), m, int(rng.integers(90, 160))):
+                w = int(rng.integers(20, 60))
+                y[c0:c0 + w] += int(rng.integers(200, 900))
+        elif kind == 1:                                   # plateaus: flat-topped peaks, equal prominences
+            y = np.repeat(rng.integers(0, 4, m // 50 + 1) * 300, 50)[:m].astype(np.int64)
+        elif kind == 2:
+            y = rng.integers(0, 1400, m).astype(np.int64)
+        else:
+            y = np.full(m, int(rng.integers(0, 3)), np.int64)
+        pages.append(y)
+    lens = [len(p) for p in pages]
+    offs = (np.concatenate(([0], np.cumsum([(m + 63) // 64 * 64 for m in lens])))[:-1]).astype(np.int64)
+    flat = np.zeros(int(offs[-1]) + lens[-1] + 64, np.int64)
+    for o, p in zip(offs, pages):
+        flat[o:o + len(p)] = p
+    got = pp.peaks_of_projections(flat, offs, lens)
+    want = pp.peaks_of_projections_numpy(flat, offs, lens)
+    assert sum(len(w[1]) for w in want) > 500
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g[0].view(np.uint64).tolist() == w[0].view(np.uint64).tolist(), k
+        assert g[1] == w[1], k
+        assert g[2].tolist() == w[2].tolist(), k
+    for tol in (0.0, 0.3, 0.95):
+        got = pp.peaks_of_projections(flat, offs[:40], lens[:40], tol=tol)
+        want = pp.peaks_of_projections_numpy(flat, offs[:40], lens[:40], tol=tol)
+        assert [g[1] for g in got] == [w[1] for w in want] and [g[2].tolist() for g in got] == [w[2].tolist() for w in want]

@@ -101,6 +101,10 @@ def _load():
     lib.ta_host_chars_of_batch.argtypes = [vp] * 10 + [i32, i32, i32, i64] + [vp] * 4
     lib.ta_host_syllable_boxes.restype = ctypes.c_int
     lib.ta_host_syllable_boxes.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, vp]
+    lib.ta_host_peak_candidates.restype = ctypes.c_int
+    lib.ta_host_peak_candidates.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    lib.ta_host_peak_select.restype = ctypes.c_int
+    lib.ta_host_peak_select.argtypes = [vp, vp, vp, i32, vp, vp, vp, ctypes.c_double, vp, vp, vp, vp]
     lib.ta_host_otsu_batch.restype = ctypes.c_int
     lib.ta_host_otsu_batch.argtypes = [vp, i32, vp]
     lib.ta_host_sharpest_rows.restype = ctypes.c_int
@@ -138,7 +142,7 @@ def _load():
 
 lib = _load()
 
-EXPORTS = ["ta_version", "ta_last_error", "ta_device_pci_bus_id", "ta_host_copy_pieces", "ta_host_chars_of_batch", "ta_host_syllable_boxes", "ta_host_otsu_batch", "ta_host_sharpest_rows", "ta_host_line_boxes", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_max_m", "ta_nw2_batch", "ta_nw2_phase1_plan", "ta_nw2_phase1_plan_batch", "ta_nw2_traceback_plan",
+EXPORTS = ["ta_version", "ta_last_error", "ta_device_pci_bus_id", "ta_host_copy_pieces", "ta_host_chars_of_batch", "ta_host_syllable_boxes", "ta_host_peak_candidates", "ta_host_peak_select", "ta_host_otsu_batch", "ta_host_sharpest_rows", "ta_host_line_boxes", "ta_nw_workspace_bytes", "ta_nw_max_m", "ta_nw_batch", "ta_nw2_workspace_bytes", "ta_nw2_max_m", "ta_nw2_batch", "ta_nw2_phase1_plan", "ta_nw2_phase1_plan_batch", "ta_nw2_traceback_plan",
            "ta_nw_general_score_bytes", "ta_nw_general_ptr_bytes", "ta_nw_general", "ta_nw_general_batch",
            "ta_lstm_packed_weight_floats", "ta_lstm_forward", "ta_lstm_f64_weight_doubles", "ta_lstm_f64_gx_bytes", "ta_lstm_xproj_f64", "ta_lstm_forward_f64", "ta_lstm_forward_f64_g4", "ta_lstm_output", "ta_lstm_output_split_weight_bytes", "ta_lstm_output_split", "ta_decode",
            "ta_decode_summary", "ta_rows_gather", "ta_linenorm_measure", "ta_linenorm_resample",

@@ -798,6 +798,21 @@ extern "C" int ta_pp_row_sums(const uint8_t* ink, int32_t h, int32_t w, int32_t*
 // rows that passed its local-maximum test.  arg[c] = d[i] where d[i] is the maximum, else
 // d[i] - min(d[lo:hi]) + 1 with [lo, hi) running from the nearest strictly higher sample (the left one
 // only if it is strictly nearer) to i, as the reference slices it.  Plain float64, evaluated left to right.
+static inline double pp_peak_arg(const double* d, int n, int i, double data_max) {
+    const double here = d[i];
+    if (here == data_max) return here;
+    int nr = i + 1, nl = i - 1;
+    while (nr < n && !(d[nr] > here)) ++nr;
+    while (nl >= 0 && !(d[nl] > here)) --nl;
+    const bool has_r = nr < n, has_l = nl >= 0;
+    if (!has_r && !has_l) return here;                               // (data_max was not the maximum: as if it were)
+    const bool go_left = has_l && (!has_r || (nr - i) > (i - nl));
+    const int lo = go_left ? nl : i, hi = go_left ? i : nr;
+    double key = d[lo];
+    for (int j = lo + 1; j < hi; ++j) key = d[j] < key ? d[j] : key;
+    return here - key + 1.0;
+}
+
 extern "C" int ta_pp_peak_prominence_args(const double* d, int32_t n, const int32_t* idx, int32_t k,
                                           double data_max, double* arg) {
     if (n < 0 || k < 0) return ta_fail(TA_EINVAL, "negative size");
@@ -806,18 +821,110 @@ extern "C" int ta_pp_peak_prominence_args(const double* d, int32_t n, const int3
     for (int c = 0; c < k; ++c) {
         const int i = idx[c];
         if (i < 0 || i >= n) return ta_fail(TA_EINVAL, "candidate row outside the projection");
-        const double here = d[i];
-        if (here == data_max) { arg[c] = here; continue; }
-        int nr = i + 1, nl = i - 1;
-        while (nr < n && !(d[nr] > here)) ++nr;
-        while (nl >= 0 && !(d[nl] > here)) --nl;
-        const bool has_r = nr < n, has_l = nl >= 0;
-        if (!has_r && !has_l) { arg[c] = here; continue; }           // (data_max was not the maximum: as if it were)
-        const bool go_left = has_l && (!has_r || (nr - i) > (i - nl));
-        const int lo = go_left ? nl : i, hi = go_left ? i : nr;
-        double key = d[lo];
-        for (int j = lo + 1; j < hi; ++j) key = d[j] < key ? d[j] : key;
-        arg[c] = here - key + 1.0;
+        arg[c] = pp_peak_arg(d, n, i, data_max);
+    }
+    return TA_OK;
+}
+
+// The text-line peaks of a batch of pages, host arithmetic in two calls with ONE numpy logarithm in between (numpy's
+// float64 log is its own SIMD routine where the CPU has AVX-512 and differs from libm's in the last bit now and then;
+// the prominences are compared with a tolerance after a division, so the logarithm stays numpy's):
+//
+// ta_host_peak_candidates: page k's row projection proj + off[k], len[k] int64 sums -> smoothed + off[k] (float64;
+//   moving_avg_filter, reference :147-157: mean over filter_size rows to either side, the ends zero; window sums of
+//   integers are exact, then one division), its local maxima (the test calculate_peak_prominence starts with, :59-72)
+//   cand_idx / cand_arg at cand_off[k] .. + cand_n[k] (cand_off[k] = off[k]: a page has fewer candidates than rows) with
+//   the ARGUMENT of each one's logarithm (ta_pp_peak_prominence_args).
+// ta_host_peak_select: with cand_log = np.log(cand_arg): per page the candidates whose prominence / the largest
+//   exceeds tol (find_peak_locations :113-144, including its removal of the first of two equal neighbours among all but
+//   the last pair), peaks + off[k] (npeaks[k] of them); and the white rows between neighbouring peaks (:222-232):
+//   for each pair the first minimum of the smoothed projection between them and the row above it, sorted, without
+//   repeats, rows + 2 * off[k] (nrows[k] of them).
+extern "C" int ta_host_peak_candidates(const int64_t* proj, const int64_t* off, const int32_t* len, int32_t n,
+                                       int32_t filter_size, double* smoothed, int32_t* cand_idx, double* cand_arg,
+                                       int32_t* cand_n) {
+    if (n < 0 || filter_size < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (n == 0) return TA_OK;
+    if (!proj || !off || !len || !smoothed || !cand_idx || !cand_arg || !cand_n) return ta_fail(TA_EINVAL, "null pointer argument");
+    const int fs = filter_size;
+    for (int32_t k = 0; k < n; ++k) {
+        if (len[k] < 0 || off[k] < 0) return ta_fail(TA_EINVAL, "negative size");
+        const int m = len[k];
+        const int64_t* p = proj + off[k];
+        double* sm = smoothed + off[k];
+        for (int i = 0; i < m; ++i) sm[i] = 0.0;
+        if (m > 2 * fs) {
+            int64_t win = 0;
+            for (int i = 0; i < 2 * fs + 1; ++i) win += p[i];
+            const double width = (double)(2 * fs + 1);
+            for (int i = fs; i < m - fs; ++i) {
+                sm[i] = (double)win / width;
+                if (i + fs + 1 < m) win += p[i + fs + 1] - p[i - fs];
+            }
+        }
+        double data_max = m ? sm[0] : 0.0;
+        for (int i = 1; i < m; ++i) data_max = sm[i] > data_max ? sm[i] : data_max;
+        int c = 0;
+        for (int i = 1; i + 1 < m; ++i) {
+            const double l = sm[i - 1], mid = sm[i], r = sm[i + 1];
+            if (l > mid || r > mid || (l == mid && r == mid)) continue;
+            cand_idx[off[k] + c] = i;
+            cand_arg[off[k] + c] = pp_peak_arg(sm, m, i, data_max);
+            ++c;
+        }
+        cand_n[k] = c;
+    }
+    return TA_OK;
+}
+
+extern "C" int ta_host_peak_select(const double* smoothed, const int64_t* off, const int32_t* len, int32_t n,
+                                   const int32_t* cand_idx, const double* cand_log, const int32_t* cand_n, double tol,
+                                   int32_t* peaks, int32_t* npeaks, int32_t* rows, int32_t* nrows) {
+    if (n < 0) return ta_fail(TA_EINVAL, "negative size");
+    if (n == 0) return TA_OK;
+    if (!smoothed || !off || !len || !cand_idx || !cand_log || !cand_n || !peaks || !npeaks || !rows || !nrows)
+        return ta_fail(TA_EINVAL, "null pointer argument");
+    if (!(tol >= 0.0)) return ta_fail(TA_EINVAL, "a negative tolerance makes every row a peak: the host language's loop covers it");
+    std::vector<int> idx;
+    std::vector<double> val;
+    for (int32_t k = 0; k < n; ++k) {
+        const int c = cand_n[k];
+        if (c < 0 || c > len[k]) return ta_fail(TA_EINVAL, "bad candidate count");
+        const int32_t* ci = cand_idx + off[k];
+        const double* cl = cand_log + off[k];
+        const double* sm = smoothed + off[k];
+        npeaks[k] = 0; nrows[k] = 0;
+        double top = 0.0;                                             // max(vals + [0])
+        for (int j = 0; j < c; ++j) top = cl[j] > top ? cl[j] : top;
+        if (top == 0.0) continue;
+        idx.clear(); val.clear();
+        for (int j = 0; j < c; ++j) {
+            const double v = cl[j] / top;
+            if (v > tol) { idx.push_back(ci[j]); val.push_back(v); }
+        }
+        // both corners of a flat-topped peak are prominent: the first of two equal neighbours goes (the reference looks
+        // at all pairs but the last one)
+        const int np0 = (int)idx.size();
+        int np = 0;
+        int32_t* out = peaks + off[k];
+        for (int j = 0; j < np0; ++j) {
+            if (j < np0 - 2 && val[j] == val[j + 1]) continue;
+            if (idx[j] < 0 || idx[j] >= len[k]) return ta_fail(TA_EINVAL, "candidate row outside the projection");
+            out[np++] = idx[j];
+        }
+        npeaks[k] = np;
+        int32_t* rw = rows + 2 * off[k];
+        int nr = 0;
+        for (int j = 0; j + 1 < np; ++j) {
+            const int a = out[j], b = out[j + 1];
+            int at = a;
+            for (int i = a + 1; i < b; ++i) if (sm[i] < sm[at]) at = i;     // np.argmin: the first minimum
+            const int lo = at - 1 > 0 ? at - 1 : 0;
+            // (peaks ascend, so the rows do: appending while skipping repeats keeps them sorted and unique)
+            if (nr == 0 || rw[nr - 1] < lo) rw[nr++] = lo;
+            if (rw[nr - 1] < at) rw[nr++] = at;
+        }
+        nrows[k] = nr;
     }
     return TA_OK;
 }

@@ -8,6 +8,7 @@ import numpy as np
 import torch
 
 from . import _native
+from . import page as page_mod
 
 TARGET_HEIGHT = 48          # CenterNormalizer target_height
 PAD = 16                    # prepare_line pad (Appendix B.2)
@@ -105,11 +106,24 @@ def measure_strips_begin(strips, device="cuda"):
         ms.wo = ms.T = np.zeros(0, np.int64)
         return ms
     hh = np.zeros(n, np.int32); ww = np.zeros(n, np.int32)
-    on_device = [isinstance(s, torch.Tensor) for s in strips]
+    spans = [isinstance(s, page_mod.DeviceStrip) for s in strips]
+    on_device = [sp or isinstance(s, torch.Tensor) for sp, s in zip(spans, strips)]
+    want_index = torch.cuda.current_device() if dev.index is None else dev.index
+    checked = set()
     for k, s in enumerate(strips):
-        if on_device[k]:
+        if spans[k]:
+            buf = s.buffer
+            if id(buf) not in checked:                # (a batch's strips share a few buffers: checked once each)
+                if buf.dim() != 1 or buf.dtype != torch.uint8 or buf.device.type != "cuda" or buf.device.index != want_index:
+                    raise TypeError("a device strip lies in a 1-D uint8 buffer on %s" % dev)
+                checked.add(id(buf))
+            if s.shape[0] * s.shape[1] == 0:
+                raise ValueError("empty or constant text-line image")
+            if s.start < 0 or s.start + s.shape[0] * s.shape[1] > buf.numel():
+                raise ValueError("a device strip lies outside its buffer")
+        elif on_device[k]:
             if (s.dim() != 2 or s.dtype != torch.uint8 or not s.is_contiguous() or s.device.type != "cuda" or
-                    s.device.index != (torch.cuda.current_device() if dev.index is None else dev.index)):
+                    s.device.index != want_index):
                 raise TypeError("a device strip is a contiguous 2-D uint8 tensor on %s" % dev)
             if s.numel() == 0:
                 raise ValueError("empty or constant text-line image")
@@ -140,7 +154,22 @@ def measure_strips_begin(strips, device="cuda"):
     if not any(on_device):
         d_pix = _upload_host_strips(strips, pix_off, dev)
     else:
-        d_pix = torch.cat([s.reshape(-1) if on_device[k] else up(np.asarray(s).ravel()) for k, s in enumerate(strips)])
+        # neighbours that follow each other in the same buffer are ONE slice of it (the preprocessing cuts a batch of
+        # pages' strips into one packed buffer, in order): a chunk's ~500 strips are two or three pieces
+        parts, k = [], 0
+        while k < n:
+            s = strips[k]
+            if spans[k]:
+                end, j = s.start + int(hh[k]) * int(ww[k]), k + 1
+                while j < n and spans[j] and strips[j].buffer is s.buffer and strips[j].start == end:
+                    end += int(hh[j]) * int(ww[j])
+                    j += 1
+                parts.append(s.buffer[s.start:end])
+                k = j
+            else:
+                parts.append(s.reshape(-1) if on_device[k] else up(np.asarray(s).ravel()))
+                k += 1
+        d_pix = parts[0] if len(parts) == 1 else torch.cat(parts)
     # the batch's metadata in one transfer (nine small arrays: a `.to(device)` from pageable memory each was 2 ms of host time)
     (ms.d_pix_off, ms.d_hh, ms.d_ww, d_gw, d_gw_off, d_gr, ms.d_col_off, d_ws_off) = _native.upload_packed(
         [pix_off[:-1].copy(), hh, ww, gw, gw_off, gr, col_off[:-1].copy(), 3 * pix_off[:-1]], dev)

@@ -103,6 +103,28 @@ class RowSpan(object):
         return self.stop - self.start
 
 
+class DeviceStrip(object):
+    """A raw strip that lies in a larger uint8 device buffer (the packed buffer the page preprocessing cuts a batch's
+    strips into): rows x cols bytes from element `start` of `buffer`.  Stands where a 2-D uint8 device tensor would
+    (`.shape`, `.dtype`, `.cpu()`), without a tensor view per strip -- a page has ~30 strips and the normaliser wants
+    them as ONE run of pixels anyway (lineest_gpu.measure_strips_begin joins neighbours in the same buffer)."""
+    __slots__ = ("buffer", "start", "shape")
+
+    def __init__(self, buffer, start, rows, cols):
+        self.buffer, self.start, self.shape = buffer, int(start), (int(rows), int(cols))
+
+    @property
+    def dtype(self):
+        return self.buffer.dtype
+
+    def tensor(self):
+        h, w = self.shape
+        return self.buffer[self.start:self.start + h * w].view(h, w)
+
+    def cpu(self):
+        return self.tensor().cpu()
+
+
 class Strip(object):
     """One text-line strip: position on the (deskewed) page plus its pixels.
 
@@ -111,8 +133,8 @@ class Strip(object):
         each side (what ocropus-rpred feeds its network) -- or a RowSpan: those rows
         inside a RowBlock (page-locked or device memory), taken by the recogniser where they lie; or
     pixels: raw (H, W) uint8 strip with white background, normalised on the device (lineest_gpu); or
-    device_pixels: the same strip as a 2-D uint8 tensor that already lives on the GPU (what the device
-        preprocessing cuts, preproc_gpu.identify_text_lines_batch) -- `.pixels` then downloads it on
+    device_pixels: the same strip as a 2-D uint8 tensor that already lives on the GPU, or a DeviceStrip (what the
+        device preprocessing cuts, preproc_gpu.identify_text_lines_batch) -- `.pixels` then downloads it on
         first use, the recogniser takes it where it is.
     width: raw strip width in pixels (sets the scale of the reported character positions).
     """

@@ -459,17 +459,8 @@ def identify_text_lines_batch(d, planes, row_sums=None):
     flat = sums.cpu().numpy().astype(np.int64)
     _mark("projections back")
     # peaks of the smoothed projections and the white lines between neighbouring text lines: host, as in the reference
-    smoothed_all, peaks_all, row_lists = [], [], []
-    for k in range(n):
-        project = flat[sums_off[k]:sums_off[k] + int(hh[k])]
-        smoothed = host.moving_avg_filter(project, host.filter_size)
-        peaks = host.find_peak_locations(smoothed)
-        rows = []
-        for a, b in zip(peaks[:-1], peaks[1:]):
-            idx = int(np.argmin(smoothed[a:b])) + a
-            rows.extend(range(max(idx - 1, 0), idx + 1))          # 2-pixel white line
-        row_lists.append(np.array(sorted(set(rows)), dtype=np.int32))
-        smoothed_all.append(smoothed); peaks_all.append(peaks)
+    found = host.peaks_of_projections(flat, sums_off, hh)
+    smoothed_all, peaks_all, row_lists = [f[0] for f in found], [f[1] for f in found], [f[2] for f in found]
     _mark("peaks found")
     # stage 5: clear those rows in a copy of the eroded plane, label it, collect the component tables
     d_rows = _native.upload_packed(row_lists, dev)
@@ -520,8 +511,7 @@ def identify_text_lines_batch(d, planes, row_sums=None):
         strips = []
         for ulx, uly, lrx, lry, off in boxes:
             hh_, ww_ = lry - uly + 1, lrx - ulx + 1
-            strips.append(page_mod.Strip(ulx, uly, hh_, width=ww_,
-                                         device_pixels=packed[off:off + hh_ * ww_].view(hh_, ww_)))
+            strips.append(page_mod.Strip(ulx, uly, hh_, width=ww_, device_pixels=page_mod.DeviceStrip(packed, off, hh_, ww_)))
         out.append((strips, peaks, smoothed))
     _mark("strips made")
     return out

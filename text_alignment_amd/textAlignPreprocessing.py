@@ -198,6 +198,63 @@ def _candidate_prominences(d, idx, data_max):
     return [np.log(v) for v in arg]
 
 
+def peaks_of_projections(flat, offs, lens, tol=prominence_tolerance, size=filter_size):
+    """[(smoothed, peaks, white rows)] of a batch of pages' row projections (page k: flat[offs[k] : offs[k] + lens[k]],
+    integer sums): moving_avg_filter, find_peak_locations and the rows `identify_text_lines` clears between
+    neighbouring peaks (reference :147-157, :113-144, :222-232) -- the library's host loops
+    (ta_host_peak_candidates / ta_host_peak_select) around ONE np.log of all pages' candidates, instead of a dozen
+    numpy calls and a Python loop per page under the interpreter lock.  peaks_of_projections_numpy is the per-page form."""
+    n = len(offs)
+    lens32 = np.ascontiguousarray(lens, dtype=np.int32)
+    if n == 0:
+        return []
+    if tol < 0 or int(lens32.min()) == 0:
+        return peaks_of_projections_numpy(flat, offs, lens, tol, size)       # (rows of prominence 0 as peaks; empty data raises)
+    from . import _native
+    lib = _native.lib
+    flat = np.ascontiguousarray(flat, dtype=np.int64)
+    off = np.ascontiguousarray(offs, dtype=np.int64)
+    if int((off + lens32).max()) > flat.size or int(off.min()) < 0:
+        raise ValueError("a page's projection lies outside the buffer")
+    smoothed = np.empty(flat.size, np.float64)
+    cand_idx, cand_arg, cand_n = np.empty(flat.size, np.int32), np.ones(flat.size, np.float64), np.zeros(n, np.int32)
+    _native.check(lib.ta_host_peak_candidates(flat.ctypes.data, off.ctypes.data, lens32.ctypes.data, n, int(size),
+                                              smoothed.ctypes.data, cand_idx.ctypes.data, cand_arg.ctypes.data,
+                                              cand_n.ctypes.data), "ta_host_peak_candidates")
+    # numpy's logarithm of every page's candidates in one call (element for element what np.log gives one at a time)
+    total = int(cand_n.sum())
+    first = np.cumsum(cand_n) - cand_n
+    pos = np.repeat(off - first, cand_n) + np.arange(total)
+    cand_log = np.zeros(flat.size, np.float64)
+    cand_log[pos] = np.log(cand_arg[pos])
+    peaks, npeaks = np.empty(flat.size, np.int32), np.zeros(n, np.int32)
+    rows, nrows = np.empty(2 * flat.size, np.int32), np.zeros(n, np.int32)
+    _native.check(lib.ta_host_peak_select(smoothed.ctypes.data, off.ctypes.data, lens32.ctypes.data, n, cand_idx.ctypes.data,
+                                          cand_log.ctypes.data, cand_n.ctypes.data, float(tol), peaks.ctypes.data,
+                                          npeaks.ctypes.data, rows.ctypes.data, nrows.ctypes.data), "ta_host_peak_select")
+    out = []
+    for k in range(n):
+        o = int(off[k])
+        out.append((smoothed[o:o + int(lens32[k])], peaks[o:o + int(npeaks[k])].tolist(),
+                    rows[2 * o:2 * o + int(nrows[k])].copy()))
+    return out
+
+
+def peaks_of_projections_numpy(flat, offs, lens, tol=prominence_tolerance, size=filter_size):
+    """peaks_of_projections page by page with this module's numpy functions"""
+    out = []
+    for o, m in zip(offs, lens):
+        project = np.asarray(flat[int(o):int(o) + int(m)]).astype(np.int64)
+        smoothed = moving_avg_filter(project, size)
+        peaks = find_peak_locations(smoothed, tol)
+        rows = []
+        for a, b in zip(peaks[:-1], peaks[1:]):
+            idx = int(np.argmin(smoothed[a:b])) + a
+            rows.extend(range(max(idx - 1, 0), idx + 1))          # 2-pixel white line
+        out.append((smoothed, peaks, np.array(sorted(set(rows)), dtype=np.int32)))
+    return out
+
+
 def _find_peak_locations_all_rows(data, tol, ranked):
     """the reference's loop over every row, for the cases the candidate form does not cover (a
     negative tolerance makes rows of prominence 0 peaks; empty data raises as the reference does)"""
