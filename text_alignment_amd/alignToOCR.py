@@ -386,10 +386,11 @@ PIPELINE_CHUNK_PAGES_RAW = 16        # raw strips: the device normaliser in fron
                                      # its measuring pass; round 6 enqueues it and waits a stage later: 16 is faster, 970 against 885)
 PIPELINE_CHUNK_PAGES_IMAGES = 16     # page images: preprocessing in front, itself in batches of 8 pages on two page threads (64 until
                                      # round 6: no faster -- 447-564 against 542-557 pages/s -- and its 1 920-line recogniser batch took a
-                                     # 17.7 GB scratch buffer from the caching allocator and gave it back on every call).  Measured and
-                                     # not kept: the line finding of the NEXT chunks started ahead on a thread of its own -- with the
-                                     # stages' launches in the library (preproc_gpu) 551-575 pages/s against 625-636 without, same box:
-                                     # three threads of Python contend for one interpreter lock
+                                     # 17.7 GB scratch buffer from the caching allocator and gave it back on every call).  Measured twice and
+                                     # not kept: the line finding of the NEXT chunk started ahead on a thread of its own -- 551-575
+                                     # pages/s against 625-636 without while the page threads launched from Python, 750-787 against
+                                     # 802-807 with a stage per library call and four page threads (same box each): the stages of the
+                                     # chunks in flight are Python, and more threads of it contend for one interpreter lock
 _side_streams = {}
 WAIT_SECONDS = [0.0]                 # wall seconds the calling thread has spent WAITING for the device inside process_batch (a
                                      # running total: callers take differences): a pass's wall time minus this is its host work

@@ -356,8 +356,13 @@ def find_lines(input_image):
     return find_lines_many([input_image])[0]
 
 
-PAGES_PER_BATCH = 8      # pages whose preprocessing shares its waits for the device (~0.2 GB of planes each)
-PAGE_THREADS = 2         # batches in flight at once, each driven by a host thread on a HIP stream of its own
+# pages whose preprocessing shares its stage calls and waits for the device (~0.2 GB of planes each), and batches in flight
+# at once, each driven by a host thread on a HIP stream of its own.  8 x 2 while every page's launches were made from
+# Python (more threads only fought for the interpreter lock); with a stage per library call (preproc_gpu, round 6) a thread
+# holds the lock for ~0.3 ms per page and four threads keep the device fed: 64 pages, same box, 8 x 2: 682-698 pages/s,
+# 4 x 4: 761-800, 4 x 8: 774-827 with half again the host time
+PAGES_PER_BATCH = 4
+PAGE_THREADS = 4
 
 
 def find_lines_many(pages):
