@@ -384,7 +384,7 @@ def _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, 
 PIPELINE_CHUNK_PAGES = 16
 PIPELINE_CHUNK_PAGES_RAW = 16        # raw strips: the device normaliser in front (32 while every chunk's first stage WAITED for
                                      # its measuring pass; round 6 enqueues it and waits a stage later: 16 is faster, 970 against 885)
-PIPELINE_CHUNK_PAGES_IMAGES = 16     # page images: preprocessing in front, itself in batches of 8 pages on two page threads (64 until
+PIPELINE_CHUNK_PAGES_IMAGES = 16     # page images: preprocessing in front, itself in batches of pages on page threads of its own (64 until
                                      # round 6: no faster -- 447-564 against 542-557 pages/s -- and its 1 920-line recogniser batch took a
                                      # 17.7 GB scratch buffer from the caching allocator and gave it back on every call).  Measured twice and
                                      # not kept: the line finding of the NEXT chunk started ahead on a thread of its own -- 551-575
