@@ -183,3 +183,30 @@ def test_colour_float_and_onebit_pages_take_the_device_path():
         assert want[2] == got[2] and np.array_equal(want[0].ink, got[0].ink)
         assert [s.pixels.shape for s in want[3]] == [s.pixels.shape for s in got[3]]
         assert all(np.array_equal(a.pixels, b.pixels) for a, b in zip(want[3], got[3]))
+
+
+def test_stage_calls_on_pages_of_different_sizes_and_parameters():
+    """One batch of pages of three different sizes through the library's stage calls (ta_pp_*_batch): each page's
+    results are what it gives alone and what the checker gives; and the run-filter parameters the stage call takes
+    (two rounds, runs of three pixels, no filter at all, no rotation) against the checker's preprocess_images."""
+    from oracle import preproc_ref as H
+    from text_alignment_amd import preproc_gpu as G
+    pages = [_noisy_page(2), np.ascontiguousarray(_noisy_page(4, angle=1.5)[40:, :-60]),
+             np.ascontiguousarray(_noisy_page(6, angle=-2.0)[:-80, 25:])]
+    assert len({p.shape for p in pages}) == 3
+    got = G.find_lines_batch(pages)
+    for page, g in zip(pages, got):
+        want = H.find_lines(page)
+        assert want[2] == g[2] and np.array_equal(want[0].ink, g[0].ink) and np.array_equal(want[1].ink, g[1].ink)
+        assert list(want[4]) == list(g[4]) and len(want[3]) == len(g[3]) >= 3
+        for x, y in zip(want[3], g[3]):
+            assert (x.offset_x, x.offset_y, x.height, x.width) == (y.offset_x, y.offset_y, y.height, y.width)
+            assert np.array_equal(x.pixels, y.pixels)
+    for kw in (dict(filter_runs=2, filter_runs_amt=2), dict(filter_runs=1, filter_runs_amt=3), dict(filter_runs=0),
+               dict(filter_runs=1, filter_runs_amt=1), dict(correct_rotation=False)):
+        d, out = G.preprocess_images_batch(pages[1:], **kw)
+        for page, (ink, eroded, angle) in zip(pages[1:], out):
+            b0, e0, a0 = H.preprocess_images(page, **kw)
+            assert a0 == angle, kw
+            assert np.array_equal(b0.ink, ink.cpu().numpy().astype(bool)), kw
+            assert np.array_equal(e0.ink, eroded.cpu().numpy().astype(bool)), kw
