@@ -272,6 +272,12 @@ def run(npages, seed0=100):
     atocr.process_batch(ipages, itrs, rec, PARAMS)         # warm: the page planes come out of torch's caching allocator
     torch.cuda.synchronize()
     img_dt, _, img_cpu = median_of(10, ipages, itrs)
+    img_lat = []
+    for k in range(5):                                     # the reference's own call shape: process(raw_image, transcript, model)
+        t1 = time.perf_counter()
+        atocr.process_batch([ipages[k]], [itrs[k]], rec, PARAMS)
+        torch.cuda.synchronize()
+        img_lat.append(time.perf_counter() - t1)
     out = {"pages": npages, "precision": {0: "f32", 1: "split", 3: "f64"}[rec.mode], "seconds": dt,
            "input": ROWS_INPUT["numpy"],
            "pages_per_s": npages / dt, "lines_per_s": npages * 30 / dt,
@@ -285,7 +291,7 @@ def run(npages, seed0=100):
                     "note": "cpu: time.process_time over the pass (all threads of the process: the interpreter's one "
                             "thread + the strip-copy pool); gpu_busy: union of device intervals of one pass (torch profiler)"},
            "page_images": {"pages": nimg, "pages_per_s": nimg / img_dt, "seconds": img_dt,
-                           "host_cpu_ms_per_page": 1e3 * img_cpu / nimg,
+                           "host_cpu_ms_per_page": 1e3 * img_cpu / nimg, "single_page_ms": 1e3 * sorted(img_lat)[2],
                            "note": "4400 x 1400 uint8 page images: csrc/ta_preproc.hip + ta_lineest.hip in front"},
            "raw_strips": {"pages_per_s": npages / raw_dt, "seconds": raw_dt, "host_cpu_ms_per_page": 1e3 * raw_cpu / npages,
                           "note": "strips as 60-row uint8 images, normalised by csrc/ta_lineest.hip"},
