@@ -210,3 +210,21 @@ def test_stage_calls_on_pages_of_different_sizes_and_parameters():
             assert a0 == angle, kw
             assert np.array_equal(b0.ink, ink.cpu().numpy().astype(bool)), kw
             assert np.array_equal(e0.ink, eroded.cpu().numpy().astype(bool)), kw
+
+
+def test_pages_that_are_torch_tensors_are_taken_where_they_lie():
+    """A page handed over as a 2-D uint8 torch tensor -- on the device, or in page-locked host memory -- goes through
+    the same stages without the staging copy: same angle, planes, peaks and strips as the numpy page, alone, mixed in
+    one batch, and through find_lines_all / process_batch's page type checks."""
+    from text_alignment_amd import alignToOCR as atocr, preproc_gpu as G
+    a, b = _noisy_page(3, angle=1.0), _noisy_page(8)
+    want = G.find_lines_batch([a, b])
+    on_dev, pinned = torch.from_numpy(b).cuda(), torch.from_numpy(a).pin_memory()
+    for got in (G.find_lines_batch([pinned, on_dev]), atocr.find_lines_all([a, on_dev]), atocr.find_lines_all([pinned, b])):
+        for w, g in zip(want, got):
+            assert w[2] == g[2] and list(w[4]) == list(g[4]) and len(w[3]) == len(g[3]) >= 4
+            assert torch.equal(w[0].plane, g[0].plane) and torch.equal(w[1].plane, g[1].plane)
+            assert all(np.array_equal(x.pixels, y.pixels) for x, y in zip(w[3], g[3]))
+    assert atocr._raw_dim(on_dev).ncols == b.shape[1] and atocr._raw_dim(on_dev).nrows == b.shape[0]
+    with pytest.raises(TypeError):
+        G.find_lines_batch([on_dev.float()])

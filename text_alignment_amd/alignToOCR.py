@@ -343,10 +343,12 @@ def _raw_dim(pg):
     dim = getattr(pg, "dim", None)
     if dim is not None and hasattr(dim, "ncols"):
         return dim
-    px = np.asarray(getattr(pg, "pixels", pg))
-    if px.ndim < 2:
+    px = getattr(pg, "pixels", pg)
+    if not hasattr(px, "shape") or type(px).__module__.split(".")[0] != "torch":   # (a tensor -- possibly on the device -- has its shape)
+        px = np.asarray(px)
+    if len(px.shape) < 2:
         raise TypeError("a page is a PreparedPage, an image object with .dim, or a 2-D / 3-D pixel array")
-    return page_mod.Dim(px.shape[1], px.shape[0])
+    return page_mod.Dim(int(px.shape[1]), int(px.shape[0]))
 
 
 def _process_batch_objects(rec, pages, raw_dims, found, strips_per_page, lines, widths, transcripts,

@@ -341,15 +341,46 @@ def open_runs_device(d, ink, length, axis):
     return out
 
 
-def _upload_pages(d, host_px):
-    """the pages of a batch on the device: gathered into ONE page-locked buffer by the library's host copy loop (no
-    interpreter lock held) and sent in one asynchronous transfer; the planes are views of one device buffer"""
-    sizes = [int(px.size) for px in host_px]
-    offs = np.concatenate(([0], np.cumsum([(sz + 255) // 256 * 256 for sz in sizes]))).astype(np.int64)
-    stage = torch.empty(max(int(offs[-1]), 1), dtype=torch.uint8, pin_memory=True)
-    _native.host_copy_pieces(stage.numpy(), host_px, offs[:-1])
-    dev = stage.to(d.dev, non_blocking=True)
-    return [dev[int(o):int(o) + sz].view(px.shape) for o, sz, px in zip(offs[:-1], sizes, host_px)]
+def _upload_pages(d, pages_px):
+    """the pages of a batch on the device.  Pageable numpy pages are gathered into ONE page-locked buffer by the
+    library's host copy loop (no interpreter lock held) and sent in one asynchronous transfer, the planes being views of
+    one device buffer; a page that is a torch tensor is taken where it lies -- on the device as it is, from page-locked
+    host memory by an asynchronous transfer of its own (no staging copy)."""
+    out = [None] * len(pages_px)
+    host_ix = []
+    for k, px in enumerate(pages_px):
+        if isinstance(px, torch.Tensor):
+            if px.device.type == "cuda":
+                if px.device.index != (torch.cuda.current_device() if d.dev.index is None else d.dev.index):
+                    raise ValueError("a device page lies on another GPU than the one that preprocesses it")
+                out[k] = px
+            else:
+                out[k] = px.to(d.dev, non_blocking=px.is_pinned())
+        else:
+            host_ix.append(k)
+    if host_ix:
+        host_px = [pages_px[k] for k in host_ix]
+        sizes = [int(px.size) for px in host_px]
+        offs = np.concatenate(([0], np.cumsum([(sz + 255) // 256 * 256 for sz in sizes]))).astype(np.int64)
+        stage = torch.empty(max(int(offs[-1]), 1), dtype=torch.uint8, pin_memory=True)
+        _native.host_copy_pieces(stage.numpy(), host_px, offs[:-1])
+        dev = stage.to(d.dev, non_blocking=True)
+        for k, o, sz, px in zip(host_ix, offs[:-1], sizes, host_px):
+            out[k] = dev[int(o):int(o) + sz].view(px.shape)
+    return out
+
+
+def _page_plane(pg):
+    """a page's uint8 greyscale plane: a C-contiguous numpy array, or a contiguous torch tensor (device or host)"""
+    px = getattr(pg, "pixels", pg)
+    if isinstance(px, torch.Tensor):
+        if px.dtype != torch.uint8 or px.dim() != 2:
+            raise TypeError("the device preprocessing takes 2-D uint8 pages")
+        return px.contiguous()
+    px = np.asarray(px)
+    if px.dtype != np.uint8 or px.ndim != 2:
+        raise TypeError("the device preprocessing takes 2-D uint8 pages")
+    return np.ascontiguousarray(px)
 
 
 def preprocess_images_batch(pages, despeckle_amt=host.despeckle_amt, filter_runs=1, filter_runs_amt=2,
@@ -357,12 +388,7 @@ def preprocess_images_batch(pages, despeckle_amt=host.despeckle_amt, filter_runs
     """[(ink, eroded, angle)] as uint8 device planes + the device handle: reference
     textAlignPreprocessing.py:160-195 for a list of uint8 greyscale pages"""
     d = _Dev(device)
-    host_px = []
-    for pg in pages:
-        px = np.asarray(getattr(pg, "pixels", pg))
-        if px.dtype != np.uint8 or px.ndim != 2:
-            raise TypeError("the device preprocessing takes 2-D uint8 pages")
-        host_px.append(np.ascontiguousarray(px))
+    host_px = [_page_plane(pg) for pg in pages]
     n = len(host_px)
     d.row_sums = None
     if n == 0:

@@ -318,7 +318,12 @@ def reported_angle(skew):
 
 # --------------------------------------------------------------------------- the two entry points
 def _pixels(input_image):
-    px = np.asarray(getattr(input_image, "pixels", input_image))
+    px = getattr(input_image, "pixels", input_image)
+    if type(px).__module__.split(".")[0] == "torch":           # a torch tensor: a 2-D uint8 page is taken where it lies (on the
+        if px.dim() == 2 and str(px.dtype) == "torch.uint8":   # device, or in page-locked host memory); anything else comes
+            return px                                          # to the host and is reduced there
+        px = px.cpu().numpy()
+    px = np.asarray(px)
     if px.ndim not in (2, 3):
         raise TypeError("a page image is a 2-D (greyscale / onebit) or 3-D (colour) array")
     return to_grey_u8(px)

@@ -26,7 +26,16 @@ if "--only" in sys.argv:
 if "--raw" in sys.argv:
     inputs = {"raw": tuple(zip(*[pb.make_page(sd + 5000, raw=True) for sd in seeds]))}
 if "--images" in sys.argv:
-    inputs = {"images": ([pb.RawPage(pb.make_page_image(9100 + k)) for k in range(n)], inputs[next(iter(inputs))][1])}
+    trs_ = inputs[next(iter(inputs))][1]
+    px = [pb.make_page_image(9100 + k) for k in range(n)]
+    where = sys.argv[sys.argv.index("--images") + 1] if sys.argv.index("--images") + 1 < len(sys.argv) else ""
+    inputs = {}
+    if where in ("", "all") or where.startswith("-") or where.isdigit():
+        inputs["images"] = ([pb.RawPage(p_) for p_ in px], trs_)
+    if where in ("pinned", "all"):                        # the same pages as tensors in page-locked host memory
+        inputs["images/pinned"] = ([pb.RawPage(torch.from_numpy(p_).pin_memory()) for p_ in px], trs_)
+    if where in ("device", "all"):                        # ... and already on the device
+        inputs["images/device"] = ([pb.RawPage(torch.from_numpy(p_).cuda()) for p_ in px], trs_)
 ref = None
 for name, inp in inputs.items():
     pages, trs = list(inp[0]), list(inp[1])

@@ -272,6 +272,14 @@ def run(npages, seed0=100):
     atocr.process_batch(ipages, itrs, rec, PARAMS)         # warm: the page planes come out of torch's caching allocator
     torch.cuda.synchronize()
     img_dt, _, img_cpu = median_of(10, ipages, itrs)
+    img_where = {}
+    for kind, move in (("pinned_pages", lambda a: torch.from_numpy(a).pin_memory()), ("device_pages", lambda a: torch.from_numpy(a).cuda())):
+        tpages = [RawPage(move(pg.pixels)) for pg in ipages]                 # the same pages as uint8 tensors, taken where they lie
+        atocr.process_batch(tpages, itrs, rec, PARAMS)
+        torch.cuda.synchronize()
+        t_dt, _, _ = median_of(10, tpages, itrs)
+        img_where[kind] = {"pages_per_s": nimg / t_dt, "seconds": t_dt}
+        del tpages
     img_lat = []
     for k in range(5):                                     # the reference's own call shape: process(raw_image, transcript, model)
         t1 = time.perf_counter()
@@ -292,6 +300,8 @@ def run(npages, seed0=100):
                             "thread + the strip-copy pool); gpu_busy: union of device intervals of one pass (torch profiler)"},
            "page_images": {"pages": nimg, "pages_per_s": nimg / img_dt, "seconds": img_dt,
                            "host_cpu_ms_per_page": 1e3 * img_cpu / nimg, "single_page_ms": 1e3 * sorted(img_lat)[2],
+                           "input": "pageable numpy arrays (staged through one page-locked buffer per batch of pages)",
+                           "pinned_pages": img_where["pinned_pages"], "device_pages": img_where["device_pages"],
                            "note": "4400 x 1400 uint8 page images: csrc/ta_preproc.hip + ta_lineest.hip in front"},
            "raw_strips": {"pages_per_s": npages / raw_dt, "seconds": raw_dt, "host_cpu_ms_per_page": 1e3 * raw_cpu / npages,
                           "note": "strips as 60-row uint8 images, normalised by csrc/ta_lineest.hip"},
