@@ -21,13 +21,17 @@ inputs = {"numpy": tuple(zip(*[pb.make_page(sd) for sd in seeds]))}
 for kind in ("pinned", "device"):
     inputs[kind] = pb.make_pages_in_blocks(seeds, kind)
 inputs["raw"] = tuple(zip(*[pb.make_page(sd + 5000, raw=True) for sd in seeds]))
-inputs["images"] = ([pb.RawPage(pb.make_page_image(9300 + k)) for k in range(min(n, 24))], list(inputs["numpy"][1])[:min(n, 24)])
+px = [pb.make_page_image(9300 + k) for k in range(min(n, 24))]
+inputs["images"] = ([pb.RawPage(p_) for p_ in px], list(inputs["numpy"][1])[:len(px)])
+# the same pages as tensors: every other one on the device, the rest in page-locked host memory
+inputs["images/tensors"] = ([pb.RawPage(torch.from_numpy(p_).cuda() if k % 2 else torch.from_numpy(p_).pin_memory())
+                             for k, p_ in enumerate(px)], list(inputs["numpy"][1])[:len(px)])
 rng = np.random.default_rng(1)
 bad = 0
 for name, inp in inputs.items():
     pages, trs = list(inp[0]), list(inp[1])
     models = [recs[k % 2] for k in range(len(pages))]
-    if name == "images":
+    if name.startswith("images"):
         atocr.PIPELINE_CHUNK_PAGES_IMAGES = 8            # several chunks of page images in flight
     ref = None
     for r in range(reps):
@@ -41,6 +45,6 @@ for name, inp in inputs.items():
         # churn: allocations of chunk-sized buffers on the default stream, written and dropped
         junk = [torch.full((int(rng.integers(1, 40)) << 20,), float(r), device="cuda") for _ in range(int(rng.integers(1, 6)))]
         del junk
-    print("%-7s %d repeats of %d pages: %s" % (name, reps, len(pages), "all equal" if bad == 0 else "%d mismatches so far" % bad))
+    print("%-14s %d repeats of %d pages: %s" % (name, reps, len(pages), "all equal" if bad == 0 else "%d mismatches so far" % bad))
 print("soak finished: %d mismatches" % bad)
 sys.exit(1 if bad else 0)
