@@ -140,20 +140,25 @@ class _Dev(object):
         n = len(labelled)
         if n == 0:
             return []
-        counts = torch.zeros(n, dtype=torch.int32, device=self.dev)
-        recs = torch.empty((n, cap, 6), dtype=torch.int32, device=self.dev)
+        table, recs, counts = self.component_buffer(n, cap)
         for k, (lab, stats) in enumerate(labelled):
             h, w = lab.shape
             _native.check(self.lib.ta_pp_components(lab.data_ptr(), stats.data_ptr(), h, w, recs[k].data_ptr(),
                                                     cap, counts[k:].data_ptr(), self.stream), "ta_pp_components")
-        return self.component_tables(n, labelled.__getitem__, recs, counts, cap)
+        return self.component_tables(n, labelled.__getitem__, table, cap)
 
-    def component_tables(self, n, labelled, recs, counts, cap):
-        """the download half of components_many: recs [n][cap][6] and counts [n] on the device -> sorted host tables
+    def component_buffer(self, n, cap):
+        """(table, recs, counts): ONE int32 device buffer holding the component records [n][cap][6] and, behind them,
+        the n counts -- so that both come back in one download (a page's table is 96 KB; a second wait costs more)"""
+        table = torch.empty(n * cap * 6 + n, dtype=torch.int32, device=self.dev)
+        return table, table[:n * cap * 6].view(n, cap, 6), table[n * cap * 6:]
+
+    def component_tables(self, n, labelled, table, cap):
+        """the download half of components_many: a component_buffer filled on the device -> sorted host tables
         (labelled(k): the (lab, stats) planes of image k, asked for only when its table has to be collected again)"""
-        cnt = counts.cpu().numpy()
-        small = int(min(cap, max(int(cnt.max()), 1)))
-        host_recs = recs[:, :small].cpu().numpy()
+        host = table.cpu().numpy()
+        cnt = host[n * cap * 6:]
+        host_recs = host[:n * cap * 6].reshape(n, cap, 6)
         out = []
         for k in range(n):
             c = int(cnt[k])
@@ -496,8 +501,7 @@ def identify_text_lines_batch(d, planes, row_sums=None):
     lab, lab_off = _carve(dev, npix, torch.int32)
     stats, stats_off = _carve(dev, 5 * npix, torch.int32)
     cap = 1 << 12
-    recs = torch.empty((n, cap, 6), dtype=torch.int32, device=dev)
-    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    table, recs, counts = d.component_buffer(n, cap)
     work_ptr, lab_ptr, stats_ptr = _addr(work, work_off), _addr(lab, lab_off), _addr(stats, stats_off)
     _native.check(lib.ta_pp_line_components_batch(n, er_ptr.ctypes.data, hh.ctypes.data, ww.ctypes.data, rows_ptr.ctypes.data,
                                                   nrows.ctypes.data, work_ptr.ctypes.data, lab_ptr.ctypes.data,
@@ -507,7 +511,7 @@ def identify_text_lines_batch(d, planes, row_sums=None):
         return (lab[lab_off[k]:lab_off[k] + int(npix[k])].view(int(hh[k]), int(ww[k])),
                 stats[stats_off[k]:stats_off[k] + 5 * int(npix[k])].view(5, int(hh[k]), int(ww[k])))
     _mark("components enqueued")
-    recs_all = d.component_tables(n, labelled, recs, counts, cap)
+    recs_all = d.component_tables(n, labelled, table, cap)
     _mark("components back")
     boxes_all, total = [], 0
     for peaks, recs_k in zip(peaks_all, recs_all):
