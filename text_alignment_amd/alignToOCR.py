@@ -391,8 +391,9 @@ PIPELINE_CHUNK_PAGES_IMAGES = 16     # page images: preprocessing in front, itse
                                      # 17.7 GB scratch buffer from the caching allocator and gave it back on every call).  Measured twice and
                                      # not kept: the line finding of the NEXT chunk started ahead on a thread of its own -- 551-575
                                      # pages/s against 625-636 without while the page threads launched from Python, 750-787 against
-                                     # 802-807 with a stage per library call and four page threads (same box each): the stages of the
-                                     # chunks in flight are Python, and more threads of it contend for one interpreter lock
+                                     # 802-807 with a stage per library call and four page threads (same box each; bound to the GPU's
+                                     # NUMA node as bench.py binds a rank: 731-789 against 801-854, three runs each, alternating): the
+                                     # stages of the chunks in flight are Python, and more threads of it contend for one interpreter lock
 _side_streams = {}
 WAIT_SECONDS = [0.0]                 # wall seconds the calling thread has spent WAITING for the device inside process_batch (a
                                      # running total: callers take differences): a pass's wall time minus this is its host work

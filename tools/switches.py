@@ -15,6 +15,8 @@ environment is the only handle -- so THEY translate it, once, after importing th
     TA_PAGE_CHUNK_IMAGES=n     alignToOCR.PIPELINE_CHUNK_PAGES_IMAGES   ... page images
     TA_PB_TWO_STREAMS=0|1      alignToOCR.TWO_STREAMS     consecutive chunks on two compute streams
     TA_PB_LEAD_DIVISOR=n       alignToOCR.LEAD_CHUNK_DIVISOR   the call's first chunk is 1/n of a chunk (1: a whole one)
+    TA_BIND=1                  sharding.bind_to_gpu_node()   the placement bench.py gives a rank (cores of the GPU's NUMA node)
+    TA_SWITCH_INTERVAL=s       sys.setswitchinterval      seconds a thread may hold the interpreter lock against a waiting one
     TA_PP_BATCH=n              textAlignPreprocessing.PAGES_PER_BATCH   page images: pages per preprocessing batch
     TA_PP_THREADS=n            textAlignPreprocessing.PAGE_THREADS      ... batches in flight (a host thread and a stream each)
 """
@@ -57,6 +59,14 @@ def apply(environ=None):
     v = env.get("TA_PB_LEAD_DIVISOR")
     if v and v.isdigit():
         put(atocr, "LEAD_CHUNK_DIVISOR", int(v))
+    if env.get("TA_BIND") == "1":                    # the placement bench.py gives a rank: cores of the GPU's NUMA node, one torch thread
+        from text_alignment_amd import sharding
+        done["bind"] = sharding.bind_to_gpu_node()
+    v = env.get("TA_SWITCH_INTERVAL")
+    if v:
+        import sys
+        sys.setswitchinterval(float(v))
+        done["sys.switchinterval"] = float(v)
     from text_alignment_amd import textAlignPreprocessing as preproc
     for var, attr in (("TA_PP_BATCH", "PAGES_PER_BATCH"), ("TA_PP_THREADS", "PAGE_THREADS")):
         v = env.get(var)
