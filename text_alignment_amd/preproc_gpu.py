@@ -7,12 +7,17 @@ removal, line components), the skew search, the rotation, the run filters and th
 uint8 greyscale pages (textAlignPreprocessing.to_grey_u8 reduces anything else).  Checked against the
 scipy restatement oracle/preproc_ref.py (tests/test_preproc_gpu.py).
 
-Batched by STAGE: a page's preprocessing is ~40 small kernels with a dozen data-dependent host
-decisions in between (Otsu threshold, labelling rounds, the two skew sweeps, peaks, component
-selection, strip sizes).  Each decision costs a wait for the device, and one page at a time those
-waits -- not the kernels -- were what a page cost.  The functions below take a LIST of pages and wait
-once per stage for all of them (`find_lines` of one page is a batch of one): per-page results are
-unchanged, the waits per page fall from ~16 to ~16 / batch.
+Batched by STAGE: a page's preprocessing is ~50 small kernels with six data-dependent host decisions in
+between (Otsu threshold, the two skew sweeps, peaks, component selection, strip sizes).  Each decision
+costs a wait for the device, and one page at a time those waits -- not the kernels -- were what a page
+cost.  The functions below take a LIST of pages and wait once per stage for all of them (`find_lines` of
+one page is a batch of one): per-page results are unchanged.  Since round 6 a stage is ONE call into the
+library for the whole batch (`ta_pp_*_batch`: host arrays of device pointers in, nothing waited for) and
+the arithmetic between two stages runs in the library's host loops (`ta_host_*`, each pinned to the numpy
+expression it replaces; the numpy forms stay here / in textAlignPreprocessing as cross-checks): a page
+thread holds the interpreter lock for ~0.3 ms per page instead of ~1 ms, which is what lets several of
+them feed one GPU (textAlignPreprocessing.find_lines_many).  STAGE_CLOCK / _mark: optional clocks at the
+stage boundaries (tools/pages_img_stages.py).
 """
 import ctypes
 
@@ -98,21 +103,9 @@ class _Dev(object):
         """(lab, stats) of a uint8 ink plane: labels and the five per-root statistics planes"""
         return self.label_many([ink])[0]
 
-    def filter(self, ink, lab, stats, min_area=0, max_height=2 ** 30):
-        h, w = ink.shape
-        _native.check(self.lib.ta_pp_filter_components(ink.data_ptr(), lab.data_ptr(), stats.data_ptr(), h, w,
-                                                       int(min_area), int(max_height), self.stream),
-                      "ta_pp_filter_components")
-
     def components(self, lab, stats, cap=1 << 12):
         """host array [ncomp][6] = {root, area, x0, y0, x1, y1}, sorted by root (raster order)"""
         return self.components_many([(lab, stats)], cap)[0]
-
-    def despeckle(self, ink, size):
-        self.despeckle_many([ink], size)
-
-    def invert(self, ink):
-        _native.check(self.lib.ta_pp_invert(ink.data_ptr(), ink.numel(), self.stream), "ta_pp_invert")
 
     # ---- many images, one wait per stage -----------------------------------------------------
     def label_many(self, inks):
@@ -128,10 +121,6 @@ class _Dev(object):
         _native.check(self.lib.ta_pp_label_batch(n, _ptr_array(inks), hh, ww, _ptr_array(labs), _ptr_array(stats),
                                                  flags.data_ptr(), self.stream), "ta_pp_label_batch")
         return list(zip(labs, stats))
-
-    def despeckle_many(self, inks, size):
-        for ink, (lab, stats) in zip(inks, self.label_many(inks)):
-            self.filter(ink, lab, stats, min_area=size)
 
     def components_many(self, labelled, cap=1 << 12):
         """component tables of [(lab, stats)]: host arrays [ncomp][6] = {root, area, x0, y0, x1, y1} sorted
@@ -194,18 +183,6 @@ def otsu_thresholds(hists):
     thr = np.zeros(len(hists), np.int32)
     _native.check(_native.lib.ta_host_otsu_batch(hists.ctypes.data, len(hists), thr.ctypes.data), "ta_host_otsu_batch")
     return thr
-
-
-def otsu_threshold_device(d, img):
-    return otsu_thresholds_device(d, [img])[0]
-
-
-def otsu_thresholds_device(d, imgs):
-    hist = torch.empty((len(imgs), 256), dtype=torch.int32, device=d.dev)
-    for k, img in enumerate(imgs):
-        _native.check(d.lib.ta_pp_histogram(img.data_ptr(), img.numel(), hist[k].data_ptr(), d.stream), "ta_pp_histogram")
-    hh = hist.cpu().numpy()
-    return [otsu_from_histogram(hh[k]) for k in range(len(imgs))]
 
 
 def rotation_angles_device(d, inks, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
@@ -294,10 +271,6 @@ def _sharpest_rows_numpy(flat, offs, nang, hs):
     return np.array(best, np.int32), np.array(some, bool)
 
 
-def rotation_angle_device(d, ink, lo=-6.0, hi=6.0, coarse=0.25, fine=0.05):
-    return rotation_angles_device(d, [ink], lo, hi, coarse, fine)[0]
-
-
 def _rotation_geometry(h, w, angle):
     """scipy.ndimage.rotate's own geometry (ndimage/_interpolation.py rotate, reshape=True): the output shape and the
     six numbers [matrix, offset] of the backward mapping"""
@@ -310,40 +283,6 @@ def _rotation_geometry(h, w, angle):
     offset = in_center - out_center
     return (int(out_shape[0]), int(out_shape[1]),
             np.array([rot[0, 0], rot[0, 1], rot[1, 0], rot[1, 1], offset[0], offset[1]], np.float64))
-
-
-def rotate_many(d, inks, angles):
-    """scipy.ndimage.rotate(float32(ink), angle, reshape=True, order=1) > 0.5 of every page, the resampling on the
-    device; the pages' mappings go up in one asynchronous transfer"""
-    geo = [None if a == 0 else _rotation_geometry(int(k.shape[0]), int(k.shape[1]), a) for k, a in zip(inks, angles)]
-    turned = [g for g in geo if g is not None]
-    maps = iter(_native.upload_packed([g[2] for g in turned], d.dev)) if turned else iter(())
-    out = []
-    for ink, g in zip(inks, geo):
-        if g is None:
-            out.append(ink.clone())
-            continue
-        h, w = ink.shape
-        oh, ow, _ = g
-        res = torch.empty((oh, ow), dtype=torch.uint8, device=d.dev)
-        _native.check(d.lib.ta_pp_rotate(ink.data_ptr(), h, w, res.data_ptr(), oh, ow, next(maps).data_ptr(), d.stream),
-                      "ta_pp_rotate")
-        out.append(res)
-    return out
-
-
-def rotate_device(d, ink, angle):
-    return rotate_many(d, [ink], [angle])[0]
-
-
-def open_runs_device(d, ink, length, axis):
-    if length <= 1:
-        return ink
-    h, w = ink.shape
-    out = torch.empty_like(ink)
-    _native.check(d.lib.ta_pp_open_runs(ink.data_ptr(), out.data_ptr(), h, w, int(length), int(axis), d.stream),
-                  "ta_pp_open_runs")
-    return out
 
 
 def _upload_pages(d, pages_px):

@@ -37,12 +37,12 @@ def wrap(owner, name):
     setattr(owner, name, timed)
 
 
-for name in ("_upload_pages", "otsu_thresholds_device", "rotation_angles_device", "rotate_many", "identify_text_lines_batch",
+for name in ("_upload_pages", "_skew_search", "identify_text_lines_batch",
              "preprocess_images_batch"):
     wrap(pg, name)
-for name in ("label_many", "components_many", "despeckle_many"):
+for name in ("component_tables",):
     wrap(pg._Dev, name)
-for name in ("moving_avg_filter", "find_peak_locations", "line_boxes"):
+for name in ("peaks_of_projections", "line_boxes"):
     wrap(preproc, name)
 
 for _ in range(2):
