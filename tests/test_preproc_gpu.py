@@ -228,3 +228,33 @@ def test_pages_that_are_torch_tensors_are_taken_where_they_lie():
     assert atocr._raw_dim(on_dev).ncols == b.shape[1] and atocr._raw_dim(on_dev).nrows == b.shape[0]
     with pytest.raises(TypeError):
         G.find_lines_batch([on_dev.float()])
+
+
+def test_byte_plane_kernels_on_aligned_and_unaligned_planes():
+    """ta_pp_histogram / ta_pp_threshold / ta_pp_invert walk a plane 16 bytes per lane where it starts on a 16-byte
+    boundary and byte by byte where it does not (a caller's view) and over the last n % 16 bytes: same results as
+    numpy for both, for sizes around the vector width, for non-0/1 bytes under the inversion."""
+    from text_alignment_amd import _native
+    lib = _native.lib
+    rng = np.random.default_rng(4)
+    st = torch.cuda.current_stream().cuda_stream
+    base = torch.from_numpy(rng.integers(0, 256, 300000 + 64).astype(np.uint8)).cuda()
+    for off in (0, 16, 3, 7):
+        for n in (0, 1, 15, 16, 17, 4099, 300000):
+            src = base[off:off + n]
+            host = src.cpu().numpy()
+            hist = torch.full((256,), 7, dtype=torch.int32, device="cuda")
+            _native.check(lib.ta_pp_histogram(src.data_ptr() if n else base.data_ptr(), n, hist.data_ptr(), st), "hist")
+            assert np.array_equal(hist.cpu().numpy(), np.bincount(host, minlength=256)), (off, n)
+            for invert in (0, 1):
+                for out_off in (0, 5):
+                    outb = torch.full((n + 37,), 9, dtype=torch.uint8, device="cuda")
+                    out = outb[out_off:out_off + n]
+                    _native.check(lib.ta_pp_threshold(src.data_ptr() if n else base.data_ptr(), n, 131, invert,
+                                                      out.data_ptr() if n else outb.data_ptr(), st), "thr")
+                    want = (host <= 131) != bool(invert)
+                    assert np.array_equal(out.cpu().numpy(), want.astype(np.uint8)), (off, n, invert, out_off)
+                    assert int(outb[out_off + n:].min()) == 9 and (out_off == 0 or int(outb[:out_off].min()) == 9)
+            work = src.clone() if off == 0 else base.clone()[off:off + n]      # (a clone of the whole keeps the misalignment)
+            _native.check(lib.ta_pp_invert(work.data_ptr() if n else base.data_ptr(), n, st), "invert")
+            assert np.array_equal(work.cpu().numpy(), (host == 0).astype(np.uint8)), (off, n)

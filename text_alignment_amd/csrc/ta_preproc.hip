@@ -23,20 +23,69 @@ namespace ta {
 
 constexpr int kPpThreads = 256;
 
+// Byte planes are walked 16 bytes per lane where the plane starts on a 16-byte boundary (every plane the package
+// allocates does; a caller's view may not: then, and for the last n % 16 bytes, one byte per lane as before).
+__device__ __forceinline__ bool pp_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// A wave has its own 256 bins (a text page is mostly paper: with one table per workgroup four waves queued on the
+// same few bins), merged at the end.
 __global__ __launch_bounds__(kPpThreads) void pp_hist_kernel(const uint8_t* img, int64_t n, uint32_t* hist) {
-    __shared__ uint32_t sh[256];
-    sh[threadIdx.x] = 0;
+    __shared__ uint32_t sh[kPpThreads / 64][256];
+    for (int k = threadIdx.x; k < (kPpThreads / 64) * 256; k += kPpThreads) (&sh[0][0])[k] = 0;
     __syncthreads();
-    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads)
-        atomicAdd(&sh[img[e]], 1u);
+    uint32_t* mine = sh[threadIdx.x >> 6];
+    const int64_t gid = (int64_t)blockIdx.x * kPpThreads + threadIdx.x, span = (int64_t)gridDim.x * kPpThreads;
+    int64_t done = 0;
+    if (pp_aligned16(img)) {
+        const int64_t n16 = n >> 4;
+        const uint4* v = reinterpret_cast<const uint4*>(img);
+        for (int64_t i = gid; i < n16; i += span) {
+            const uint4 q = v[i];
+            const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                atomicAdd(&mine[wds[k] & 255u], 1u); atomicAdd(&mine[(wds[k] >> 8) & 255u], 1u);
+                atomicAdd(&mine[(wds[k] >> 16) & 255u], 1u); atomicAdd(&mine[wds[k] >> 24], 1u);
+            }
+        }
+        done = n16 << 4;
+    }
+    for (int64_t e = done + gid; e < n; e += span) atomicAdd(&mine[img[e]], 1u);
     __syncthreads();
-    if (sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+    uint32_t total = 0;
+#pragma unroll
+    for (int wv = 0; wv < kPpThreads / 64; ++wv) total += sh[wv][threadIdx.x];
+    if (total) atomicAdd(&hist[threadIdx.x], total);
 }
+static_assert(kPpThreads == 256, "one bin per thread at the end");
 
 // ink = (img <= thr), or its complement
 __global__ __launch_bounds__(kPpThreads) void pp_threshold_kernel(const uint8_t* img, int64_t n, int thr,
                                                                   int invert, uint8_t* ink) {
-    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) {
+    const int64_t gid = (int64_t)blockIdx.x * kPpThreads + threadIdx.x, span = (int64_t)gridDim.x * kPpThreads;
+    int64_t done = 0;
+    if (pp_aligned16(img) && pp_aligned16(ink)) {
+        const int64_t n16 = n >> 4;
+        const uint4* v = reinterpret_cast<const uint4*>(img);
+        uint4* o = reinterpret_cast<uint4*>(ink);
+        for (int64_t i = gid; i < n16; i += span) {
+            const uint4 q = v[i];
+            uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t r = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int px = (int)((wds[k] >> (8 * b)) & 255u) <= thr;
+                    r |= (uint32_t)(invert ? !px : px) << (8 * b);
+                }
+                wds[k] = r;
+            }
+            o[i] = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+        }
+        done = n16 << 4;
+    }
+    for (int64_t e = done + gid; e < n; e += span) {
         const int v = img[e] <= thr;
         ink[e] = (uint8_t)(invert ? !v : v);
     }
@@ -327,8 +376,23 @@ __global__ __launch_bounds__(kPpThreads) void pp_filter_kernel(uint8_t* ink, con
 }
 
 __global__ __launch_bounds__(kPpThreads) void pp_invert_kernel(uint8_t* ink, int64_t n) {
-    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads)
-        ink[e] = !ink[e];
+    const int64_t gid = (int64_t)blockIdx.x * kPpThreads + threadIdx.x, span = (int64_t)gridDim.x * kPpThreads;
+    int64_t done = 0;
+    if (pp_aligned16(ink)) {
+        const int64_t n16 = n >> 4;
+        uint4* v = reinterpret_cast<uint4*>(ink);
+        // per byte !b: 0x01 where the byte is zero, 0x00 where it is not (whatever non-zero value it holds)
+        auto inv = [](uint32_t x) -> uint32_t {
+            const uint32_t nz = ((x | ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u) >> 7;
+            return nz ^ 0x01010101u;
+        };
+        for (int64_t i = gid; i < n16; i += span) {
+            const uint4 q = v[i];
+            v[i] = make_uint4(inv(q.x), inv(q.y), inv(q.z), inv(q.w));
+        }
+        done = n16 << 4;
+    }
+    for (int64_t e = done + gid; e < n; e += span) ink[e] = !ink[e];
 }
 
 // row histogram of the page rotated by each candidate angle, from the ink coordinates of the
@@ -575,6 +639,11 @@ static int pp_blocks(int64_t n) {
     const int64_t b = (n + kPpThreads - 1) / kPpThreads;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
+// the byte-plane kernels that take 16 bytes per lane: a lane per 16 bytes (and enough for the scalar tail / fallback)
+static int pp_blocks16(int64_t n) {
+    const int64_t b = ((n + 15) / 16 + kPpThreads - 1) / kPpThreads;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
 
 }  // namespace ta
 
@@ -589,7 +658,7 @@ extern "C" int ta_pp_histogram(const uint8_t* img, int64_t n, uint32_t* hist256,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(hist256, 0, 256 * sizeof(uint32_t), st);
     if (e != hipSuccess) return ta_fail_hip(e, "histogram memset");
-    if (n) hipLaunchKernelGGL(pp_hist_kernel, dim3(pp_blocks(n) > 1024 ? 1024 : pp_blocks(n)), dim3(kPpThreads), 0, st, img, n, hist256);
+    if (n) hipLaunchKernelGGL(pp_hist_kernel, dim3(pp_blocks16(n) > 1024 ? 1024 : pp_blocks16(n)), dim3(kPpThreads), 0, st, img, n, hist256);
     PP_LAUNCH_CHECK("pp_hist_kernel");
     return TA_OK;
 }
@@ -597,7 +666,7 @@ extern "C" int ta_pp_histogram(const uint8_t* img, int64_t n, uint32_t* hist256,
 extern "C" int ta_pp_threshold(const uint8_t* img, int64_t n, int32_t thr, int32_t invert, uint8_t* ink, void* stream) {
     if (n < 0) return ta_fail(TA_EINVAL, "negative size");
     if (!img || !ink) return ta_fail(TA_EINVAL, "null pointer argument");
-    if (n) hipLaunchKernelGGL(pp_threshold_kernel, dim3(pp_blocks(n)), dim3(kPpThreads), 0,
+    if (n) hipLaunchKernelGGL(pp_threshold_kernel, dim3(pp_blocks16(n)), dim3(kPpThreads), 0,
                               reinterpret_cast<hipStream_t>(stream), img, n, thr, invert, ink);
     PP_LAUNCH_CHECK("pp_threshold_kernel");
     return TA_OK;
@@ -698,7 +767,7 @@ extern "C" int ta_pp_filter_components(uint8_t* ink, const int32_t* lab, const i
 extern "C" int ta_pp_invert(uint8_t* ink, int64_t n, void* stream) {
     if (n < 0) return ta_fail(TA_EINVAL, "negative size");
     if (!ink) return ta_fail(TA_EINVAL, "null pointer argument");
-    if (n) hipLaunchKernelGGL(pp_invert_kernel, dim3(pp_blocks(n)), dim3(kPpThreads), 0,
+    if (n) hipLaunchKernelGGL(pp_invert_kernel, dim3(pp_blocks16(n)), dim3(kPpThreads), 0,
                               reinterpret_cast<hipStream_t>(stream), ink, n);
     PP_LAUNCH_CHECK("pp_invert_kernel");
     return TA_OK;
@@ -983,7 +1052,7 @@ extern "C" int ta_pp_histogram_batch(int32_t n, const uint8_t* const* img, const
         if (npix[i] < 0) return ta_fail(TA_EINVAL, "negative size");
         if (npix[i] == 0) continue;
         if (!img[i]) return ta_fail(TA_EINVAL, "null pointer argument");
-        hipLaunchKernelGGL(pp_hist_kernel, dim3(pp_blocks(npix[i]) > 1024 ? 1024 : pp_blocks(npix[i])), dim3(kPpThreads), 0, st,
+        hipLaunchKernelGGL(pp_hist_kernel, dim3(pp_blocks16(npix[i]) > 1024 ? 1024 : pp_blocks16(npix[i])), dim3(kPpThreads), 0, st,
                            img[i], npix[i], hist + (size_t)i * 256);
     }
     PP_LAUNCH_CHECK("pp_hist_kernel");
@@ -1009,7 +1078,7 @@ extern "C" int ta_pp_binarise_batch(int32_t n, const uint8_t* const* img, const 
         if (np && (!img[i] || !ink[i] || !lab[i] || !stats[i] || !points[i])) return ta_fail(TA_EINVAL, "null pointer argument");
         const int hs = (h[i] + step[i] - 1) / step[i], wsm = (w[i] + step[i] - 1) / step[i];
         if (hs > 65535 || wsm > 65535) return ta_fail(TA_ELIMIT, "decimated page too large for 16-bit point coordinates");
-        if (np) hipLaunchKernelGGL(pp_threshold_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, img[i], np, thr[i], 0, ink[i]);
+        if (np) hipLaunchKernelGGL(pp_threshold_kernel, dim3(pp_blocks16(np)), dim3(kPpThreads), 0, st, img[i], np, thr[i], 0, ink[i]);
     }
     for (int round = 0; round < 3; ++round) {
         rc = ta_pp_label_batch(n, ink, h, w, lab, stats, reinterpret_cast<int32_t*>(counts), stream);
@@ -1020,7 +1089,7 @@ extern "C" int ta_pp_binarise_batch(int32_t n, const uint8_t* const* img, const 
             hipLaunchKernelGGL(pp_filter_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, ink[i], lab[i], np, stats[i],
                                stats[i] + 2 * np, stats[i] + 4 * np, round < 2 ? despeckle : 0, round < 2 ? (1 << 30) : max_height);
             // round 0 works on the ink, round 1 on the background (inverted before and after), round 2 on the ink again
-            if (round < 2) hipLaunchKernelGGL(pp_invert_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, ink[i], np);
+            if (round < 2) hipLaunchKernelGGL(pp_invert_kernel, dim3(pp_blocks16(np)), dim3(kPpThreads), 0, st, ink[i], np);
         }
     }
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)n * sizeof(uint32_t), st);
