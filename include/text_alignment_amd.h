@@ -429,6 +429,13 @@ int ta_pp_cut_strips(const uint8_t* ink, int32_t h, int32_t w, const int64_t* bo
  * named like arrays are [host] arrays of n [dev] pointers / sizes; everything is enqueued on `stream`, nothing is
  * waited for; per page the kernels and their order are those of the single-page entry points above.
  *
+ * The two stages that need connected components (ta_pp_binarise_batch, ta_pp_line_components_batch) find them over
+ * RUNS since round 6 (a text page's ~6 M pixels are a few hundred thousand horizontal runs; a wave per row finds
+ * them, one union-find pass joins each with the touching runs of the row above, 8-connectivity; a component's root is
+ * its raster-first run): same components, areas, boxes and root pixels as ta_pp_label gives, a fifth of the memory
+ * traffic; the holes are filled from the runs of PAPER, without inverting the plane and back.  lab[i] / stats[i] are
+ * then scratch for the run tables (pages under 8 columns, or flags & TA_PP_LABEL_PIXELS: the per-pixel form).
+ *
  * ta_pp_histogram_batch: hist [dev] = uint32[n][256] of img[i][0..npix[i]).
  * ta_pp_binarise_batch (:167-186): ink[i] = img[i] thresholded at thr[i], despeckled (components under `despeckle`
  *   pixels; ink, then background), components taller than max_height rows dropped; points[i] / counts[i] [dev uint32[n]]
@@ -443,10 +450,12 @@ int ta_pp_cut_strips(const uint8_t* ink, int32_t h, int32_t w, const int64_t* bo
  * ta_pp_cut_strips_batch: ta_pp_cut_strips per page into ONE packed buffer (the boxes carry their offsets).
  */
 int ta_pp_histogram_batch(int32_t n, const uint8_t* const* img, const int64_t* npix, uint32_t* hist, void* stream);
+#define TA_PP_LABEL_PIXELS 1   /* flags of the two stages that label: a label per PIXEL (ta_pp_label_batch) instead of
+                                * connected components over RUNS -- the form of rounds 3-5, kept as the cross-check */
 int ta_pp_binarise_batch(int32_t n, const uint8_t* const* img, const int32_t* h, const int32_t* w, const int32_t* thr,
                          int32_t despeckle, int32_t max_height, uint8_t* const* ink, int32_t* const* lab,
                          int32_t* const* stats, const int32_t* step, uint32_t* const* points, uint32_t* counts,
-                         void* stream);
+                         int32_t flags, void* stream);
 int ta_pp_angle_histograms_points_batch(int32_t n, const uint32_t* const* points, const uint32_t* counts,
                                         const int32_t* hs, const int32_t* ws, const double* const* cos_sin,
                                         const int32_t* nang, uint32_t* const* hist, void* stream);
@@ -457,7 +466,7 @@ int ta_pp_deskew_batch(int32_t n, const uint8_t* const* ink, const int32_t* h, c
 int ta_pp_line_components_batch(int32_t n, const uint8_t* const* eroded, const int32_t* h, const int32_t* w,
                                 const int32_t* const* rows, const int32_t* nrows, uint8_t* const* work,
                                 int32_t* const* lab, int32_t* const* stats, int32_t* recs, int32_t cap,
-                                int32_t* counts, void* stream);
+                                int32_t* counts, int32_t flags, void* stream);
 int ta_pp_cut_strips_batch(int32_t n, const uint8_t* const* ink, const int32_t* h, const int32_t* w,
                            const int64_t* const* boxes, const int32_t* nstrips, uint8_t* packed, void* stream);
 

@@ -258,3 +258,63 @@ def test_byte_plane_kernels_on_aligned_and_unaligned_planes():
             work = src.clone() if off == 0 else base.clone()[off:off + n]      # (a clone of the whole keeps the misalignment)
             _native.check(lib.ta_pp_invert(work.data_ptr() if n else base.data_ptr(), n, st), "invert")
             assert np.array_equal(work.cpu().numpy(), (host == 0).astype(np.uint8)), (off, n)
+
+
+def test_components_over_runs_equal_the_per_pixel_labelling(monkeypatch):
+    """The two stages that need connected components find them over RUNS (csrc/ta_preproc.hip, pp_runs_*); the
+    per-pixel labelling of rounds 3-5 stays behind a flag of the stage calls.  Same cleaned planes, angles, peaks,
+    strips and -- record for record -- component tables from both, on noisy text pages (specks, holes, a tall stroke),
+    a blank page, a page of specks, a checkerboard (the most runs a page can have), single-pixel-wide strokes that touch
+    only diagonally, and pages whose widths are not multiples of 64."""
+    from text_alignment_amd import _native, preproc_gpu as G
+    rng = np.random.default_rng(12)
+    a, b = _noisy_page(21, angle=0.7), np.ascontiguousarray(_noisy_page(22)[:, :-37])
+    blank = np.full((300, 200), 255, np.uint8)
+    checker = np.where((np.add.outer(np.arange(160), np.arange(131)) % 2) == 0, 0, 255).astype(np.uint8)
+    diag = np.full((400, 333), 255, np.uint8)
+    for k in range(300):
+        diag[20 + k, 10 + k] = 0                                  # one 8-connected diagonal: 300 pixels, 300 runs
+        diag[20 + k, 320 - k] = 0
+    diag[200:390:3, 100:250] = 0                                  # stripes
+    holes = np.full((500, 400), 255, np.uint8)
+    holes[50:450, 50:350] = 0
+    for _ in range(200):
+        y, x = int(rng.integers(60, 430)), int(rng.integers(60, 330))
+        s_ = int(rng.integers(1, 14))
+        holes[y:y + s_, x:x + s_] = 255                          # holes of 1 .. 169 pixels: some filled, some not
+    pages = [a, b, blank, checker, diag, holes]
+
+    def run(flags):
+        monkeypatch.setattr(G, "LABEL_FLAGS", flags)
+        d, pre = G.preprocess_images_batch(pages)
+        planes = [(i.cpu().numpy(), e.cpu().numpy(), ang) for i, e, ang in pre]
+        lines = G.identify_text_lines_batch(d, [(i, e) for i, e, _ in pre], row_sums=d.row_sums)
+        return planes, [([(s.offset_x, s.offset_y, s.height, s.width) for s in st], [s.pixels for s in st], list(pk))
+                        for st, pk, _ in lines]
+    runs, pixels = run(0), run(_native.TA_PP_LABEL_PIXELS)
+    for k, (r, p) in enumerate(zip(runs[0], pixels[0])):
+        assert r[2] == p[2], k
+        assert np.array_equal(r[0], p[0]) and np.array_equal(r[1], p[1]), k
+    for k, (r, p) in enumerate(zip(runs[1], pixels[1])):
+        assert r[0] == p[0] and r[2] == p[2], k
+        assert all(np.array_equal(x, y) for x, y in zip(r[1], p[1])), k
+    assert len(runs[1][0][0]) >= 4 and len(runs[1][1][0]) >= 4
+    # the component tables themselves: root pixel, area, box of every component of a labelled plane
+    d = G._Dev()
+    for page in pages:
+        plane = torch.from_numpy((page < 128).astype(np.uint8)).cuda()
+        h, w = plane.shape
+        tables = []
+        for flags in (0, _native.TA_PP_LABEL_PIXELS):
+            work = torch.empty_like(plane)
+            lab = torch.empty(h * w, dtype=torch.int32, device="cuda")
+            stats = torch.empty(5 * h * w, dtype=torch.int32, device="cuda")
+            table, recs, counts = d.component_buffer(1, 1 << 16)
+            ptr = lambda t: np.array([t.data_ptr()], dtype=np.uint64)
+            hh, ww, nrows = np.array([h], np.int32), np.array([w], np.int32), np.array([0], np.int32)
+            pe, pw, pl, ps, pr = ptr(plane), ptr(work), ptr(lab), ptr(stats), np.zeros(1, np.uint64)
+            _native.check(_native.lib.ta_pp_line_components_batch(1, pe.ctypes.data, hh.ctypes.data, ww.ctypes.data, pr.ctypes.data,
+                                                                  nrows.ctypes.data, pw.ctypes.data, pl.ctypes.data, ps.ctypes.data,
+                                                                  recs.data_ptr(), 1 << 16, counts.data_ptr(), flags, d.stream), "stage")
+            tables.append(d.component_tables(1, None, table, 1 << 16)[0])
+        assert tables[0].shape == tables[1].shape and np.array_equal(tables[0], tables[1]), page.shape

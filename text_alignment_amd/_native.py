@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TA_HIP_LIB") or os.path.join(_HERE, "libta_hip.so")
 
 TA_OK = 0
+TA_PP_LABEL_PIXELS = 1          # flags of ta_pp_binarise_batch / ta_pp_line_components_batch (see the header)
 TA_EINVAL, TA_ERANGE, TA_EHIP, TA_ELIMIT = -1, -2, -3, -4
 TA_NW_FILL, TA_NW_TRACEBACK, TA_NW_CODES8, TA_NW_WIDE, TA_NW_NARROW = 1, 2, 4, 8, 16
 TA_NW_OPENS_SAME, TA_NW_ALPHABET_SHIFT = 32, 8
@@ -129,10 +130,10 @@ def _load():
           "ta_pp_ink_points": [vp, i32, i32, i32, vp, vp, vp],
           "ta_pp_angle_histograms_points": [vp, vp, i32, i32, vp, i32, vp, vp],
           "ta_pp_histogram_batch": [i32, vp, vp, vp, vp],
-          "ta_pp_binarise_batch": [i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp],
+          "ta_pp_binarise_batch": [i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp],
           "ta_pp_angle_histograms_points_batch": [i32, vp, vp, vp, vp, vp, vp, vp, vp],
           "ta_pp_deskew_batch": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp],
-          "ta_pp_line_components_batch": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp],
+          "ta_pp_line_components_batch": [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp],
           "ta_pp_cut_strips_batch": [i32, vp, vp, vp, vp, vp, vp, vp]}
     for name, args in pp.items():
         getattr(lib, name).restype = ctypes.c_int

@@ -635,6 +635,318 @@ __global__ __launch_bounds__(kPpThreads) void pp_fill_kernel(int32_t* a, int64_t
     for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) a[e] = v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Connected components over RUNS.  A text page is nine tenths paper: its ~6 M pixels are a few hundred thousand horizontal
+// runs of ink (or, for the hole filling, of paper), and everything a labelling is used for here -- drop the components
+// under an area, fill the holes under an area, drop the components over a height, list the components with their boxes --
+// needs the components of the runs, not a label per pixel.  One pass finds the runs (a wave per row: the starts and ends
+// of a 64-pixel segment's runs are two bit tricks on its ballot), one lock-free union-find pass joins every run with the
+// runs of the row above that touch it (8-connectivity: column ranges that overlap after widening one by a pixel), one
+// pass flattens and gathers area and bounding box per root (combined per wave and per workgroup first: the page
+// background is one component of most of the paper runs).  Runs are numbered in raster order (a scan over the rows'
+// counts), the smaller index wins a union, so a component's root is its raster-first run and the root's first pixel the
+// component's raster-first pixel -- the label the per-pixel labelling (ta_pp_label) gives it.
+struct PpRuns {
+    int32_t* row_cnt;    // [h]      runs in each row
+    int32_t* row_off;    // [h + 1]  first run of each row; row_off[h] = number of runs
+    int32_t* x0;         // [cap]    first / last column of a run, its row, its parent (union-find), and per ROOT:
+    int32_t* x1;
+    int32_t* yrow;
+    int32_t* parent;
+    int32_t* area;       //          pixels, and the bounding box
+    int32_t* bx0; int32_t* by0; int32_t* bx1; int32_t* by1;
+};
+
+__device__ __forceinline__ bool pp_run_pixel(const uint8_t* p, int x, int w, int want) { return x < w && ((p[x] != 0) == (want != 0)); }
+
+// (a lane's loads are single bytes, 64 B per instruction and wave: kRunUnroll segments' loads are issued before the first
+// ballot, so a row costs a few memory latencies instead of one per 64 pixels)
+constexpr int kRunUnroll = 8;
+__global__ __launch_bounds__(kPpThreads) void pp_runs_count_kernel(const uint8_t* ink, int h, int w, int want, PpRuns R) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * (kPpThreads / 64) + (threadIdx.x >> 6);
+    if (row >= h) return;                                    // (a whole wave: the row is the wave's)
+    const uint8_t* p = ink + (int64_t)row * w;
+    int cnt = 0;
+    unsigned long long carry = 0;
+    for (int xs = 0; xs < w; xs += 64 * kRunUnroll) {
+        bool on[kRunUnroll];
+#pragma unroll
+        for (int u = 0; u < kRunUnroll; ++u) on[u] = pp_run_pixel(p, xs + 64 * u + lane, w, want);
+#pragma unroll
+        for (int u = 0; u < kRunUnroll; ++u) {
+            const unsigned long long m = __ballot(on[u]);
+            cnt += (int)__popcll(m & ~((m << 1) | carry));
+            carry = m >> 63;
+        }
+    }
+    if (lane == 0) R.row_cnt[row] = cnt;
+}
+
+// exclusive scan of the rows' run counts (one workgroup: a page has a few thousand rows)
+__global__ __launch_bounds__(1024) void pp_runs_scan_kernel(int h, PpRuns R) {
+    __shared__ int part[1024];
+    const int per = (h + 1023) / 1024, a = threadIdx.x * per, b = min(a + per, h);
+    int sum = 0;
+    for (int r = a; r < b; ++r) sum += R.row_cnt[r];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                     // Hillis-Steele, inclusive
+        const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int off = part[threadIdx.x] - sum;
+    for (int r = a; r < b; ++r) { R.row_off[r] = off; off += R.row_cnt[r]; }
+    if (threadIdx.x == 1023) R.row_off[h] = part[1023];
+}
+
+__global__ __launch_bounds__(kPpThreads) void pp_runs_write_kernel(const uint8_t* ink, int h, int w, int want, PpRuns R) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * (kPpThreads / 64) + (threadIdx.x >> 6);
+    if (row >= h) return;
+    const uint8_t* p = ink + (int64_t)row * w;
+    const int base = R.row_off[row];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int nstart = 0, nend = 0;
+    unsigned long long carry = 0;
+    for (int xs = 0; xs < w; xs += 64 * kRunUnroll) {
+        bool on[kRunUnroll + 1];                             // (one more: the ends of a segment's runs need the next one's first pixel)
+#pragma unroll
+        for (int u = 0; u <= kRunUnroll; ++u) on[u] = pp_run_pixel(p, xs + 64 * u + lane, w, want);
+        unsigned long long m = __ballot(on[0]);
+#pragma unroll
+        for (int u = 0; u < kRunUnroll; ++u) {
+            const unsigned long long next = __ballot(on[u + 1]);
+            const int x = xs + 64 * u + lane;
+            const unsigned long long starts = m & ~((m << 1) | carry);
+            if ((starts >> lane) & 1ull) {
+                const int i = base + nstart + (int)__popcll(starts & below);
+                R.x0[i] = x; R.yrow[i] = row; R.parent[i] = i;
+                R.area[i] = 0; R.bx0[i] = 0x7fffffff; R.by0[i] = 0x7fffffff; R.bx1[i] = -1; R.by1[i] = -1;
+            }
+            nstart += (int)__popcll(starts);
+            const unsigned long long ends = m & ~((m >> 1) | ((next & 1ull) << 63));
+            if ((ends >> lane) & 1ull) R.x1[base + nend + (int)__popcll(ends & below)] = x;
+            nend += (int)__popcll(ends);
+            carry = m >> 63;
+            m = next;
+        }
+    }
+}
+
+// every run with the runs of the row above whose columns reach its own widened by one: 8-connectivity.  In two passes:
+// first inside BANDS of kRunBand rows (no tree grows deeper than a band), a flatten, then across the band borders --
+// joined all at once, the runs of the paper (one component over the whole page) hung in chains as long as the page is
+// tall, and every later find walked them (42 us a call; the smaller index wins, so every chain leads to the top).
+constexpr int kRunBand = 32;
+__device__ __forceinline__ void pp_run_join_up(const PpRuns& R, int i, int y) {
+    const int lo = R.x0[i] - 1, hi = R.x1[i] + 1;
+    int a = R.row_off[y - 1], b = R.row_off[y];
+    const int end = b;
+    while (a < b) {                                          // first run of the row above that ends at lo or beyond
+        const int mid = (a + b) >> 1;
+        if (R.x1[mid] < lo) a = mid + 1; else b = mid;
+    }
+    for (int j = a; j < end && R.x0[j] <= hi; ++j) uf_link(R.parent, i, j);
+}
+// inside the bands: a workgroup per band, the band's runs and their union-find in LDS (a find is a chain of dependent
+// loads, up to a band deep where a stroke -- or the paper -- runs down the page: from LDS a hop is a tenth of what it is
+// from L2); a band with more runs than fit takes the same steps on the global arrays.  Leaves parent[] FLAT inside
+// every band (each run points at its band's root run).
+constexpr int kBandRuns = 4096;           // runs of a band held in LDS: 3 x 4 bytes each (48 KB)
+template <bool LDS>
+__device__ __forceinline__ void pp_runs_band(const PpRuns& R, int first, int n, int y0, int y1, int* lx0, int* lx1, int* lpar,
+                                             const int* roff) {
+    // (LDS: lx0 / lx1 / lpar hold the band's runs, indices are band-local; else they are R.x0 / R.x1 / R.parent + first)
+    if (LDS) {
+        for (int k = threadIdx.x; k < n; k += kPpThreads) { lx0[k] = R.x0[first + k]; lx1[k] = R.x1[first + k]; lpar[k] = k; }
+        __syncthreads();
+    }
+    auto find = [&](int a) { while (true) { const int p_ = lpar[a]; if (p_ == a) return a; a = p_; } };
+    for (int i = threadIdx.x; i < n; i += kPpThreads) {       // a thread per run; its row from the band's row offsets (LDS)
+        int ya = 0, yb = y1 - y0;                             // largest r with roff[r] <= i
+        while (yb - ya > 1) { const int mid = (ya + yb) >> 1; if (roff[mid] <= i) ya = mid; else yb = mid; }
+        if (ya == 0) continue;                                // the band's first row: joined across the border later
+        const int ra = roff[ya], pa = roff[ya - 1];
+        const int lo = lx0[i] - 1, hi = lx1[i] + 1;
+        int a = pa, b = ra;
+        while (a < b) { const int mid = (a + b) >> 1; if (lx1[mid] < lo) a = mid + 1; else b = mid; }
+        for (int j = a; j < ra && lx0[j] <= hi; ++j) {
+            int u = i, v = j;
+            while (true) {                                    // lock-free union: the smaller index wins
+                u = find(u); v = find(v);
+                if (u == v) break;
+                if (u > v) { const int t = u; u = v; v = t; }
+                const int old = atomicMin(&lpar[v], u);
+                if (old == v) break;
+                v = old;
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += kPpThreads) {
+        const int r = find(k);
+        if (LDS) R.parent[first + k] = first + r;
+        else lpar[k] = r;                                     // (global: parents are band-relative here, made absolute below)
+    }
+}
+__global__ __launch_bounds__(kPpThreads) void pp_runs_union_kernel(int h, PpRuns R) {
+    __shared__ int lx0[kBandRuns], lx1[kBandRuns], lpar[kBandRuns], roff[kRunBand + 1];
+    const int y0 = blockIdx.x * kRunBand, y1 = min(y0 + kRunBand, h);
+    if (y0 >= h) return;
+    const int first = R.row_off[y0], n = R.row_off[y1] - first;
+    if (threadIdx.x <= y1 - y0) roff[threadIdx.x] = R.row_off[y0 + threadIdx.x] - first;       // band-relative row offsets
+    __syncthreads();
+    if (n <= kBandRuns) {
+        pp_runs_band<true>(R, first, n, y0, y1, lx0, lx1, lpar, roff);
+    } else {
+        // too many runs for LDS (a page of noise): the same on the global arrays, with band-relative parents meanwhile
+        int* gpar = R.parent + first;
+        for (int k = threadIdx.x; k < n; k += kPpThreads) gpar[k] = k;
+        __syncthreads();
+        pp_runs_band<false>(R, first, n, y0, y1, R.x0 + first, R.x1 + first, gpar, roff);
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += kPpThreads) gpar[k] += first;
+    }
+}
+__global__ __launch_bounds__(kPpThreads) void pp_runs_union_borders_kernel(int h, PpRuns R) {      // a workgroup per band border
+    const int y = (blockIdx.x + 1) * kRunBand;
+    if (y >= h) return;
+    for (int i = R.row_off[y] + threadIdx.x; i < R.row_off[y + 1]; i += kPpThreads) pp_run_join_up(R, i, y);
+}
+
+__global__ __launch_bounds__(kPpThreads) void pp_runs_flatten_kernel(int h, PpRuns R) {
+    const int total = R.row_off[h];
+    for (int i = blockIdx.x * kPpThreads + threadIdx.x; i < total; i += gridDim.x * kPpThreads) {
+        int r = i;
+        while (R.parent[r] != r) r = R.parent[r];
+        R.parent[i] = r;
+    }
+}
+
+// parent[i] = root; area and bounding box of every root (pp_stats_kernel's two-level combination: lanes of a wave
+// that share a root first, then a hash table per workgroup, then memory)
+__global__ __launch_bounds__(kPpThreads) void pp_runs_stats_kernel(int h, PpRuns R) {
+    __shared__ int32_t t_key[kStatSlots], t_area[kStatSlots], t_x0[kStatSlots], t_y0[kStatSlots],
+        t_x1[kStatSlots], t_y1[kStatSlots];
+    for (int k = threadIdx.x; k < kStatSlots; k += kPpThreads) {
+        t_key[k] = -1; t_area[k] = 0; t_x0[k] = 0x7fffffff; t_y0[k] = 0x7fffffff; t_x1[k] = -1; t_y1[k] = -1;
+    }
+    __syncthreads();
+    const int total = R.row_off[h];
+    const int span = gridDim.x * kPpThreads, lane = threadIdx.x & 63;
+    auto put = [&](int32_t root, int cnt, int mnx, int mny, int mxx, int mxy) {
+        unsigned slot = ((unsigned)root * 2654435761u) >> 24;
+        int found = -1;
+        for (int probe = 0; probe < 8; ++probe) {
+            const int32_t was = atomicCAS(&t_key[slot], -1, root);
+            if (was == -1 || was == root) { found = (int)slot; break; }
+            slot = (slot + 1) & (kStatSlots - 1);
+        }
+        if (found >= 0) {
+            atomicAdd(&t_area[found], cnt);
+            atomicMin(&t_x0[found], mnx); atomicMin(&t_y0[found], mny);
+            atomicMax(&t_x1[found], mxx); atomicMax(&t_y1[found], mxy);
+        } else {
+            atomicAdd(&R.area[root], cnt);
+            atomicMin(&R.bx0[root], mnx); atomicMin(&R.by0[root], mny);
+            atomicMax(&R.bx1[root], mxx); atomicMax(&R.by1[root], mxy);
+        }
+    };
+    for (int base = blockIdx.x * kPpThreads; base < total; base += span) {          // uniform trip count per wave
+        const int i = base + threadIdx.x;
+        int32_t r = -1;
+        int len = 0, ax0 = 0, ax1 = 0, ay = 0;
+        if (i < total) {
+            r = i;
+            while (R.parent[r] != r) r = R.parent[r];        // (no union is running any more: plain reads)
+            R.parent[i] = r;
+            ax0 = R.x0[i]; ax1 = R.x1[i]; ay = R.yrow[i]; len = ax1 - ax0 + 1;
+        }
+        // The runs of a wave are neighbours in raster order.  Paper runs mostly share ONE root (the page background):
+        // the wave combines the lanes of its two most frequent-looking roots (the first lane's, then the first other's)
+        // before the table; ink runs are letters, a root each: those lanes go to the table on their own, side by side.
+        unsigned long long todo = __ballot(r >= 0);
+        for (int pass = 0; pass < 2 && todo; ++pass) {
+            const int leader = __builtin_ctzll(todo);
+            const int32_t root = __shfl(r, leader, 64);
+            const bool same = (r == root);
+            const unsigned long long grp = __ballot(same);
+            if (__popcll(grp) >= 4) {
+                int cnt = same ? len : 0;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+                const int mnx = wave_min(same ? ax0 : 0x7fffffff), mny = wave_min(same ? ay : 0x7fffffff);
+                const int mxx = wave_max(same ? ax1 : -1), mxy = wave_max(same ? ay : -1);
+                if (lane == leader) put(root, cnt, mnx, mny, mxx, mxy);
+                if (same) r = -1;                             // done
+            }
+            todo &= ~grp;
+        }
+        if (r >= 0) put(r, len, ax0, ay, ax1, ay);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kStatSlots; k += kPpThreads) {
+        const int32_t root = t_key[k];
+        if (root < 0) continue;
+        atomicAdd(&R.area[root], t_area[k]);
+        atomicMin(&R.bx0[root], t_x0[k]); atomicMin(&R.by0[root], t_y0[k]);
+        atomicMax(&R.bx1[root], t_x1[k]); atomicMax(&R.by1[root], t_y1[k]);
+    }
+}
+
+// the runs of components under min_area pixels or over max_height rows take the value `fill` (0: ink runs dropped;
+// 1: paper runs -- holes -- filled)
+__global__ __launch_bounds__(kPpThreads) void pp_runs_filter_kernel(uint8_t* ink, int h, int w, PpRuns R, int min_area,
+                                                                    int max_height, int fill) {
+    const int total = R.row_off[h];
+    for (int i = blockIdx.x * kPpThreads + threadIdx.x; i < total; i += gridDim.x * kPpThreads) {
+        const int r = R.parent[i];
+        const bool keep = R.area[r] >= min_area && (R.by1[r] - R.by0[r] + 1) <= max_height;
+        if (keep) continue;
+        uint8_t* p = ink + (int64_t)R.yrow[i] * w;
+        for (int x = R.x0[i]; x <= R.x1[i]; ++x) p[x] = (uint8_t)fill;
+    }
+}
+
+// records {root pixel, area, x0, y0, x1, y1} of every component, as pp_collect_kernel writes them
+__global__ __launch_bounds__(kPpThreads) void pp_runs_collect_kernel(int h, int w, PpRuns R, int32_t* recs, int32_t cap,
+                                                                     int32_t* count) {
+    const int total = R.row_off[h];
+    for (int i = blockIdx.x * kPpThreads + threadIdx.x; i < total; i += gridDim.x * kPpThreads) {
+        if (R.parent[i] != i) continue;
+        const int k = atomicAdd(count, 1);
+        if (k < cap) {
+            int32_t* r = recs + (int64_t)k * 6;
+            r[0] = (int32_t)((int64_t)R.yrow[i] * w + R.x0[i]); r[1] = R.area[i];
+            r[2] = R.bx0[i]; r[3] = R.by0[i]; r[4] = R.bx1[i]; r[5] = R.by1[i];
+        }
+    }
+}
+
+// the run tables of a page inside the scratch the labelling entry points are given (lab: h*w int32, stats: 5*h*w):
+// a row has at most ceil(w / 2) runs; pages under 8 columns do not fit and take the per-pixel labelling
+static bool pp_runs_fit(int h, int w) { return w >= 8 && h >= 1; }
+static PpRuns pp_runs_in(int32_t* lab, int32_t* stats, int h, int w) {
+    const int64_t cap = (int64_t)h * ((w + 1) / 2);
+    PpRuns R;
+    R.x0 = stats; R.x1 = stats + cap; R.yrow = stats + 2 * cap; R.parent = stats + 3 * cap; R.area = stats + 4 * cap;
+    R.by0 = stats + 5 * cap; R.by1 = stats + 6 * cap; R.bx0 = stats + 7 * cap;
+    R.bx1 = lab; R.row_cnt = lab + cap; R.row_off = lab + cap + h;
+    return R;
+}
+constexpr int kRunBlocks = 256;           // workgroups of the per-run kernels (grid-stride; the run count lives on the device)
+// runs of value `want` of one page, joined into components with their statistics: seven launches, nothing waited for
+static void pp_runs_label(const uint8_t* ink, int h, int w, int want, const PpRuns& R, hipStream_t st) {
+    const int rows_per_wg = kPpThreads / 64, wgs = (h + rows_per_wg - 1) / rows_per_wg;
+    hipLaunchKernelGGL(pp_runs_count_kernel, dim3(wgs), dim3(kPpThreads), 0, st, ink, h, w, want, R);
+    hipLaunchKernelGGL(pp_runs_scan_kernel, dim3(1), dim3(1024), 0, st, h, R);
+    hipLaunchKernelGGL(pp_runs_write_kernel, dim3(wgs), dim3(kPpThreads), 0, st, ink, h, w, want, R);
+    hipLaunchKernelGGL(pp_runs_union_kernel, dim3((h + kRunBand - 1) / kRunBand), dim3(kPpThreads), 0, st, h, R);
+    if (h > kRunBand) hipLaunchKernelGGL(pp_runs_union_borders_kernel, dim3((h - 1) / kRunBand), dim3(kPpThreads), 0, st, h, R);
+    hipLaunchKernelGGL(pp_runs_stats_kernel, dim3(kRunBlocks), dim3(kPpThreads), 0, st, h, R);
+}
+
 static int pp_blocks(int64_t n) {
     const int64_t b = (n + kPpThreads - 1) / kPpThreads;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -1066,30 +1378,47 @@ extern "C" int ta_pp_histogram_batch(int32_t n, const uint8_t* const* img, const
 extern "C" int ta_pp_binarise_batch(int32_t n, const uint8_t* const* img, const int32_t* h, const int32_t* w,
                                     const int32_t* thr, int32_t despeckle, int32_t max_height, uint8_t* const* ink,
                                     int32_t* const* lab, int32_t* const* stats, const int32_t* step,
-                                    uint32_t* const* points, uint32_t* counts, void* stream) {
+                                    uint32_t* const* points, uint32_t* counts, int32_t flags, void* stream) {
     int rc = pp_check_pages(n, h, w);
     if (rc != TA_OK) return rc;
     if (n == 0) return TA_OK;
     if (!img || !thr || !ink || !lab || !stats || !step || !points || !counts) return ta_fail(TA_EINVAL, "null pointer argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    bool by_runs = !(flags & TA_PP_LABEL_PIXELS);
     for (int i = 0; i < n; ++i) {
         const int64_t np = (int64_t)h[i] * w[i];
         if (step[i] < 1) return ta_fail(TA_EINVAL, "bad size");
         if (np && (!img[i] || !ink[i] || !lab[i] || !stats[i] || !points[i])) return ta_fail(TA_EINVAL, "null pointer argument");
         const int hs = (h[i] + step[i] - 1) / step[i], wsm = (w[i] + step[i] - 1) / step[i];
         if (hs > 65535 || wsm > 65535) return ta_fail(TA_ELIMIT, "decimated page too large for 16-bit point coordinates");
+        if (np && !pp_runs_fit(h[i], w[i])) by_runs = false;
         if (np) hipLaunchKernelGGL(pp_threshold_kernel, dim3(pp_blocks16(np)), dim3(kPpThreads), 0, st, img[i], np, thr[i], 0, ink[i]);
     }
-    for (int round = 0; round < 3; ++round) {
-        rc = ta_pp_label_batch(n, ink, h, w, lab, stats, reinterpret_cast<int32_t*>(counts), stream);
-        if (rc != TA_OK) return rc;
-        for (int i = 0; i < n; ++i) {
-            const int64_t np = (int64_t)h[i] * w[i];
-            if (!np) continue;
-            hipLaunchKernelGGL(pp_filter_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, ink[i], lab[i], np, stats[i],
-                               stats[i] + 2 * np, stats[i] + 4 * np, round < 2 ? despeckle : 0, round < 2 ? (1 << 30) : max_height);
-            // round 0 works on the ink, round 1 on the background (inverted before and after), round 2 on the ink again
-            if (round < 2) hipLaunchKernelGGL(pp_invert_kernel, dim3(pp_blocks16(np)), dim3(kPpThreads), 0, st, ink[i], np);
+    if (by_runs) {
+        // three labellings over runs: ink specks out, paper specks (holes) in -- the runs of PAPER are labelled, no
+        // inversion of the plane and back --, tall components out
+        for (int round = 0; round < 3; ++round) {
+            for (int i = 0; i < n; ++i) {
+                if (!((int64_t)h[i] * w[i])) continue;
+                const PpRuns R = pp_runs_in(lab[i], stats[i], h[i], w[i]);
+                const int want = round == 1 ? 0 : 1;
+                pp_runs_label(ink[i], h[i], w[i], want, R, st);
+                hipLaunchKernelGGL(pp_runs_filter_kernel, dim3(kRunBlocks), dim3(kPpThreads), 0, st, ink[i], h[i], w[i], R,
+                                   round < 2 ? despeckle : 0, round < 2 ? (1 << 30) : max_height, want ? 0 : 1);
+            }
+        }
+    } else {
+        for (int round = 0; round < 3; ++round) {
+            rc = ta_pp_label_batch(n, ink, h, w, lab, stats, reinterpret_cast<int32_t*>(counts), stream);
+            if (rc != TA_OK) return rc;
+            for (int i = 0; i < n; ++i) {
+                const int64_t np = (int64_t)h[i] * w[i];
+                if (!np) continue;
+                hipLaunchKernelGGL(pp_filter_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, ink[i], lab[i], np, stats[i],
+                                   stats[i] + 2 * np, stats[i] + 4 * np, round < 2 ? despeckle : 0, round < 2 ? (1 << 30) : max_height);
+                // round 0 works on the ink, round 1 on the background (inverted before and after), round 2 on the ink again
+                if (round < 2) hipLaunchKernelGGL(pp_invert_kernel, dim3(pp_blocks16(np)), dim3(kPpThreads), 0, st, ink[i], np);
+            }
         }
     }
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)n * sizeof(uint32_t), st);
@@ -1170,29 +1499,41 @@ extern "C" int ta_pp_deskew_batch(int32_t n, const uint8_t* const* ink, const in
 extern "C" int ta_pp_line_components_batch(int32_t n, const uint8_t* const* eroded, const int32_t* h, const int32_t* w,
                                            const int32_t* const* rows, const int32_t* nrows, uint8_t* const* work,
                                            int32_t* const* lab, int32_t* const* stats, int32_t* recs, int32_t cap,
-                                           int32_t* counts, void* stream) {
+                                           int32_t* counts, int32_t flags, void* stream) {
     int rc = pp_check_pages(n, h, w);
     if (rc != TA_OK) return rc;
     if (n == 0) return TA_OK;
     if (!eroded || !rows || !nrows || !work || !lab || !stats || !recs || !counts || cap < 0) return ta_fail(TA_EINVAL, "bad argument");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    bool by_runs = !(flags & TA_PP_LABEL_PIXELS);
     for (int i = 0; i < n; ++i) {
         const int64_t np = (int64_t)h[i] * w[i];
         if (!np) continue;
-        if (!eroded[i] || !work[i] || nrows[i] < 0 || (nrows[i] && !rows[i])) return ta_fail(TA_EINVAL, "bad argument");
+        if (!eroded[i] || !work[i] || !lab[i] || !stats[i] || nrows[i] < 0 || (nrows[i] && !rows[i])) return ta_fail(TA_EINVAL, "bad argument");
+        if (!pp_runs_fit(h[i], w[i])) by_runs = false;
         hipError_t e = hipMemcpyAsync(work[i], eroded[i], (size_t)np, hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return ta_fail_hip(e, "plane copy");
         if (nrows[i]) hipLaunchKernelGGL(pp_clear_rows_kernel, dim3(nrows[i]), dim3(kPpThreads), 0, st, work[i], w[i], rows[i], nrows[i]);
     }
-    rc = ta_pp_label_batch(n, work, h, w, lab, stats, counts, stream);
-    if (rc != TA_OK) return rc;
+    if (!by_runs) {
+        rc = ta_pp_label_batch(n, work, h, w, lab, stats, counts, stream);
+        if (rc != TA_OK) return rc;
+    }
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)n * sizeof(int32_t), st);
     if (e != hipSuccess) return ta_fail_hip(e, "component count memset");
     for (int i = 0; i < n; ++i) {
         const int64_t np = (int64_t)h[i] * w[i];
-        if (np) hipLaunchKernelGGL(pp_collect_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, lab[i], np, stats[i],
-                                   stats[i] + np, stats[i] + 2 * np, stats[i] + 3 * np, stats[i] + 4 * np,
-                                   recs + (size_t)i * cap * 6, cap, counts + i);
+        if (!np) continue;
+        if (by_runs) {
+            const PpRuns R = pp_runs_in(lab[i], stats[i], h[i], w[i]);
+            pp_runs_label(work[i], h[i], w[i], 1, R, st);
+            hipLaunchKernelGGL(pp_runs_collect_kernel, dim3(kRunBlocks), dim3(kPpThreads), 0, st, h[i], w[i], R,
+                               recs + (size_t)i * cap * 6, cap, counts + i);
+        } else {
+            hipLaunchKernelGGL(pp_collect_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, lab[i], np, stats[i],
+                               stats[i] + np, stats[i] + 2 * np, stats[i] + 3 * np, stats[i] + 4 * np,
+                               recs + (size_t)i * cap * 6, cap, counts + i);
+        }
     }
     PP_LAUNCH_CHECK("line component stage kernels");
     return TA_OK;

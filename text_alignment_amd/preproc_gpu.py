@@ -51,6 +51,8 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+LABEL_FLAGS = 0          # flags of the two stage calls that label: 0 = components over runs; _native.TA_PP_LABEL_PIXELS = a label per
+                         # pixel (rounds 3-5; the tests run both and compare)
 STAGE_CLOCK = None       # tools/pages_img_stages.py puts a list here: (thread, checkpoint name, perf_counter) per checkpoint
 
 
@@ -363,7 +365,7 @@ def preprocess_images_batch(pages, despeckle_amt=host.despeckle_amt, filter_runs
     _native.check(lib.ta_pp_binarise_batch(n, img_ptr.ctypes.data, hh.ctypes.data, ww.ctypes.data, thrs.ctypes.data,
                                            int(despeckle_amt), int(host.sat_area_thresh), ink_ptr.ctypes.data,
                                            lab_ptr.ctypes.data, stats_ptr.ctypes.data, d_steps.ctypes.data,
-                                           pts_ptr.ctypes.data, counts.data_ptr(), st), "ta_pp_binarise_batch")
+                                           pts_ptr.ctypes.data, counts.data_ptr(), LABEL_FLAGS, st), "ta_pp_binarise_batch")
     _mark("binarise enqueued")
     # stage 3: the skew search (two sweeps, a download each; variances and the choice on the host)
     skews = _skew_search(d, pts_ptr, counts, hs, ws, -6, 6)
@@ -444,11 +446,11 @@ def identify_text_lines_batch(d, planes, row_sums=None):
     work_ptr, lab_ptr, stats_ptr = _addr(work, work_off), _addr(lab, lab_off), _addr(stats, stats_off)
     _native.check(lib.ta_pp_line_components_batch(n, er_ptr.ctypes.data, hh.ctypes.data, ww.ctypes.data, rows_ptr.ctypes.data,
                                                   nrows.ctypes.data, work_ptr.ctypes.data, lab_ptr.ctypes.data,
-                                                  stats_ptr.ctypes.data, recs.data_ptr(), cap, counts.data_ptr(), st),
+                                                  stats_ptr.ctypes.data, recs.data_ptr(), cap, counts.data_ptr(), LABEL_FLAGS, st),
                   "ta_pp_line_components_batch")
     def labelled(k):
-        return (lab[lab_off[k]:lab_off[k] + int(npix[k])].view(int(hh[k]), int(ww[k])),
-                stats[stats_off[k]:stats_off[k] + 5 * int(npix[k])].view(5, int(hh[k]), int(ww[k])))
+        # (a page with more components than the table holds: labelled again per pixel, whose planes ta_pp_components reads)
+        return d.label(work[work_off[k]:work_off[k] + int(npix[k])].view(int(hh[k]), int(ww[k])))
     _mark("components enqueued")
     recs_all = d.component_tables(n, labelled, table, cap)
     _mark("components back")

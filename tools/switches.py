@@ -17,6 +17,7 @@ environment is the only handle -- so THEY translate it, once, after importing th
     TA_PB_LEAD_DIVISOR=n       alignToOCR.LEAD_CHUNK_DIVISOR   the call's first chunk is 1/n of a chunk (1: a whole one)
     TA_BIND=1                  sharding.bind_to_gpu_node()   the placement bench.py gives a rank (cores of the GPU's NUMA node)
     TA_SWITCH_INTERVAL=s       sys.setswitchinterval      seconds a thread may hold the interpreter lock against a waiting one
+    TA_PP_LABEL_PIXELS=1       preproc_gpu.LABEL_FLAGS    connected components by a label per pixel (rounds 3-5) instead of over runs
     TA_PP_BATCH=n              textAlignPreprocessing.PAGES_PER_BATCH   page images: pages per preprocessing batch
     TA_PP_THREADS=n            textAlignPreprocessing.PAGE_THREADS      ... batches in flight (a host thread and a stream each)
 """
@@ -67,6 +68,9 @@ def apply(environ=None):
         import sys
         sys.setswitchinterval(float(v))
         done["sys.switchinterval"] = float(v)
+    if env.get("TA_PP_LABEL_PIXELS") == "1":
+        from text_alignment_amd import _native, preproc_gpu
+        put(preproc_gpu, "LABEL_FLAGS", _native.TA_PP_LABEL_PIXELS)
     from text_alignment_amd import textAlignPreprocessing as preproc
     for var, attr in (("TA_PP_BATCH", "PAGES_PER_BATCH"), ("TA_PP_THREADS", "PAGE_THREADS")):
         v = env.get(var)
