@@ -657,12 +657,22 @@ struct PpRuns {
     int32_t* bx0; int32_t* by0; int32_t* bx1; int32_t* by1;
 };
 
+// the pages of one stage call, for kernels launched ONCE per batch (blockIdx.y = page): in a stream a page's forty small
+// kernels run one after the other whatever the device could hold, so a batch's chain is as long as its launches are many
+constexpr int kRunPages = 8;
+struct PpRunsBatch {
+    const uint8_t* ink[kRunPages];
+    int h[kRunPages], w[kRunPages];
+    PpRuns R[kRunPages];
+};
+
 __device__ __forceinline__ bool pp_run_pixel(const uint8_t* p, int x, int w, int want) { return x < w && ((p[x] != 0) == (want != 0)); }
 
 // (a lane's loads are single bytes, 64 B per instruction and wave: kRunUnroll segments' loads are issued before the first
 // ballot, so a row costs a few memory latencies instead of one per 64 pixels)
 constexpr int kRunUnroll = 8;
-__global__ __launch_bounds__(kPpThreads) void pp_runs_count_kernel(const uint8_t* ink, int h, int w, int want, PpRuns R) {
+__global__ __launch_bounds__(kPpThreads) void pp_runs_count_kernel(PpRunsBatch B, int want) {
+    const uint8_t* ink = B.ink[blockIdx.y]; const int h = B.h[blockIdx.y], w = B.w[blockIdx.y]; const PpRuns& R = B.R[blockIdx.y];
     const int lane = threadIdx.x & 63, row = blockIdx.x * (kPpThreads / 64) + (threadIdx.x >> 6);
     if (row >= h) return;                                    // (a whole wave: the row is the wave's)
     const uint8_t* p = ink + (int64_t)row * w;
@@ -683,7 +693,8 @@ __global__ __launch_bounds__(kPpThreads) void pp_runs_count_kernel(const uint8_t
 }
 
 // exclusive scan of the rows' run counts (one workgroup: a page has a few thousand rows)
-__global__ __launch_bounds__(1024) void pp_runs_scan_kernel(int h, PpRuns R) {
+__global__ __launch_bounds__(1024) void pp_runs_scan_kernel(PpRunsBatch B) {
+    const int h = B.h[blockIdx.y]; const PpRuns& R = B.R[blockIdx.y];
     __shared__ int part[1024];
     const int per = (h + 1023) / 1024, a = threadIdx.x * per, b = min(a + per, h);
     int sum = 0;
@@ -701,7 +712,8 @@ __global__ __launch_bounds__(1024) void pp_runs_scan_kernel(int h, PpRuns R) {
     if (threadIdx.x == 1023) R.row_off[h] = part[1023];
 }
 
-__global__ __launch_bounds__(kPpThreads) void pp_runs_write_kernel(const uint8_t* ink, int h, int w, int want, PpRuns R) {
+__global__ __launch_bounds__(kPpThreads) void pp_runs_write_kernel(PpRunsBatch B, int want) {
+    const uint8_t* ink = B.ink[blockIdx.y]; const int h = B.h[blockIdx.y], w = B.w[blockIdx.y]; const PpRuns& R = B.R[blockIdx.y];
     const int lane = threadIdx.x & 63, row = blockIdx.x * (kPpThreads / 64) + (threadIdx.x >> 6);
     if (row >= h) return;
     const uint8_t* p = ink + (int64_t)row * w;
@@ -790,7 +802,8 @@ __device__ __forceinline__ void pp_runs_band(const PpRuns& R, int first, int n, 
         else lpar[k] = r;                                     // (global: parents are band-relative here, made absolute below)
     }
 }
-__global__ __launch_bounds__(kPpThreads) void pp_runs_union_kernel(int h, PpRuns R) {
+__global__ __launch_bounds__(kPpThreads) void pp_runs_union_kernel(PpRunsBatch B) {
+    const int h = B.h[blockIdx.y]; const PpRuns& R = B.R[blockIdx.y];
     __shared__ int lx0[kBandRuns], lx1[kBandRuns], lpar[kBandRuns], roff[kRunBand + 1];
     const int y0 = blockIdx.x * kRunBand, y1 = min(y0 + kRunBand, h);
     if (y0 >= h) return;
@@ -809,24 +822,17 @@ __global__ __launch_bounds__(kPpThreads) void pp_runs_union_kernel(int h, PpRuns
         for (int k = threadIdx.x; k < n; k += kPpThreads) gpar[k] += first;
     }
 }
-__global__ __launch_bounds__(kPpThreads) void pp_runs_union_borders_kernel(int h, PpRuns R) {      // a workgroup per band border
+__global__ __launch_bounds__(kPpThreads) void pp_runs_union_borders_kernel(PpRunsBatch B) {      // a workgroup per band border
+    const int h = B.h[blockIdx.y]; const PpRuns& R = B.R[blockIdx.y];
     const int y = (blockIdx.x + 1) * kRunBand;
     if (y >= h) return;
     for (int i = R.row_off[y] + threadIdx.x; i < R.row_off[y + 1]; i += kPpThreads) pp_run_join_up(R, i, y);
 }
 
-__global__ __launch_bounds__(kPpThreads) void pp_runs_flatten_kernel(int h, PpRuns R) {
-    const int total = R.row_off[h];
-    for (int i = blockIdx.x * kPpThreads + threadIdx.x; i < total; i += gridDim.x * kPpThreads) {
-        int r = i;
-        while (R.parent[r] != r) r = R.parent[r];
-        R.parent[i] = r;
-    }
-}
-
 // parent[i] = root; area and bounding box of every root (pp_stats_kernel's two-level combination: lanes of a wave
 // that share a root first, then a hash table per workgroup, then memory)
-__global__ __launch_bounds__(kPpThreads) void pp_runs_stats_kernel(int h, PpRuns R) {
+__global__ __launch_bounds__(kPpThreads) void pp_runs_stats_kernel(PpRunsBatch B) {
+    const int h = B.h[blockIdx.y]; const PpRuns& R = B.R[blockIdx.y];
     __shared__ int32_t t_key[kStatSlots], t_area[kStatSlots], t_x0[kStatSlots], t_y0[kStatSlots],
         t_x1[kStatSlots], t_y1[kStatSlots];
     for (int k = threadIdx.x; k < kStatSlots; k += kPpThreads) {
@@ -897,8 +903,8 @@ __global__ __launch_bounds__(kPpThreads) void pp_runs_stats_kernel(int h, PpRuns
 
 // the runs of components under min_area pixels or over max_height rows take the value `fill` (0: ink runs dropped;
 // 1: paper runs -- holes -- filled)
-__global__ __launch_bounds__(kPpThreads) void pp_runs_filter_kernel(uint8_t* ink, int h, int w, PpRuns R, int min_area,
-                                                                    int max_height, int fill) {
+__global__ __launch_bounds__(kPpThreads) void pp_runs_filter_kernel(PpRunsBatch B, int min_area, int max_height, int fill) {
+    uint8_t* ink = const_cast<uint8_t*>(B.ink[blockIdx.y]); const int h = B.h[blockIdx.y], w = B.w[blockIdx.y]; const PpRuns& R = B.R[blockIdx.y];
     const int total = R.row_off[h];
     for (int i = blockIdx.x * kPpThreads + threadIdx.x; i < total; i += gridDim.x * kPpThreads) {
         const int r = R.parent[i];
@@ -910,8 +916,9 @@ __global__ __launch_bounds__(kPpThreads) void pp_runs_filter_kernel(uint8_t* ink
 }
 
 // records {root pixel, area, x0, y0, x1, y1} of every component, as pp_collect_kernel writes them
-__global__ __launch_bounds__(kPpThreads) void pp_runs_collect_kernel(int h, int w, PpRuns R, int32_t* recs, int32_t cap,
-                                                                     int32_t* count) {
+__global__ __launch_bounds__(kPpThreads) void pp_runs_collect_kernel(PpRunsBatch B, int32_t* recs_all, int32_t cap, int32_t* counts) {
+    const int h = B.h[blockIdx.y], w = B.w[blockIdx.y]; const PpRuns& R = B.R[blockIdx.y];
+    int32_t* recs = recs_all + (size_t)blockIdx.y * cap * 6; int32_t* count = counts + blockIdx.y;
     const int total = R.row_off[h];
     for (int i = blockIdx.x * kPpThreads + threadIdx.x; i < total; i += gridDim.x * kPpThreads) {
         if (R.parent[i] != i) continue;
@@ -935,16 +942,19 @@ static PpRuns pp_runs_in(int32_t* lab, int32_t* stats, int h, int w) {
     R.bx1 = lab; R.row_cnt = lab + cap; R.row_off = lab + cap + h;
     return R;
 }
-constexpr int kRunBlocks = 256;           // workgroups of the per-run kernels (grid-stride; the run count lives on the device)
-// runs of value `want` of one page, joined into components with their statistics: seven launches, nothing waited for
-static void pp_runs_label(const uint8_t* ink, int h, int w, int want, const PpRuns& R, hipStream_t st) {
-    const int rows_per_wg = kPpThreads / 64, wgs = (h + rows_per_wg - 1) / rows_per_wg;
-    hipLaunchKernelGGL(pp_runs_count_kernel, dim3(wgs), dim3(kPpThreads), 0, st, ink, h, w, want, R);
-    hipLaunchKernelGGL(pp_runs_scan_kernel, dim3(1), dim3(1024), 0, st, h, R);
-    hipLaunchKernelGGL(pp_runs_write_kernel, dim3(wgs), dim3(kPpThreads), 0, st, ink, h, w, want, R);
-    hipLaunchKernelGGL(pp_runs_union_kernel, dim3((h + kRunBand - 1) / kRunBand), dim3(kPpThreads), 0, st, h, R);
-    if (h > kRunBand) hipLaunchKernelGGL(pp_runs_union_borders_kernel, dim3((h - 1) / kRunBand), dim3(kPpThreads), 0, st, h, R);
-    hipLaunchKernelGGL(pp_runs_stats_kernel, dim3(kRunBlocks), dim3(kPpThreads), 0, st, h, R);
+constexpr int kRunBlocks = 256;           // workgroups per page of the per-run kernels (grid-stride; the run count lives on the device)
+// runs of value `want` of the batch's pages, joined into components with their statistics: six launches for ALL pages of
+// the batch (blockIdx.y = page; grids sized for the tallest), nothing waited for
+static void pp_runs_label(const PpRunsBatch& B, int npages, int want, hipStream_t st) {
+    int hmax = 1;
+    for (int i = 0; i < npages; ++i) hmax = B.h[i] > hmax ? B.h[i] : hmax;
+    const int rows_per_wg = kPpThreads / 64, wgs = (hmax + rows_per_wg - 1) / rows_per_wg;
+    hipLaunchKernelGGL(pp_runs_count_kernel, dim3(wgs, npages), dim3(kPpThreads), 0, st, B, want);
+    hipLaunchKernelGGL(pp_runs_scan_kernel, dim3(1, npages), dim3(1024), 0, st, B);
+    hipLaunchKernelGGL(pp_runs_write_kernel, dim3(wgs, npages), dim3(kPpThreads), 0, st, B, want);
+    hipLaunchKernelGGL(pp_runs_union_kernel, dim3((hmax + kRunBand - 1) / kRunBand, npages), dim3(kPpThreads), 0, st, B);
+    if (hmax > kRunBand) hipLaunchKernelGGL(pp_runs_union_borders_kernel, dim3((hmax - 1) / kRunBand, npages), dim3(kPpThreads), 0, st, B);
+    hipLaunchKernelGGL(pp_runs_stats_kernel, dim3(kRunBlocks, npages), dim3(kPpThreads), 0, st, B);
 }
 
 static int pp_blocks(int64_t n) {
@@ -1396,14 +1406,20 @@ extern "C" int ta_pp_binarise_batch(int32_t n, const uint8_t* const* img, const 
     }
     if (by_runs) {
         // three labellings over runs: ink specks out, paper specks (holes) in -- the runs of PAPER are labelled, no
-        // inversion of the plane and back --, tall components out
-        for (int round = 0; round < 3; ++round) {
-            for (int i = 0; i < n; ++i) {
+        // inversion of the plane and back --, tall components out; kRunPages pages per launch
+        for (int p0 = 0; p0 < n; p0 += kRunPages) {
+            PpRunsBatch B;
+            int m = 0;
+            for (int i = p0; i < n && i < p0 + kRunPages; ++i) {
                 if (!((int64_t)h[i] * w[i])) continue;
-                const PpRuns R = pp_runs_in(lab[i], stats[i], h[i], w[i]);
+                B.ink[m] = ink[i]; B.h[m] = h[i]; B.w[m] = w[i]; B.R[m] = pp_runs_in(lab[i], stats[i], h[i], w[i]);
+                ++m;
+            }
+            if (!m) continue;
+            for (int round = 0; round < 3; ++round) {
                 const int want = round == 1 ? 0 : 1;
-                pp_runs_label(ink[i], h[i], w[i], want, R, st);
-                hipLaunchKernelGGL(pp_runs_filter_kernel, dim3(kRunBlocks), dim3(kPpThreads), 0, st, ink[i], h[i], w[i], R,
+                pp_runs_label(B, m, want, st);
+                hipLaunchKernelGGL(pp_runs_filter_kernel, dim3(kRunBlocks, m), dim3(kPpThreads), 0, st, B,
                                    round < 2 ? despeckle : 0, round < 2 ? (1 << 30) : max_height, want ? 0 : 1);
             }
         }
@@ -1521,18 +1537,29 @@ extern "C" int ta_pp_line_components_batch(int32_t n, const uint8_t* const* erod
     }
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)n * sizeof(int32_t), st);
     if (e != hipSuccess) return ta_fail_hip(e, "component count memset");
-    for (int i = 0; i < n; ++i) {
-        const int64_t np = (int64_t)h[i] * w[i];
-        if (!np) continue;
-        if (by_runs) {
-            const PpRuns R = pp_runs_in(lab[i], stats[i], h[i], w[i]);
-            pp_runs_label(work[i], h[i], w[i], 1, R, st);
-            hipLaunchKernelGGL(pp_runs_collect_kernel, dim3(kRunBlocks), dim3(kPpThreads), 0, st, h[i], w[i], R,
-                               recs + (size_t)i * cap * 6, cap, counts + i);
-        } else {
-            hipLaunchKernelGGL(pp_collect_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, lab[i], np, stats[i],
-                               stats[i] + np, stats[i] + 2 * np, stats[i] + 3 * np, stats[i] + 4 * np,
-                               recs + (size_t)i * cap * 6, cap, counts + i);
+    if (by_runs) {
+        for (int p0 = 0; p0 < n; ) {
+            // consecutive non-empty pages, kRunPages per launch (their tables are consecutive in recs / counts)
+            while (p0 < n && !((int64_t)h[p0] * w[p0])) ++p0;
+            if (p0 >= n) break;
+            PpRunsBatch B;
+            int m = 0;
+            while (p0 + m < n && m < kRunPages && (int64_t)h[p0 + m] * w[p0 + m]) {
+                const int i = p0 + m;
+                B.ink[m] = work[i]; B.h[m] = h[i]; B.w[m] = w[i]; B.R[m] = pp_runs_in(lab[i], stats[i], h[i], w[i]);
+                ++m;
+            }
+            pp_runs_label(B, m, 1, st);
+            hipLaunchKernelGGL(pp_runs_collect_kernel, dim3(kRunBlocks, m), dim3(kPpThreads), 0, st, B,
+                               recs + (size_t)p0 * cap * 6, cap, counts + p0);
+            p0 += m;
+        }
+    } else {
+        for (int i = 0; i < n; ++i) {
+            const int64_t np = (int64_t)h[i] * w[i];
+            if (np) hipLaunchKernelGGL(pp_collect_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, lab[i], np, stats[i],
+                                       stats[i] + np, stats[i] + 2 * np, stats[i] + 3 * np, stats[i] + 4 * np,
+                                       recs + (size_t)i * cap * 6, cap, counts + i);
         }
     }
     PP_LAUNCH_CHECK("line component stage kernels");
