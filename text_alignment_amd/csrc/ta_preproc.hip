@@ -29,7 +29,7 @@ __device__ __forceinline__ bool pp_aligned16(const void* p) { return (reinterpre
 
 // A wave has its own 256 bins (a text page is mostly paper: with one table per workgroup four waves queued on the
 // same few bins), merged at the end.
-__global__ __launch_bounds__(kPpThreads) void pp_hist_kernel(const uint8_t* img, int64_t n, uint32_t* hist) {
+__device__ __forceinline__ void pp_hist_kernel_body(const uint8_t* img, int64_t n, uint32_t* hist) {
     __shared__ uint32_t sh[kPpThreads / 64][256];
     for (int k = threadIdx.x; k < (kPpThreads / 64) * 256; k += kPpThreads) (&sh[0][0])[k] = 0;
     __syncthreads();
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kPpThreads) void pp_hist_kernel(const uint8_t* img,
 static_assert(kPpThreads == 256, "one bin per thread at the end");
 
 // ink = (img <= thr), or its complement
-__global__ __launch_bounds__(kPpThreads) void pp_threshold_kernel(const uint8_t* img, int64_t n, int thr,
+__device__ __forceinline__ void pp_threshold_kernel_body(const uint8_t* img, int64_t n, int thr,
                                                                   int invert, uint8_t* ink) {
     const int64_t gid = (int64_t)blockIdx.x * kPpThreads + threadIdx.x, span = (int64_t)gridDim.x * kPpThreads;
     int64_t done = 0;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kPpThreads) void pp_angle_hist_kernel(const uint8_t
 // and every angle of both sweeps then walks the list instead of the page -- 49 + 21 passes over ~55 k points
 // instead of over 685 k pixels.  points[i] = (row << 16) | column of the decimated grid, in no particular
 // order; *count (device) receives their number.
-__global__ __launch_bounds__(kPpThreads) void pp_ink_points_kernel(const uint8_t* ink, int h, int w, int step,
+__device__ __forceinline__ void pp_ink_points_kernel_body(const uint8_t* ink, int h, int w, int step,
                                                                    uint32_t* points, uint32_t* count) {
     const int hs = (h + step - 1) / step, wsm = (w + step - 1) / step;
     const int64_t n = (int64_t)hs * wsm;
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(kPpThreads) void pp_ink_points_kernel(const uint8_t
 }
 
 // hist[a][row] from the point list: the arithmetic of pp_angle_hist_kernel per point (float64, same operation order)
-__global__ __launch_bounds__(kPpThreads) void pp_angle_hist_points_kernel(const uint32_t* points, const uint32_t* count,
+__device__ __forceinline__ void pp_angle_hist_points_kernel_body(const uint32_t* points, const uint32_t* count,
                                                                           int hs, int wsm, const double* cs,
                                                                           uint32_t* hist) {
     __shared__ uint32_t bins[kAngleBins];
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(kPpThreads) void pp_angle_hist_points_kernel(const 
 }
 
 // scipy.ndimage.affine_transform(float32(ink), M, offset, order = 1, mode = 'constant', cval = 0) > 0.5
-__global__ __launch_bounds__(kPpThreads) void pp_rotate_kernel(const uint8_t* ink, int h, int w, uint8_t* out,
+__device__ __forceinline__ void pp_rotate_kernel_body(const uint8_t* ink, int h, int w, uint8_t* out,
                                                                int oh, int ow, const double* mo) {
     const double m00 = mo[0], m01 = mo[1], m10 = mo[2], m11 = mo[3], off0 = mo[4], off1 = mo[5];
     const int64_t n = (int64_t)oh * ow;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(kPpThreads) void pp_rotate_kernel(const uint8_t* in
 
 // opening with a line of `len` pixels along the axis: a pixel survives iff some window of `len`
 // consecutive pixels containing it is all ink
-__global__ __launch_bounds__(kPpThreads) void pp_open_runs_kernel(const uint8_t* in, uint8_t* out, int h, int w,
+__device__ __forceinline__ void pp_open_runs_kernel_body(const uint8_t* in, uint8_t* out, int h, int w,
                                                                   int len, int axis) {
     const int64_t n = (int64_t)h * w;
     const int L = axis == 0 ? h : w;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(kPpThreads) void pp_open_runs_kernel(const uint8_t*
     }
 }
 
-__global__ __launch_bounds__(kPpThreads) void pp_row_sums_kernel(const uint8_t* ink, int h, int w, int32_t* sums) {
+__device__ __forceinline__ void pp_row_sums_kernel_body(const uint8_t* ink, int h, int w, int32_t* sums) {
     __shared__ int sh[kPpThreads];
     const int y = blockIdx.x;
     int acc = 0;
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(kPpThreads) void pp_row_sums_kernel(const uint8_t* 
 
 // the text-line strips of a page, cut out of its ink plane into one packed buffer as the greyscale images the
 // reference saves for the recogniser (ink black on white): boxes[s] = {ulx, uly, lrx, lry, offset into out}
-__global__ __launch_bounds__(kPpThreads) void pp_cut_strips_kernel(const uint8_t* __restrict__ ink, int w,
+__device__ __forceinline__ void pp_cut_strips_kernel_body(const uint8_t* __restrict__ ink, int w,
                                                                    const int64_t* __restrict__ boxes,
                                                                    uint8_t* __restrict__ out) {
     const int64_t* b = boxes + 5 * (int64_t)blockIdx.y;
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(kPpThreads) void pp_cut_strips_kernel(const uint8_t
     }
 }
 
-__global__ __launch_bounds__(kPpThreads) void pp_clear_rows_kernel(uint8_t* ink, int w, const int32_t* rows, int nrows) {
+__device__ __forceinline__ void pp_clear_rows_kernel_body(uint8_t* ink, int w, const int32_t* rows, int nrows) {
     const int r = rows[blockIdx.x];
     for (int x = threadIdx.x; x < w; x += kPpThreads) ink[(int64_t)r * w + x] = 0;
 }
@@ -955,6 +955,78 @@ static void pp_runs_label(const PpRunsBatch& B, int npages, int want, hipStream_
     hipLaunchKernelGGL(pp_runs_union_kernel, dim3((hmax + kRunBand - 1) / kRunBand, npages), dim3(kPpThreads), 0, st, B);
     if (hmax > kRunBand) hipLaunchKernelGGL(pp_runs_union_borders_kernel, dim3((hmax - 1) / kRunBand, npages), dim3(kPpThreads), 0, st, B);
     hipLaunchKernelGGL(pp_runs_stats_kernel, dim3(kRunBlocks, npages), dim3(kPpThreads), 0, st, B);
+}
+
+
+// ---- the kernels above as launches: one image (the single-page entry points) ...
+__global__ __launch_bounds__(kPpThreads) void pp_hist_kernel(const uint8_t* img, int64_t n, uint32_t* hist) { pp_hist_kernel_body(img, n, hist); }
+__global__ __launch_bounds__(kPpThreads) void pp_threshold_kernel(const uint8_t* img, int64_t n, int thr, int invert, uint8_t* ink) { pp_threshold_kernel_body(img, n, thr, invert, ink); }
+__global__ __launch_bounds__(kPpThreads) void pp_ink_points_kernel(const uint8_t* ink, int h, int w, int step, uint32_t* points, uint32_t* count) { pp_ink_points_kernel_body(ink, h, w, step, points, count); }
+__global__ __launch_bounds__(kPpThreads) void pp_angle_hist_points_kernel(const uint32_t* points, const uint32_t* count, int hs, int wsm, const double* cs, uint32_t* hist) { pp_angle_hist_points_kernel_body(points, count, hs, wsm, cs, hist); }
+__global__ __launch_bounds__(kPpThreads) void pp_rotate_kernel(const uint8_t* ink, int h, int w, uint8_t* out, int oh, int ow, const double* mo) { pp_rotate_kernel_body(ink, h, w, out, oh, ow, mo); }
+__global__ __launch_bounds__(kPpThreads) void pp_open_runs_kernel(const uint8_t* in, uint8_t* out, int h, int w, int len, int axis) { pp_open_runs_kernel_body(in, out, h, w, len, axis); }
+__global__ __launch_bounds__(kPpThreads) void pp_row_sums_kernel(const uint8_t* ink, int h, int w, int32_t* sums) { pp_row_sums_kernel_body(ink, h, w, sums); }
+__global__ __launch_bounds__(kPpThreads) void pp_cut_strips_kernel(const uint8_t* __restrict__ ink, int w, const int64_t* __restrict__ boxes, uint8_t* __restrict__ out) { pp_cut_strips_kernel_body(ink, w, boxes, out); }
+__global__ __launch_bounds__(kPpThreads) void pp_clear_rows_kernel(uint8_t* ink, int w, const int32_t* rows, int nrows) { pp_clear_rows_kernel_body(ink, w, rows, nrows); }
+
+// ... and the pages of a stage call in ONE launch (blockIdx.z = page; grids sized for the largest page, every body is
+// grid-stride or returns for what lies beyond its page): in a stream a batch's chain is as long as its launches are many
+struct PpPages {
+    const void* a[kRunPages]; void* b[kRunPages]; const void* c[kRunPages]; void* d[kRunPages];
+    int h[kRunPages], w[kRunPages], i0[kRunPages], i1[kRunPages];
+    long long n[kRunPages];
+};
+__global__ __launch_bounds__(kPpThreads) void pp_hist_pages_kernel(PpPages B) {
+    const int p = blockIdx.z;
+    pp_hist_kernel_body((const uint8_t*)B.a[p], B.n[p], (uint32_t*)B.b[p]);
+}
+__global__ __launch_bounds__(kPpThreads) void pp_threshold_pages_kernel(PpPages B) {
+    const int p = blockIdx.z;
+    pp_threshold_kernel_body((const uint8_t*)B.a[p], B.n[p], B.i0[p], 0, (uint8_t*)B.b[p]);
+}
+__global__ __launch_bounds__(kPpThreads) void pp_ink_points_pages_kernel(PpPages B) {
+    const int p = blockIdx.z;
+    pp_ink_points_kernel_body((const uint8_t*)B.a[p], B.h[p], B.w[p], B.i0[p], (uint32_t*)B.b[p], (uint32_t*)B.d[p]);
+}
+__global__ __launch_bounds__(kPpThreads) void pp_angle_hist_points_pages_kernel(PpPages B) {      // i0 = hs, i1 = ws, n = angles
+    const int p = blockIdx.z;
+    if ((long long)blockIdx.y >= B.n[p] || !B.i0[p] || !B.i1[p]) return;
+    pp_angle_hist_points_kernel_body((const uint32_t*)B.a[p], (const uint32_t*)B.c[p], B.i0[p], B.i1[p], (const double*)B.d[p],
+                                     (uint32_t*)B.b[p]);
+}
+__global__ __launch_bounds__(kPpThreads) void pp_rotate_pages_kernel(PpPages B) {                 // i0 = oh, i1 = ow, c = map or NULL
+    const int p = blockIdx.z;
+    if (B.c[p]) { pp_rotate_kernel_body((const uint8_t*)B.a[p], B.h[p], B.w[p], (uint8_t*)B.b[p], B.i0[p], B.i1[p], (const double*)B.c[p]); return; }
+    const uint8_t* src = (const uint8_t*)B.a[p];
+    uint8_t* dst = (uint8_t*)B.b[p];
+    const int64_t n = (int64_t)B.i0[p] * B.i1[p];                                                 // (not turned: a copy)
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) dst[e] = src[e];
+}
+__global__ __launch_bounds__(kPpThreads) void pp_open_runs_pages_kernel(PpPages B, int len, int axis) {
+    const int p = blockIdx.z;
+    pp_open_runs_kernel_body((const uint8_t*)B.a[p], (uint8_t*)B.b[p], B.h[p], B.w[p], len, axis);
+}
+__global__ __launch_bounds__(kPpThreads) void pp_copy_pages_kernel(PpPages B) {
+    const int p = blockIdx.z;
+    const uint8_t* src = (const uint8_t*)B.a[p];
+    uint8_t* dst = (uint8_t*)B.b[p];
+    const int64_t n = B.n[p];
+    for (int64_t e = (int64_t)blockIdx.x * kPpThreads + threadIdx.x; e < n; e += (int64_t)gridDim.x * kPpThreads) dst[e] = src[e];
+}
+__global__ __launch_bounds__(kPpThreads) void pp_row_sums_pages_kernel(PpPages B) {
+    const int p = blockIdx.z;
+    if ((int)blockIdx.x >= B.h[p]) return;
+    pp_row_sums_kernel_body((const uint8_t*)B.a[p], B.h[p], B.w[p], (int32_t*)B.b[p]);
+}
+__global__ __launch_bounds__(kPpThreads) void pp_clear_rows_pages_kernel(PpPages B) {             // c = rows, i0 = their number
+    const int p = blockIdx.z;
+    if ((int)blockIdx.x >= B.i0[p]) return;
+    pp_clear_rows_kernel_body((uint8_t*)B.b[p], B.w[p], (const int32_t*)B.c[p], B.i0[p]);
+}
+__global__ __launch_bounds__(kPpThreads) void pp_cut_strips_pages_kernel(PpPages B, uint8_t* out) {   // c = boxes, i0 = their number
+    const int p = blockIdx.z;
+    if ((int)blockIdx.y >= B.i0[p]) return;
+    pp_cut_strips_kernel_body((const uint8_t*)B.a[p], B.w[p], (const int64_t*)B.c[p], out);
 }
 
 static int pp_blocks(int64_t n) {
@@ -1372,10 +1444,19 @@ extern "C" int ta_pp_histogram_batch(int32_t n, const uint8_t* const* img, const
     if (e != hipSuccess) return ta_fail_hip(e, "histogram memset");
     for (int i = 0; i < n; ++i) {
         if (npix[i] < 0) return ta_fail(TA_EINVAL, "negative size");
-        if (npix[i] == 0) continue;
-        if (!img[i]) return ta_fail(TA_EINVAL, "null pointer argument");
-        hipLaunchKernelGGL(pp_hist_kernel, dim3(pp_blocks16(npix[i]) > 1024 ? 1024 : pp_blocks16(npix[i])), dim3(kPpThreads), 0, st,
-                           img[i], npix[i], hist + (size_t)i * 256);
+        if (npix[i] && !img[i]) return ta_fail(TA_EINVAL, "null pointer argument");
+    }
+    for (int p0 = 0; p0 < n; p0 += kRunPages) {
+        PpPages B;
+        int m = 0;
+        int64_t big = 0;
+        for (int i = p0; i < n && i < p0 + kRunPages; ++i) {
+            if (!npix[i]) continue;
+            B.a[m] = img[i]; B.n[m] = npix[i]; B.b[m] = hist + (size_t)i * 256;
+            big = npix[i] > big ? npix[i] : big;
+            ++m;
+        }
+        if (m) hipLaunchKernelGGL(pp_hist_pages_kernel, dim3(pp_blocks16(big) > 1024 ? 1024 : pp_blocks16(big), 1, m), dim3(kPpThreads), 0, st, B);
     }
     PP_LAUNCH_CHECK("pp_hist_kernel");
     return TA_OK;
@@ -1402,7 +1483,19 @@ extern "C" int ta_pp_binarise_batch(int32_t n, const uint8_t* const* img, const 
         const int hs = (h[i] + step[i] - 1) / step[i], wsm = (w[i] + step[i] - 1) / step[i];
         if (hs > 65535 || wsm > 65535) return ta_fail(TA_ELIMIT, "decimated page too large for 16-bit point coordinates");
         if (np && !pp_runs_fit(h[i], w[i])) by_runs = false;
-        if (np) hipLaunchKernelGGL(pp_threshold_kernel, dim3(pp_blocks16(np)), dim3(kPpThreads), 0, st, img[i], np, thr[i], 0, ink[i]);
+    }
+    for (int p0 = 0; p0 < n; p0 += kRunPages) {
+        PpPages B;
+        int m = 0;
+        int64_t big = 0;
+        for (int i = p0; i < n && i < p0 + kRunPages; ++i) {
+            const int64_t np = (int64_t)h[i] * w[i];
+            if (!np) continue;
+            B.a[m] = img[i]; B.n[m] = np; B.i0[m] = thr[i]; B.b[m] = ink[i];
+            big = np > big ? np : big;
+            ++m;
+        }
+        if (m) hipLaunchKernelGGL(pp_threshold_pages_kernel, dim3(pp_blocks16(big), 1, m), dim3(kPpThreads), 0, st, B);
     }
     if (by_runs) {
         // three labellings over runs: ink specks out, paper specks (holes) in -- the runs of PAPER are labelled, no
@@ -1439,11 +1532,19 @@ extern "C" int ta_pp_binarise_batch(int32_t n, const uint8_t* const* img, const 
     }
     hipError_t e = hipMemsetAsync(counts, 0, (size_t)n * sizeof(uint32_t), st);
     if (e != hipSuccess) return ta_fail_hip(e, "point count memset");
-    for (int i = 0; i < n; ++i) {
-        const int hs = (h[i] + step[i] - 1) / step[i], wsm = (w[i] + step[i] - 1) / step[i];
-        const int64_t np = (int64_t)hs * wsm;
-        if (np) hipLaunchKernelGGL(pp_ink_points_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, ink[i], h[i], w[i], step[i],
-                                   points[i], counts + i);
+    for (int p0 = 0; p0 < n; p0 += kRunPages) {
+        PpPages B;
+        int m = 0;
+        int64_t big = 0;
+        for (int i = p0; i < n && i < p0 + kRunPages; ++i) {
+            const int hs = (h[i] + step[i] - 1) / step[i], wsm = (w[i] + step[i] - 1) / step[i];
+            const int64_t np = (int64_t)hs * wsm;
+            if (!np) continue;
+            B.a[m] = ink[i]; B.h[m] = h[i]; B.w[m] = w[i]; B.i0[m] = step[i]; B.b[m] = points[i]; B.d[m] = counts + i;
+            big = np > big ? np : big;
+            ++m;
+        }
+        if (m) hipLaunchKernelGGL(pp_ink_points_pages_kernel, dim3(pp_blocks(big), 1, m), dim3(kPpThreads), 0, st, B);
     }
     PP_LAUNCH_CHECK("binarise stage kernels");
     return TA_OK;
@@ -1456,10 +1557,29 @@ extern "C" int ta_pp_angle_histograms_points_batch(int32_t n, const uint32_t* co
     if (n < 0) return ta_fail(TA_EINVAL, "negative size");
     if (n == 0) return TA_OK;
     if (!points || !counts || !hs || !ws || !cos_sin || !nang || !hist) return ta_fail(TA_EINVAL, "null pointer argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     for (int i = 0; i < n; ++i) {
-        const int rc = ta_pp_angle_histograms_points(points[i], counts + i, hs[i], ws[i], cos_sin[i], nang[i], hist[i], stream);
-        if (rc != TA_OK) return rc;
+        if (hs[i] < 0 || ws[i] < 0 || nang[i] < 0) return ta_fail(TA_EINVAL, "bad size");
+        if (!points[i] || !cos_sin[i] || !hist[i]) return ta_fail(TA_EINVAL, "null pointer argument");
     }
+    for (int p0 = 0; p0 < n; p0 += kRunPages) {
+        PpPages B;
+        int m = 0, amax = 0;
+        for (int i = p0; i < n && i < p0 + kRunPages; ++i) {
+            if (!nang[i] || !hs[i]) continue;
+            hipError_t e = hipMemsetAsync(hist[i], 0, sizeof(uint32_t) * (size_t)nang[i] * hs[i], st);
+            if (e != hipSuccess) return ta_fail_hip(e, "angle histogram memset");
+            B.a[m] = points[i]; B.c[m] = counts + i; B.i0[m] = hs[i]; B.i1[m] = ws[i]; B.d[m] = const_cast<double*>(cos_sin[i]);
+            B.n[m] = nang[i]; B.b[m] = hist[i];
+            amax = nang[i] > amax ? nang[i] : amax;
+            ++m;
+        }
+        if (!m) continue;
+        int slices = 512 / amax;
+        slices = slices < 1 ? 1 : (slices > 16 ? 16 : slices);
+        hipLaunchKernelGGL(pp_angle_hist_points_pages_kernel, dim3(slices, amax, m), dim3(kPpThreads), 0, st, B);
+    }
+    PP_LAUNCH_CHECK("pp_angle_hist_points_kernel");
     return TA_OK;
 }
 
@@ -1480,30 +1600,40 @@ extern "C" int ta_pp_deskew_batch(int32_t n, const uint8_t* const* ink, const in
         const int64_t np = (int64_t)oh[i] * ow[i];
         if (!np) continue;
         if (!ink[i] || !out[i] || !tmp[i] || !eroded[i] || !sums[i]) return ta_fail(TA_EINVAL, "null pointer argument");
-        if (mo[i]) {
-            hipLaunchKernelGGL(pp_rotate_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, ink[i], h[i], w[i], out[i], oh[i], ow[i], mo[i]);
-        } else {
-            if (oh[i] != h[i] || ow[i] != w[i]) return ta_fail(TA_EINVAL, "a page that is not rotated keeps its size");
-            hipError_t e = hipMemcpyAsync(out[i], ink[i], (size_t)np, hipMemcpyDeviceToDevice, st);
-            if (e != hipSuccess) return ta_fail_hip(e, "plane copy");
-        }
+        if (!mo[i] && (oh[i] != h[i] || ow[i] != w[i])) return ta_fail(TA_EINVAL, "a page that is not rotated keeps its size");
     }
-    for (int i = 0; i < n; ++i) {
-        const int64_t np = (int64_t)oh[i] * ow[i];
-        if (!np) continue;
-        const uint8_t* src = out[i];
+    for (int p0 = 0; p0 < n; p0 += kRunPages) {
+        PpPages R, A, C, S;                                  // rotation | opening along the rows | along the columns | row sums
+        int m = 0, hmax = 0;
+        int64_t big = 0;
+        for (int i = p0; i < n && i < p0 + kRunPages; ++i) {
+            const int64_t np = (int64_t)oh[i] * ow[i];
+            if (!np) continue;
+            R.a[m] = ink[i]; R.h[m] = h[i]; R.w[m] = w[i]; R.b[m] = out[i]; R.i0[m] = oh[i]; R.i1[m] = ow[i]; R.c[m] = mo[i];
+            A.a[m] = out[i]; A.b[m] = tmp[i]; A.h[m] = oh[i]; A.w[m] = ow[i];
+            C.a[m] = tmp[i]; C.b[m] = eroded[i]; C.h[m] = oh[i]; C.w[m] = ow[i];
+            S.a[m] = eroded[i]; S.h[m] = oh[i]; S.w[m] = ow[i]; S.b[m] = sums[i];
+            big = np > big ? np : big;
+            hmax = oh[i] > hmax ? oh[i] : hmax;
+            ++m;
+        }
+        if (!m) continue;
+        hipLaunchKernelGGL(pp_rotate_pages_kernel, dim3(pp_blocks(big), 1, m), dim3(kPpThreads), 0, st, R);
+        bool opened = false;
         if (runs_len > 1) {
             for (int r = 0; r < rounds; ++r) {
-                hipLaunchKernelGGL(pp_open_runs_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, src, tmp[i], oh[i], ow[i], runs_len, 0);
-                hipLaunchKernelGGL(pp_open_runs_kernel, dim3(pp_blocks(np)), dim3(kPpThreads), 0, st, tmp[i], eroded[i], oh[i], ow[i], runs_len, 1);
-                src = eroded[i];
+                hipLaunchKernelGGL(pp_open_runs_pages_kernel, dim3(pp_blocks(big), 1, m), dim3(kPpThreads), 0, st, A, runs_len, 0);
+                hipLaunchKernelGGL(pp_open_runs_pages_kernel, dim3(pp_blocks(big), 1, m), dim3(kPpThreads), 0, st, C, runs_len, 1);
+                for (int k = 0; k < m; ++k) A.a[k] = C.b[k];      // a second round opens what the first left
+                opened = true;
             }
         }
-        if (src != eroded[i]) {
-            hipError_t e = hipMemcpyAsync(eroded[i], out[i], (size_t)np, hipMemcpyDeviceToDevice, st);
-            if (e != hipSuccess) return ta_fail_hip(e, "plane copy");
+        if (!opened) {                                       // no filter: eroded = a copy of the plane
+            PpPages K;
+            for (int k = 0; k < m; ++k) { K.a[k] = R.b[k]; K.b[k] = C.b[k]; K.n[k] = (long long)R.i0[k] * R.i1[k]; }
+            hipLaunchKernelGGL(pp_copy_pages_kernel, dim3(pp_blocks16(big), 1, m), dim3(kPpThreads), 0, st, K);
         }
-        hipLaunchKernelGGL(pp_row_sums_kernel, dim3(oh[i]), dim3(kPpThreads), 0, st, eroded[i], oh[i], ow[i], sums[i]);
+        hipLaunchKernelGGL(pp_row_sums_pages_kernel, dim3(hmax, 1, m), dim3(kPpThreads), 0, st, S);
     }
     PP_LAUNCH_CHECK("deskew stage kernels");
     return TA_OK;
@@ -1527,9 +1657,22 @@ extern "C" int ta_pp_line_components_batch(int32_t n, const uint8_t* const* erod
         if (!np) continue;
         if (!eroded[i] || !work[i] || !lab[i] || !stats[i] || nrows[i] < 0 || (nrows[i] && !rows[i])) return ta_fail(TA_EINVAL, "bad argument");
         if (!pp_runs_fit(h[i], w[i])) by_runs = false;
-        hipError_t e = hipMemcpyAsync(work[i], eroded[i], (size_t)np, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return ta_fail_hip(e, "plane copy");
-        if (nrows[i]) hipLaunchKernelGGL(pp_clear_rows_kernel, dim3(nrows[i]), dim3(kPpThreads), 0, st, work[i], w[i], rows[i], nrows[i]);
+    }
+    for (int p0 = 0; p0 < n; p0 += kRunPages) {
+        PpPages K;
+        int m = 0, rmax = 0;
+        int64_t big = 0;
+        for (int i = p0; i < n && i < p0 + kRunPages; ++i) {
+            const int64_t np = (int64_t)h[i] * w[i];
+            if (!np) continue;
+            K.a[m] = eroded[i]; K.b[m] = work[i]; K.n[m] = np; K.w[m] = w[i]; K.c[m] = rows[i]; K.i0[m] = nrows[i];
+            big = np > big ? np : big;
+            rmax = nrows[i] > rmax ? nrows[i] : rmax;
+            ++m;
+        }
+        if (!m) continue;
+        hipLaunchKernelGGL(pp_copy_pages_kernel, dim3(pp_blocks16(big), 1, m), dim3(kPpThreads), 0, st, K);
+        if (rmax) hipLaunchKernelGGL(pp_clear_rows_pages_kernel, dim3(rmax, 1, m), dim3(kPpThreads), 0, st, K);
     }
     if (!by_runs) {
         rc = ta_pp_label_batch(n, work, h, w, lab, stats, counts, stream);
@@ -1573,9 +1716,22 @@ extern "C" int ta_pp_cut_strips_batch(int32_t n, const uint8_t* const* ink, cons
     if (rc != TA_OK) return rc;
     if (n == 0) return TA_OK;
     if (!ink || !boxes || !nstrips) return ta_fail(TA_EINVAL, "null pointer argument");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     for (int i = 0; i < n; ++i) {
-        rc = ta_pp_cut_strips(ink[i], h[i], w[i], boxes[i], nstrips[i], packed, stream);
-        if (rc != TA_OK) return rc;
+        if (nstrips[i] < 0) return ta_fail(TA_EINVAL, "negative size");
+        if (nstrips[i] && (!ink[i] || !boxes[i] || !packed)) return ta_fail(TA_EINVAL, "null pointer argument");
     }
+    for (int p0 = 0; p0 < n; p0 += kRunPages) {
+        PpPages B;
+        int m = 0, smax = 0;
+        for (int i = p0; i < n && i < p0 + kRunPages; ++i) {
+            if (!nstrips[i]) continue;
+            B.a[m] = ink[i]; B.w[m] = w[i]; B.c[m] = boxes[i]; B.i0[m] = nstrips[i];
+            smax = nstrips[i] > smax ? nstrips[i] : smax;
+            ++m;
+        }
+        if (m) hipLaunchKernelGGL(pp_cut_strips_pages_kernel, dim3(64, smax, m), dim3(kPpThreads), 0, st, B, packed);
+    }
+    PP_LAUNCH_CHECK("pp_cut_strips_kernel");
     return TA_OK;
 }
