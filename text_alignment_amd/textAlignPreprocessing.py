@@ -364,10 +364,12 @@ def find_lines(input_image):
 # pages whose preprocessing shares its stage calls and waits for the device (~0.2 GB of planes each), and batches in flight
 # at once, each driven by a host thread on a HIP stream of its own.  8 x 2 while every page's launches were made from
 # Python (more threads only fought for the interpreter lock); with a stage per library call (preproc_gpu, round 6) a thread
-# holds the lock for ~0.3 ms per page and four threads keep the device fed: 64 pages, same box, 8 x 2: 682-698 pages/s,
-# 4 x 4: 761-800, 4 x 8: 774-827 with half again the host time
-PAGES_PER_BATCH = 4
-PAGE_THREADS = 4
+# holds the lock for ~0.3 ms per page and 4 x 4 kept the device fed better (64 pages, same box, 8 x 2: 682-698 pages/s,
+# 4 x 4: 761-800); once every kernel of a stage is ONE launch for the batch's pages (csrc/ta_preproc.hip, blockIdx.z =
+# page: a stream runs a page's small kernels one after the other, so larger batches no longer lengthen the chain) 8 x 2
+# again: 950-990 pages/s against 890-925 for 4 x 4, with 1.6 instead of 2.3 ms of host time per page
+PAGES_PER_BATCH = 8
+PAGE_THREADS = 2
 
 
 def find_lines_many(pages):
