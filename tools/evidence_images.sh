@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/ev_images
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_pages_images" -o pg -- python3 "$REPO/tools/pages_img_time.py" 32 > "$OUT/kt_pages_images.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_pages_images" -o pg -- python3 "$REPO/tools/pages_img_time.py" 32 8 1 > "$OUT/kt_pages_images.log" 2>&1
 echo "page images kernel trace done"
 cp $(find "$OUT/kt_pages_images" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats_pages_images.csv"
 cd "$REPO"
