@@ -276,9 +276,10 @@ int ta_lstm_forward(const float* x, const int64_t* row_off, const int32_t* T,
  *
  * ta_lstm_xproj_f64: the input projection of every row at once, gx[dir][r][16 (unit / 4) + 8 (gate / 2) + 2 (unit % 4) + gate % 2] =
  *   W_gate[unit][0 .. 48] . [1; x[r]] in float64 for the `rows` rows at x; gx = ta_lstm_f64_gx_bytes(rows) bytes
- *   ([2][rows][400] doubles; the buffer is private to the pair of calls, its layout is the recurrence kernel's).  wx = ta_lstm_f64_weight_doubles(1) doubles [dir 2][tile 25][k-step 13][lane 64] =
- *   W_gate(2 (i / 8) + i % 2)[unit 4 tile + (i % 8) / 2][kp 4 kstep + lane / 16], i = lane % 16, kp: 0 bias, 1..48 x,
- *   49..51 zero (B fragments of v_mfma_f64_16x16x4_f64: column i of a tile = its position in a row of gx).
+ *   ([2][rows][400] doubles; the buffer is private to the pair of calls, its layout is the recurrence kernel's).  wx = ta_lstm_f64_weight_doubles(1) doubles [dir 2][tile 25][slot 13][lane 64]:
+ *   slots 0..11 = W_gate(2 (i / 8) + i % 2)[unit 4 tile + (i % 8) / 2][1 + 4 slot + lane / 16], i = lane % 16 (the weights of
+ *   x[4 slot + lane / 16]: B fragments of v_mfma_f64_16x16x4_f64, column i of a tile = its position in a row of gx);
+ *   slot 12 = the column's bias W_gate(..)[unit ..][0] in every lane of the column (what the accumulators start from).
  * ta_lstm_forward_f64: the recurrence over `ngroups` groups of 16 lines (group_lines = int32[ngroups][16], -1 =
  *   empty slot) whose rows lie in [gx_row0, gx_row0 + gx_rows) -- row_off / hout use ABSOLUTE rows, gx holds the
  *   projection of rows gx_row0 .. only.  wh = ta_lstm_f64_weight_doubles(0) doubles

@@ -115,12 +115,13 @@ def test_sixteen_line_fragments(packed):
                 for g in range(4):
                     assert abs(dreg[L, g] - want_h[g, 4 * tile + L // 16, L % 16]) < 1e-12
         # the projection: Gx[row][gx_index(unit, gate)] with gx_index = 16 (unit // 4) + 8 (gate // 2) + 2 (unit % 4) + gate % 2
-        xa = np.concatenate([np.ones((16, 1)), x, np.zeros((16, 3))], axis=1)    # [row][52]
-        want_x = np.einsum("guk,rk->rug", Wg[:, :, :49], xa[:, :49])               # [row][unit][gate]
+        xa = np.concatenate([np.ones((16, 1)), x], axis=1)                        # [row][49]
+        want_x = np.einsum("guk,rk->rug", Wg[:, :, :49], xa)                        # [row][unit][gate]
         for tile in (0, 13, 24):
-            dreg = np.zeros((64, 4))
-            for kk in range(13):
-                dreg = _mfma_f64_16x16x4(xa[lane % 16, 4 * kk + lane // 16], wx[d, tile, kk], dreg)
+            dreg = np.repeat(wx[d, tile, 12][:, None], 4, axis=1)                  # the accumulators start from the bias
+            assert np.array_equal(wx[d, tile, 12][:16], wx[d, tile, 12][48:])      # (the same in every lane of a column)
+            for kk in range(12):
+                dreg = _mfma_f64_16x16x4(x[lane % 16, 4 * kk + lane // 16], wx[d, tile, kk], dreg)
             for L in (0, 21, 63):
                 for r in range(4):
                     row, col = 4 * r + L // 16, L % 16                          # D[i][j]: i = row of x, j = column of the tile

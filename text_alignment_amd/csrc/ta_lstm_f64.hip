@@ -11,7 +11,7 @@
 //
 //  Kx lstm_xproj_f64_kernel   Gx[dir][row][gx_index(unit, gate)] = W[:, :49] . [1; x_row] for EVERY row of the batch at
 //                             once (no dependence between timesteps): a weight-stationary f64 GEMM on
-//                             v_mfma_f64_16x16x4_f64, rows x 52 x 400 per direction.
+//                             v_mfma_f64_16x16x4_f64, rows x 48 x 400 per direction (+ the bias the accumulators start from).
 //  Kr lstm_seq_f64_kernel     one workgroup of FOUR waves (one per SIMD, 512 registers each) per (16 lines,
 //                             direction).  The recurrent weights W[:, 49:] (4 x 100 x 100 float64 = 320 KB) live in
 //                             the CU's registers as A fragments for the whole kernel (the first 120 doubles of a wave
@@ -51,8 +51,8 @@ constexpr int kLines = 16;          // lines per workgroup (MFMA M)
 constexpr int kCols = 4 * kNs;      // 400 pre-activations per step, column = 4 * unit + gate
 constexpr int kTiles = kCols / 16;  // 25 column tiles
 constexpr int kKH = kNs / 4;        // 25 k-steps over h
-constexpr int kXK = 52;             // [1, x(48), 3 zeros]
-constexpr int kKX = kXK / 4;        // 13 k-steps over [1, x]
+constexpr int kKXM = kNi / 4;       // projection: 12 k-steps over x; the bias is what the accumulators start from
+constexpr int kKX = kKXM + 1;       // fragments per tile in the packed input weights: the 12 k-steps + the bias fragment
 constexpr int kW = 4;               // waves per workgroup
 constexpr int kMaxNT = 7;           // tile slots per wave in the packed recurrent weights: six own tiles + the 25th
 constexpr int kOwnTiles = 6;        // recurrence: tiles a wave owns (6 wave .. 6 wave + 5); the 25th is split along k
@@ -237,12 +237,17 @@ __device__ __forceinline__ double lstm_cell_f64(double gi, double gf, double go,
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kx: Gx[dir][row][4 unit + gate] = sum_kp W_gate[unit][kp] * [1, x_row, 0, 0, 0][kp]     (kp < 52, float64)
+// Kx: Gx[dir][row][4 unit + gate] = bias + sum_k W_gate[unit][1 + k] * x_row[k]     (k < 48, float64)
+// The accumulators START from the bias and twelve k-steps run over x alone.  Until round 6 the constant 1 was input 0 of a
+// 52-wide padded row (13 k-steps): its first fma was fma(1, b, 0) = b and its last three added 0 * 0 -- the chain of
+// fmas over x1 .. x48 in between is the same one, so Gx is the same to the bit (but for the sign of an exact zero) with
+// a thirteenth of the matrix instructions gone.
 struct XprojArgs {
     const float* x;        // [rows][48], the rows of this call
     int64_t rows;
-    const double* wx;      // [dir 2][tile 25][k-step 13][lane 64]: B fragments, column j = lane % 16 of the tile = the (unit, gate) whose
-                           // gx_index is 16 tile + j: W_gate(2 (j / 8) + j % 2)[unit 4 tile + (j % 8) / 2][kp 4 kstep + lane / 16]
+    const double* wx;      // [dir 2][tile 25][slot 13][lane 64]: B fragments, column j = lane % 16 of the tile = the (unit, gate) whose
+                           // gx_index is 16 tile + j: slots 0..11 W_gate(2 (j / 8) + j % 2)[unit 4 tile + (j % 8) / 2][1 + 4 slot + lane / 16]
+                           // (the 48 weights of x), slot 12 the column's BIAS W_gate(..)[unit ..][0] in every lane of the column
     double* gx;            // [dir 2][rows][400], gx_index(unit, gate) inside a row
 };
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -254,39 +259,38 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 template <int NT>
 __device__ __forceinline__ void xproj_body(const XprojArgs& a, int dir, int wave, int lane) {
     const int tile0 = tile0_of(wave);
-    double Bx[NT][kKX];
+    double Bx[NT][kKXM], bias[NT];
     {
         const double* wp = a.wx + ((size_t)(dir * kTiles + tile0) * kKX) * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < NT; ++s)
+        for (int s = 0; s < NT; ++s) {
 #pragma unroll
-            for (int kk = 0; kk < kKX; ++kk) Bx[s][kk] = wp[((size_t)s * kKX + kk) * 64];
+            for (int kk = 0; kk < kKXM; ++kk) Bx[s][kk] = wp[((size_t)s * kKX + kk) * 64];
+            bias[s] = wp[((size_t)s * kKX + kKXM) * 64];
+        }
     }
     const int64_t ntiles = (a.rows + 15) / 16;
     const int li = lane & 15, kq = lane >> 4;
     double* gxd = a.gx + (size_t)dir * a.rows * kCols;
-    // this lane's A values of a row tile: [1, x, 0 0 0][4 kk + kq] of row tile * 16 + li (rows past the end: clamped)
-    auto load_tile = [&](int64_t tile, float (&dst)[kKX]) {
+    // this lane's A values of a row tile: x[4 kk + kq] of row tile * 16 + li (rows past the end: clamped)
+    auto load_tile = [&](int64_t tile, float (&dst)[kKXM]) {
         const int64_t row = min(min(tile, ntiles - 1) * 16 + li, a.rows - 1);
-        const float* xr = a.x + row * kNi;
+        const float* xr = a.x + row * kNi + kq;
 #pragma unroll
-        for (int kk = 0; kk < kKX; ++kk) {
-            const int kp = 4 * kk + kq;                        // kp = 0: the constant 1; 49 .. 51: zero padding
-            dst[kk] = (kp >= 1 && kp <= kNi) ? xr[kp - 1] : (kp == 0 ? 1.0f : 0.0f);
-        }
+        for (int kk = 0; kk < kKXM; ++kk) dst[kk] = xr[4 * kk];
     };
-    float A[kKX], An[kKX];
+    float A[kKXM], An[kKXM];
     load_tile(blockIdx.x, A);
 #if TA_XPROJ_ORDER == 1
-    // Column tile by column tile: the 13 k-steps of ONE tile (a dependent chain: 64 cycles per MFMA all the same), then the
+    // Column tile by column tile: the 12 k-steps of ONE tile (a dependent chain: 64 cycles per MFMA all the same), then the
     // four row stores of the tile BEFORE it -- issued in the shadow of the chain's last MFMA, so a wave's stores are spread
     // over its MFMA stream (4 per 832 cycles) instead of coming as 28 in a burst when all four waves of the CU have
     // finished a row tile together and the matrix pipes idle until the shared store path has drained.
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         load_tile(tile + gridDim.x, An);                       // flies under this tile's MFMAs
-        double Ad[kKX];
+        double Ad[kKXM];
 #pragma unroll
-        for (int kk = 0; kk < kKX; ++kk) Ad[kk] = (double)A[kk];
+        for (int kk = 0; kk < kKXM; ++kk) Ad[kk] = (double)A[kk];
         double* orow[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -298,10 +302,10 @@ __device__ __forceinline__ void xproj_body(const XprojArgs& a, int dir, int wave
         f64x4 prev = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < NT; ++s) {
-            f64x4 cur = {0.0, 0.0, 0.0, 0.0};
+            f64x4 cur = {bias[s], bias[s], bias[s], bias[s]};
 #pragma unroll
-            for (int kk = 0; kk < kKX; ++kk)
-#if defined(TA_XPROJ_ABL) && (TA_XPROJ_ABL & 2)       // timing ablation: one MFMA per tile instead of 13
+            for (int kk = 0; kk < kKXM; ++kk)
+#if defined(TA_XPROJ_ABL) && (TA_XPROJ_ABL & 2)       // timing ablation: one MFMA per tile instead of 12
                 if (kk == 0)
 #endif
                 cur = __builtin_amdgcn_mfma_f64_16x16x4f64(Ad[kk], Bx[s][kk], cur, 0, 0, 0);
@@ -319,7 +323,7 @@ __device__ __forceinline__ void xproj_body(const XprojArgs& a, int dir, int wave
 #pragma unroll
         for (int r = 0; r < 4; ++r) orow[r][16 * (NT - 1)] = prev[r];
 #pragma unroll
-        for (int kk = 0; kk < kKX; ++kk) A[kk] = An[kk];
+        for (int kk = 0; kk < kKXM; ++kk) A[kk] = An[kk];
     }
     return;
 #endif
@@ -327,9 +331,9 @@ __device__ __forceinline__ void xproj_body(const XprojArgs& a, int dir, int wave
         load_tile(tile + gridDim.x, An);                       // flies under this tile's MFMAs
         f64x4 acc[NT];
 #pragma unroll
-        for (int s = 0; s < NT; ++s) acc[s] = (f64x4){0.0, 0.0, 0.0, 0.0};
+        for (int s = 0; s < NT; ++s) acc[s] = (f64x4){bias[s], bias[s], bias[s], bias[s]};
 #pragma unroll
-        for (int kk = 0; kk < kKX; ++kk) {
+        for (int kk = 0; kk < kKXM; ++kk) {
             const double av = (double)A[kk];
 #pragma unroll
             for (int s = 0; s < NT; ++s) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bx[s][kk], acc[s], 0, 0, 0);
@@ -344,7 +348,7 @@ __device__ __forceinline__ void xproj_body(const XprojArgs& a, int dir, int wave
             }
         }
 #pragma unroll
-        for (int kk = 0; kk < kKX; ++kk) A[kk] = An[kk];
+        for (int kk = 0; kk < kKXM; ++kk) A[kk] = An[kk];
     }
 }
 

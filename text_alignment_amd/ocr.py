@@ -183,8 +183,10 @@ def _pack_lstm_f64(model):
     pre-activations of a step are tiled as 25 tiles of 16 rows = (4 gates) x (4 units), row i = 4 gate + unit-in-tile;
     a wave owns tiles 6 wave .. 6 wave + 5 (slots 0..5); slot 6 is tile 24, which the waves split along k.
     wh [dir 2][wave 4][slot 7][k-step 25][lane 64] = W_gate(i // 4)[unit 4 tile(wave, slot) + i % 4][49 + 4 kstep + lane // 16]
-    wx [dir 2][tile 25][k-step 13][lane 64]        = W_gate(2 (i // 8) + i % 2)[unit 4 tile + (i % 8) // 2][kp = 4 kstep + lane // 16]
-                                                     (kp <= 48; B fragments, column i of a tile = position i of the tile in a row of Gx)
+    wx [dir 2][tile 25][slot 13][lane 64]          = W_gate(2 (i // 8) + i % 2)[unit 4 tile + (i % 8) // 2][1 + 4 slot + lane // 16]
+                                                     for slots 0..11 (B fragments over x alone, column i of a tile = position i of
+                                                     the tile in a row of Gx); slot 12 = the column's bias W_gate(..)[unit ..][0] in
+                                                     every lane of the column: the projection's accumulators start from it
     with i = lane % 16; peep [dir 2][WIP, WFP, WOP][100]."""
     wh = np.zeros((2, 4, 7, 25, 64), dtype=np.float64)
     wx = np.zeros((2, 25, 13, 64), dtype=np.float64)
@@ -193,13 +195,12 @@ def _pack_lstm_f64(model):
     i, kq = lane % 16, lane // 16
     for d, w in enumerate((model.fwd, model.rev)):
         Wg = np.stack([np.asarray(w[name], dtype=np.float64) for name in ("WGI", "WGF", "WGO", "WCI")])   # [gate][unit][149]
-        Wx = np.zeros((4, NS, 52), dtype=np.float64)
-        Wx[:, :, :1 + NI] = Wg[:, :, :1 + NI]
         Wh = Wg[:, :, 1 + NI:]                                                                                  # [gate][unit][100]
         for tile in range(25):                      # B fragments: column j = lane % 16 is the (unit, gate) at in-row index 16 tile + j
             units, gates = 4 * tile + (i % 8) // 2, 2 * (i // 8) + i % 2
-            for kk in range(13):
-                wx[d, tile, kk] = Wx[gates, units, 4 * kk + kq]
+            for kk in range(12):
+                wx[d, tile, kk] = Wg[gates, units, 1 + 4 * kk + kq]
+            wx[d, tile, 12] = Wg[gates, units, 0]
         for wv in range(4):
             for s in range(7):
                 units = 4 * (6 * wv + s if s < 6 else 24) + i % 4
