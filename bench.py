@@ -268,7 +268,7 @@ def bench_ocr(args, rank, precision=None, nlines=None):
         roof = {"bound": "mfma", "achieved": tf, "peak": F64_MFMA_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tf / F64_MFMA_PEAK_TF, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "%s (+ lstm_xproj_f64_kernel)" % ("lstm_seq4_f64_kernel" if st["group_size"] == 4 else "lstm_seq_f64_kernel"),
-                "flops": "algorithmic: 238400 per timestep, all of them float64 (no padding: 25 x 25 tiles are exactly 400 x 100; the x part pads 49 -> 52)",
+                "flops": "algorithmic: 238400 per timestep, all of them float64 (no padding: 25 x 25 tiles are exactly 400 x 100; the x part is twelve k-steps of four over the 48 inputs, the bias is what the accumulators start from)",
                 "peak_is": "f64 matrix peak: v_mfma_f64_16x16x4_f64 at 64 cycles per SIMD, v_mfma_f64_4x4x4_4b_f64 at 16 -- the same 16 "
                            "multiply-adds per cycle and SIMD (measured, profiles/r04_mfma_f64.txt, r05_mfma_f64_4x4.txt)"}
     elif f32:

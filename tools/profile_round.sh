@@ -14,6 +14,8 @@
 set -eo pipefail
 ROUND=${1:-r06}
 PART=${2:-all}           # traces | pmc | all (a gpurun call is limited to 20 minutes: run the two parts in two calls)
+                         # f64: only the runs that see the float64 recogniser kernels (after one of them changed; the
+                         #      summariser lays the new entries over the round's existing summaries)
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$ROUND
 mkdir -p "$OUT"
@@ -115,5 +117,29 @@ export TA_OCR_GROUP=16
 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_f64" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f64 > "$OUT/ocr_pmc_f64.log" 2>&1
 echo "ocr pmc f64 done"
 unset TA_OCR_GROUP
+fi
+if [ "$PART" = f64 ]; then
+export TA_OCR_CLASS_SPLIT=0
+export TA_OCR_F64_PIPE=0
+export TA_OCR_GROUP=4
+for n in 30 1920 5760; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_${n}_f64_g4" -o ocr -- python3 "$REPO/tools/ocr_only.py" $n f64 > "$OUT/kt_ocr_${n}_f64_g4.log" 2>&1
+  echo "ocr $n f64 (groups of 4) kernel trace done"
+done
+TA_OCR_GROUP=16 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_1920_f64" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f64 > "$OUT/kt_ocr_1920_f64.log" 2>&1
+echo "ocr 1920 f64 (groups of 16) kernel trace done"
+for g in 4 16; do
+  for ctr in WRITE_SIZE FETCH_SIZE; do
+    TA_OCR_GROUP=$g timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d "$OUT/ocr_f64g${g}_$ctr" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f64 > "$OUT/ocr_f64g${g}_$ctr.log" 2>&1
+    echo "ocr f64 groups of $g $ctr done"
+  done
+done
+TA_OCR_GROUP=4 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_f64g4" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f64 > "$OUT/ocr_pmc_f64g4.log" 2>&1
+echo "ocr pmc f64 groups of 4 done"
+TA_OCR_GROUP=16 timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -d "$OUT/ocr_pmc_f64" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f64 > "$OUT/ocr_pmc_f64.log" 2>&1
+echo "ocr pmc f64 done"
+unset TA_OCR_GROUP TA_OCR_CLASS_SPLIT TA_OCR_F64_PIPE
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_ocr_1920_f64_classes" -o ocr -- python3 "$REPO/tools/ocr_only.py" 1920 f64 > "$OUT/kt_ocr_1920_f64_classes.log" 2>&1
+echo "ocr 1920 f64 (length classes) kernel trace done"
 fi
 echo "now run: python3 tools/profile_summarise.py $ROUND gpurun_out/prof_$ROUND"

@@ -26,6 +26,15 @@ def counter_means(path, counter, only="nw_"):
     return {k: v[0] / v[1] for k, v in acc.items()}
 
 
+def _kept(path, key):
+    """entries of an existing summary that a PARTIAL collection (one part of tools/profile_round.sh re-run after a kernel
+    changed) does not replace: the new entries are laid over them"""
+    if not os.path.exists(path):
+        return {}
+    with open(path) as fh:
+        return json.load(fh).get(key, {})
+
+
 def main():
     rnd, out = sys.argv[1], sys.argv[2]
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -42,6 +51,8 @@ def main():
                               ("one", "%s_nw_hbm_traffic.json", "one-pass aligner (--one-pass)")):
         wr = counter_means(os.path.join(out, mode + "_WRITE_SIZE"), "WRITE_SIZE")
         rd = counter_means(os.path.join(out, mode + "_FETCH_SIZE"), "FETCH_SIZE")
+        if not wr and not rd:           # a partial collection (tools/profile_round.sh <round> f64): the file of the full one stays
+            continue
         kernels = {}
         for k in sorted(set(wr) | set(rd)):
             w, r = wr.get(k, 0.0), rd.get(k, 0.0)
@@ -79,6 +90,7 @@ def main():
         if ks:
             modes["%s_g%d_1920" % (prec, g)] = {"kernels": ks, "hbm_bytes_per_pass": sum(ks.values())}
     if modes:
+        modes = dict(_kept(os.path.join(prof, "%s_ocr_hbm_traffic.json" % rnd), "modes"), **modes)
         with open(os.path.join(prof, "%s_ocr_hbm_traffic.json" % rnd), "w") as fh:
             json.dump({"command": "TA_OCR_CLASS_SPLIT=0 TA_OCR_F64_PIPE=0 TA_OCR_GROUP=<g> rocprofv3 --pmc WRITE_SIZE (and, separately, "
                                   "FETCH_SIZE) --output-format csv -- python3 tools/ocr_only.py 1920 <mode>",
@@ -114,6 +126,7 @@ def main():
                 d["busy_cycles_per_mfma"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["SQ_INSTS_MFMA"]
             kernels["%s [precision=%s]" % (k, prec)] = d
     if kernels:
+        kernels = dict(_kept(os.path.join(prof, "%s_ocr_pmc_mfma.json" % rnd), "kernels"), **kernels)
         with open(os.path.join(prof, "%s_ocr_pmc_mfma.json" % rnd), "w") as fh:
             json.dump({"command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU "
                                   "SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU --output-format csv -- python3 "
