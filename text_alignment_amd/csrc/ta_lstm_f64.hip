@@ -77,7 +77,7 @@ __device__ __forceinline__ unsigned long long prof_now() {
 // the four gates of one (row, unit) and moves them with two 16-byte accesses; the four lanes of a row's tile make each
 // access a contiguous 64-byte piece.
 __host__ __device__ constexpr int gx_index(int unit, int gate) { return 16 * (unit / 4) + 8 * (gate / 2) + 2 * (unit % 4) + (gate % 2); }
-// The projection's column tiles per wave: 0..6, 7..12, 13..18, 19..24 -- four waves, one per SIMD, 284 registers each.
+// The projection's column tiles per wave: 0..6, 7..12, 13..18, 19..24 -- four waves, one per SIMD, ~290 registers each.
 // (Giving the waves the 25th tile in turn, row tile by row tile, measured SLOWER: 6.1 against 5.4 ms per 2.76 M rows.
 // Round 6, -DTA_XPROJ_WAVES=8: EIGHT waves of 4 / 3 tiles at 180 registers, two per SIMD, so that one wave's row stores
 // could issue under its SIMD partner's MFMAs -- bit-identical Gx, 6.25 against 5.17 ms: slower.  A wave then writes
