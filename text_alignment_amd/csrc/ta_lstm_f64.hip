@@ -352,7 +352,12 @@ __device__ __forceinline__ void xproj_body(const XprojArgs& a, int dir, int wave
     }
 }
 
-__global__ __launch_bounds__(kXW * 64) void lstm_xproj_f64_kernel(XprojArgs a) {
+#ifdef TA_XPROJ_OCC2            // timing builds: two four-wave workgroups per CU (the compiler must fit 256 registers: it spills)
+#define TA_XPROJ_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define TA_XPROJ_ATTR
+#endif
+__global__ __launch_bounds__(kXW * 64) TA_XPROJ_ATTR void lstm_xproj_f64_kernel(XprojArgs a) {
     const int dir = blockIdx.y, lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave == 0) xproj_body<ntiles_of(0)>(a, dir, wave, lane);
