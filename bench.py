@@ -91,6 +91,32 @@ def measured_mfma_busy(kernel):
     return None, None
 
 
+# float64 recurrence on groups of four lines: what a SIMD must ISSUE per timestep of a workgroup.  Its float64 matrix and
+# float64 vector instructions do not overlap (profiles/r05_simd_pair.txt: 2 765 + 1 985 = 4 795 cycles), so the floor of a
+# step is their sum: 150 + 9 v_mfma_f64_4x4x4_4b_f64 at 16 cycles (profiles/r05_mfma_f64_4x4.txt) on the busiest SIMD and
+# the 127 + 120 vector instructions of its two waves at 4 cycles each (tools/isa_loop_counts.py on csrc/ta_lstm_f64.hip).
+F64G4_MFMA_PER_SIMD_STEP, F64G4_VALU_PER_SIMD_STEP = 159, 247
+
+
+def f64_issue_floor():
+    """{issue floor, measured cycles per step, their ratio} of lstm_seq4_f64_kernel from the cycle counters kept under
+    profiles/ (f64_step_cycles.txt, a -DTA_F64_PROFILE build) -- read from that file, not measured in this run."""
+    import re
+    name, path = _profile_file("f64_step_cycles.txt")
+    try:
+        with open(path) as f:
+            m = re.search(r"total (\d+)", f.read())             # the first entry is the four-line kernel
+        measured = int(m.group(1))
+    except (OSError, TypeError, AttributeError, ValueError):
+        return {}
+    floor = 16 * F64G4_MFMA_PER_SIMD_STEP + 4 * F64G4_VALU_PER_SIMD_STEP
+    return {"binding_unit": "f64 datapath of a SIMD (its float64 matrix and vector instructions do not overlap)",
+            "issue_floor_cycles_per_step": floor, "measured_cycles_per_step": measured, "issue_floor_frac": floor / measured,
+            "issue_floor_source": "profiles/%s (step), profiles/%s (no overlap), %d MFMAs x 16 + %d VALU x 4 cycles "
+                                  "per SIMD and step" % (name, _profile_file("simd_pair.txt")[0], F64G4_MFMA_PER_SIMD_STEP,
+                                                         F64G4_VALU_PER_SIMD_STEP)}
+
+
 def make_nw_batch(tsc, nprob, n, m, seed0, distinct=256, two_phase=False):
     from tools.synth import synth_pair_ids      # seeded input generator shared with the tests
     uniq = [synth_pair_ids(n, m, seed0 + k) for k in range(min(nprob, distinct))]
@@ -271,6 +297,8 @@ def bench_ocr(args, rank, precision=None, nlines=None):
                 "flops": "algorithmic: 238400 per timestep, all of them float64 (no padding: 25 x 25 tiles are exactly 400 x 100; the x part is twelve k-steps of four over the 48 inputs, the bias is what the accumulators start from)",
                 "peak_is": "f64 matrix peak: v_mfma_f64_16x16x4_f64 at 64 cycles per SIMD, v_mfma_f64_4x4x4_4b_f64 at 16 -- the same 16 "
                            "multiply-adds per cycle and SIMD (measured, profiles/r04_mfma_f64.txt, r05_mfma_f64_4x4.txt)"}
+        if st["group_size"] == 4:
+            roof.update(f64_issue_floor())
     elif f32:
         # exact f32 arithmetic of this recurrence is bounded by the f32-input MFMA rate; algorithmic
         # flops per timestep: 2 dirs x 4 gates x 100 units x 149 inputs x 2
