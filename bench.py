@@ -594,8 +594,11 @@ def main():
     # torch's intra-op pool down to one thread (text_alignment_amd.sharding.bind_to_gpu_node; silent where the host
     # does not name a NUMA node for the device)
     from text_alignment_amd import sharding as _sh
-    placement = {"bound": False, "reason": "--no-bind"} if args.no_bind else _sh.bind_to_gpu_node(
-        dev_index, local_rank=local, local_world=int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    try:
+        placement = {"bound": False, "reason": "--no-bind"} if args.no_bind else _sh.bind_to_gpu_node(
+            dev_index, local_rank=local, local_world=int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    except Exception as exc:        # placement is an optimisation: a host it cannot read must not cost the run
+        placement = {"bound": False, "reason": "bind_to_gpu_node raised %r" % (exc,)}
     dist = None
     if world > 1 or (args.force_dist and "RANK" in os.environ):
         import torch.distributed as dist
